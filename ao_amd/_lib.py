@@ -1,0 +1,89 @@
+"""ctypes binding of the C-ABI library (include/ao_mi355.h).
+
+The product path has no CPU fallback: if the library is missing or a call
+fails, this raises.  `lib()` loads ao_amd/_C_mi355.so (built in-tree by
+ao_amd/build.py).
+"""
+import ctypes
+import os
+import re
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_C_mi355.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ao_mi355.h")
+
+AO_OK = 0
+AO_ERR_INVALID_ARGUMENT = -1
+AO_ERR_NULL_POINTER = -2
+AO_ERR_HIP = -3
+
+_lock = threading.Lock()
+_lib = None
+
+_P = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_INT = ctypes.c_int
+
+# name -> argtypes (restype is int for all but the two noted)
+_SIGNATURES = {
+    "ao_abi_version": [],
+    "ao_prof_enable": [_INT],
+    "ao_prof_collect": [_P, _INT, _P],
+    "ao_int4_convert_weight_to_int4pack": [_P, _P, _I64, _I64, _INT, _P],
+    "ao_int4_unpack_int4pack": [_P, _P, _I64, _I64, _INT, _P],
+    "ao_int4_weight_int4pack_mm": [_P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
+    "ao_int4_dequantize": [_P, _P, _P, _I64, _I64, _INT, _P],
+    "ao_int4_quantize_tinygemm": [_P, _P, _P, _I64, _I64, _INT, _P],
+    "ao_int4_set_tuning": [_INT, _INT],
+}
+
+
+class BackendUnavailable(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Entry points declared in include/ao_mi355.h (parsed from the header)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ao_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load the shared library once; raise loudly if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise BackendUnavailable(
+                f"{LIB_PATH} not found: build it with `python -m ao_amd.build` "
+                "(the MI355X backend has no CPU/eager fallback)"
+            )
+        l = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so is stale
+            fn.argtypes = argtypes
+            fn.restype = _INT
+        l.ao_last_error.argtypes = []
+        l.ao_last_error.restype = ctypes.c_char_p
+        _lib = l
+    return _lib
+
+
+def last_error():
+    return lib().ao_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Turn a status code into the exception the reference op would raise."""
+    if rc == AO_OK:
+        return
+    msg = last_error()
+    if rc == AO_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,541 @@
+// int4 weight-only ("tinygemm", tile-packed-to-4d) kernels for gfx950.
+//
+// Weight format (bit-exact with aten::_convert_weight_to_int4pack on ROCm, the
+// on-disk format of Int4TilePackedTo4dTensor): qdata is int32
+// [N/8][K/128][32][4] by shape, but indexed on ROCm as [N/16][K/128][64][4]:
+// one 1 KiB block = one wavefront-load (64 lanes x 16 B) = a 16(n) x 128(k)
+// tile.  Lane l owns n = l & 15 and, in each of the 8 inner k-tiles (16 k
+// each), the 4 consecutive k's starting at (l >> 4) * 4.  Word j of the lane
+// packs inner k-tiles 2j and 2j+1 as v0|v2<<4|v4<<8|v6<<12|v1<<16|v3<<20|v5<<24|v7<<28.
+// That ownership is exactly the B-operand ownership of the 16x16 MFMA family, so
+// a dequantised word is a ready v_mfma_f32_16x16x32_bf16 B fragment
+// (k-slots 0-3 = tile 2j, 4-7 = tile 2j+1; the A fragment uses the same slots).
+//
+// Reference call sites replaced (torchao 0.19.0 snapshot):
+//   int4_tile_packed_to_4d_tensor.py:202  aten::_convert_weight_to_int4pack
+//   int4_tile_packed_to_4d_tensor.py:287  aten::_weight_int4pack_mm
+//   quant_primitives.py:999-1007          dequant rounding sequence (the oracle)
+//   quant_primitives.py:1299-1335,577-599 tinygemm qparams / quantize
+#include "common.h"
+
+namespace ao {
+namespace {
+
+// ---------------------------------------------------------------------------
+// Dequantise one packed word (8 nibbles) into four packed-bf16 pairs
+// (w0w1, w2w3 | w4w5, w6w7) with the oracle's rounding sequence:
+//     w = bf16( bf16( (q - 8) * s ) + z )
+// (q-8)*s is exact in fp32 (4-bit x 8-bit significands), so the first
+// v_cvt_pk_bf16_f32 is the single rounding torch's bf16 multiply performs; the
+// fp32 add + second v_cvt_pk_bf16_f32 is torch's bf16 add.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void dequant_word(uint32_t p, float s, float neg8s, float z,
+                                             uint32_t (&out)[4]) {
+  uint32_t lo = p & 0x0F0F0F0Fu;         // bytes: v0, v4, v1, v5
+  uint32_t hi = (p >> 4) & 0x0F0F0F0Fu;  // bytes: v2, v6, v3, v7
+  // keep the masked words opaque so the byte extracts lower to v_cvt_f32_ubyteN
+  asm("" : "+v"(lo));
+  asm("" : "+v"(hi));
+  const float f0 = (float)(lo & 0xffu), f4 = (float)((lo >> 8) & 0xffu);
+  const float f1 = (float)((lo >> 16) & 0xffu), f5 = (float)(lo >> 24);
+  const float f2 = (float)(hi & 0xffu), f6 = (float)((hi >> 8) & 0xffu);
+  const float f3 = (float)((hi >> 16) & 0xffu), f7 = (float)(hi >> 24);
+  const f32x2 q[4] = {{f0, f1}, {f2, f3}, {f4, f5}, {f6, f7}};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 t = q[i] * s + neg8s;                 // exact (q-8)*s
+    const uint32_t tp = pack_bf16x2(t.x, t.y);        // rounding #1
+    const f32x2 tr = {bf16_lo_to_f32(tp), bf16_hi_to_f32(tp)};
+    const f32x2 w = tr + z;                           // fp32 add, like torch
+    out[i] = pack_bf16x2(w.x, w.y);                   // rounding #2
+  }
+}
+
+// ---------------------------------------------------------------------------
+// y[M,N] = x[M,K] @ dequant(qdata)^T     (aten::_weight_int4pack_mm)
+//
+// grid = (N/16, ceil(M/16)); block = WPB waves.  A workgroup owns one 16-wide
+// n-tile for one slab of <=16 rows; its waves split K into contiguous ranges of
+// 1 KiB weight blocks.  Each wave streams its blocks straight into VGPRs
+// (non-temporal dwordx4, DEPTH blocks in flight), dequantises in registers and
+// feeds v_mfma_f32_16x16x32_bf16.  x never goes through a block-wide barrier:
+// each wave stages the 128-k slice it needs into a private LDS slab in fragment
+// order and reads it back as A fragments (rows >= M alias one zero row).
+// One barrier at the end for the cross-wave (split-K) reduction.
+// ---------------------------------------------------------------------------
+template <int MAXM>
+struct XRegs {
+  // MAXM <= 4: one dword (2 bf16) per row per lane;  MAXM > 4: MAXM/4 x 16 B
+  static constexpr int kDwords = (MAXM <= 4) ? MAXM : MAXM;  // MAXM/4 * 4 dwords
+  uint32_t v[kDwords];
+};
+
+template <int G, int MAXM, int DEPTH>
+__global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
+    const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
+    const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K) {
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);              // groups per 128-k block
+  constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;          // bytes, padded vs bank conflicts
+  constexpr int SLAB = (MAXM + 1) * ROWSTRIDE;                // per-wave x slab (+ zero row)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int ntile = blockIdx.x;
+  const int m0 = blockIdx.y * 16;
+  const int rows = min(16, M - m0);
+  const int kblocks = K >> 7;
+  const int kb0 = (kblocks * wave) / nwaves;
+  const int kb1 = (kblocks * (wave + 1)) / nwaves;
+
+  char* slab = smem + wave * SLAB;
+  float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
+
+  // zero row (index MAXM) of this wave's slab: 256 B
+  *reinterpret_cast<uint32_t*>(slab + MAXM * ROWSTRIDE + lane * 4) = 0u;
+
+  const int n = ntile * 16 + (lane & 15);
+  const int kq = lane >> 4;
+  const u32x4* wp = qdata + (size_t)ntile * kblocks * 64 + lane;
+  const uint16_t* xrow0 = x + (size_t)m0 * K;
+
+  // LDS addresses
+  const int mrow = lane & 15;
+  const char* a_base = slab + ((mrow < rows) ? mrow : MAXM) * ROWSTRIDE + kq * 64;
+  int st_off;  // byte offset (within a row) this lane stores its x piece at
+  if (MAXM <= 4) {
+    // dword = k = 2*lane, 2*lane+1
+    st_off = ((lane >> 1) & 3) * 64 + (lane >> 4) * 16 + (((lane >> 3) & 1) * 4 + (lane & 1) * 2) * 2;
+  } else {
+    // 16-B piece c = lane & 15 of row (lane >> 4) + 4*i: k = 8c .. 8c+7
+    const int c = lane & 15;
+    st_off = ((c & 1) * 2) * 64 + (c >> 2) * 16 + (((c >> 1) & 1) * 4) * 2;
+  }
+
+  struct Stage {
+    u32x4 w;
+    uint32_t sz[NG];
+    XRegs<MAXM> xr;
+  };
+  Stage st[DEPTH];
+
+  // Loads are unconditional (rows beyond `rows` re-read the last valid row; the
+  // LDS copy of such a row is never read) so that the steady-state loop is
+  // straight-line code and the compiler can use counted s_waitcnt vmcnt(N).
+  const int last_row = rows - 1;
+  auto issue = [&](Stage& s, int kb) {
+    s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
+    const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
+    if (MAXM <= 4) {
+#pragma unroll
+      for (int r = 0; r < MAXM; ++r) {
+        const int rr = min(r, last_row);
+        s.xr.v[r] = *reinterpret_cast<const uint32_t*>(xrow0 + (size_t)rr * K + kb * 128 + lane * 2);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXM / 4; ++i) {
+        const int rr = min((lane >> 4) + 4 * i, last_row);
+        const u32x4 t = *reinterpret_cast<const u32x4*>(xrow0 + (size_t)rr * K + kb * 128 + (lane & 15) * 8);
+        s.xr.v[4 * i + 0] = t.x; s.xr.v[4 * i + 1] = t.y;
+        s.xr.v[4 * i + 2] = t.z; s.xr.v[4 * i + 3] = t.w;
+      }
+    }
+  };
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
+  auto consume = [&](const Stage& s) {
+    // stage x (wave-private: DS ops of one wave execute in order, no barrier)
+    if (MAXM <= 4) {
+#pragma unroll
+      for (int r = 0; r < MAXM; ++r)
+        *reinterpret_cast<uint32_t*>(slab + r * ROWSTRIDE + st_off) = s.xr.v[r];
+    } else {
+#pragma unroll
+      for (int i = 0; i < MAXM / 4; ++i) {
+        const int r = (lane >> 4) + 4 * i;
+        char* d = slab + r * ROWSTRIDE + st_off;
+        *reinterpret_cast<u32x2*>(d) = u32x2{s.xr.v[4 * i + 0], s.xr.v[4 * i + 1]};
+        *reinterpret_cast<u32x2*>(d + 64) = u32x2{s.xr.v[4 * i + 2], s.xr.v[4 * i + 3]};
+      }
+    }
+    u32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
+
+    const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
+      const float sc = bf16_lo_to_f32(s.sz[gi]);
+      const float zp = bf16_hi_to_f32(s.sz[gi]);
+      uint32_t b[4];
+      dequant_word(wds[j], sc, -8.0f * sc, zp, b);
+      const u32x4 bv = {b[0], b[1], b[2], b[3]};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
+                                                    __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+    }
+  };
+
+  // prologue: DEPTH blocks in flight (indices clamped into the wave's range; a
+  // wave with fewer than DEPTH blocks just re-reads its last one, unused)
+  const int kb_last = max(kb1 - 1, kb0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
+
+  int kb = kb0;
+  // steady state: every consumed stage is refilled, no branches in the body
+  for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      consume(st[d]);
+      issue(st[d], kb + d + DEPTH);
+    }
+  }
+  // drain: fewer than 2*DEPTH blocks left
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (kb + d < kb1) {
+      consume(st[d]);
+      if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
+    }
+  }
+  kb += DEPTH;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (kb + d < kb1) consume(st[d]);
+  }
+
+  // cross-wave reduction: red[wave][row][col]
+  {
+    float* r = red + wave * 256 + (kq * 4) * 16 + (lane & 15);
+    r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
+  }
+  __syncthreads();
+  const int tid = threadIdx.x;
+  if (tid < 256) {
+    const int row = tid >> 4, col = tid & 15;
+    if (row < rows) {
+      float sum = 0.f;
+      for (int w = 0; w < nwaves; ++w) sum += red[w * 256 + tid];
+      y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pack / unpack / dequantize / fused quantize
+// ---------------------------------------------------------------------------
+
+// one thread per output word: (ntile16, ksuper, t, j)
+__global__ void int4_pack_kernel(const uint8_t* __restrict__ w_u8, uint32_t* __restrict__ out,
+                                 int64_t N, int64_t K, int64_t total_words) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_words) return;
+  const int j = idx & 3;
+  const int t = (idx >> 2) & 63;
+  const int64_t blk = idx >> 8;  // ntile * ksuper_count + ksuper
+  const int64_t ks_count = K >> 7;
+  const int64_t nt = blk / ks_count, ks = blk % ks_count;
+  const int64_t n = nt * 16 + (t & 15);
+  const uint8_t* row = w_u8 + n * (K >> 1);
+  uint32_t v[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t k0 = (ks * 8 + 2 * j + h) * 16 + (t >> 4) * 4;  // multiple of 4
+    const uint8_t b0 = row[k0 >> 1], b1 = row[(k0 >> 1) + 1];
+    v[4 * h + 0] = b0 >> 4; v[4 * h + 1] = b0 & 0xF;  // even k in the high nibble
+    v[4 * h + 2] = b1 >> 4; v[4 * h + 3] = b1 & 0xF;
+  }
+  out[idx] = v[0] | (v[2] << 4) | (v[4] << 8) | (v[6] << 12) | (v[1] << 16) | (v[3] << 20) |
+             (v[5] << 24) | (v[7] << 28);
+}
+
+__global__ void int4_unpack_kernel(const uint32_t* __restrict__ qdata, uint8_t* __restrict__ w_u8,
+                                   int64_t N, int64_t K, int64_t total_words) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_words) return;
+  const int j = idx & 3;
+  const int t = (idx >> 2) & 63;
+  const int64_t blk = idx >> 8;
+  const int64_t ks_count = K >> 7;
+  const int64_t nt = blk / ks_count, ks = blk % ks_count;
+  const int64_t n = nt * 16 + (t & 15);
+  const uint32_t p = qdata[idx];
+  uint32_t v[8];
+  v[0] = p & 0xF; v[2] = (p >> 4) & 0xF; v[4] = (p >> 8) & 0xF; v[6] = (p >> 12) & 0xF;
+  v[1] = (p >> 16) & 0xF; v[3] = (p >> 20) & 0xF; v[5] = (p >> 24) & 0xF; v[7] = (p >> 28) & 0xF;
+  uint8_t* row = w_u8 + n * (K >> 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t k0 = (ks * 8 + 2 * j + h) * 16 + (t >> 4) * 4;
+    row[k0 >> 1] = (uint8_t)((v[4 * h + 0] << 4) | v[4 * h + 1]);
+    row[(k0 >> 1) + 1] = (uint8_t)((v[4 * h + 2] << 4) | v[4 * h + 3]);
+  }
+}
+
+// one thread per packed word -> 8 bf16 of the [N][K] dequantised weight
+template <int G>
+__global__ void int4_dequant_kernel(const uint32_t* __restrict__ qdata,
+                                    const uint32_t* __restrict__ sz, uint16_t* __restrict__ w,
+                                    int64_t N, int64_t K, int64_t total_words) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_words) return;
+  const int j = idx & 3;
+  const int t = (idx >> 2) & 63;
+  const int64_t blk = idx >> 8;
+  const int64_t ks_count = K >> 7;
+  const int64_t nt = blk / ks_count, ks = blk % ks_count;
+  const int64_t n = nt * 16 + (t & 15);
+  const int64_t kbase = ks * 128 + (2 * j) * 16 + (t >> 4) * 4;
+  const uint32_t szv = sz[(kbase / G) * N + n];  // both inner tiles share the group (G >= 32)
+  const float s = bf16_lo_to_f32(szv), z = bf16_hi_to_f32(szv);
+  uint32_t b[4];
+  dequant_word(qdata[idx], s, -8.0f * s, z, b);
+  u32x2* d0 = reinterpret_cast<u32x2*>(w + n * K + kbase);
+  u32x2* d1 = reinterpret_cast<u32x2*>(w + n * K + kbase + 16);
+  *d0 = u32x2{b[0], b[1]};
+  *d1 = u32x2{b[2], b[3]};
+}
+
+// Fused choose_qparams + quantize + tile-pack + scale/zero pack.
+// One wave per (ntile16, span of max(128, G) k).  All arithmetic replays the
+// reference's bf16 op sequence (each op: fp32 compute, RNE to bf16).
+template <int G>
+__global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __restrict__ w,
+                                                           u32x4* __restrict__ qdata,
+                                                           uint32_t* __restrict__ sz, int64_t N,
+                                                           int64_t K) {
+  constexpr int KB_PER = (G > 128) ? (G / 128) : 1;  // 128-k blocks per wave
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);     // groups per 128-k block
+  const int lane = threadIdx.x;
+  const int64_t kblocks = K >> 7;
+  const int64_t span = blockIdx.x;  // ntile * (kblocks / KB_PER) + s
+  const int64_t spans_per_tile = kblocks / KB_PER;
+  const int64_t nt = span / spans_per_tile;
+  const int64_t kb_first = (span % spans_per_tile) * KB_PER;
+  const int64_t n = nt * 16 + (lane & 15);
+  const int kq = lane >> 4;
+
+  float v[KB_PER][8][4];
+  float gmin[KB_PER * NG], gmax[KB_PER * NG];
+#pragma unroll
+  for (int i = 0; i < KB_PER * NG; ++i) { gmin[i] = INFINITY; gmax[i] = -INFINITY; }
+
+#pragma unroll
+  for (int b = 0; b < KB_PER; ++b) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const u32x2 raw = *reinterpret_cast<const u32x2*>(w + n * K + (kb_first + b) * 128 + t * 16 + kq * 4);
+      v[b][t][0] = bf16_lo_to_f32(raw.x); v[b][t][1] = bf16_hi_to_f32(raw.x);
+      v[b][t][2] = bf16_lo_to_f32(raw.y); v[b][t][3] = bf16_hi_to_f32(raw.y);
+      const int gi = (G >= 128) ? 0 : (b * NG + (t * 16) / G);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        gmin[gi] = fminf(gmin[gi], v[b][t][i]);
+        gmax[gi] = fmaxf(gmax[gi], v[b][t][i]);
+      }
+    }
+  }
+  // reduce over the 4 lanes (kq) that share n
+#pragma unroll
+  for (int i = 0; i < KB_PER * NG; ++i) {
+    if (G >= 128 && i > 0) break;
+    gmin[i] = fminf(gmin[i], __shfl_xor(gmin[i], 16)); gmin[i] = fminf(gmin[i], __shfl_xor(gmin[i], 32));
+    gmax[i] = fmaxf(gmax[i], __shfl_xor(gmax[i], 16)); gmax[i] = fmaxf(gmax[i], __shfl_xor(gmax[i], 32));
+  }
+
+  constexpr int GROUPS = (G >= 128) ? 1 : NG;
+  float sc[GROUPS], zp[GROUPS], minv[GROUPS];
+#pragma unroll
+  for (int i = 0; i < GROUPS; ++i) {
+    float s = round_bf16(round_bf16(gmax[i] - gmin[i]) / 15.0f);
+    s = fmaxf(s, 1.1754943508222875e-38f);  // bf16 smallest normal (default eps)
+    const float s8 = round_bf16(s * 8.0f);
+    const float z = round_bf16(gmin[i] + s8);
+    sc[i] = s; zp[i] = z;
+    minv[i] = round_bf16(z - s8);
+    const int64_t kg = (G >= 128) ? ((kb_first * 128) / G) : (kb_first * NG + i);
+    if (kq == 0) sz[kg * N + n] = (uint32_t)f32_to_bf16_bits(s) | ((uint32_t)f32_to_bf16_bits(z) << 16);
+  }
+
+#pragma unroll
+  for (int b = 0; b < KB_PER; ++b) {
+    uint32_t words[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t q[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = 2 * j + h;
+        const int gi = (G >= 128) ? 0 : ((t * 16) / G);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = round_bf16(round_bf16(v[b][t][i] - minv[gi]) / sc[gi]);
+          const float r = fminf(fmaxf(rintf(d), 0.f), 15.f);
+          q[4 * h + i] = (uint32_t)(int)r;
+        }
+      }
+      words[j] = q[0] | (q[2] << 4) | (q[4] << 8) | (q[6] << 12) | (q[1] << 16) | (q[3] << 20) |
+                 (q[5] << 24) | (q[7] << 28);
+    }
+    qdata[(nt * kblocks + kb_first + b) * 64 + lane] = u32x4{words[0], words[1], words[2], words[3]};
+  }
+}
+
+int g_tune_wpb = 0;
+
+template <int G, int MAXM>
+int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
+              int64_t N, int64_t K, hipStream_t stream) {
+  constexpr int DEPTH = 4;
+  constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;
+  constexpr int SLAB = (MAXM + 1) * ROWSTRIDE;
+  const int kblocks = (int)(K >> 7);
+  const int64_t ntiles = N >> 4;
+  const int64_t mslabs = (M + 15) / 16;
+  // waves per workgroup: keep >= ~4 weight blocks per wave, and at least ~8
+  // waves per CU across the grid; 4 <= WPB <= 16 (>= 256 threads for the epilogue)
+  int wpb = 4;
+  while (wpb < 16 && kblocks / (wpb * 2) >= 4) wpb *= 2;
+  if (ntiles * mslabs >= 2048 && wpb > 4) wpb /= 2;
+  if (g_tune_wpb >= 4 && g_tune_wpb <= 16) wpb = g_tune_wpb;
+  if (MAXM > 4 && wpb > 8) wpb = 8;  // 16-row variant is built for <= 512 threads
+  if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
+  const size_t smem = (size_t)wpb * (SLAB + 1024);
+  dim3 grid((unsigned)ntiles, (unsigned)mslabs), block(wpb * 64);
+  ao::launch((int4_mm_kernel<G, MAXM, DEPTH>), grid, block, smem, stream, x,
+                     reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
+                     (int)M, (int)N, (int)K);
+  AO_LAUNCH_CHECK("int4_mm_kernel launch");
+  return AO_OK;
+}
+
+template <int G>
+int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
+                int64_t N, int64_t K, hipStream_t stream) {
+  if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
+  if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
+  return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+}
+
+int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
+  AO_REQUIRE(N > 0 && K > 0, "%s: N and K must be positive, got N=%lld K=%lld", fn, (long long)N, (long long)K);
+  AO_REQUIRE(N % 16 == 0, "%s: N=%lld must be a multiple of 16 (gfx950 n-tile)", fn, (long long)N);
+  AO_REQUIRE(K % 128 == 0, "%s: K=%lld must be a multiple of inner_k_tiles*16 = 128", fn, (long long)K);
+  if (group_size != 0) {
+    AO_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256,
+               "%s: qGroupSize must be one of 32, 64, 128, 256, got %d", fn, group_size);
+    AO_REQUIRE(K % group_size == 0, "%s: K=%lld not divisible by qGroupSize=%d", fn, (long long)K, group_size);
+  }
+  AO_REQUIRE(N < (1ll << 31) && K < (1ll << 31), "%s: N, K must fit int32", fn);
+  return AO_OK;
+}
+
+}  // namespace
+}  // namespace ao
+
+using namespace ao;
+
+extern "C" int ao_int4_set_tuning(int waves_per_block, int /*reserved*/) {
+  g_tune_wpb = waves_per_block;
+  return AO_OK;
+}
+
+extern "C" int ao_int4_convert_weight_to_int4pack(const uint8_t* w_u8, int32_t* qdata, int64_t N,
+                                                  int64_t K, int inner_k_tiles, void* stream) {
+  AO_REQUIRE_PTR(w_u8);
+  AO_REQUIRE_PTR(qdata);
+  AO_REQUIRE(inner_k_tiles == 8, "ao_int4_convert_weight_to_int4pack: innerKTiles must be 8 (torchao fixes it), got %d", inner_k_tiles);
+  if (int rc = check_int4_shape(__func__, N, K, 0)) return rc;
+  const int64_t words = N * K / 8;
+  const int threads = 256;
+  ao::launch(int4_pack_kernel, dim3((unsigned)((words + threads - 1) / threads)), dim3(threads), 0,
+                     (hipStream_t)stream, w_u8, reinterpret_cast<uint32_t*>(qdata), N, K, words);
+  AO_LAUNCH_CHECK("int4_pack_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_int4_unpack_int4pack(const int32_t* qdata, uint8_t* w_u8, int64_t N, int64_t K,
+                                       int inner_k_tiles, void* stream) {
+  AO_REQUIRE_PTR(w_u8);
+  AO_REQUIRE_PTR(qdata);
+  AO_REQUIRE(inner_k_tiles == 8, "ao_int4_unpack_int4pack: innerKTiles must be 8, got %d", inner_k_tiles);
+  if (int rc = check_int4_shape(__func__, N, K, 0)) return rc;
+  const int64_t words = N * K / 8;
+  const int threads = 256;
+  ao::launch(int4_unpack_kernel, dim3((unsigned)((words + threads - 1) / threads)), dim3(threads), 0,
+                     (hipStream_t)stream, reinterpret_cast<const uint32_t*>(qdata), w_u8, N, K, words);
+  AO_LAUNCH_CHECK("int4_unpack_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_int4_weight_int4pack_mm(const uint16_t* x, const int32_t* qdata,
+                                          const uint16_t* scale_and_zero, uint16_t* y, int64_t M,
+                                          int64_t N, int64_t K, int group_size, void* stream) {
+  AO_REQUIRE_PTR(qdata);
+  AO_REQUIRE_PTR(scale_and_zero);
+  if (int rc = check_int4_shape(__func__, N, K, group_size)) return rc;
+  AO_REQUIRE(M >= 0 && M < (1ll << 31), "ao_int4_weight_int4pack_mm: bad M=%lld", (long long)M);
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(y);
+  AO_REQUIRE((M + 15) / 16 <= 65535, "ao_int4_weight_int4pack_mm: M=%lld too large for one launch", (long long)M);
+  hipStream_t s = (hipStream_t)stream;
+  switch (group_size) {
+    case 32: return dispatch_mm<32>(x, qdata, scale_and_zero, y, M, N, K, s);
+    case 64: return dispatch_mm<64>(x, qdata, scale_and_zero, y, M, N, K, s);
+    case 128: return dispatch_mm<128>(x, qdata, scale_and_zero, y, M, N, K, s);
+    default: return dispatch_mm<256>(x, qdata, scale_and_zero, y, M, N, K, s);
+  }
+}
+
+extern "C" int ao_int4_dequantize(const int32_t* qdata, const uint16_t* scale_and_zero,
+                                  uint16_t* w_bf16, int64_t N, int64_t K, int group_size,
+                                  void* stream) {
+  AO_REQUIRE_PTR(qdata);
+  AO_REQUIRE_PTR(scale_and_zero);
+  AO_REQUIRE_PTR(w_bf16);
+  if (int rc = check_int4_shape(__func__, N, K, group_size)) return rc;
+  const int64_t words = N * K / 8;
+  const int threads = 256;
+  dim3 grid((unsigned)((words + threads - 1) / threads)), block(threads);
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(qdata);
+  const uint32_t* sz = reinterpret_cast<const uint32_t*>(scale_and_zero);
+  hipStream_t s = (hipStream_t)stream;
+  switch (group_size) {
+    case 32: ao::launch(int4_dequant_kernel<32>, grid, block, 0, s, q, sz, w_bf16, N, K, words); break;
+    case 64: ao::launch(int4_dequant_kernel<64>, grid, block, 0, s, q, sz, w_bf16, N, K, words); break;
+    case 128: ao::launch(int4_dequant_kernel<128>, grid, block, 0, s, q, sz, w_bf16, N, K, words); break;
+    default: ao::launch(int4_dequant_kernel<256>, grid, block, 0, s, q, sz, w_bf16, N, K, words); break;
+  }
+  AO_LAUNCH_CHECK("int4_dequant_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata, uint16_t* scale_and_zero,
+                                         int64_t N, int64_t K, int group_size, void* stream) {
+  AO_REQUIRE_PTR(w);
+  AO_REQUIRE_PTR(qdata);
+  AO_REQUIRE_PTR(scale_and_zero);
+  if (int rc = check_int4_shape(__func__, N, K, group_size)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  u32x4* q = reinterpret_cast<u32x4*>(qdata);
+  uint32_t* sz = reinterpret_cast<uint32_t*>(scale_and_zero);
+  const int64_t kb_per = group_size > 128 ? group_size / 128 : 1;
+  const int64_t spans = (N / 16) * ((K / 128) / kb_per);
+  AO_REQUIRE(spans < (1ll << 31), "ao_int4_quantize_tinygemm: tensor too large for one launch");
+  dim3 grid((unsigned)spans), block(64);
+  switch (group_size) {
+    case 32: ao::launch(int4_quantize_kernel<32>, grid, block, 0, s, w, q, sz, N, K); break;
+    case 64: ao::launch(int4_quantize_kernel<64>, grid, block, 0, s, w, q, sz, N, K); break;
+    case 128: ao::launch(int4_quantize_kernel<128>, grid, block, 0, s, w, q, sz, N, K); break;
+    default: ao::launch(int4_quantize_kernel<256>, grid, block, 0, s, w, q, sz, N, K); break;
+  }
+  AO_LAUNCH_CHECK("int4_quantize_kernel launch");
+  return AO_OK;
+}

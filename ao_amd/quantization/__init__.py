@@ -1,0 +1,11 @@
+from .config import (  # noqa: F401
+    AOBaseConfig,
+    Float8DynamicActivationFloat8WeightConfig,
+    Int4ChooseQParamsAlgorithm,
+    Int4PackingFormat,
+    Int4WeightOnlyConfig,
+    Int8DynamicActivationInt8WeightConfig,
+)
+from .granularity import PerGroup, PerRow, PerTensor  # noqa: F401
+from .int4_tensor import Int4TilePackedTo4dTensor  # noqa: F401
+from .quant_api import quantize_  # noqa: F401

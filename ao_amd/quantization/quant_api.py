@@ -1,0 +1,108 @@
+"""quantize_(model, config): swap nn.Linear weights for low-bit tensor subclasses.
+
+Mirror of torchao/quantization/quant_api.py:249-317 (quantize_),
+:120-166 (_replace_with_custom_fn_if_matches_filter, _is_linear) and
+torchao/quantization/transform_module.py:16-52 (handler registry).
+"""
+import logging
+from typing import Callable, Dict, Optional, Type
+
+import torch
+import torch.nn as nn
+
+from .config import (
+    AOBaseConfig,
+    Float8DynamicActivationFloat8WeightConfig,
+    Int4ChooseQParamsAlgorithm,
+    Int4PackingFormat,
+    Int4WeightOnlyConfig,
+    Int8DynamicActivationInt8WeightConfig,
+)
+
+logger = logging.getLogger(__name__)
+
+_QUANTIZE_CONFIG_HANDLER: Dict[Type[AOBaseConfig], Callable] = {}
+
+
+def register_quantize_module_handler(config_type):
+    def deco(fn):
+        _QUANTIZE_CONFIG_HANDLER[config_type] = fn
+        return fn
+
+    return deco
+
+
+def _is_linear(mod, *args):
+    """reference quant_api.py:166: plain nn.Linear whose weight is not yet quantized"""
+    from .base_tensor import LowBitTensorBase
+
+    return (
+        isinstance(mod, nn.Linear)
+        and hasattr(mod, "weight")
+        and not isinstance(mod.weight, LowBitTensorBase)
+    )
+
+
+def _replace_with_custom_fn_if_matches_filter(model, replacement_fn, filter_fn, cur_fqn="", device=None):
+    if filter_fn(model, cur_fqn[:-1]):
+        if device is not None:
+            model.to(device=device)
+        return replacement_fn(model)
+    for name, child in list(model.named_children()):
+        new_child = _replace_with_custom_fn_if_matches_filter(
+            child, replacement_fn, filter_fn, f"{cur_fqn}{name}.", device
+        )
+        if new_child is not child and new_child is not None:
+            setattr(model, name, new_child)
+    if device is not None:
+        model.to(device=device)
+    return model
+
+
+def quantize_(model: nn.Module, config: AOBaseConfig, filter_fn: Optional[Callable] = None, device=None):
+    """Quantize the weights of every matching nn.Linear in place.
+
+    filter_fn(module, fqn) -> bool selects modules (default: every nn.Linear).
+    Raises AssertionError for configs without a registered handler, like the
+    reference (quant_api.py:307-317)."""
+    filter_fn = _is_linear if filter_fn is None else filter_fn
+    if not isinstance(config, AOBaseConfig):
+        raise AssertionError(
+            "Passing a generic Callable to `quantize_` is no longer recommended; pass an AOBaseConfig instance"
+        )
+    handler = _QUANTIZE_CONFIG_HANDLER.get(type(config))
+    if handler is None:
+        raise AssertionError(f"unexpected config type: {type(config)}")
+    _replace_with_custom_fn_if_matches_filter(model, lambda m: handler(m, config), filter_fn, device=device)
+
+
+def _int4_weight_only_quantize_tensor(weight, config):
+    """reference quant_api.py:538-594"""
+    from .int4_tensor import Int4TilePackedTo4dTensor
+
+    group_size = config.group_size
+    if weight.shape[-1] % group_size != 0:
+        logger.info(
+            f"Skipping quantizing weight with int4 weight only quantization because the shape of weight {weight.shape} is not compatible with group_size {group_size}"
+        )
+        return weight
+    block_size = [1 for _ in range(weight.ndim - 1)] + [group_size]
+    assert config.version == 2
+    if config.int4_choose_qparams_algorithm == Int4ChooseQParamsAlgorithm.HQQ:
+        raise NotImplementedError("Int4ChooseQParamsAlgorithm.HQQ is not implemented on the MI355X path yet")
+    if config.int4_packing_format == Int4PackingFormat.TILE_PACKED_TO_4D:
+        return Int4TilePackedTo4dTensor.from_hp(weight, block_size, ntile_size=config.int4_tile_packed_ntile)
+    raise ValueError(
+        f"Unsupported int4 packing format on MI355X: {config.int4_packing_format} "
+        "(only tile_packed_to_4d is implemented; plain/preshuffled need the un-vendored mslk kernels)"
+    )
+
+
+@register_quantize_module_handler(Int4WeightOnlyConfig)
+def _int4_weight_only_transform(module, config, *, parameter_name="weight"):
+    assert hasattr(module, parameter_name), (
+        f"applying int4 weight only quant requires module to have {parameter_name} attribute but {module} does not have one"
+    )
+    new_weight = _int4_weight_only_quantize_tensor(getattr(module, parameter_name), config)
+    setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
+    return module

@@ -1,0 +1,111 @@
+/*
+ * ao_mi355.h -- C ABI of the MI355X (gfx950) low-bit linear backend.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  All
+ * pointers are DEVICE pointers (HBM) unless a name ends in `_host`; `stream` is
+ * a hipStream_t passed as void* (NULL = the default stream).  Every entry point
+ * is asynchronous with respect to the host: it validates its arguments on the
+ * host, enqueues kernels on `stream` and returns.  Inputs are borrowed and never
+ * written; outputs must be caller-allocated (the Python host layer in
+ * ao_amd/ops.py allocates them the way the reference ops allocate-and-return).
+ *
+ * Return value: AO_OK (0) or a negative AO_ERR_* code; ao_last_error() gives
+ * the thread-local human readable message (the host layer raises RuntimeError /
+ * ValueError from it, mirroring STD_TORCH_CHECK in
+ * torchao/csrc/cuda/mx_kernels/mxfp8_extension.cpp:95-134).  The library never
+ * calls exit().
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the torchao checkout, lines from the 0.19.0 snapshot).
+ * bf16 tensors are passed as uint16_t*, fp8 e4m3fn / e8m0 as uint8_t*.
+ */
+#ifndef AO_MI355_H
+#define AO_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AO_OK 0
+#define AO_ERR_INVALID_ARGUMENT (-1) /* shape / alignment / enum not supported */
+#define AO_ERR_NULL_POINTER (-2)
+#define AO_ERR_HIP (-3) /* a HIP runtime call failed; message has hipGetErrorString */
+
+#define AO_MI355_ABI_VERSION 1
+
+/* Library / ABI version and last error of the calling thread. */
+int ao_abi_version(void);
+const char* ao_last_error(void);
+
+/* Per-launch kernel timing for benchmarks: after ao_prof_enable(n) the next n
+ * kernel launches of this library are bracketed with HIP extension events that
+ * timestamp the dispatch itself (begin/end of the kernel, no launch gaps).
+ * ao_prof_collect() waits for them, writes the durations in milliseconds in
+ * launch order to a HOST array and disables profiling.  Not thread-safe; do not
+ * use during graph capture. */
+int ao_prof_enable(int max_records);
+int ao_prof_collect(float* ms_out_host, int capacity, int* n_out_host);
+
+/* ------------------------------------------------------------------------- *
+ * int4 weight-only, tinygemm "tile packed to 4d" format
+ * ------------------------------------------------------------------------- */
+
+/* Replaces aten::_convert_weight_to_int4pack(Tensor self, int innerKTiles) as
+ * called at torchao/quantization/quantize_/workflows/int4/
+ * int4_tile_packed_to_4d_tensor.py:202.
+ *   w_u8   uint8 [N][K/2], even k in the high nibble (:199-201)
+ *   qdata  int32 [N/8][K/(inner_k_tiles*16)][32][inner_k_tiles/2], gfx950 tile
+ *          order (one wavefront owns a 16(n) x 128(k) tile)
+ * Requires N % 16 == 0, K % (inner_k_tiles*16) == 0, inner_k_tiles == 8. */
+int ao_int4_convert_weight_to_int4pack(const uint8_t* w_u8, int32_t* qdata,
+                                       int64_t N, int64_t K, int inner_k_tiles,
+                                       void* stream);
+
+/* Inverse of the above (bit-exact): qdata -> uint8 [N][K/2].  Used by
+ * Int4TilePackedTo4dTensor.dequantize()/slicing tests; no reference op
+ * (the reference unpacks by multiplying with an identity matrix,
+ * torchao/quantization/utils.py:198-226). */
+int ao_int4_unpack_int4pack(const int32_t* qdata, uint8_t* w_u8, int64_t N,
+                            int64_t K, int inner_k_tiles, void* stream);
+
+/* Replaces aten::_weight_int4pack_mm(Tensor self, Tensor mat2, int qGroupSize,
+ * Tensor qScaleAndZeros) as called at int4_tile_packed_to_4d_tensor.py:287.
+ *   x               bf16 [M][K]
+ *   qdata           int32 4-D as above (N x K logical)
+ *   scale_and_zero  bf16 [K/group_size][N][2]   (torchao/quantization/utils.py:299-313)
+ *   y               bf16 [M][N]
+ * y[m][n] = sum_k x[m][k] * bf16(bf16((q[n][k]-8) * s[k/g][n]) + z[k/g][n]),
+ * fp32 accumulation (the dequant->bf16-matmul oracle, quant_primitives.py:999-1007).
+ * group_size in {32, 64, 128, 256}; N % 16 == 0; K % 128 == 0; K % group_size == 0. */
+int ao_int4_weight_int4pack_mm(const uint16_t* x, const int32_t* qdata,
+                               const uint16_t* scale_and_zero, uint16_t* y,
+                               int64_t M, int64_t N, int64_t K, int group_size,
+                               void* stream);
+
+/* Dequantize the packed weight to bf16 [N][K] with the oracle's rounding
+ * sequence.  Replaces groupwise_affine_dequantize_tensor
+ * (torchao/quantization/utils.py:445-455) for the packed format. */
+int ao_int4_dequantize(const int32_t* qdata, const uint16_t* scale_and_zero,
+                       uint16_t* w_bf16, int64_t N, int64_t K, int group_size,
+                       void* stream);
+
+/* Fused weight preparation: _choose_qparams_affine_tinygemm +
+ * _quantize_affine_tinygemm + nibble pack + _convert_weight_to_int4pack +
+ * pack_tinygemm_scales_and_zeros (int4_tile_packed_to_4d_tensor.py:129-236,
+ * quant_primitives.py:1299-1335,577-599; utils.py:299-313) in one pass.
+ *   w  bf16 [N][K] (already padded: N % 16 == 0, K % 128 == 0, K % g == 0). */
+int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
+                              uint16_t* scale_and_zero, int64_t N, int64_t K,
+                              int group_size, void* stream);
+
+/* Launch-shape override for tuning sweeps (bench/tools only): waves per
+ * workgroup (0 = heuristic) and prefetch depth (0 = default) of the int4 mm. */
+int ao_int4_set_tuning(int waves_per_block, int reserved);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AO_MI355_H */

@@ -1,0 +1,69 @@
+"""CPU: host-side mirror of the reference interface (configs, quantize_, errors)."""
+import pytest
+import torch
+
+from ao_amd import ops
+from ao_amd.quantization import (
+    Int4PackingFormat,
+    Int4TilePackedTo4dTensor,
+    Int4WeightOnlyConfig,
+    quantize_,
+)
+from ao_amd.quantization.int4_tensor import find_multiple
+
+
+def test_find_multiple():
+    assert find_multiple(4096, 1024) == 4096
+    assert find_multiple(4097, 1024) == 5120
+    assert find_multiple(1, 16) == 16
+
+
+def test_config_defaults_and_validation():
+    c = Int4WeightOnlyConfig()
+    assert c.group_size == 128 and c.int4_packing_format == Int4PackingFormat.TILE_PACKED_TO_4D
+    assert c.int4_tile_packed_ntile == 16 and c.version == 2
+    with pytest.raises(AssertionError):
+        Int4WeightOnlyConfig(int4_tile_packed_ntile=12)
+
+
+def test_quantize_rejects_non_config():
+    m = torch.nn.Linear(128, 16)
+    with pytest.raises(AssertionError):
+        quantize_(m, lambda x: x)
+
+
+def test_cant_initialize_in_cpu():
+    # reference: test_int4_tile_packed_to_4d_tensor.py:194-202
+    m = torch.nn.Sequential(torch.nn.Linear(1024, 32, bias=False)).to(torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        quantize_(m, Int4WeightOnlyConfig(group_size=128))
+
+
+def test_incompatible_group_size_is_skipped_silently():
+    # reference quant_api.py:549-553: weight left unquantized
+    m = torch.nn.Sequential(torch.nn.Linear(100, 32, bias=False)).to(torch.bfloat16)
+    quantize_(m, Int4WeightOnlyConfig(group_size=128))
+    assert type(m[0].weight.data) is torch.Tensor
+
+
+def test_from_hp_argument_checks():
+    w = torch.zeros(32, 1024, dtype=torch.float32)
+    with pytest.raises(AssertionError):
+        Int4TilePackedTo4dTensor.from_hp(w, [1, 128])  # bf16 only
+    w = w.to(torch.bfloat16)
+    with pytest.raises(AssertionError):
+        Int4TilePackedTo4dTensor.from_hp(w, [2, 128])  # per-group only
+    with pytest.raises(AssertionError):
+        Int4TilePackedTo4dTensor.from_hp(w, [128])
+
+
+def test_ops_refuse_cpu_tensors():
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.convert_weight_to_int4pack(torch.zeros(16, 64, dtype=torch.uint8), 8)
+    with pytest.raises(RuntimeError):
+        ops.weight_int4pack_mm(
+            torch.zeros(1, 128, dtype=torch.bfloat16),
+            torch.zeros(2, 1, 32, 4, dtype=torch.int32),
+            128,
+            torch.zeros(1, 16, 2, dtype=torch.bfloat16),
+        )
