@@ -70,7 +70,9 @@ struct XRegs {
   uint32_t v[kDwords];
 };
 
-template <int G, int MAXM, int DEPTH>
+// ABL: ablation builds for profiling only (0 = product kernel; 1 = loads but no
+// dequant/MFMA; 2 = dequant/MFMA but no weight loads)
+template <int G, int MAXM, int DEPTH, int ABL = 0>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
     const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K) {
@@ -125,7 +127,11 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   // straight-line code and the compiler can use counted s_waitcnt vmcnt(N).
   const int last_row = rows - 1;
   auto issue = [&](Stage& s, int kb) {
-    s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
+    if (ABL == 2) {
+      s.w = u32x4{(uint32_t)lane * 0x01010101u, (uint32_t)kb, 0x12345678u, (uint32_t)lane};
+    } else {
+      s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
+    }
     const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
 #pragma unroll
     for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
@@ -149,6 +155,10 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 
   auto consume = [&](const Stage& s) {
+    if (ABL == 1) {
+      acc.x += bits_to_f32((s.w.x ^ s.w.y ^ s.w.z ^ s.w.w ^ s.sz[0] ^ s.xr.v[0]) & 0x3f800000u);
+      return;
+    }
     // stage x (wave-private: DS ops of one wave execute in order, no barrier)
     if (MAXM <= 4) {
 #pragma unroll
@@ -388,6 +398,7 @@ __global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __res
 }
 
 int g_tune_wpb = 0;
+int g_tune_mode = 0;  // profiling only: 1/2 = ablations, 12/18 = prefetch depth 2/8 (G=128, M=1)
 
 template <int G, int MAXM>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
@@ -408,6 +419,19 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
   const size_t smem = (size_t)wpb * (SLAB + 1024);
   dim3 grid((unsigned)ntiles, (unsigned)mslabs), block(wpb * 64);
+  if (G == 128 && MAXM == 1 && g_tune_mode != 0) {
+    const u32x4* q4 = reinterpret_cast<const u32x4*>(qdata);
+    const uint32_t* sz4 = reinterpret_cast<const uint32_t*>(sz);
+    switch (g_tune_mode) {
+      case 1: ao::launch((int4_mm_kernel<128, 1, 4, 1>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 2: ao::launch((int4_mm_kernel<128, 1, 4, 2>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 12: ao::launch((int4_mm_kernel<128, 1, 2, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 18: ao::launch((int4_mm_kernel<128, 1, 8, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      default: ao::set_error("bad tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
+    }
+    AO_LAUNCH_CHECK("int4_mm_kernel (tuning variant) launch");
+    return AO_OK;
+  }
   ao::launch((int4_mm_kernel<G, MAXM, DEPTH>), grid, block, smem, stream, x,
                      reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
                      (int)M, (int)N, (int)K);
@@ -441,8 +465,9 @@ int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
 
 using namespace ao;
 
-extern "C" int ao_int4_set_tuning(int waves_per_block, int /*reserved*/) {
+extern "C" int ao_int4_set_tuning(int waves_per_block, int mode) {
   g_tune_wpb = waves_per_block;
+  g_tune_mode = mode;
   return AO_OK;
 }
 

@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wpb", type=int, default=0, help="tuning: waves per workgroup override")
+    ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
     return ap.parse_args()
 
 
@@ -171,8 +172,8 @@ def main():
 
     from ao_amd import _lib
 
-    if args.wpb:
-        _lib.lib().ao_int4_set_tuning(args.wpb, 0)
+    if args.wpb or args.mode:
+        _lib.lib().ao_int4_set_tuning(args.wpb, args.mode)
 
     model = Int4Linears(device, args.batch, args.layers)
     stream = torch.cuda.Stream(device=device)

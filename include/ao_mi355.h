@@ -102,8 +102,9 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
                               int group_size, void* stream);
 
 /* Launch-shape override for tuning sweeps (bench/tools only): waves per
- * workgroup (0 = heuristic) and prefetch depth (0 = default) of the int4 mm. */
-int ao_int4_set_tuning(int waves_per_block, int reserved);
+ * workgroup (0 = heuristic) and a profiling mode (0 = product kernel; 1/2 =
+ * ablation builds, 12/18 = prefetch depth 2/8) of the int4 mm. */
+int ao_int4_set_tuning(int waves_per_block, int mode);
 
 #ifdef __cplusplus
 }

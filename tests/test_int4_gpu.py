@@ -181,7 +181,8 @@ def test_quantize_linear_sqnr(shape, out_features, bias):
     assert sqnr > 20, sqnr  # reference bar: test_int4_tile_packed_to_4d_tensor.py:65
     # and against the dequant oracle path through the same weight
     wdq = lin.weight.dequantize()
-    y2 = torch.nn.functional.linear(x, wdq, lin.bias)
+    y2 = torch.nn.functional.linear(x, wdq, lin.bias).detach()
+    y = y.detach()
     assert _rel(y.float().cpu().numpy(), y2.float().cpu().numpy()) <= 2e-3
 
 
