@@ -1,0 +1,257 @@
+// Tiled MFMA GEMM for 1-byte operands on gfx950: y = epilogue(A[M,K] @ B[N,K]^T)
+//   * int8 x int8 -> int32  (aten::_int_mm / the Int8Tensor linear:
+//     torchao/quantization/quantize_/workflows/int8/kernels.py:114-144,
+//     int8_tensor.py:305-359) on v_mfma_i32_32x32x32_i8
+//   * e4m3 x e4m3 -> fp32   (aten::_scaled_mm rowwise, torchao/float8/inference.py:
+//     86-123) on v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (the
+//     K=64 form is the only full-rate fp8 path on CDNA4)
+// Both operands are K-contiguous ("NT"), so A and B tiles are staged the same
+// way: 128 x 128-byte tiles, 16 B per thread per pass, through padded LDS rows
+// (144 B stride: ds_read_b128 conflict-free), double buffered, one barrier per
+// K step.  4 waves as 2x2, each 64x64 = 2x2 MFMA tiles of 32x32.
+// The epilogue applies the reference's scaling sequence in registers and stores
+// bf16 (or raw int32 for _int_mm).
+#include "common.h"
+
+namespace ao {
+
+int fp8_rowwise_stream(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b,
+                       const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K, hipStream_t stream);
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, BK = 128;  // BK in bytes == elements
+constexpr int LDS_STRIDE = BK + 16;          // 144 B
+constexpr int TILE_BYTES = BM * LDS_STRIDE;  // one operand tile
+constexpr int THREADS = 256;
+
+enum Epilogue { EPI_INT8_SCALED = 0, EPI_INT32 = 1, EPI_FP8_ROWWISE = 2 };
+
+struct Gemm8Args {
+  const uint8_t* a;  // [M][K]
+  const uint8_t* b;  // [N][K]
+  const float* row_scale;  // [M]
+  const float* col_scale;  // [N]
+  const uint16_t* bias;    // [N] bf16 or null
+  void* out;               // bf16 [M][N] or int32 [M][N]
+  int M, N, K;
+};
+
+template <int EPI>
+struct Acc {
+  using type = f32x16;
+};
+template <>
+struct Acc<EPI_INT8_SCALED> {
+  using type = i32x16;
+};
+template <>
+struct Acc<EPI_INT32> {
+  using type = i32x16;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(THREADS) void gemm8_kernel(Gemm8Args p) {
+  constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE);
+  using acc_t = typename Acc<EPI>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][A tile | B tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // global -> register staging: 4 passes x 16 B per operand per thread
+  // chunk c = pass * 256 + tid: row = c >> 3 (8 chunks per 128-B row), col16 = c & 7
+  const int srow = tid >> 3, scol = (tid & 7) * 16;
+  const uint8_t* ag[4];
+  const uint8_t* bg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = srow + i * 32;
+    ag[i] = p.a + (size_t)min(m0 + r, p.M - 1) * p.K + scol;
+    bg[i] = p.b + (size_t)min(n0 + r, p.N - 1) * p.K + scol;
+  }
+  const int ktiles = (p.K + BK - 1) / BK;
+
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int k = kt * BK + scol;
+    const bool in = (k + 16 <= p.K);  // K % 16 == 0: a chunk is entirely in or out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = in ? *reinterpret_cast<const u32x4*>(ag[i] + (size_t)kt * BK) : u32x4{0, 0, 0, 0};
+      rb[i] = in ? *reinterpret_cast<const u32x4*>(bg[i] + (size_t)kt * BK) : u32x4{0, 0, 0, 0};
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * 2 * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = (srow + i * 32) * LDS_STRIDE + scol;
+      *reinterpret_cast<u32x4*>(base + off) = ra[i];
+      *reinterpret_cast<u32x4*>(base + TILE_BYTES + off) = rb[i];
+    }
+  };
+
+  acc_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+  // fragment addressing: row = lane & 31 of the 32-row tile, 32 bytes at (lane >> 5) * 32 of each 64-byte chunk
+  const int frow = lane & 31, fk = (lane >> 5) * 32;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ktiles) gload(kt + 1);
+    const char* abase = smem + buf * 2 * TILE_BYTES + (wm * 64 + frow) * LDS_STRIDE + fk;
+    const char* bbase = smem + buf * 2 * TILE_BYTES + TILE_BYTES + (wn * 64 + frow) * LDS_STRIDE + fk;
+#pragma unroll
+    for (int kc = 0; kc < BK / 64; ++kc) {
+      u32x4 af[2][2], bf[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i][0] = *reinterpret_cast<const u32x4*>(abase + i * 32 * LDS_STRIDE + kc * 64);
+        af[i][1] = *reinterpret_cast<const u32x4*>(abase + i * 32 * LDS_STRIDE + kc * 64 + 16);
+        bf[i][0] = *reinterpret_cast<const u32x4*>(bbase + i * 32 * LDS_STRIDE + kc * 64);
+        bf[i][1] = *reinterpret_cast<const u32x4*>(bbase + i * 32 * LDS_STRIDE + kc * 64 + 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (IS_INT) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const i32x4 av = {(int)af[i][h].x, (int)af[i][h].y, (int)af[i][h].z, (int)af[i][h].w};
+              const i32x4 bv = {(int)bf[j][h].x, (int)bf[j][h].y, (int)bf[j][h].z, (int)bf[j][h].w};
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[i][j], 0, 0, 0);
+            }
+          } else {
+            const i32x8 av = {(int)af[i][0].x, (int)af[i][0].y, (int)af[i][0].z, (int)af[i][0].w,
+                              (int)af[i][1].x, (int)af[i][1].y, (int)af[i][1].z, (int)af[i][1].w};
+            const i32x8 bv = {(int)bf[j][0].x, (int)bf[j][0].y, (int)bf[j][0].z, (int)bf[j][0].w,
+                              (int)bf[j][1].x, (int)bf[j][1].y, (int)bf[j][1].z, (int)bf[j][1].w};
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 0, 0, 0, 127, 0, 127);
+          }
+        }
+    }
+    if (kt + 1 < ktiles) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (gn >= p.N) continue;
+      float cs = 1.f, bias = 0.f;
+      if (EPI != EPI_INT32) {
+        cs = p.col_scale[gn];
+        if (p.bias != nullptr) bias = bf16_lo_to_f32(p.bias[gn]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm >= p.M) continue;
+        if (EPI == EPI_INT32) {
+          reinterpret_cast<int32_t*>(p.out)[(size_t)gm * p.N + gn] = (int32_t)acc[i][j][r];
+        } else if (EPI == EPI_INT8_SCALED) {
+          // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+          const float t = round_bf16((float)acc[i][j][r] * p.row_scale[gm]);
+          float y = t * cs;
+          if (p.bias != nullptr) y += bias;
+          reinterpret_cast<uint16_t*>(p.out)[(size_t)gm * p.N + gn] = f32_to_bf16_bits(y);
+        } else {
+          float y = (float)acc[i][j][r] * p.row_scale[gm] * cs;
+          if (p.bias != nullptr) y += bias;
+          reinterpret_cast<uint16_t*>(p.out)[(size_t)gm * p.N + gn] = f32_to_bf16_bits(y);
+        }
+      }
+    }
+}
+
+template <int EPI>
+int launch_gemm8(const Gemm8Args& p, hipStream_t stream) {
+  dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM)), block(THREADS);
+  const size_t smem = 2 * 2 * TILE_BYTES;  // 73,728 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(gemm8_kernel)");
+    attr_set = true;
+  }
+  ao::launch(gemm8_kernel<EPI>, grid, block, smem, stream, p);
+  AO_LAUNCH_CHECK("gemm8_kernel launch");
+  return AO_OK;
+}
+
+int check_gemm_shape(const char* fn, int64_t M, int64_t N, int64_t K) {
+  AO_REQUIRE(M >= 0 && N > 0 && K > 0, "%s: bad shape M=%lld N=%lld K=%lld", fn, (long long)M, (long long)N, (long long)K);
+  AO_REQUIRE(K % 16 == 0, "%s: K=%lld must be a multiple of 16", fn, (long long)K);
+  AO_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "%s: dimension too large", fn);
+  AO_REQUIRE((M + BM - 1) / BM <= 65535, "%s: M=%lld too large for one launch", fn, (long long)M);
+  return AO_OK;
+}
+
+}  // namespace
+}  // namespace ao
+
+using namespace ao;
+
+extern "C" int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const int8_t* wq, const float* w_scale,
+                                 const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (int rc = check_gemm_shape(__func__, M, N, K)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(xq);
+  AO_REQUIRE_PTR(x_scale);
+  AO_REQUIRE_PTR(wq);
+  AO_REQUIRE_PTR(w_scale);
+  AO_REQUIRE_PTR(y);
+  Gemm8Args p{reinterpret_cast<const uint8_t*>(xq), reinterpret_cast<const uint8_t*>(wq), x_scale, w_scale, bias, y,
+              (int)M, (int)N, (int)K};
+  return launch_gemm8<EPI_INT8_SCALED>(p, (hipStream_t)stream);
+}
+
+extern "C" int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, int64_t M, int64_t N, int64_t K,
+                              void* stream) {
+  if (int rc = check_gemm_shape(__func__, M, N, K)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(a);
+  AO_REQUIRE_PTR(b_t);
+  AO_REQUIRE_PTR(c);
+  Gemm8Args p{reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b_t), nullptr, nullptr, nullptr, c,
+              (int)M, (int)N, (int)K};
+  return launch_gemm8<EPI_INT32>(p, (hipStream_t)stream);
+}
+
+extern "C" int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b,
+                                const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (int rc = check_gemm_shape(__func__, M, N, K)) return rc;
+  AO_REQUIRE(N % 16 == 0, "ao_fp8_scaled_mm: N=%lld must be a multiple of 16", (long long)N);
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(a);
+  AO_REQUIRE_PTR(b);
+  AO_REQUIRE_PTR(scale_a);
+  AO_REQUIRE_PTR(scale_b);
+  AO_REQUIRE_PTR(y);
+  // decode-size batches are weight-bandwidth bound: stream the weights (stream8_kernels.hip)
+  if (M <= 64 && K % 128 == 0)
+    return fp8_rowwise_stream(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
+  Gemm8Args p{a, b, scale_a, scale_b, bias, y, (int)M, (int)N, (int)K};
+  return launch_gemm8<EPI_FP8_ROWWISE>(p, (hipStream_t)stream);
+}

@@ -52,6 +52,99 @@ __device__ __forceinline__ void dequant_word(uint32_t p, float s, float neg8s, f
 }
 
 // ---------------------------------------------------------------------------
+// MFMA-assisted variants of the same exact sequence.  The VALU issue rates
+// measured on gfx950 (profiles/ubench_valu_r01.txt: ~4.4 cycles for cvt/shift/
+// VOP3, ~2.2 per value for packed-fp32 and plain VOP2) make the all-VALU replay
+// ~18 cycles per weight; the matrix pipe is idle in a GEMV, so the steps that
+// are pure data movement + one IEEE add are moved onto it with an identity
+// A-operand:   D = I * B + C   returns each lane's own four bf16 values widened
+// to fp32 plus C (one product per output, so the fp32 result is the correctly
+// rounded b + c):
+//   #1  B = bf16(128 + q) built with one v_perm per pair, C = -136  ->  q - 8
+//   #2  B = t = bf16((q-8)*s),                          C = z      ->  fl32(t + z)
+// DQ: 0 = all VALU, 1 = #2 on a 16x16x16 MFMA, 2 = #1 and #2 on 4x4x4 MFMAs,
+//     3 = #1 and #2 on 16x16x16 MFMAs.
+// ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int DQ>
+__device__ __forceinline__ s16x4 identity_fragment(int lane) {
+  // row `i` of the identity held by this lane as an A operand (4 bf16, k' = base..base+3)
+  int hot;  // which of the 4 elements is 1.0 (or -1 for none)
+  if (DQ == 2 || DQ == 4) {
+    hot = lane & 3;  // 4x4x4: lane holds row (lane & 3), k = 0..3
+  } else {
+    const int i = lane & 15, base = (lane >> 4) * 4;  // 16x16x16: k' = base..base+3
+    hot = (i >= base && i < base + 4) ? (i - base) : -1;
+  }
+  s16x4 f;
+  f.x = hot == 0 ? (short)0x3F80 : (short)0;
+  f.y = hot == 1 ? (short)0x3F80 : (short)0;
+  f.z = hot == 2 ? (short)0x3F80 : (short)0;
+  f.w = hot == 3 ? (short)0x3F80 : (short)0;
+  return f;
+}
+
+template <int DQ>
+__device__ __forceinline__ f32x4 widen_add(s16x4 ident, uint32_t lo_pair, uint32_t hi_pair, f32x4 c) {
+  const u32x2 bb = {lo_pair, hi_pair};
+  const s16x4 b = __builtin_bit_cast(s16x4, bb);
+  if (DQ == 2 || DQ == 4) return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ident, b, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ident, b, c, 0, 0, 0);
+}
+
+template <int DQ>
+__device__ __forceinline__ void dequant_word_mfma(uint32_t p, float s, float neg8s, float z, s16x4 ident,
+                                                  uint32_t (&out)[4]) {
+  uint32_t lo = p & 0x0F0F0F0Fu;         // bytes: v0, v4, v1, v5
+  uint32_t hi = (p >> 4) & 0x0F0F0F0Fu;  // bytes: v2, v6, v3, v7
+  uint32_t tp[4];                        // t = bf16((q-8)*s) as packed pairs 01,23,45,67
+  if (DQ == 4) {
+    // a byte holding q (0..15) read as OCP e4m3 is q * 2^-9 (subnormal spacing ==
+    // first-binade spacing), so v_cvt_scalef32_pk_f32_fp8 with scale 2^9 converts
+    // two nibbles per instruction, exactly.
+    const f32x2 r0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, false);  // q0, q4
+    const f32x2 r1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, true);   // q1, q5
+    const f32x2 r2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, false);  // q2, q6
+    const f32x2 r3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, true);   // q3, q7
+    const f32x2 t0 = r0 * s + neg8s, t1 = r1 * s + neg8s, t2 = r2 * s + neg8s, t3 = r3 * s + neg8s;
+    tp[0] = pack_bf16x2(t0.x, t1.x); tp[1] = pack_bf16x2(t2.x, t3.x);
+    tp[2] = pack_bf16x2(t0.y, t1.y); tp[3] = pack_bf16x2(t2.y, t3.y);
+  } else if (DQ >= 2) {
+    const uint32_t k43 = 0x43434343u;    // bf16 0x43xx = 128 + xx
+    const uint32_t q01 = __builtin_amdgcn_perm(k43, lo, 0x04020400u);
+    const uint32_t q45 = __builtin_amdgcn_perm(k43, lo, 0x04030401u);
+    const uint32_t q23 = __builtin_amdgcn_perm(k43, hi, 0x04020400u);
+    const uint32_t q67 = __builtin_amdgcn_perm(k43, hi, 0x04030401u);
+    const f32x4 m136 = {-136.f, -136.f, -136.f, -136.f};
+    const f32x4 u0 = widen_add<DQ>(ident, q01, q23, m136);  // q0..q3 - 8, exact
+    const f32x4 u1 = widen_add<DQ>(ident, q45, q67, m136);  // q4..q7 - 8
+    const f32x2 a = f32x2{u0.x, u0.y} * s, b = f32x2{u0.z, u0.w} * s;
+    const f32x2 c = f32x2{u1.x, u1.y} * s, d = f32x2{u1.z, u1.w} * s;
+    tp[0] = pack_bf16x2(a.x, a.y); tp[1] = pack_bf16x2(b.x, b.y);
+    tp[2] = pack_bf16x2(c.x, c.y); tp[3] = pack_bf16x2(d.x, d.y);
+  } else {
+    asm("" : "+v"(lo));
+    asm("" : "+v"(hi));
+    const float f0 = (float)(lo & 0xffu), f4 = (float)((lo >> 8) & 0xffu);
+    const float f1 = (float)((lo >> 16) & 0xffu), f5 = (float)(lo >> 24);
+    const float f2 = (float)(hi & 0xffu), f6 = (float)((hi >> 8) & 0xffu);
+    const float f3 = (float)((hi >> 16) & 0xffu), f7 = (float)(hi >> 24);
+    const f32x2 q[4] = {{f0, f1}, {f2, f3}, {f4, f5}, {f6, f7}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 t = q[i] * s + neg8s;
+      tp[i] = pack_bf16x2(t.x, t.y);
+    }
+  }
+  const f32x4 zz = {z, z, z, z};
+  const f32x4 w0 = widen_add<DQ>(ident, tp[0], tp[1], zz);  // fl32(t + z), lanes' own values
+  const f32x4 w1 = widen_add<DQ>(ident, tp[2], tp[3], zz);
+  out[0] = pack_bf16x2(w0.x, w0.y); out[1] = pack_bf16x2(w0.z, w0.w);
+  out[2] = pack_bf16x2(w1.x, w1.y); out[3] = pack_bf16x2(w1.z, w1.w);
+}
+
+// ---------------------------------------------------------------------------
 // y[M,N] = x[M,K] @ dequant(qdata)^T     (aten::_weight_int4pack_mm)
 //
 // grid = (N/16, ceil(M/16)); block = WPB waves.  A workgroup owns one 16-wide
@@ -72,7 +165,7 @@ struct XRegs {
 
 // ABL: ablation builds for profiling only (0 = product kernel; 1 = loads but no
 // dequant/MFMA; 2 = dequant/MFMA but no weight loads)
-template <int G, int MAXM, int DEPTH, int ABL = 0>
+template <int G, int MAXM, int DEPTH, int ABL = 0, int DQ = 4>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
     const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K) {
@@ -153,6 +246,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   };
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const s16x4 ident = identity_fragment<DQ>(lane);
 
   auto consume = [&](const Stage& s) {
     if (ABL == 1) {
@@ -184,7 +278,8 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
       const float sc = bf16_lo_to_f32(s.sz[gi]);
       const float zp = bf16_hi_to_f32(s.sz[gi]);
       uint32_t b[4];
-      dequant_word(wds[j], sc, -8.0f * sc, zp, b);
+      if (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
+      else dequant_word_mfma<DQ>(wds[j], sc, -8.0f * sc, zp, ident, b);
       const u32x4 bv = {b[0], b[1], b[2], b[3]};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
                                                     __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
@@ -398,7 +493,7 @@ __global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __res
 }
 
 int g_tune_wpb = 0;
-int g_tune_mode = 0;  // profiling only: 1/2 = ablations, 12/18 = prefetch depth 2/8 (G=128, M=1)
+int g_tune_mode = 0;  // profiling only: 1/2 = ablations, 12/18 = prefetch depth 2/8, 21/22/23 = dequant variant DQ (G=128, M=1)
 
 template <int G, int MAXM>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
@@ -423,10 +518,17 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
     const u32x4* q4 = reinterpret_cast<const u32x4*>(qdata);
     const uint32_t* sz4 = reinterpret_cast<const uint32_t*>(sz);
     switch (g_tune_mode) {
-      case 1: ao::launch((int4_mm_kernel<128, 1, 4, 1>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 2: ao::launch((int4_mm_kernel<128, 1, 4, 2>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 1: ao::launch((int4_mm_kernel<128, 1, 4, 1, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 2: ao::launch((int4_mm_kernel<128, 1, 4, 2, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
       case 12: ao::launch((int4_mm_kernel<128, 1, 2, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
       case 18: ao::launch((int4_mm_kernel<128, 1, 8, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 20: ao::launch((int4_mm_kernel<128, 1, 4, 0, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 21: ao::launch((int4_mm_kernel<128, 1, 4, 0, 1>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 22: ao::launch((int4_mm_kernel<128, 1, 4, 0, 2>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 24: ao::launch((int4_mm_kernel<128, 1, 4, 0, 4>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 34: ao::launch((int4_mm_kernel<128, 1, 4, 2, 4>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 32: ao::launch((int4_mm_kernel<128, 1, 4, 2, 2>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
+      case 23: ao::launch((int4_mm_kernel<128, 1, 4, 0, 3>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
       default: ao::set_error("bad tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
     }
     AO_LAUNCH_CHECK("int4_mm_kernel (tuning variant) launch");

@@ -15,6 +15,13 @@ __all__ = [
     "weight_int4pack_mm",
     "int4_dequantize",
     "int4_quantize_tinygemm",
+    "int8_quantize_rowwise",
+    "int8_scaled_mm",
+    "int_mm",
+    "fp8_quantize_rowwise",
+    "fp8_scaled_mm",
+    "mxfp8_quantize",
+    "mxfp8_grouped_mm",
 ]
 
 
@@ -171,3 +178,193 @@ def int4_quantize_tinygemm(w: torch.Tensor, group_size: int):
             _lib.lib().ao_int4_quantize_tinygemm(_ptr(w), _ptr(qdata), _ptr(sz), n, k, group_size, _stream())
         )
     return qdata, sz
+
+
+# ---------------------------------------------------------------------------
+# int8 dynamic activation x int8 weight
+# ---------------------------------------------------------------------------
+def _as_rows(name, x, dtype):
+    if x.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {x.dtype}")
+    if x.dim() != 2:
+        raise RuntimeError(f"{name}: expected a 2-D tensor, got {x.dim()}-D")
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def int8_quantize_rowwise(x: torch.Tensor):
+    """Int8Tensor.from_hp(x, PerRow()) (symmetric, eps = fp32 eps):
+    torchao/quantization/quantize_/workflows/int8/int8_tensor.py:176-248.
+    x bf16 [M, K] -> (qdata int8 [M, K], scale fp32 [M, 1])."""
+    dev = _require_gpu("int8_quantize_rowwise", x)
+    x = _as_rows("int8_quantize_rowwise", x, torch.bfloat16)
+    m, k = x.shape
+    q = torch.empty((m, k), dtype=torch.int8, device=dev)
+    s = torch.empty((m, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ao_int8_quantize_rowwise(_ptr(x), _ptr(q), _ptr(s), m, k, _stream()))
+    return q, s
+
+
+def int8_scaled_mm(xq, x_scale, wq, w_scale, bias=None):
+    """_int_scaled_matmul + weight-scale epilogue of the Int8Tensor linear
+    (int8/kernels.py:114-144, int8_tensor.py:305-359).
+    xq int8 [M, K]; x_scale fp32 [M(,1)]; wq int8 [N, K]; w_scale fp32 [N(,1)];
+    bias bf16 [N] or None -> bf16 [M, N]."""
+    dev = _require_gpu("int8_scaled_mm", xq, x_scale, wq, w_scale, bias)
+    xq = _as_rows("int8_scaled_mm", xq, torch.int8)
+    wq = _as_rows("int8_scaled_mm", wq, torch.int8)
+    m, k = xq.shape
+    n, k2 = wq.shape
+    if k != k2:
+        raise RuntimeError(f"int8_scaled_mm: K mismatch {k} vs {k2}")
+    x_scale = x_scale.reshape(-1).to(torch.float32).contiguous()
+    w_scale = w_scale.reshape(-1).to(torch.float32).contiguous()
+    if x_scale.numel() != m or w_scale.numel() != n:
+        raise RuntimeError("int8_scaled_mm: scales must be per-row ([M] and [N])")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+        if bias.numel() != n:
+            raise RuntimeError("int8_scaled_mm: bias must have N elements")
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            _lib.lib().ao_int8_scaled_mm(
+                _ptr(xq), _ptr(x_scale), _ptr(wq), _ptr(w_scale), _ptr(bias), _ptr(y), m, n, k, _stream()
+            )
+        )
+    return y
+
+
+def int_mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """aten::_int_mm(self int8 [M, K], mat2 int8 [K, N]) -> int32 [M, N]
+    (call sites: int8/kernels.py:38-40,70).  mat2 is expected K-major (the
+    `.t()` of a row-major [N, K] weight, as the reference passes it); other
+    layouts are made so with one copy."""
+    dev = _require_gpu("int_mm", a, b)
+    a = _as_rows("int_mm", a, torch.int8)
+    if b.dtype != torch.int8 or b.dim() != 2:
+        raise RuntimeError("int_mm: mat2 must be a 2-D int8 tensor")
+    if a.shape[1] != b.shape[0]:
+        raise RuntimeError(f"int_mm: shapes {tuple(a.shape)} and {tuple(b.shape)} cannot be multiplied")
+    b_t = b.t()
+    if not b_t.is_contiguous():
+        b_t = b_t.contiguous()
+    m, k = a.shape
+    n = b_t.shape[0]
+    c = torch.empty((m, n), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ao_int8_int_mm(_ptr(a), _ptr(b_t), _ptr(c), m, n, k, _stream()))
+    return c
+
+
+# ---------------------------------------------------------------------------
+# float8 e4m3fn rowwise
+# ---------------------------------------------------------------------------
+def fp8_quantize_rowwise(x: torch.Tensor):
+    """Float8Tensor.from_hp(x, float8_e4m3fn, PerRow())
+    (quantize_/workflows/float8/float8_tensor.py:167-253).
+    x bf16 [M, K] -> (qdata float8_e4m3fn [M, K], scale fp32 [M, 1])."""
+    dev = _require_gpu("fp8_quantize_rowwise", x)
+    x = _as_rows("fp8_quantize_rowwise", x, torch.bfloat16)
+    m, k = x.shape
+    q = torch.empty((m, k), dtype=torch.uint8, device=dev)
+    s = torch.empty((m, 1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ao_fp8_quantize_rowwise(_ptr(x), _ptr(q), _ptr(s), m, k, _stream()))
+    return q.view(torch.float8_e4m3fn), s
+
+
+def _fp8_bytes(name, t):
+    if t.dtype == torch.float8_e4m3fn:
+        t = t.view(torch.uint8)
+    elif t.dtype != torch.uint8:
+        raise RuntimeError(f"{name}: expected float8_e4m3fn data, got {t.dtype}")
+    return t
+
+
+def fp8_scaled_mm(a, b, scale_a, scale_b, bias=None):
+    """aten::_scaled_mm with rowwise scales (torchao/float8/inference.py:104-123),
+    out_dtype bf16.  a e4m3 [M, K] row-major; b e4m3 [K, N] column-major (i.e. the
+    `.t()` of a row-major [N, K] weight); scale_a fp32 [M, 1]; scale_b fp32 [1, N]."""
+    dev = _require_gpu("fp8_scaled_mm", a, b, scale_a, scale_b, bias)
+    a = _fp8_bytes("fp8_scaled_mm", a)
+    b = _fp8_bytes("fp8_scaled_mm", b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0]:
+        raise RuntimeError(f"fp8_scaled_mm: shapes {tuple(a.shape)} and {tuple(b.shape)} cannot be multiplied")
+    if not a.is_contiguous():
+        a = a.contiguous()
+    b_t = b.t()
+    if not b_t.is_contiguous():
+        b_t = b_t.contiguous()
+    m, k = a.shape
+    n = b_t.shape[0]
+    scale_a = scale_a.reshape(-1).to(torch.float32).contiguous()
+    scale_b = scale_b.reshape(-1).to(torch.float32).contiguous()
+    if scale_a.numel() != m or scale_b.numel() != n:
+        raise RuntimeError("fp8_scaled_mm: only rowwise scaling is implemented (scale_a [M,1], scale_b [1,N])")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            _lib.lib().ao_fp8_scaled_mm(
+                _ptr(a), _ptr(b_t), _ptr(scale_a), _ptr(scale_b), _ptr(bias), _ptr(y), m, n, k, _stream()
+            )
+        )
+    return y
+
+
+# ---------------------------------------------------------------------------
+# MXFP8
+# ---------------------------------------------------------------------------
+MX_SCALE_MODES = {"floor": 0, "rceil": 1}
+
+
+def mxfp8_quantize(x: torch.Tensor, scaling_mode: str = "rceil"):
+    """Rowwise (1x32) MXFP8 cast: torchao::mxfp8_quantize(rowwise=True) /
+    to_mx(x, float8_e4m3fn, 32, mode) (prototype/mx_formats/mx_tensor.py:228-409).
+    x bf16 [..., C] -> (data float8_e4m3fn [..., C], scale float8_e8m0fnu [..., C/32])."""
+    dev = _require_gpu("mxfp8_quantize", x)
+    if x.dtype != torch.bfloat16:
+        raise RuntimeError(f"mxfp8_quantize: expected bfloat16, got {x.dtype}")
+    if not x.is_contiguous():
+        raise RuntimeError("mxfp8_quantize: expected a contiguous tensor")  # to_mx asserts the same
+    mode = MX_SCALE_MODES.get(str(getattr(scaling_mode, "value", scaling_mode)).lower())
+    if mode is None:
+        raise RuntimeError(f"mxfp8_quantize: unsupported scaling mode {scaling_mode!r} (floor | rceil)")
+    c = x.shape[-1]
+    if c % 32 != 0:
+        raise RuntimeError(f"mxfp8_quantize: the last dimension of shape {tuple(x.shape)} must be divisible by 32")
+    r = x.numel() // c
+    q = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    s = torch.empty((*x.shape[:-1], c // 32), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ao_mxfp8_quantize_rowwise(_ptr(x), _ptr(q), _ptr(s), r, c, mode, _stream()))
+    return q.view(torch.float8_e4m3fn), s.view(torch.float8_e8m0fnu)
+
+
+def mxfp8_grouped_mm(a, a_scale, b, b_scale, offs):
+    """aten::_scaled_grouped_mm for MXFP8 (mxfp8_grouped_mm.py:541), numerics of the
+    emulated path (:959-1023).  a e4m3 [M, K]; a_scale e8m0 [M, K/32]; b e4m3
+    [E, N, K]; b_scale e8m0 [E, N, K/32]; offs int32 [E] -> bf16 [M, N]."""
+    dev = _require_gpu("mxfp8_grouped_mm", a, a_scale, b, b_scale, offs)
+    a = _fp8_bytes("mxfp8_grouped_mm", a).contiguous()
+    b = _fp8_bytes("mxfp8_grouped_mm", b).contiguous()
+    a_scale = a_scale.view(torch.uint8).contiguous()
+    b_scale = b_scale.view(torch.uint8).contiguous()
+    if a.dim() != 2 or b.dim() != 3 or a.shape[1] != b.shape[2]:
+        raise RuntimeError(f"mxfp8_grouped_mm: A must be [M, K] and B [E, N, K], got {tuple(a.shape)} {tuple(b.shape)}")
+    m, k = a.shape
+    e, n, _ = b.shape
+    if tuple(a_scale.shape) != (m, k // 32) or tuple(b_scale.shape) != (e, n, k // 32):
+        raise RuntimeError("mxfp8_grouped_mm: scales must be [M, K/32] and [E, N, K/32]")
+    if offs.dtype != torch.int32 or offs.numel() != e:
+        raise RuntimeError("mxfp8_grouped_mm: offs must be int32 [E]")
+    out = torch.zeros((m, n), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            _lib.lib().ao_mxfp8_grouped_mm(
+                _ptr(a), _ptr(a_scale), _ptr(b), _ptr(b_scale), _ptr(offs.contiguous()), _ptr(out), m, n, k, e, _stream()
+            )
+        )
+    return out

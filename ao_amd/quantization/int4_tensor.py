@@ -150,7 +150,12 @@ def _(func, types, args, kwargs):
             f"K slices must align to {unit} columns"
         )
         kend = find_multiple(end, unit)
-        qdata = self.qdata[:, start // 128 : kend // 128].contiguous()
+        # the 4-D shape [N/8, K/128, 32, 4] is nominal on ROCm: memory is
+        # [N/16][K/128][64][4] (one wavefront tile per 16 rows x 128 k), so a K
+        # slice has to be taken in that view and re-labelled afterwards
+        n16, kb = self.qdata.shape[0] // 2, self.qdata.shape[1]
+        q = self.qdata.reshape(n16, kb, 64, 4)[:, start // 128 : kend // 128].contiguous()
+        qdata = q.reshape(n16 * 2, q.shape[1], 32, 4)
         sz = self.scale_and_zero[start // g : kend // g].contiguous()
     new_shape = list(self.shape)
     new_shape[dim] = end - start

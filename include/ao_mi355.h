@@ -106,6 +106,82 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
  * ablation builds, 12/18 = prefetch depth 2/8) of the int4 mm. */
 int ao_int4_set_tuning(int waves_per_block, int mode);
 
+/* ------------------------------------------------------------------------- *
+ * int8 dynamic activation x int8 weight
+ * ------------------------------------------------------------------------- */
+
+/* Per-row symmetric int8 quantization of a bf16 matrix: replaces
+ * Int8Tensor.from_hp(x, PerRow) = choose_qparams_affine(SYMMETRIC, eps=fp32 eps)
+ * + quantize_affine (torchao/quantization/quantize_/workflows/int8/
+ * int8_tensor.py:176-248; quant_primitives.py:1534-1583,463-485).
+ *   x bf16 [M][K] -> q int8 [M][K], scale fp32 [M] */
+int ao_int8_quantize_rowwise(const uint16_t* x, int8_t* q, float* scale,
+                             int64_t M, int64_t K, void* stream);
+
+/* Replaces _int_scaled_matmul/safe_int_mm -> aten::_int_mm plus the scale
+ * epilogue of the Int8Tensor linear (int8/kernels.py:114-144, int8_tensor.py:
+ * 315-359):  y = bf16( bf16( (xq @ wq^T)_i32 * x_scale[m] ) * w_scale[n] ) (+bias).
+ *   xq int8 [M][K]; wq int8 [N][K] (row-major weight, i.e. the reference's
+ *   weight.qdata before its .contiguous().t()); x_scale fp32 [M];
+ *   w_scale fp32 [N]; bias bf16 [N] or NULL; y bf16 [M][N].  K % 16 == 0. */
+int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const int8_t* wq,
+                      const float* w_scale, const uint16_t* bias, uint16_t* y,
+                      int64_t M, int64_t N, int64_t K, void* stream);
+
+/* Plain aten::_int_mm (int8/kernels.py:38-40,70): c int32 [M][N] = a[M][K] @ b_t[N][K]^T. */
+int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, int64_t M,
+                   int64_t N, int64_t K, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * float8 (OCP e4m3fn) rowwise
+ * ------------------------------------------------------------------------- */
+
+/* Replaces Float8Tensor.from_hp(x, e4m3, PerRow): _choose_scale_float8 +
+ * _quantize_affine_float8 (float8_tensor.py:167-253; quant_primitives.py:
+ * 2172-2212,2271-2287): scale[r] = f32(bf16(amax_r / 448)), q = e4m3(clamp(x/scale)).
+ *   x bf16 [M][K] -> q e4m3fn [M][K], scale fp32 [M] */
+int ao_fp8_quantize_rowwise(const uint16_t* x, uint8_t* q, float* scale,
+                            int64_t M, int64_t K, void* stream);
+
+/* Replaces aten::_scaled_mm with rowwise scales as called from
+ * addmm_float8_unwrapped_inference (torchao/float8/inference.py:86-123):
+ *   y = bf16( (a @ b^T)_f32 * scale_a[m] * scale_b[n] + bias[n] )
+ *   a e4m3fn [M][K] row-major; b e4m3fn [N][K] row-major (== the reference's
+ *   column-major [K][N] mat2); scale_a fp32 [M]; scale_b fp32 [N];
+ *   bias bf16 [N] or NULL; y bf16 [M][N].  K % 16 == 0, N % 16 == 0. */
+int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float* scale_a,
+                     const float* scale_b, const uint16_t* bias, uint16_t* y,
+                     int64_t M, int64_t N, int64_t K, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * MXFP8 (e4m3 elements, E8M0 scale per 32 along the contraction dim)
+ * ------------------------------------------------------------------------- */
+
+#define AO_MX_SCALE_FLOOR 0
+#define AO_MX_SCALE_RCEIL 1
+
+/* Replaces torchao::mxfp8_quantize (rowwise 1x32 cast; schema
+ * torchao/prototype/mx_formats/kernels.py:1022-1026; semantics to_mx,
+ * torchao/prototype/mx_formats/mx_tensor.py:228-409).
+ *   x bf16 [R][C] (C % 32 == 0) -> q e4m3fn [R][C], scale e8m0 [R][C/32]. */
+int ao_mxfp8_quantize_rowwise(const uint16_t* x, uint8_t* q, uint8_t* scale_e8m0,
+                              int64_t R, int64_t C, int scaling_mode,
+                              void* stream);
+
+/* Replaces aten::_scaled_grouped_mm as called from _compute_fwd_sm100
+ * (torchao/prototype/moe_training/mxfp8_grouped_mm.py:541), with the numerics of
+ * _emulated_mxfp8_scaled_grouped_mm_2d_3d (:959-1023):
+ *   out[offs[e-1]:offs[e]] = dq(a_rows) @ dq(b[e])^T,  dq = fp8 * 2^(scale-127)
+ *   a e4m3 [M_total][K]; a_scale e8m0 [M_total][K/32];
+ *   b e4m3 [E][N][K] (each expert row-major [N][K]); b_scale e8m0 [E][N][K/32];
+ *   offs int32 [E] cumulative group ends; out bf16 [M_total][N].
+ * Scale layout is plain row-major (CDNA4 scaled-MFMA takes scales in VGPRs; the
+ * cuBLAS 128x4 "blocked" swizzle of mx_block_rearrange_2d_M_groups is not used). */
+int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale,
+                        const uint8_t* b, const uint8_t* b_scale,
+                        const int32_t* offs, uint16_t* out, int64_t M_total,
+                        int64_t N, int64_t K, int64_t E, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

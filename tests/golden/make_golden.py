@@ -64,6 +64,95 @@ def make_int4():
     print("int4_tinygemm.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def make_int8_fp8():
+    from torchao.quantization.granularity import PerRow
+    from torchao.quantization.quantize_.workflows.float8.float8_tensor import Float8Tensor
+    from torchao.quantization.quantize_.workflows.int8.int8_tensor import Int8Tensor
+
+    gen = torch.Generator().manual_seed(77)
+    m, n, k = 19, 48, 256
+    x = torch.randn(m, k, generator=gen).to(torch.bfloat16)
+    x[2] *= 300.0          # large row
+    x[3] *= 1e-3           # small row
+    x[4] = 0               # all-zero row (int8: scale clamps to eps; fp8: scale 0 -> NaN)
+    w = (torch.randn(n, k, generator=gen) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(n, generator=gen).to(torch.bfloat16)
+    out = {"x": bits(x), "w": bits(w), "bias": bits(bias)}
+    xi, wi = Int8Tensor.from_hp(x, PerRow()), Int8Tensor.from_hp(w, PerRow())
+    out.update(int8_xq=xi.qdata.numpy(), int8_xs=xi.scale.flatten().numpy(),
+               int8_wq=wi.qdata.numpy(), int8_ws=wi.scale.flatten().numpy())
+    # the reference's GPU-path epilogue formulas (int8_tensor.py:305-359, kernels.py:143-144) on CPU tensors
+    c = (xi.qdata.to(torch.int32) @ wi.qdata.to(torch.int32).t())
+    out["int8_c"] = c.numpy()
+    y = (c * xi.scale.reshape(-1, 1)).to(torch.bfloat16)
+    y = y * wi.scale.flatten()
+    y = y + bias
+    out["int8_y"] = bits(y.to(torch.bfloat16))
+    xf = x.clone(); xf[4] = torch.randn(k, generator=gen).to(torch.bfloat16) * 1e-6
+    out["fp8_x"] = bits(xf)
+    xq, wq = Float8Tensor.from_hp(xf, torch.float8_e4m3fn, PerRow()), Float8Tensor.from_hp(w, torch.float8_e4m3fn, PerRow())
+    out.update(fp8_xq=xq.qdata.view(torch.uint8).numpy(), fp8_xs=xq.scale.flatten().numpy(),
+               fp8_wq=wq.qdata.view(torch.uint8).numpy(), fp8_ws=wq.scale.flatten().numpy())
+    # dequant -> fp32 matmul with the reference's dequantize() (CPU _scaled_mm has no rowwise mode)
+    yf = (xq.dequantize().float() @ wq.dequantize().float().t()) + bias.float()
+    out["fp8_y_dequant_f32"] = yf.numpy()
+    x0 = torch.zeros(2, k, dtype=torch.bfloat16)
+    z = Float8Tensor.from_hp(x0, torch.float8_e4m3fn, PerRow())
+    out.update(fp8_zero_q=z.qdata.view(torch.uint8).numpy(), fp8_zero_s=z.scale.flatten().numpy())
+    np.savez_compressed(os.path.join(HERE, "int8_fp8.npz"), **out)
+    print("int8_fp8.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
+def make_mx():
+    from torchao.prototype.moe_training.mxfp8_grouped_mm import _emulated_mxfp8_scaled_grouped_mm_2d_3d
+    from torchao.prototype.mx_formats.config import ScaleCalculationMode
+    from torchao.prototype.mx_formats.mx_tensor import to_mx
+    from torchao.testing import _mxfp8_test_utils as T
+
+    out = {}
+    # the reference's own bitwise contract (torchao/testing/_mxfp8_test_utils.py:22-235)
+    for mode_name in ("rceil", "floor"):
+        c = T.make_mxfp8_semantic_cases(torch.bfloat16, mode_name, device="cpu")
+        out[f"sem_{mode_name}_x"] = bits(c.inputs)
+        out[f"sem_{mode_name}_data"] = c.expected_data.numpy()
+        out[f"sem_{mode_name}_scale"] = c.expected_scales.numpy()
+        out[f"sem_{mode_name}_names"] = np.array(c.names)
+    vals, exp = T.make_f32_to_e8m0_rceil_cases(device="cpu")
+    out["e8m0_rceil_in"] = vals.numpy().view(np.uint32)
+    out["e8m0_rceil_out"] = exp.numpy()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(24, 256, generator=gen).to(torch.bfloat16)
+    x[0] *= 1e4; x[1] *= 1e-6; x[2] = 0; x[3, :32] = 448.0; x[4, :32] = 449.0; x[5, 32:64] = -57344.0
+    x[6, :32] = torch.tensor([2.0 ** (-i) for i in range(32)]).to(torch.bfloat16)
+    x[7, :32] = 1.17549435e-38
+    out["x"] = bits(x)
+    for name, mode in (("rceil", ScaleCalculationMode.RCEIL), ("floor", ScaleCalculationMode.FLOOR)):
+        s, d = to_mx(x, torch.float8_e4m3fn, 32, mode)
+        out[f"{name}_scale"] = s.view(torch.uint8).numpy()
+        out[f"{name}_data"] = d.view(torch.uint8).numpy()
+    # grouped GEMM: E=3, ragged groups (one empty)
+    E, N, K, M = 3, 32, 256, 40
+    a = torch.randn(M, K, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(E, N, K, generator=gen) * 0.1).to(torch.bfloat16)
+    offs = torch.tensor([16, 16, 40], dtype=torch.int32)
+    a_s, a_d = to_mx(a, torch.float8_e4m3fn, 32, ScaleCalculationMode.RCEIL)
+    w_s, w_d = to_mx(w, torch.float8_e4m3fn, 32, ScaleCalculationMode.RCEIL)
+    # reference layout: B_data [E, K, N] (K-major), B_scale [E, K/32, N]
+    y = _emulated_mxfp8_scaled_grouped_mm_2d_3d(
+        a_d, a_s, w_d.transpose(-2, -1), w_s.transpose(-2, -1), offs=offs, out_dtype=torch.bfloat16
+    )
+    out.update(g_a=bits(a), g_w=bits(w), g_offs=offs.numpy(),
+               g_a_data=a_d.view(torch.uint8).numpy(), g_a_scale=a_s.view(torch.uint8).numpy(),
+               g_w_data=w_d.view(torch.uint8).numpy(), g_w_scale=w_s.view(torch.uint8).numpy(), g_y=bits(y))
+    np.savez_compressed(os.path.join(HERE, "mx.npz"), **out)
+    print("mx.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
+def make_rest():
+    make_int8_fp8()
+    make_mx()
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     make_int4()

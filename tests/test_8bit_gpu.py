@@ -1,0 +1,228 @@
+"""GPU parity tests: int8 dynamic, float8 rowwise and MXFP8 kernels (through the
+C ABI) against the CPU oracles and the reference-generated golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, bf16_bits_to_f32, np_from_torch_bf16, torch_bf16_from_f32
+from oracle import bf16, fp8_ref as F, int8_ref as I, mx_ref as MX
+
+pytestmark = pytest.mark.gpu
+
+from ao_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _randn_bf16(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def _nan_aware_equal(got, exp):
+    nan_e, nan_g = (exp & 0x7F) == 0x7F, (got & 0x7F) == 0x7F
+    return np.array_equal(nan_e, nan_g) and np.array_equal(got[~nan_g], exp[~nan_e])
+
+
+@pytest.fixture(scope="module")
+def g8():
+    return np.load(os.path.join(GOLDEN, "int8_fp8.npz"))
+
+
+@pytest.fixture(scope="module")
+def gmx():
+    return np.load(os.path.join(GOLDEN, "mx.npz"))
+
+
+# ---- int8 -------------------------------------------------------------------------
+def test_int8_quantize_golden(g8):
+    for t in ("x", "w"):
+        q, s = ops.int8_quantize_rowwise(torch_bf16_from_f32(bf16_bits_to_f32(g8[t])))
+        assert np.array_equal(q.cpu().numpy(), g8[f"int8_{t}q"])
+        assert np.array_equal(s.flatten().cpu().numpy(), g8[f"int8_{t}s"])
+
+
+@pytest.mark.parametrize("m,k", [(1, 4096), (7, 128), (300, 14336), (64, 8)])
+def test_int8_quantize_vs_oracle(m, k):
+    x = _randn_bf16((m, k), m + k, 3.0)
+    x[0, : min(k, 64)] = 0
+    q, s = ops.int8_quantize_rowwise(x.to(DEV))
+    qo, so = I.quantize_rowwise(x.float().numpy())
+    assert np.array_equal(s.flatten().cpu().numpy(), so)
+    assert np.array_equal(q.cpu().numpy(), qo)
+
+
+def test_int8_scaled_mm_golden(g8):
+    y = ops.int8_scaled_mm(
+        torch.from_numpy(g8["int8_xq"]).to(DEV), torch.from_numpy(g8["int8_xs"]).to(DEV),
+        torch.from_numpy(g8["int8_wq"]).to(DEV), torch.from_numpy(g8["int8_ws"]).to(DEV),
+        torch_bf16_from_f32(bf16_bits_to_f32(g8["bias"])),
+    )
+    assert np.array_equal(y.view(torch.int16).cpu().numpy().view(np.uint16), g8["int8_y"])
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 16, 64), (5, 48, 256), (128, 128, 128), (130, 200, 1040), (513, 384, 4096)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_int8_linear_vs_oracle(m, n, k, bias):
+    x = _randn_bf16((m, k), 11 * m + k)
+    w = _randn_bf16((n, k), 13 * n + k, 0.05)
+    b = _randn_bf16((n,), 5) if bias else None
+    xq, xs = ops.int8_quantize_rowwise(x.to(DEV))
+    wq, ws = ops.int8_quantize_rowwise(w.to(DEV))
+    y = ops.int8_scaled_mm(xq, xs, wq, ws, None if b is None else b.to(DEV))
+    y_ref = I.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+    # integer GEMM + the reference's rounding sequence: bit-exact
+    assert np.array_equal(np_from_torch_bf16(y), y_ref)
+    c = ops.int_mm(xq, wq.t())
+    assert np.array_equal(c.cpu().numpy(), I.int_mm(xq.cpu().numpy(), wq.cpu().numpy()))
+
+
+def test_int8_extremes_exact():
+    """int32 accumulation at full range: K * 127 * 128 stays exact."""
+    m, n, k = 33, 64, 8192
+    a = torch.full((m, k), -128, dtype=torch.int8)
+    b = torch.full((n, k), 127, dtype=torch.int8)
+    a[1::2] = 127
+    c = ops.int_mm(a.to(DEV), b.to(DEV).t())
+    assert np.array_equal(c.cpu().numpy(), I.int_mm(a.numpy(), b.numpy()))
+
+
+# ---- fp8 -------------------------------------------------------------------------
+def test_fp8_quantize_golden(g8):
+    q, s = ops.fp8_quantize_rowwise(torch_bf16_from_f32(bf16_bits_to_f32(g8["fp8_x"])))
+    assert np.array_equal(s.flatten().cpu().numpy(), g8["fp8_xs"])
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), g8["fp8_xq"])
+    q, s = ops.fp8_quantize_rowwise(torch.zeros(2, 256, dtype=torch.bfloat16, device=DEV))
+    assert np.all((q.view(torch.uint8).cpu().numpy() & 0x7F) == 0x7F)  # 0/0 -> NaN like the reference
+    assert np.all(s.cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("m,k", [(1, 4096), (9, 128), (257, 8192)])
+def test_fp8_quantize_vs_oracle(m, k):
+    x = _randn_bf16((m, k), 3 * m + k, 5.0)
+    x[0, 0] = 1e-30  # exercises fp8 subnormals after scaling
+    q, s = ops.fp8_quantize_rowwise(x.to(DEV))
+    qo, so = F.quantize_rowwise(x.float().numpy())
+    assert np.array_equal(s.flatten().cpu().numpy(), so)
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), qo)
+
+
+def test_fp8_cast_every_representable_neighbourhood():
+    """RNE of the hardware cast around every e4m3 value and midpoint."""
+    pos = F.E4M3[:127].astype(np.float64)
+    pts = np.concatenate([pos, (pos[1:] + pos[:-1]) / 2, np.nextafter(((pos[1:] + pos[:-1]) / 2).astype(np.float32), 0), np.nextafter(((pos[1:] + pos[:-1]) / 2).astype(np.float32), 1e9)])
+    pts = np.concatenate([pts, -pts]).astype(np.float32)
+    pts = pts[np.abs(pts) <= 448]
+    k = ((len(pts) + 255) // 256) * 256
+    buf = np.zeros(k, np.float32); buf[: len(pts)] = pts
+    buf[-1] = 448.0  # amax = 448 -> scale exactly 1.0
+    xb = bf16.bf16_round(buf)  # inputs must be bf16
+    q, s = ops.fp8_quantize_rowwise(torch_bf16_from_f32(xb[None, :]))
+    qo, so = F.quantize_rowwise(xb[None, :])
+    assert float(s[0, 0]) == 1.0 == float(so[0])
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), qo)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 16, 128), (3, 48, 256), (64, 128, 4096), (65, 128, 512), (300, 208, 1040), (2048, 256, 1024)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_fp8_linear_vs_oracle(m, n, k, bias):
+    x = _randn_bf16((m, k), 7 * m + k)
+    w = _randn_bf16((n, k), 3 * n + k, 0.05)
+    b = _randn_bf16((n,), 9) if bias else None
+    xq, xs = ops.fp8_quantize_rowwise(x.to(DEV))
+    wq, ws = ops.fp8_quantize_rowwise(w.to(DEV))
+    y = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), None if b is None else b.to(DEV))
+    y_ref = F.scaled_mm(
+        xq.view(torch.uint8).cpu().numpy(), wq.view(torch.uint8).cpu().numpy(),
+        xs.flatten().cpu().numpy(), ws.flatten().cpu().numpy(), None if b is None else b.float().numpy(),
+    )
+    yn = np_from_torch_bf16(y)
+    assert _rel(yn, y_ref) <= 1e-3  # BASELINE.json tolerance
+    # elementwise: one bf16 ulp, plus fp32 accumulation-order noise on cancelling sums
+    atol = 1e-5 * np.sqrt(k) * float(np.abs(y_ref).max())
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + atol)
+
+
+def test_fp8_vs_torch_scaled_mm_if_available():
+    x = _randn_bf16((32, 512), 1).to(DEV)
+    w = _randn_bf16((64, 512), 2, 0.05).to(DEV)
+    xq, xs = ops.fp8_quantize_rowwise(x)
+    wq, ws = ops.fp8_quantize_rowwise(w)
+    try:
+        ref = torch._scaled_mm(xq, wq.t(), scale_a=xs, scale_b=ws.t(), out_dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        pytest.skip(f"torch._scaled_mm rowwise unavailable here: {e}")
+    y = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t())
+    assert _rel(np_from_torch_bf16(y), np_from_torch_bf16(ref)) < 5e-3
+
+
+# ---- MXFP8 -------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["rceil", "floor"])
+def test_mxfp8_semantic_contract(gmx, name):
+    x = torch_bf16_from_f32(bf16_bits_to_f32(gmx[f"sem_{name}_x"]))
+    q, s = ops.mxfp8_quantize(x, name)
+    assert np.array_equal(s.view(torch.uint8).flatten().cpu().numpy(), gmx[f"sem_{name}_scale"].flatten())
+    got, exp = q.view(torch.uint8).cpu().numpy(), gmx[f"sem_{name}_data"]
+    for i, nm in enumerate(gmx[f"sem_{name}_names"]):
+        assert _nan_aware_equal(got[i], exp[i]), nm
+
+
+@pytest.mark.parametrize("name", ["rceil", "floor"])
+def test_mxfp8_quantize_golden_and_oracle(gmx, name):
+    x = torch_bf16_from_f32(bf16_bits_to_f32(gmx["x"]))
+    q, s = ops.mxfp8_quantize(x, name)
+    assert np.array_equal(s.view(torch.uint8).cpu().numpy(), gmx[f"{name}_scale"])
+    assert _nan_aware_equal(q.view(torch.uint8).cpu().numpy(), gmx[f"{name}_data"])
+    big = _randn_bf16((64, 4096), 3, 10.0)
+    q, s = ops.mxfp8_quantize(big.to(DEV), name)
+    qo, so = MX.to_mx(big.float().numpy(), MX.RCEIL if name == "rceil" else MX.FLOOR)
+    assert np.array_equal(s.view(torch.uint8).cpu().numpy(), so)
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), qo)
+
+
+def test_mxfp8_grouped_mm_golden(gmx):
+    y = ops.mxfp8_grouped_mm(
+        torch.from_numpy(gmx["g_a_data"]).to(DEV), torch.from_numpy(gmx["g_a_scale"]).to(DEV),
+        torch.from_numpy(gmx["g_w_data"]).to(DEV), torch.from_numpy(gmx["g_w_scale"]).to(DEV),
+        torch.from_numpy(gmx["g_offs"]).to(DEV),
+    )
+    ref = bf16_bits_to_f32(gmx["g_y"])
+    rows = int(gmx["g_offs"][-1])
+    yn = np_from_torch_bf16(y)[:rows]
+    assert _rel(yn, ref[:rows]) <= 1e-3
+    assert np.all(np.abs(yn - ref[:rows]) <= np.abs(ref[:rows]) * 2.0 ** -7 + 1e-5)
+
+
+@pytest.mark.parametrize("sizes", [[16, 16, 16, 16], [32, 0, 5, 27], [1, 70, 3, 0], [128, 0, 0, 0]])
+def test_mxfp8_grouped_mm_vs_oracle(sizes):
+    E, N, K = len(sizes), 64, 512
+    M = sum(sizes)
+    a = _randn_bf16((M, K), 21)
+    w = _randn_bf16((E, N, K), 22, 0.1)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32)
+    a_d, a_s = ops.mxfp8_quantize(a.to(DEV), "rceil")
+    w_d, w_s = ops.mxfp8_quantize(w.to(DEV), "rceil")
+    y = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+    y_ref = MX.grouped_mm(
+        a_d.view(torch.uint8).cpu().numpy(), a_s.view(torch.uint8).cpu().numpy(),
+        w_d.view(torch.uint8).cpu().numpy(), w_s.view(torch.uint8).cpu().numpy(), offs.numpy(),
+    )
+    yn = np_from_torch_bf16(y)
+    assert _rel(yn, y_ref) <= 1e-3
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + 1e-5)
+    # SQNR vs the unquantised bf16 grouped matmul: reference bar >= 27 dB (test_mxfp8_grouped_mm.py:120-122)
+    full = np.zeros_like(y_ref)
+    st = 0
+    for e, sz in enumerate(sizes):
+        full[st : st + sz] = a[st : st + sz].float().numpy() @ w[e].float().numpy().T
+        st += sz
+    sqnr = 20 * np.log10(np.linalg.norm(full) / np.linalg.norm(full - yn))
+    assert sqnr >= 27, sqnr

@@ -39,6 +39,25 @@ OPS = {
     "v_rndne_f32": "v_rndne_f32 {d}, {a}",
     "v_max_f32": "v_max_f32 {d}, {a}, {d}",
     "v_cvt_i32_f32": "v_cvt_i32_f32 {d}, {a}",
+    "v_fmac_f32": "v_fmac_f32 {d}, {a}, {b}",
+    "v_add_f32": "v_add_f32 {d}, {a}, {d}",
+    "v_sub_f32": "v_sub_f32 {d}, {a}, {d}",
+    "v_or_b32": "v_or_b32 {d}, {a}, {d}",
+    "v_xor_b32": "v_xor_b32 {d}, {a}, {d}",
+    "v_mov_b32": "v_mov_b32 {d}, {a}",
+    "v_lshrrev_b32": "v_lshrrev_b32 {d}, 4, {a}",
+    "v_fmamk_f32": "v_fmamk_f32 {d}, {a}, 0x40490fdb, {d}",
+    "v_mad_u32_u24": "v_mad_u32_u24 {d}, {a}, {b}, {d}",
+    "v_cvt_pk_f32_fp8": "v_cvt_pk_f32_fp8 {D}, {a}",
+    "v_cvt_scalef32_pk_f32_fp8": "v_cvt_scalef32_pk_f32_fp8 {D}, {a}, {b}",
+    "v_cvt_scalef32_pk_bf16_fp8": "v_cvt_scalef32_pk_bf16_fp8 {d}, {a}, {b}",
+    "v_cvt_scalef32_pk_f32_fp4": "v_cvt_scalef32_pk_f32_fp4 {D}, {a}, {b}",
+    "v_cvt_f32_ubyte1_sdwa": "v_cvt_f32_u32_sdwa {d}, {a} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1",
+    "v_add_f32_sdwa_word1": "v_add_f32_sdwa {d}, {a}, {d} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD",
+    "v_pk_add_f32_opsel": "v_pk_add_f32 {D}, {A}, {D} op_sel_hi:[0,1]",
+    "v_dot4_i32_i8": "v_dot4_i32_i8 {d}, {a}, {b}, {d}",
+    "v_alignbit_b32": "v_alignbit_b32 {d}, {a}, {b}, 16",
+    "v_cvt_f32_f16": "v_cvt_f32_f16 {d}, {a}",
 }
 MFMA = {
     "v_mfma_f32_16x16x32_bf16": ("v_mfma_f32_16x16x32_bf16 {C4}, {A4}, {B4}, {C4}", 4),
@@ -105,6 +124,26 @@ def main():
   if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }}''')
         table.append(f'{{"{name}", {fn}, {per_iter}}}')
+    valu_lines = "\\n\\t".join(valu_body(OPS["v_pk_fma_f32"]))
+    ml, _ = mfma_body(*MFMA["v_mfma_f32_4x4x4_16b_bf16"])
+    mfma_lines = "\\n\\t".join(ml)
+    ml2, _ = mfma_body(*MFMA["v_mfma_f32_16x16x32_bf16"])
+    mfma2_lines = "\\n\\t".join(ml2)
+    for nm, ml_ in (("mixed4x4", mfma_lines), ("mixed16x16x32", mfma2_lines)):
+        src.append(f"""__global__ __launch_bounds__(1024) void k_{nm}(unsigned long long* out, int iters, int mode) {{
+  // mode 0: all waves VALU; 1: all waves MFMA; 2: waves 0-3 VALU + waves 4-7 MFMA (same SIMDs)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool do_mfma = (mode == 1) || (mode == 2 && wave >= 4);
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (do_mfma) {{
+    for (int i = 0; i < iters; ++i) asm volatile("{ml_}" ::: {clob}, "vcc");
+  }} else {{
+    for (int i = 0; i < iters; ++i) asm volatile("{valu_lines}" ::: {clob}, "vcc");
+  }}
+  asm volatile("s_nop 7\\n\\ts_nop 7" ::: "memory");
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[wave] = t1 - t0;
+}}""")
     src.append("static K kernels[] = {" + ", ".join(table) + "};")
     src.append(r'''
 int main(int argc, char** argv) {
@@ -126,6 +165,20 @@ int main(int argc, char** argv) {
       res[c] = (double)mx / ((double)iters * k.per_iter * (cfg[c] / 256));
     }
     printf("%-36s %10.2f %10.2f %10.2f\n", k.name, res[0], res[1], res[2]);
+  }
+  for (int which = 0; which < 2; ++which) {
+    for (int mode = 0; mode < 3; ++mode) {
+      hipMemset(d, 0, 1 << 16);
+      for (int r = 0; r < 2; ++r) {
+        if (which == 0) hipLaunchKernelGGL(k_mixed4x4, dim3(1), dim3(512), 0, 0, d, iters, mode);
+        else hipLaunchKernelGGL(k_mixed16x16x32, dim3(1), dim3(512), 0, 0, d, iters, mode);
+      }
+      hipDeviceSynchronize();
+      unsigned long long h[8]; hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
+      printf("mixed %s mode %d (0=VALU x8 waves,1=MFMA x8,2=4 VALU + 4 MFMA): cycles/iter-block per wave:", which ? "16x16x32" : "4x4x4", mode);
+      for (int w = 0; w < 8; ++w) printf(" %.0f", (double)h[w] / iters);
+      printf("\n");
+    }
   }
   return 0;
 }''')
