@@ -333,6 +333,345 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// M == 1 (decode) GEMV:  y[1,N] = x[1,K] @ dequant(qdata)^T
+//
+// grid = N/16 workgroups, WPB waves each; a workgroup owns one 16-wide n-tile,
+// its waves split K into contiguous runs of 1 KiB weight blocks.
+//   1. every wave issues its x-staging loads and then its first DEPTH weight
+//      blocks (non-temporal dwordx4 straight to VGPRs) + their scale/zero words;
+//   2. the workgroup writes x ONCE into LDS in A-fragment order
+//      xs[kb][kq][j][8] (k = 128 kb + 32 j + 16 h + 4 kq + i at slot 4 h + i), so
+//      the main loop's A operands are four ds_read_b128 at a per-lane running
+//      address -- no per-block x traffic, no per-block LDS store; lanes that do
+//      not hold row 0 of the 16x16 MFMA tile read a shared 64-byte zero row;
+//   3. main loop: dequantise in registers (exact oracle rounding), 4 MFMAs per
+//      block, refill the ring;
+//   4. one barrier for the cross-wave (split-K) reduction of 16 floats per wave.
+// ---------------------------------------------------------------------------
+template <int G, int DEPTH, int DQ, int ABL = 0, int WPE = 8>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void int4_gemv_kernel(const uint16_t* __restrict__ x,
+                                                        const u32x4* __restrict__ qdata,
+                                                        const uint32_t* __restrict__ sz,
+                                                        uint16_t* __restrict__ y, int N, int K) {
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K*2 xs][64 zero][nwaves*16 f32]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int ntile = blockIdx.x;
+  const int kblocks = K >> 7;
+  const int kb0 = (kblocks * wave) / nwaves;
+  const int kb1 = (kblocks * (wave + 1)) / nwaves;
+  const int n = ntile * 16 + (lane & 15);
+  const int kq = lane >> 4;
+
+  char* xs = smem;
+  char* zero_row = smem + (size_t)K * 2;
+  float* red = reinterpret_cast<float*>(zero_row + 64);
+
+  // ---- 1a. x staging loads: 8-byte units, dest unit d <- source unit of the same 128-k block
+  constexpr int MAXU = 8;  // units per thread kept in registers per pass
+  const int units = K >> 2;
+  u32x2 xu[MAXU];
+  auto src_unit = [](int d) {
+    const int du = d & 31;  // dest unit within the block: kq*8 + j*2 + h
+    return (d & ~31) + 8 * ((du >> 1) & 3) + 4 * (du & 1) + (du >> 3);
+  };
+#pragma unroll
+  for (int r = 0; r < MAXU; ++r) {
+    const int d = tid + r * (int)blockDim.x;
+    if (d < units) xu[r] = *reinterpret_cast<const u32x2*>(x + (size_t)src_unit(d) * 4);
+  }
+
+  // ---- 1b. weight ring
+  struct Stage {
+    u32x4 w;
+    uint32_t sz[NG];
+  };
+  Stage st[DEPTH];
+  const u32x4* wp = qdata + ((size_t)ntile * kblocks) * 64 + lane;
+  auto issue = [&](Stage& s, int kb) {
+    if (ABL == 2) {
+      s.w = u32x4{(uint32_t)lane * 0x01010101u, (uint32_t)kb, 0x12345678u, (uint32_t)lane};
+    } else {
+      s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
+    }
+    const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
+  };
+  const int kb_last = max(kb1 - 1, kb0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
+
+  // ---- 2. x -> LDS (fragment order), zero row
+#pragma unroll
+  for (int r = 0; r < MAXU; ++r) {
+    const int d = tid + r * (int)blockDim.x;
+    if (d < units) *reinterpret_cast<u32x2*>(xs + (size_t)d * 8) = xu[r];
+  }
+  for (int d = tid + MAXU * (int)blockDim.x; d < units; d += blockDim.x)  // K > 32 * threads: rare
+    *reinterpret_cast<u32x2*>(xs + (size_t)d * 8) = *reinterpret_cast<const u32x2*>(x + (size_t)src_unit(d) * 4);
+  if (tid < 16) reinterpret_cast<uint32_t*>(zero_row)[tid] = 0u;
+  __syncthreads();
+
+  // ---- 3. main loop
+  const bool row0 = (lane & 15) == 0;
+  const char* a_ptr = row0 ? (xs + ((size_t)kb0 * 4 + kq) * 64) : zero_row;
+  const int a_step = row0 ? 256 : 0;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const s16x4 ident = identity_fragment<DQ>(lane);
+
+  auto consume = [&](const Stage& s) {
+    if (ABL == 1) {
+      acc.x += bits_to_f32((s.w.x ^ s.w.y ^ s.w.z ^ s.w.w ^ s.sz[0]) & 0x3f800000u);
+      return;
+    }
+    u32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_ptr + j * 16);
+    a_ptr += a_step;
+    const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
+      const float sc = bf16_lo_to_f32(s.sz[gi]);
+      const float zp = bf16_hi_to_f32(s.sz[gi]);
+      uint32_t b[4];
+      if (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
+      else dequant_word_mfma<DQ>(wds[j], sc, -8.0f * sc, zp, ident, b);
+      const u32x4 bv = {b[0], b[1], b[2], b[3]};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
+                                                    __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+    }
+  };
+
+  int kb = kb0;
+  for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      consume(st[d]);
+      issue(st[d], kb + d + DEPTH);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (kb + d < kb1) {
+      consume(st[d]);
+      if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
+    }
+  }
+  kb += DEPTH;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (kb + d < kb1) consume(st[d]);
+  }
+
+  // ---- 4. split-K reduction: row 0 of the tile lives in acc.x of lanes 0..15
+  if (lane < 16) red[wave * 16 + lane] = acc.x;
+  __syncthreads();
+  if (tid < 16) {
+    float sum = 0.f;
+    for (int w = 0; w < nwaves; ++w) sum += red[w * 16 + tid];
+    y[ntile * 16 + tid] = f32_to_bf16_bits(sum);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// M == 1 GEMV, wave-private variant (no workgroup barrier before the reduction):
+// each wave stages only the x slice of ITS k-range into a private LDS slab in
+// A-fragment order (one 16-byte global load + two ds_write_b64 per lane per 4
+// weight blocks), then streams its weight blocks.  The dequant chain of word
+// j+1 (VALU) is software-pipelined against the MFMAs of word j.
+// ---------------------------------------------------------------------------
+struct DqA { uint32_t tp[4]; };  // t = bf16((q-8)*s), packed pairs 01,23,45,67
+
+// FMA: 0 = v_pk_fma_f32 (2 values / op), 1 = scalar v_fma_f32, 2 = v_mul_f32 + v_add_f32 (VOP2 pairs)
+__device__ __forceinline__ float fma_asm(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float mul_add_asm(float a, float b, float c) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+template <int FMA>
+__device__ __forceinline__ f32x2 scale_shift(f32x2 q, float s, float neg8s) {
+  if (FMA == 1) return f32x2{fma_asm(q.x, s, neg8s), fma_asm(q.y, s, neg8s)};
+  if (FMA == 2) return f32x2{mul_add_asm(q.x, s, neg8s), mul_add_asm(q.y, s, neg8s)};
+  return q * s + neg8s;
+}
+
+template <int FMA = 0>
+__device__ __forceinline__ DqA dq_stage_a(uint32_t p, float s, float neg8s) {
+  const uint32_t lo = p & 0x0F0F0F0Fu;         // bytes: v0, v4, v1, v5
+  const uint32_t hi = (p >> 4) & 0x0F0F0F0Fu;  // bytes: v2, v6, v3, v7
+  const f32x2 r0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, false);  // q0, q4
+  const f32x2 r1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, true);   // q1, q5
+  const f32x2 r2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, false);  // q2, q6
+  const f32x2 r3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, true);   // q3, q7
+  const f32x2 t0 = scale_shift<FMA>(r0, s, neg8s), t1 = scale_shift<FMA>(r1, s, neg8s);
+  const f32x2 t2 = scale_shift<FMA>(r2, s, neg8s), t3 = scale_shift<FMA>(r3, s, neg8s);
+  DqA a;
+  a.tp[0] = pack_bf16x2(t0.x, t1.x); a.tp[1] = pack_bf16x2(t2.x, t3.x);
+  a.tp[2] = pack_bf16x2(t0.y, t1.y); a.tp[3] = pack_bf16x2(t2.y, t3.y);
+  return a;
+}
+
+template <int G, int SCHED, int WPE, int ABL = 0, int FMA = 0>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void int4_gemv3_kernel(
+    const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz,
+    uint16_t* __restrict__ y, int N, int K, int slab_bytes) {
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);
+  constexpr int DEPTH = 4;
+  constexpr int MAXCH = 4;  // x chunks (4 blocks each) per wave: <= 16 weight blocks per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [nwaves][slab_bytes] + [nwaves*16 f32]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int ntile = blockIdx.x;
+  const int kblocks = K >> 7;
+  const int kb0 = (kblocks * wave) / nwaves;
+  const int kb1 = (kblocks * (wave + 1)) / nwaves;
+  const int nb = kb1 - kb0;
+  const int n = ntile * 16 + (lane & 15);
+  const int kq = lane >> 4;
+
+  char* slab = smem + (size_t)wave * slab_bytes;  // [nb][4 kq][4 j][16 B] then a 64-byte zero row
+  char* zero_row = slab + slab_bytes - 64;
+  float* red = reinterpret_cast<float*>(smem + (size_t)nwaves * slab_bytes);
+
+  // x slice loads: chunk c covers blocks kb0 + 4c .. +3, lane owns 8 consecutive k
+  u32x4 xc[MAXCH];
+#pragma unroll
+  for (int c = 0; c < MAXCH; ++c) {
+    const int blk = 4 * c + (lane >> 4);
+    if (blk < nb) xc[c] = *reinterpret_cast<const u32x4*>(x + (size_t)(kb0 + blk) * 128 + (lane & 15) * 8);
+  }
+
+  struct Stage {
+    u32x4 w;
+    uint32_t sz[NG];
+  };
+  Stage st[DEPTH];
+  const u32x4* wp = qdata + ((size_t)ntile * kblocks) * 64 + lane;
+  auto issue = [&](Stage& s, int kb) {
+    if (ABL == 2) {
+      s.w = u32x4{(uint32_t)lane * 0x01010101u, (uint32_t)kb, 0x12345678u, (uint32_t)lane};
+    } else {
+      s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
+    }
+    const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
+  };
+  const int kb_last = max(kb1 - 1, kb0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
+
+  // x -> private slab.  Lane's 8 k's of block `blk`: offset o = (lane & 15) * 8 inside the block,
+  // j = o >> 5, h = (o >> 4) & 1, and the two 4-k halves belong to kq = 2*(lane&1) and 2*(lane&1)+1.
+  {
+    const int l15 = lane & 15;
+    const int j = l15 >> 2, h = (l15 >> 1) & 1, kq_lo = (l15 & 1) * 2;
+    const int in_blk = kq_lo * 64 + j * 16 + h * 8;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+      const int blk = 4 * c + (lane >> 4);
+      if (blk < nb) {
+        char* d = slab + blk * 256 + in_blk;
+        *reinterpret_cast<u32x2*>(d) = u32x2{xc[c].x, xc[c].y};
+        *reinterpret_cast<u32x2*>(d + 64) = u32x2{xc[c].z, xc[c].w};
+      }
+    }
+    if (lane < 16) reinterpret_cast<uint32_t*>(zero_row)[lane] = 0u;
+  }
+
+  const bool row0 = (lane & 15) == 0;
+  const char* a_ptr = row0 ? (slab + kq * 64) : zero_row;
+  const int a_step = row0 ? 256 : 0;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const s16x4 ident = identity_fragment<4>(lane);
+
+  auto consume = [&](const Stage& s) {
+    if (ABL == 1) {
+      acc.x += bits_to_f32((s.w.x ^ s.w.y ^ s.w.z ^ s.w.w ^ s.sz[0]) & 0x3f800000u);
+      return;
+    }
+    u32x4 a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_ptr + j * 16);
+    a_ptr += a_step;
+    const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
+    float sc[4], zp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
+      sc[j] = bf16_lo_to_f32(s.sz[gi]);
+      zp[j] = bf16_hi_to_f32(s.sz[gi]);
+    }
+    DqA ta = dq_stage_a<FMA>(wds[0], sc[0], -8.0f * sc[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 zz = {zp[j], zp[j], zp[j], zp[j]};
+      const f32x4 w0 = widen_add<4>(ident, ta.tp[0], ta.tp[1], zz);  // MFMA 4x4x4: fl32(t + z)
+      const f32x4 w1 = widen_add<4>(ident, ta.tp[2], ta.tp[3], zz);
+      if (j < 3) ta = dq_stage_a<FMA>(wds[j + 1], sc[j + 1], -8.0f * sc[j + 1]);  // next word's VALU under the MFMAs
+      const u32x4 bv = {pack_bf16x2(w0.x, w0.y), pack_bf16x2(w0.z, w0.w), pack_bf16x2(w1.x, w1.y),
+                        pack_bf16x2(w1.z, w1.w)};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
+                                                    __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+      if (SCHED == 1) {
+        // per word: MFMA4, 6 VALU, MFMA4, 6 VALU (stage A of the next word), 4 VALU (cvt_pk), MFMA16, 3 VALU
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+      }
+    }
+  };
+
+  int kb = kb0;
+  for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      consume(st[d]);
+      issue(st[d], kb + d + DEPTH);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (kb + d < kb1) {
+      consume(st[d]);
+      if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
+    }
+  }
+  kb += DEPTH;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (kb + d < kb1) consume(st[d]);
+  }
+
+  if (lane < 16) red[wave * 16 + lane] = acc.x;
+  __syncthreads();
+  if (tid < 16) {
+    float sum = 0.f;
+    for (int w = 0; w < nwaves; ++w) sum += red[w * 16 + tid];
+    y[ntile * 16 + tid] = f32_to_bf16_bits(sum);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // pack / unpack / dequantize / fused quantize
 // ---------------------------------------------------------------------------
 
@@ -514,7 +853,7 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
   const size_t smem = (size_t)wpb * (SLAB + 1024);
   dim3 grid((unsigned)ntiles, (unsigned)mslabs), block(wpb * 64);
-  if (G == 128 && MAXM == 1 && g_tune_mode != 0) {
+  if (G == 128 && MAXM == 1 && g_tune_mode != 0 && g_tune_mode != 99) {
     const u32x4* q4 = reinterpret_cast<const u32x4*>(qdata);
     const uint32_t* sz4 = reinterpret_cast<const uint32_t*>(sz);
     switch (g_tune_mode) {
@@ -541,9 +880,91 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   return AO_OK;
 }
 
+template <int G, int DEPTH, int DQ, int ABL, int WPE = 8>
+int launch_gemv_variant(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N,
+                        int64_t K, int wpb, hipStream_t stream) {
+  const size_t smem = (size_t)K * 2 + 64 + (size_t)wpb * 16 * sizeof(float);
+  auto kern = int4_gemv_kernel<G, DEPTH, DQ, ABL, WPE>;
+  if (smem > 48 * 1024) {
+    static size_t granted = 0;  // monotonic; a racing duplicate call is harmless
+    if (smem > granted) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(int4_gemv_kernel)");
+      granted = smem;
+    }
+  }
+  ao::launch(kern, dim3((unsigned)(N >> 4)), dim3(wpb * 64), smem, stream, x, reinterpret_cast<const u32x4*>(qdata),
+             reinterpret_cast<const uint32_t*>(sz), y, (int)N, (int)K);
+  AO_LAUNCH_CHECK("int4_gemv_kernel launch");
+  return AO_OK;
+}
+
+template <int G, int SCHED, int WPE, int ABL, int FMA = 0>
+int launch_gemv3_variant(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N,
+                         int64_t K, int wpb, hipStream_t stream) {
+  const int kblocks = (int)(K >> 7);
+  const int nb_max = (kblocks + wpb - 1) / wpb;
+  const int slab = nb_max * 256 + 64;
+  const size_t smem = (size_t)wpb * slab + (size_t)wpb * 16 * sizeof(float);
+  ao::launch(int4_gemv3_kernel<G, SCHED, WPE, ABL, FMA>, dim3((unsigned)(N >> 4)), dim3(wpb * 64), smem, stream, x,
+             reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)N, (int)K, slab);
+  AO_LAUNCH_CHECK("int4_gemv3_kernel launch");
+  return AO_OK;
+}
+
+constexpr int64_t kGemvMaxK = 65536;  // x (2 B/k) must fit LDS next to the reduction scratch
+
+template <int G>
+int launch_gemv(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N, int64_t K,
+                hipStream_t stream) {
+  const int kblocks = (int)(K >> 7);
+  const int64_t ntiles = N >> 4;
+  // waves per workgroup: >= ~4 weight blocks per wave; all workgroups co-resident (8 waves/SIMD)
+  int wpb = 4;
+  while (wpb < 16 && kblocks / (wpb * 2) >= 4) wpb *= 2;
+  if (ntiles * wpb > 256 * 32 && wpb > 4) wpb /= 2;
+  if (g_tune_wpb >= 1 && g_tune_wpb <= 16) wpb = g_tune_wpb;
+  if (wpb > kblocks) wpb = kblocks;
+  if (g_tune_mode >= 300 && g_tune_mode < 400) {
+    while (kblocks > 16 * wpb) wpb *= 2;  // <= 16 blocks per wave
+    if (wpb > 16) { ao::set_error("gemv3: K too large"); return AO_ERR_INVALID_ARGUMENT; }
+    switch (g_tune_mode) {
+      case 300: return launch_gemv3_variant<G, 0, 6, 0>(x, qdata, sz, y, N, K, wpb, stream);
+      case 301: return launch_gemv3_variant<G, 1, 6, 0>(x, qdata, sz, y, N, K, wpb, stream);
+      case 304: return launch_gemv3_variant<G, 0, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
+      case 305: return launch_gemv3_variant<G, 1, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
+      case 308: return launch_gemv3_variant<G, 0, 8, 0>(x, qdata, sz, y, N, K, wpb, stream);
+      case 309: return launch_gemv3_variant<G, 1, 8, 0>(x, qdata, sz, y, N, K, wpb, stream);
+      case 311: return launch_gemv3_variant<G, 0, 6, 1>(x, qdata, sz, y, N, K, wpb, stream);
+      case 312: return launch_gemv3_variant<G, 0, 6, 2>(x, qdata, sz, y, N, K, wpb, stream);
+      case 313: return launch_gemv3_variant<G, 1, 6, 2>(x, qdata, sz, y, N, K, wpb, stream);
+      case 320: return launch_gemv3_variant<G, 0, 6, 0, 1>(x, qdata, sz, y, N, K, wpb, stream);
+      case 321: return launch_gemv3_variant<G, 1, 6, 0, 1>(x, qdata, sz, y, N, K, wpb, stream);
+      case 322: return launch_gemv3_variant<G, 0, 6, 2, 1>(x, qdata, sz, y, N, K, wpb, stream);
+      case 330: return launch_gemv3_variant<G, 0, 6, 0, 2>(x, qdata, sz, y, N, K, wpb, stream);
+      case 331: return launch_gemv3_variant<G, 1, 6, 0, 2>(x, qdata, sz, y, N, K, wpb, stream);
+      case 332: return launch_gemv3_variant<G, 0, 6, 2, 2>(x, qdata, sz, y, N, K, wpb, stream);
+      default: ao::set_error("bad gemv3 tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
+    }
+  }
+  switch (g_tune_mode) {
+    case 0: case 100: return launch_gemv_variant<G, 4, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
+    case 101: return launch_gemv_variant<G, 4, 4, 1>(x, qdata, sz, y, N, K, wpb, stream);
+    case 102: return launch_gemv_variant<G, 4, 4, 2>(x, qdata, sz, y, N, K, wpb, stream);
+    case 110: return launch_gemv_variant<G, 4, 0, 0>(x, qdata, sz, y, N, K, wpb, stream);
+    case 112: return launch_gemv_variant<G, 4, 2, 0>(x, qdata, sz, y, N, K, wpb, stream);
+    case 120: return launch_gemv_variant<G, 2, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
+    case 180: return launch_gemv_variant<G, 8, 4, 0, 4>(x, qdata, sz, y, N, K, wpb, stream);
+    case 104: return launch_gemv_variant<G, 4, 4, 0, 4>(x, qdata, sz, y, N, K, wpb, stream);
+    case 106: return launch_gemv_variant<G, 4, 4, 0, 6>(x, qdata, sz, y, N, K, wpb, stream);
+    default: ao::set_error("bad gemv tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
+  }
+}
+
 template <int G>
 int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
                 int64_t N, int64_t K, hipStream_t stream) {
+  if (M == 1 && K <= kGemvMaxK && (g_tune_mode == 0 || g_tune_mode >= 100)) return launch_gemv<G>(x, qdata, sz, y, N, K, stream);
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
   return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);

@@ -66,7 +66,7 @@ def mx_dequant_bf16(codes, scale):
     return bf16.mul(v, np.repeat(s, BLOCK, axis=-1))
 
 
-def grouped_mm(a, a_scale, b, b_scale, offs):
+def grouped_mm(a, a_scale, b, b_scale, offs, return_abs=False):
     """_emulated_mxfp8_scaled_grouped_mm_2d_3d
     (torchao/prototype/moe_training/mxfp8_grouped_mm.py:959-1023):
     out[offs[e-1]:offs[e]] = dq(a_rows) @ dq(b[e])^T in bf16, fp32 accumulate.
@@ -74,11 +74,16 @@ def grouped_mm(a, a_scale, b, b_scale, offs):
     A = mx_dequant_bf16(a, a_scale).astype(np.float64)
     E, N, K = b.shape
     out = np.zeros((a.shape[0], N), dtype=np.float32)
+    mag = np.zeros((a.shape[0], N), dtype=np.float32)  # sum_k |a||b| (tolerance scale for the tests)
     start = 0
     for e in range(E):
         end = int(offs[e])
         if end > start:
             Bd = mx_dequant_bf16(b[e], b_scale[e]).astype(np.float64)
             out[start:end] = (A[start:end] @ Bd.T).astype(np.float32)
+            if return_abs:
+                mag[start:end] = (np.abs(A[start:end]) @ np.abs(Bd).T).astype(np.float32)
         start = end
+    if return_abs:
+        return bf16.bf16_round(out), mag
     return bf16.bf16_round(out)

@@ -198,7 +198,8 @@ def test_mxfp8_grouped_mm_golden(gmx):
     rows = int(gmx["g_offs"][-1])
     yn = np_from_torch_bf16(y)[:rows]
     assert _rel(yn, ref[:rows]) <= 1e-3
-    assert np.all(np.abs(yn - ref[:rows]) <= np.abs(ref[:rows]) * 2.0 ** -7 + 1e-5)
+    mag = MX.grouped_mm(gmx["g_a_data"], gmx["g_a_scale"], gmx["g_w_data"], gmx["g_w_scale"], gmx["g_offs"], return_abs=True)[1]
+    assert np.all(np.abs(yn - ref[:rows]) <= np.abs(ref[:rows]) * 2.0 ** -7 + mag[:rows] * 2.0 ** -16)
 
 
 @pytest.mark.parametrize("sizes", [[16, 16, 16, 16], [32, 0, 5, 27], [1, 70, 3, 0], [128, 0, 0, 0]])
@@ -211,13 +212,15 @@ def test_mxfp8_grouped_mm_vs_oracle(sizes):
     a_d, a_s = ops.mxfp8_quantize(a.to(DEV), "rceil")
     w_d, w_s = ops.mxfp8_quantize(w.to(DEV), "rceil")
     y = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
-    y_ref = MX.grouped_mm(
+    y_ref, mag = MX.grouped_mm(
         a_d.view(torch.uint8).cpu().numpy(), a_s.view(torch.uint8).cpu().numpy(),
-        w_d.view(torch.uint8).cpu().numpy(), w_s.view(torch.uint8).cpu().numpy(), offs.numpy(),
+        w_d.view(torch.uint8).cpu().numpy(), w_s.view(torch.uint8).cpu().numpy(), offs.numpy(), return_abs=True,
     )
     yn = np_from_torch_bf16(y)
     assert _rel(yn, y_ref) <= 1e-3
-    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + 1e-5)
+    # element-wise: one bf16 ulp of the result + fp32 accumulation-order noise, which scales
+    # with sum|a||b| (cancelling outputs), 2^-18 of it measured on the scaled MFMA
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
     # SQNR vs the unquantised bf16 grouped matmul: reference bar >= 27 dB (test_mxfp8_grouped_mm.py:120-122)
     full = np.zeros_like(y_ref)
     st = 0
