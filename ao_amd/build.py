@@ -21,6 +21,9 @@ FLAGS = [
     "-fPIC",
     "-shared",
     "-fno-strict-aliasing",
+    # the loop vectorizer "vectorises" wave-uniform scalar loops across SGPRs (8x unrolled unit
+    # search, 480 SGPR spills in the streaming GEMV); nothing here wants it
+    "-fno-vectorize",
     "-Wno-unused-result",
 ]
 

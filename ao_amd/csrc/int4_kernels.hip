@@ -19,6 +19,13 @@
 #include "common.h"
 
 namespace ao {
+// int4_stream_kernels.hip: the balanced streaming M = 1 kernel (the product decode path)
+bool int4_gemv_stream_supported(int64_t K);
+void int4_gemv_stream_set_waves(int waves);
+void int4_gemv_stream_set_trace(unsigned long long* p);
+int launch_int4_gemv_stream(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N,
+                            int64_t K, int group_size, int ablation, hipStream_t stream);
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -384,6 +391,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
     const int d = tid + r * (int)blockDim.x;
     if (d < units) xu[r] = *reinterpret_cast<const u32x2*>(x + (size_t)src_unit(d) * 4);
   }
+  // The CU's vector-memory pipe serves requests in issue order across waves: put every wave's x
+  // loads in the pipe before any wave's 4 KiB of weights (int4_stream_kernels.hip, trace build).
+  __builtin_amdgcn_s_barrier();
 
   // ---- 1b. weight ring
   struct Stage {
@@ -415,7 +425,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
   for (int d = tid + MAXU * (int)blockDim.x; d < units; d += blockDim.x)  // K > 32 * threads: rare
     *reinterpret_cast<u32x2*>(xs + (size_t)d * 8) = *reinterpret_cast<const u32x2*>(x + (size_t)src_unit(d) * 4);
   if (tid < 16) reinterpret_cast<uint32_t*>(zero_row)[tid] = 0u;
-  __syncthreads();
+  // LDS-only barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. for the whole
+  // weight ring issued above -- the loads would no longer overlap the x staging
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   // ---- 3. main loop
   const bool row0 = (lane & 15) == 0;
@@ -964,6 +976,12 @@ int launch_gemv(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
 template <int G>
 int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
                 int64_t N, int64_t K, hipStream_t stream) {
+  // M == 1: mode 0 = product path (balanced streaming kernel); 400-402 = the same with ablations;
+  // 100-399 = earlier one-workgroup-per-tile variants kept for A/B profiling
+  if (M == 1 && int4_gemv_stream_supported(K) && (g_tune_mode == 0 || (g_tune_mode >= 400 && g_tune_mode <= 403))) {
+    int4_gemv_stream_set_waves(g_tune_wpb);  // 8 or (default) 16 waves per workgroup
+    return launch_int4_gemv_stream(x, qdata, sz, y, N, K, G, g_tune_mode >= 400 ? g_tune_mode - 400 : 0, stream);
+  }
   if (M == 1 && K <= kGemvMaxK && (g_tune_mode == 0 || g_tune_mode >= 100)) return launch_gemv<G>(x, qdata, sz, y, N, K, stream);
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
@@ -987,6 +1005,11 @@ int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
 }  // namespace ao
 
 using namespace ao;
+
+extern "C" int ao_int4_set_trace(unsigned long long* trace_dev) {
+  int4_gemv_stream_set_trace(trace_dev);
+  return AO_OK;
+}
 
 extern "C" int ao_int4_set_tuning(int waves_per_block, int mode) {
   g_tune_wpb = waves_per_block;

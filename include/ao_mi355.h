@@ -105,6 +105,9 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
  * workgroup (0 = heuristic) and a profiling mode (0 = product kernel; 1/2 =
  * ablation builds, 12/18 = prefetch depth 2/8) of the int4 mm. */
 int ao_int4_set_tuning(int waves_per_block, int mode);
+/* Profiling only: device buffer [grid][6] of 100 MHz s_memrealtime stamps written by the
+ * trace build of the M = 1 kernel (tuning mode 403); NULL disables. */
+int ao_int4_set_trace(unsigned long long* trace_dev);
 
 /* ------------------------------------------------------------------------- *
  * int8 dynamic activation x int8 weight

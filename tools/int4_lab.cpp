@@ -16,6 +16,7 @@
 typedef int (*mm_fn)(const uint16_t*, const int32_t*, const uint16_t*, uint16_t*, int64_t, int64_t, int64_t, int, void*);
 typedef int (*tune_fn)(int, int);
 typedef const char* (*err_fn)(void);
+typedef int (*trace_fn)(unsigned long long*);
 
 __global__ void fill_kernel(uint32_t* p, size_t n, uint32_t seed, int kind) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,6 +31,7 @@ __global__ void fill_kernel(uint32_t* p, size_t n, uint32_t seed, int kind) {
 
 int main(int argc, char** argv) {
   int M = 1, G = 128;
+  setvbuf(stdout, nullptr, _IONBF, 0);
   std::vector<std::pair<int, int>> cfgs;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "-m")) M = atoi(argv[++i]);
@@ -43,7 +45,8 @@ int main(int argc, char** argv) {
   mm_fn mm = (mm_fn)dlsym(h, "ao_int4_weight_int4pack_mm");
   tune_fn tune = (tune_fn)dlsym(h, "ao_int4_set_tuning");
   err_fn lasterr = (err_fn)dlsym(h, "ao_last_error");
-  struct Shape { const char* name; int64_t N, K; } shapes[] = {{"o", 4096, 4096}, {"qkv", 6144, 4096}, {"gate", 14336, 4096}, {"down", 4096, 14336}};
+  trace_fn set_trace = (trace_fn)dlsym(h, "ao_int4_set_trace");
+  struct Shape { const char* name; int64_t N, K; } shapes[] = {{"o", 4096, 4096}, {"qkv", 6144, 4096}, {"gate", 14336, 4096}, {"down", 4096, 14336}, {"gateup", 28672, 4096}};
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   printf("M=%d G=%d   in-graph us/launch on cold weights (GB/s = algorithmic bytes / time)\n", M, G);
@@ -61,6 +64,39 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> yref, ycur((size_t)M * sh.N);
     for (auto& c : cfgs) {
       tune(c.first, c.second);
+      { int rc = mm(x, (const int32_t*)q, (const uint16_t*)sz, y, M, sh.N, sh.K, G, s);  // warm: lazy workspace alloc is not capturable
+        if (rc) { printf("mm failed: %s\n", lasterr()); return 1; } CK(hipStreamSynchronize(s)); }
+      if (c.second == 403) {
+        // trace build: 100 MHz stamps; per workgroup [64]: wave 0 {entry, x landed, barrier, first blk, last blk, exit},
+        // then from [8] per wave {first blk, last blk, exit}
+        const int TS = 64, NWG = 1024;
+        unsigned long long* tr; CK(hipMalloc(&tr, NWG * TS * 8)); CK(hipMemset(tr, 0, NWG * TS * 8));
+        set_trace(tr);
+        for (int i = 0; i < 3; ++i) mm(x, (const int32_t*)(q + qbytes * (i % sets)), (const uint16_t*)(sz + szbytes * (i % sets)), y, M, sh.N, sh.K, G, s);
+        CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> ht(NWG * TS); CK(hipMemcpy(ht.data(), tr, ht.size() * 8, hipMemcpyDeviceToHost));
+        set_trace(nullptr); CK(hipFree(tr));
+        unsigned long long t0 = ~0ull; int nwg = 0;
+        for (int w = 0; w < NWG; ++w) if (ht[w * TS]) { nwg++; if (ht[w * TS] < t0) t0 = ht[w * TS]; }
+        const char* names[6] = {"entry", "x landed", "barrier", "first blk", "last blk", "exit"};
+        printf("%-5s trace, wave 0 of %d workgroups (us since first entry, min/mean/max): ", sh.name, nwg);
+        for (int k = 0; k < 6; ++k) {
+          double mn = 1e30, mx = 0, sum = 0;
+          for (int w = 0; w < NWG; ++w) if (ht[w * TS]) { double v = (ht[w * TS + k] - t0) * 0.01; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; }
+          printf("%s %.2f/%.2f/%.2f  ", names[k], mn, sum / nwg, mx);
+        }
+        const char* wn[3] = {"first blk", "last blk", "exit"};
+        printf("\n      all waves: ");
+        for (int k = 0; k < 3; ++k) {
+          double mn = 1e30, mx = 0, sum = 0; int n = 0;
+          for (int w = 0; w < NWG; ++w) if (ht[w * TS]) for (int v = 0; v < 16; ++v) {
+            unsigned long long t = ht[w * TS + 8 + 3 * v + k]; if (!t) continue;
+            double u = (t - t0) * 0.01; mn = u < mn ? u : mn; mx = u > mx ? u : mx; sum += u; ++n; }
+          printf("%s %.2f/%.2f/%.2f  ", wn[k], mn, n ? sum / n : 0.0, mx);
+        }
+        printf("\n");
+        continue;
+      }
       hipGraph_t g; hipGraphExec_t ge;
       CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
       for (int i = 0; i < sets; ++i) {
