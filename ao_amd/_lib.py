@@ -37,6 +37,7 @@ _SIGNATURES = {
     "ao_int4_quantize_tinygemm": [_P, _P, _P, _I64, _I64, _INT, _P],
     "ao_int4_set_tuning": [_INT, _INT],
     "ao_int4_set_trace": [_P],
+    "ao_int4_mm_kernel_name": [_I64, _I64, _I64, _INT],
     "ao_int8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _P],
     "ao_int8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_int8_int_mm": [_P, _P, _P, _I64, _I64, _I64, _P],
@@ -79,6 +80,7 @@ def lib():
             fn.restype = _INT
         l.ao_last_error.argtypes = []
         l.ao_last_error.restype = ctypes.c_char_p
+        l.ao_int4_mm_kernel_name.restype = ctypes.c_char_p
         _lib = l
     return _lib
 

@@ -924,6 +924,7 @@ int launch_gemv3_variant(const uint16_t* x, const int32_t* qdata, const uint16_t
   return AO_OK;
 }
 
+constexpr int64_t kManyTiles = 1024;  // n-tiles from which the per-tile grid beats the persistent one
 constexpr int64_t kGemvMaxK = 65536;  // x (2 B/k) must fit LDS next to the reduction scratch
 
 template <int G>
@@ -976,11 +977,16 @@ int launch_gemv(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
 template <int G>
 int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
                 int64_t N, int64_t K, hipStream_t stream) {
-  // M == 1: mode 0 = product path (balanced streaming kernel); 400-402 = the same with ablations;
-  // 100-399 = earlier one-workgroup-per-tile variants kept for A/B profiling
-  if (M == 1 && int4_gemv_stream_supported(K) && (g_tune_mode == 0 || (g_tune_mode >= 400 && g_tune_mode <= 403))) {
+  // M == 1 product dispatch (mode 0), measured in-graph on cold weights (profiles/int4_lab_r01.txt):
+  //   * fewer than kManyTiles n-tiles: the balanced streaming kernel (one workgroup per CU) -- start-up
+  //     and tile imbalance dominate there;
+  //   * more (merged gate_up_proj: 1792 tiles): one small workgroup per tile, scheduled by the
+  //     hardware, whose register ring has the cheaper per-block issue cost (19.8 vs 22.5 us).
+  // Modes 400-403 force the streaming kernel (+ablation/trace builds), 100-399 the per-tile variants.
+  const bool force_stream = g_tune_mode >= 400 && g_tune_mode <= 403;
+  if (M == 1 && int4_gemv_stream_supported(K) && ((g_tune_mode == 0 && (N >> 4) < kManyTiles) || force_stream)) {
     int4_gemv_stream_set_waves(g_tune_wpb);  // 8 or (default) 16 waves per workgroup
-    return launch_int4_gemv_stream(x, qdata, sz, y, N, K, G, g_tune_mode >= 400 ? g_tune_mode - 400 : 0, stream);
+    return launch_int4_gemv_stream(x, qdata, sz, y, N, K, G, force_stream ? g_tune_mode - 400 : 0, stream);
   }
   if (M == 1 && K <= kGemvMaxK && (g_tune_mode == 0 || g_tune_mode >= 100)) return launch_gemv<G>(x, qdata, sz, y, N, K, stream);
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
@@ -1005,6 +1011,13 @@ int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
 }  // namespace ao
 
 using namespace ao;
+
+extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size) {
+  (void)group_size;
+  if (M == 1 && int4_gemv_stream_supported(K) && (N >> 4) < kManyTiles) return "int4_gemv_stream_kernel";
+  if (M == 1 && K <= kGemvMaxK) return "int4_gemv_kernel";
+  return "int4_mm_kernel";
+}
 
 extern "C" int ao_int4_set_trace(unsigned long long* trace_dev) {
   int4_gemv_stream_set_trace(trace_dev);

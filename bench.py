@@ -4,12 +4,18 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one token (bs=1, seq=1) through every linear of Llama-3-8B:
-32 layers x {qkv 6144x4096, o 4096x4096, gate 14336x4096, up 14336x4096,
-down 4096x14336}, Int4WeightOnlyConfig(group_size=128), tile-packed weights
-(BASELINE.json configs[1]).  Every layer owns distinct weights (3.7 GB resident
-in HBM, far beyond the 256 MiB Infinity Cache), inputs are synthetic and already
-in HBM, one stream, launches replayed from a hipGraph.
+One "step" = one token (bs=1, seq=1) through every linear of Llama-3-8B,
+Int4WeightOnlyConfig(group_size=128), tile-packed weights (BASELINE.json
+configs[1]).  The 218.1 M weights of a layer are laid out the way the serving
+stack the reference targets (vLLM) instantiates the model:
+    qkv_proj 6144x4096, o_proj 4096x4096, gate_up_proj 28672x4096, down_proj 4096x14336
+(merged column-parallel projections are ONE nn.Linear there, so quantize_() sees
+one weight and F.linear issues one op).  --unmerged runs gate_proj and up_proj
+as two 14336x4096 linears (the HF module layout); same bytes, one more launch
+per layer; its tokens/s is also reported in config.unmerged_tokens_per_s.
+Every layer owns distinct weights (3.7 GB resident in HBM, far beyond the
+256 MiB Infinity Cache), inputs are synthetic and already in HBM, one stream,
+launches replayed from a hipGraph.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- dominant kernel (int4_mm_kernel): algorithmic bytes per launch /
@@ -34,7 +40,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
-LLAMA3_8B_LINEARS = [  # (name, N, K)
+LLAMA3_8B_MERGED = [  # (name, N, K): vLLM's Llama modules
+    ("qkv_proj", 6144, 4096),
+    ("o_proj", 4096, 4096),
+    ("gate_up_proj", 28672, 4096),
+    ("down_proj", 4096, 14336),
+]
+LLAMA3_8B_UNMERGED = [  # HF module layout (qkv still merged, as SURVEY.md 8d)
     ("qkv", 6144, 4096),
     ("o", 4096, 4096),
     ("gate", 14336, 4096),
@@ -58,6 +70,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1, help="tokens per step (bs); BASELINE headline is 1")
     ap.add_argument("--layers", type=int, default=N_LAYERS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--unmerged", action="store_true", help="gate_proj and up_proj as two linears (HF layout)")
+    ap.add_argument("--no-second-layout", action="store_true", help="skip the short run of the other module layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wpb", type=int, default=0, help="tuning: waves per workgroup override")
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
@@ -67,7 +81,7 @@ def parse_args():
 class Int4Linears:
     """All packed weights of the synthetic model + a raw C-ABI launch list."""
 
-    def __init__(self, device, batch, layers):
+    def __init__(self, device, batch, layers, shapes):
         from ao_amd import _lib, ops
 
         self.lib = _lib.lib()
@@ -76,8 +90,9 @@ class Int4Linears:
         self.launches = []  # (x_ptr, q_ptr, sz_ptr, y_ptr, M, N, K, name)
         self.keep = []
         gen = torch.Generator(device=device).manual_seed(0)
+        self.shapes = shapes
         for layer in range(layers):
-            for name, n, k in LLAMA3_8B_LINEARS:
+            for name, n, k in shapes:
                 # random-init weights of the real shape, quantized by the product kernel
                 w = torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02
                 qdata, sz = ops.int4_quantize_tinygemm(w, GROUP)
@@ -124,7 +139,7 @@ def cpu_baseline(batch):
     per_linear = {}
     while True:
         t_layer_once = 0.0
-        for name, n, k in LLAMA3_8B_LINEARS:
+        for name, n, k in LLAMA3_8B_MERGED:
             qdata = rng.integers(-(2**31), 2**31 - 1, size=(n // 8, k // 128, 32, 4), dtype=np.int64).astype(np.int32)
             sz = np.empty((k // GROUP, n, 2), dtype=np.uint16)
             sz[..., 0] = 0x3B00 + rng.integers(0, 64, size=sz.shape[:2])  # scale ~ 2e-3 (bf16 bits)
@@ -146,42 +161,21 @@ def cpu_baseline(batch):
         "unit": "tokens/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"1 of {N_LAYERS} layers (5 linears, 218.1M int4 weights, bs={batch}), mean of {reps} reps, x{N_LAYERS} extrapolated; "
+        "sample": f"1 of {N_LAYERS} layers (4 merged linears, 218.1M int4 weights, bs={batch}), mean of {reps} reps, x{N_LAYERS} extrapolated; "
         f"oracle/lowbit_ref.c (gcc -O3 -fopenmp, {threads} threads, host has {os.cpu_count()} cpus)",
         "ms_per_layer": t_layer * 1e3,
     }
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
-
-    from ao_amd import _lib
-
-    if args.wpb or args.mode:
-        _lib.lib().ao_int4_set_tuning(args.wpb, args.mode)
-
-    model = Int4Linears(device, args.batch, args.layers)
+def build_and_time(args, device, shapes, steps, warmup, dist, world):
+    """Build the synthetic model for `shapes`, capture one step into a hipGraph, time `steps` replays.
+    Returns (model, stream, elapsed_s, graph_used)."""
+    model = Int4Linears(device, args.batch, args.layers, shapes)
     stream = torch.cuda.Stream(device=device)
     sp = stream.cuda_stream
-
     graph = None
     with torch.cuda.stream(stream):
-        model.step(sp)  # first touch
+        model.step(sp)  # first touch (also allocates the library's split-K workspace outside capture)
         stream.synchronize()
         if not args.no_graph:
             try:
@@ -205,11 +199,11 @@ def main():
         torch.cuda.synchronize(device)
 
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             run_step()
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             run_step()
         torch.cuda.synchronize(device)
         elapsed = time.perf_counter() - t0
@@ -218,29 +212,94 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         sync_all()
+    return model, stream, elapsed, graph is not None
 
-        # live per-kernel timing (eager pass, HIP extension events on `stream`)
-        prof = None
-        if rank == 0:
-            durs = []
-            for _ in range(3):
-                durs.append(profile_kernels(model, sp))
-            prof = np.mean(np.stack(durs), axis=0)  # ms per launch, launch order
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    (profiles/int4_pmc_r01.json, written by scripts/pmc_summary.py from a separate counter run of
+    this same command); None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "int4_pmc_r01.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    return d, path
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    if args.wpb or args.mode:
+        lib.ao_int4_set_tuning(args.wpb, args.mode)
+
+    shapes = LLAMA3_8B_UNMERGED if args.unmerged else LLAMA3_8B_MERGED
+    model, stream, elapsed, graphed = build_and_time(args, device, shapes, args.steps, args.warmup, dist, world)
+    sp = stream.cuda_stream
     ms_per_step = elapsed * 1e3 / args.steps
     tokens_per_s = args.batch * world * args.steps / elapsed
+
+    # live per-kernel timing (eager pass, HIP extension events on `stream`)
+    prof = None
+    if rank == 0:
+        with torch.cuda.stream(stream):
+            durs = [profile_kernels(model, sp) for _ in range(3)]
+        prof = np.mean(np.stack(durs), axis=0)  # ms per launch, launch order
+
+    # the other module layout, for the record (rank 0 of a 1-GPU run only: it doubles resident weights)
+    other_tok_s = None
+    if rank == 0 and world == 1 and not args.no_second_layout:
+        del_model = model  # keep the first model alive until its numbers are computed below
+        other_shapes = LLAMA3_8B_MERGED if args.unmerged else LLAMA3_8B_UNMERGED
+        steps2 = min(args.steps, 20)
+        m2, _, e2, _ = build_and_time(args, device, other_shapes, steps2, min(args.warmup, 3), None, 1)
+        other_tok_s = args.batch * steps2 / e2
+        del m2
+        torch.cuda.empty_cache()
 
     if rank == 0:
         bytes_step = model.bytes_per_step()
         n_launch = len(model.launches)
-        avg_ms = float(prof.mean())
-        achieved = (bytes_step / n_launch) / (avg_ms * 1e-3) / 1e9
-        per_shape = {}
-        for name, n, k in LLAMA3_8B_LINEARS:
+        per_shape, kernels = {}, {}
+        for name, n, k in shapes:
             idx = [i for i, l in enumerate(model.launches) if l[7] == name]
             b = algorithmic_bytes(args.batch, n, k, GROUP)
             ms = float(prof[idx].mean())
-            per_shape[name] = {"N": n, "K": k, "bytes": b, "us": ms * 1e3, "GBps": b / (ms * 1e-3) / 1e9}
+            kern = lib.ao_int4_mm_kernel_name(args.batch, n, k, GROUP).decode()
+            per_shape[name] = {"N": n, "K": k, "bytes": b, "us": ms * 1e3, "GBps": b / (ms * 1e-3) / 1e9, "kernel": kern}
+            kk = kernels.setdefault(kern, {"launches_per_step": 0, "bytes_per_step": 0, "ms_per_step": 0.0})
+            kk["launches_per_step"] += len(idx)
+            kk["bytes_per_step"] += b * len(idx)
+            kk["ms_per_step"] += float(prof[idx].sum())
+        for kk in kernels.values():
+            kk["avg_kernel_us"] = kk["ms_per_step"] * 1e3 / kk["launches_per_step"]
+            kk["algorithmic_bytes_per_launch"] = kk["bytes_per_step"] / kk["launches_per_step"]
+            kk["GBps"] = kk["bytes_per_step"] / (kk["ms_per_step"] * 1e-3) / 1e9
+        dom = max(kernels, key=lambda k_: kernels[k_]["ms_per_step"])
+        achieved = kernels[dom]["GBps"]
+        pmc, pmc_path = pmc_traffic()
+        traffic = None
+        if pmc is not None and dom in pmc.get("kernels", {}):
+            traffic = pmc["kernels"][dom].get("hbm_bytes_per_launch")
+        roofline_tok_s = HBM_PEAK_GBS * 1e9 / bytes_step * args.batch
         out = {
             "metric": "linear-layer tokens/sec, Llama-3-8B int4-wo (tinygemm g128), bs=%d" % args.batch,
             "value": tokens_per_s,
@@ -255,26 +314,31 @@ def main():
             "dtype": "bf16 x int4 (dequant bf16, fp32 accumulate)",
             "data": "synthetic (random-init weights of the Llama-3-8B linear shapes, quantized on device)",
             "config": {
-                "workload": "Int4WeightOnlyConfig(group_size=128) Llama-3-8B linear shapes, bs=%d seq=1, %d layers x {qkv,o,gate,up,down}"
-                % (args.batch, args.layers),
-                "launch": "hipGraph replay" if graph is not None else "eager",
+                "workload": "Int4WeightOnlyConfig(group_size=128) Llama-3-8B linear shapes, bs=%d seq=1, %d layers x {%s}"
+                % (args.batch, args.layers, ", ".join("%s %dx%d" % s_ for s_ in shapes)),
+                "module_layout": "HF (gate_proj, up_proj separate)" if args.unmerged else "vLLM (merged qkv_proj, gate_up_proj)",
+                "launch": "hipGraph replay" if graphed else "eager",
                 "parallelism": "dp%d (one token stream per GPU, no collective)" % world,
                 "bytes_per_token": bytes_step,
-                "hbm_roofline_tokens_per_s": HBM_PEAK_GBS * 1e9 / bytes_step * args.batch,
-                "frac_of_hbm_roofline_end_to_end": (tokens_per_s / world) / (HBM_PEAK_GBS * 1e9 / bytes_step * args.batch),
+                "hbm_roofline_tokens_per_s": roofline_tok_s,
+                "frac_of_hbm_roofline_end_to_end": (tokens_per_s / world) / roofline_tok_s,
+                ("merged_tokens_per_s" if args.unmerged else "unmerged_tokens_per_s"): other_tok_s,
             },
             "roofline": {
-                "kernel": "int4_mm_kernel<G=128,MAXM=%d>" % (1 if args.batch == 1 else (4 if args.batch <= 4 else 16)),
+                "kernel": dom,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "avg_kernel_us": avg_ms * 1e3,
+                "traffic": traffic,
+                "traffic_source": (os.path.relpath(pmc_path, ROOT) if traffic is not None else None),
+                "avg_kernel_us": kernels[dom]["avg_kernel_us"],
+                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
                 "launches_per_step": n_launch,
-                "algorithmic_bytes_per_launch": bytes_step / n_launch,
                 "sum_kernel_ms_per_step": float(prof.sum()),
+                "all_launches_GBps": (bytes_step / (float(prof.sum()) * 1e-3)) / 1e9,
+                "kernels": kernels,
                 "per_shape": per_shape,
             },
         }

@@ -105,6 +105,9 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
  * workgroup (0 = heuristic) and a profiling mode (0 = product kernel; 1/2 =
  * ablation builds, 12/18 = prefetch depth 2/8) of the int4 mm. */
 int ao_int4_set_tuning(int waves_per_block, int mode);
+/* Name of the kernel ao_int4_weight_int4pack_mm launches for this problem (product dispatch, no
+ * tuning override): what a profiler's kernel table should be matched against.  Static string. */
+const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size);
 /* Profiling only: device buffer [grid][6] of 100 MHz s_memrealtime stamps written by the
  * trace build of the M = 1 kernel (tuning mode 403); NULL disables. */
 int ao_int4_set_trace(unsigned long long* trace_dev);

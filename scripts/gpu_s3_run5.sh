@@ -1,0 +1,24 @@
+#!/bin/bash
+# Session-3 GPU pass 5: full parity suite, smoke, headline bench, rocprofv3 kernel stats + PMC passes.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+echo "== pytest gpu ==" ; timeout 900 python -m pytest tests -m gpu -q -x --timeout 300 2>&1 | tee $O/pytest_gpu.log | tail -5
+echo "== smoke ==" ; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+echo "== bench ==" ; timeout 600 python bench.py 2>$O/bench.err | tee $O/bench_r01.json | cut -c1-6000
+tail -3 $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+echo "== rocprof stats =="
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o int4 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-second-layout > $O/rocprof_stats.log 2>&1
+find $O/prof_stats -name "*.csv" | head; f=$(find $O/prof_stats -name "*kernel_stats.csv" | head -1); head -8 "$f"
+echo "== rocprof pmc FETCH_SIZE =="
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_pmc_fetch -o int4 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-layout > $O/rocprof_pmc_fetch.log 2>&1
+echo "== rocprof pmc WRITE_SIZE =="
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_pmc_write -o int4 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-layout > $O/rocprof_pmc_write.log 2>&1
+cd $R
+python scripts/pmc_summary.py $O/prof_pmc_fetch $O/prof_pmc_write -o $O/int4_pmc_r01.json | head -40
+# counter CSVs are large: keep only the summary and the stats
+rm -rf $O/prof_pmc_fetch/*/*.db $O/prof_pmc_write/*/*.db 2>/dev/null
+find $O/prof_pmc_fetch $O/prof_pmc_write -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
