@@ -1,0 +1,122 @@
+"""Tensor-parallel linears over RCCL for the TP-linear benchmark (BASELINE config 4).
+
+torchao itself has no TP code: its subclasses implement aten.slice so that a caller (vLLM, DTensor)
+can shard them (int4_tile_packed_to_4d_tensor.py:302-385, float8_tensor.py:732-839,
+int8_tensor.py:362-422; harness torchao/testing/utils.py:370-519).  This module is that caller,
+MI355X-first: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI),
+Megatron pairing -- {q,k,v,gate,up} column-parallel (output features N split, no exchange),
+{o,down} row-parallel (input features K split, ONE all-reduce(sum) of the bf16 [M, hidden] partial
+per linear, issued on the compute stream right behind the GEMM).
+
+Sharding units: N in multiples of 16 (one int4 n-tile; also the fp8/int8 kernels' store width),
+K in multiples of lcm(128, group_size) for int4 (one packed k-block) and of 128 for the 8-bit
+GEMMs.  Row-parallel 8-bit shards keep the per-row WEIGHT scale of the full K (a slice of a tensor
+quantized before sharding) and quantize the ACTIVATION shard locally -- what a serving stack that
+calls F.linear(x_shard, w_shard) per rank gets from the reference subclasses too.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ["shard_bounds", "shard_unit", "ColumnParallelLinear", "RowParallelLinear", "shard_linear_", "tp_mlp"]
+
+
+def shard_bounds(size: int, world: int, rank: int, unit: int = 1) -> Tuple[int, int]:
+    """[start, end) of rank's contiguous shard of `size`, in multiples of `unit`; the first
+    (size/unit) % world ranks get one extra unit.  Raises if size is not a multiple of unit."""
+    if size % unit != 0:
+        raise ValueError(f"cannot shard {size} in units of {unit}")
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    units = size // unit
+    base, extra = divmod(units, world)
+    start = rank * base + min(rank, extra)
+    return start * unit, (start + base + (1 if rank < extra else 0)) * unit
+
+
+def shard_unit(weight: torch.Tensor, dim: int) -> int:
+    """Smallest slice the weight's packed layout allows along `dim` (0 = N, 1 = K)."""
+    block = getattr(weight, "block_size", None)
+    name = type(weight).__name__
+    if name == "Int4TilePackedTo4dTensor":
+        return 16 if dim == 0 else max(128, int(block[-1]))
+    if name in ("Int8Tensor", "Float8Tensor"):
+        return 16 if dim == 0 else 128
+    return 1
+
+
+class ColumnParallelLinear(nn.Module):
+    """y_local = x @ W[n0:n1].T (+ b[n0:n1]); no collective (gather_output=False, Megatron style)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], group=None):
+        super().__init__()
+        self.group = group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        n0, n1 = shard_bounds(weight.shape[0], world, rank, shard_unit(weight, 0))
+        self.weight = nn.Parameter(weight[n0:n1], requires_grad=False)
+        self.bias = None if bias is None else nn.Parameter(bias[n0:n1].clone(), requires_grad=False)
+        self.rows = (n0, n1)
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+class RowParallelLinear(nn.Module):
+    """y = all_reduce_sum_r( x[..., k0:k1] @ W[:, k0:k1].T ) + b.  `input_is_parallel`: x already
+    holds only this rank's K shard (the output of a ColumnParallelLinear)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], group=None, input_is_parallel: bool = True):
+        super().__init__()
+        self.group = group
+        self.input_is_parallel = input_is_parallel
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        k0, k1 = shard_bounds(weight.shape[1], world, rank, shard_unit(weight, 1))
+        self.weight = nn.Parameter(weight[:, k0:k1], requires_grad=False)
+        self.bias = None if bias is None else nn.Parameter(bias.clone(), requires_grad=False)
+        self.cols = (k0, k1)
+
+    def forward(self, x):
+        if not self.input_is_parallel:
+            x = x[..., self.cols[0] : self.cols[1]]
+        y = F.linear(x, self.weight, None)
+        # one exchange step per row-parallel linear: bf16 [M, N] partial sums.  On 8 MI355X over
+        # xGMI RCCL picks a direct (all links) algorithm for these sizes; the call is asynchronous
+        # on the current stream, the next kernel on that stream orders behind it.
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        if self.bias is not None:
+            y = y + self.bias.to(y.dtype)
+        return y
+
+
+def shard_linear_(module: nn.Linear, style: str, group=None, input_is_parallel: bool = True) -> nn.Module:
+    """Replace an (already quantized or plain) nn.Linear by its TP shard; style "colwise" | "rowwise"
+    (the names of torchao/testing/utils.py:370-467's DTensor harness)."""
+    bias = module.bias.detach() if module.bias is not None else None
+    w = module.weight.detach() if type(module.weight.data) is torch.Tensor else module.weight
+    if style == "colwise":
+        return ColumnParallelLinear(w, bias, group)
+    if style == "rowwise":
+        return RowParallelLinear(w, bias, group, input_is_parallel)
+    raise ValueError(f"unknown TP style {style!r} (colwise | rowwise)")
+
+
+def tp_mlp(gate_up: nn.Linear, down: nn.Linear, group=None) -> nn.Module:
+    """Megatron MLP: merged gate_up column-parallel (each rank holds its gate rows and its up rows),
+    SiLU(gate) * up locally, down row-parallel + all-reduce."""
+
+    class _MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            w, b = gate_up.weight, gate_up.bias
+            half = w.shape[0] // 2
+            self.gate = ColumnParallelLinear(w[:half], None if b is None else b[:half], group)
+            self.up = ColumnParallelLinear(w[half:], None if b is None else b[half:], group)
+            self.down = shard_linear_(down, "rowwise", group)
+
+        def forward(self, x):
+            return self.down(F.silu(self.gate(x)) * self.up(x))
+
+    return _MLP()

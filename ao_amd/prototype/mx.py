@@ -1,0 +1,81 @@
+"""MXFP8 (block 32, e4m3 elements, E8M0 scales): cast and MoE grouped GEMM forward, MI355X-native.
+
+Host-side mirror of
+  * torchao/prototype/mx_formats/mx_tensor.py:228-409  to_mx(x, float8_e4m3fn, 32, mode)
+  * torchao/prototype/moe_training/mxfp8_grouped_mm.py:56-239,330-371
+    _to_mxfp8_then_scaled_grouped_mm -- FORWARD only, numerics of the reference's
+    emulated path (:959-1023): both operands dequantised per 32-block, fp32 accumulate, bf16 out.
+CDNA4's scaled MFMA takes the E8M0 bytes as register operands, so scales stay in plain [rows, K/32]
+layout: no 128x4 "blocked" swizzle and no per-group row padding are needed on this path
+(torchao::mx_block_rearrange_2d_M_groups / fused_pad_token_groups have no work to do here).
+"""
+from enum import Enum
+from typing import Optional
+
+import torch
+
+from .. import ops
+
+__all__ = ["ScaleCalculationMode", "to_mx", "mx_dequantize", "_to_mxfp8_then_scaled_grouped_mm"]
+
+BLOCK = 32
+
+
+class ScaleCalculationMode(Enum):
+    """reference mx_formats/config.py: FLOOR (QuantizeTensorToMXKwargs default) and RCEIL (inference
+    and MoE default, inference_workflow.py:112, mxfp8_grouped_mm.py:64)"""
+
+    FLOOR = "floor"
+    RCEIL = "rceil"
+
+
+def to_mx(data_hp: torch.Tensor, elem_dtype: torch.dtype = torch.float8_e4m3fn, block_size: int = BLOCK,
+          scaling_mode: ScaleCalculationMode = ScaleCalculationMode.FLOOR):
+    """(scale_e8m0 [..., C/32], data_e4m3 [..., C]) -- the reference's return order (mx_tensor.py:409)."""
+    if elem_dtype != torch.float8_e4m3fn:
+        raise NotImplementedError(f"to_mx on MI355X implements float8_e4m3fn elements only, got {elem_dtype}")
+    if block_size != BLOCK:
+        raise NotImplementedError(f"to_mx on MI355X implements block_size 32 only, got {block_size}")
+    assert data_hp.dtype in (torch.bfloat16,), f"{data_hp.dtype} is not supported yet (bfloat16 only on MI355X)"
+    assert data_hp.shape[-1] % block_size == 0, (
+        f"the last dimension of shape {data_hp.shape} must be divisible by block_size {block_size}"
+    )
+    assert data_hp.is_contiguous(), "unsupported"
+    q, s = ops.mxfp8_quantize(data_hp, scaling_mode)
+    return s, q
+
+
+def mx_dequantize(scale_e8m0: torch.Tensor, data_lp: torch.Tensor, output_dtype=torch.bfloat16) -> torch.Tensor:
+    """reference mx_tensor.py:412-471 (torch ops on the GPU; a checker, not a hot path)"""
+    s = torch.exp2(scale_e8m0.view(torch.uint8).to(torch.float32) - 127.0)
+    x = data_lp.to(torch.float32).reshape(*data_lp.shape[:-1], -1, BLOCK) * s.unsqueeze(-1)
+    return x.reshape(data_lp.shape).to(output_dtype)
+
+
+def _to_mxfp8_then_scaled_grouped_mm(
+    A: torch.Tensor,
+    B_t: torch.Tensor,
+    offs: Optional[torch.Tensor] = None,
+    block_size: int = BLOCK,
+    out_dtype: Optional[torch.dtype] = torch.bfloat16,
+    scale_calculation_mode: ScaleCalculationMode = ScaleCalculationMode.RCEIL,
+) -> torch.Tensor:
+    """Forward of the reference's MXFP8 MoE grouped GEMM.
+
+    A     bf16 [M_total, K]   tokens, grouped by expert
+    B_t   bf16 [E, K, N]      expert weights, "transposed" view of [E, N, K] (strides (N*K, 1, N))
+    offs  int32 [E]           cumulative group ends along M
+    ->    bf16 [M_total, N]
+    Raises like the reference for unsupported arguments (:167-200)."""
+    assert A.ndim == 2, "A must be 2D"
+    assert B_t.ndim == 3, "B must be 3D"
+    assert block_size == BLOCK, "Only block_size=32 is supported"
+    assert offs is not None, "offs must be provided for 2d-2d and 2d-3d grouped mm"
+    assert out_dtype == torch.bfloat16, "Only bfloat16 out_dtype is supported"
+    assert A.dtype == torch.bfloat16 and B_t.dtype == torch.bfloat16, "A and B_t must be bfloat16"
+    assert A.shape[-1] == B_t.shape[-2], f"shape {A.shape} and {B_t.shape} are not compatible for _scaled_grouped_mm"
+    a_q, a_s = ops.mxfp8_quantize(A.contiguous(), scale_calculation_mode)
+    # weights: 1x32 blocks along K of the [E, N, K] tensor (the reference quantises B_t.transpose(-2, -1))
+    b = B_t.transpose(-2, -1).contiguous()
+    b_q, b_s = ops.mxfp8_quantize(b, scale_calculation_mode)
+    return ops.mxfp8_grouped_mm(a_q, a_s, b_q, b_s, offs.to(torch.int32))

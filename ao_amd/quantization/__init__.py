@@ -7,5 +7,7 @@ from .config import (  # noqa: F401
     Int8DynamicActivationInt8WeightConfig,
 )
 from .granularity import PerGroup, PerRow, PerTensor  # noqa: F401
+from .float8_tensor import Float8Tensor, QuantizeTensorToFloat8Kwargs  # noqa: F401
 from .int4_tensor import Int4TilePackedTo4dTensor  # noqa: F401
+from .int8_tensor import Int8Tensor, QuantizeTensorToInt8Kwargs  # noqa: F401
 from .quant_api import quantize_  # noqa: F401

@@ -1,0 +1,138 @@
+"""Float8Tensor: float8 e4m3 rowwise weight with dynamic rowwise activations, MI355X-native.
+
+Host-side mirror of torchao/quantization/quantize_/workflows/float8/float8_tensor.py for the branch
+SURVEY.md 8(a9, a10) scopes -- PerRow, KernelPreference TORCH/AUTO on AMD, i.e. what
+`_float8_addmm_impl` (:338-469) sends to aten::_scaled_mm through
+torchao/float8/inference.py:86-123.  gfx950 uses OCP e4m3fn (max 448), as the reference selects for
+MI350 (torchao/float8/config.py:80-83).  Arithmetic: ao_fp8_quantize_rowwise, ao_fp8_scaled_mm.
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .base_tensor import LowBitTensorBase, aten
+from .granularity import Granularity, PerRow
+
+__all__ = ["Float8Tensor", "QuantizeTensorToFloat8Kwargs"]
+
+
+@dataclass
+class QuantizeTensorToFloat8Kwargs:
+    """reference float8_tensor.py:50-81 (PerRow / e4m3fn only)"""
+
+    float8_dtype: torch.dtype = torch.float8_e4m3fn
+    granularity: Granularity = field(default_factory=PerRow)
+
+
+def _check(granularity, float8_dtype):
+    if not isinstance(granularity, PerRow):
+        raise NotImplementedError(f"Float8Tensor on MI355X implements PerRow only, got {granularity}")
+    if float8_dtype != torch.float8_e4m3fn:
+        raise NotImplementedError(f"Float8Tensor on MI355X implements float8_e4m3fn only, got {float8_dtype}")
+
+
+class Float8Tensor(LowBitTensorBase):
+    """
+    Tensor attributes (reference :84-140):
+      qdata  float8_e4m3fn [N, K]
+      scale  fp32 [N, 1]
+    Non-tensor attributes: block_size ([1, K]), dtype (original hp dtype), act_quant_kwargs.
+    """
+
+    tensor_data_names = ["qdata", "scale"]
+    tensor_attribute_names = ["block_size", "dtype_", "act_quant_kwargs"]
+    optional_tensor_data_names = ["act_pre_scale"]
+
+    def __new__(cls, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None):
+        kwargs = dict(device=qdata.device, dtype=dtype_, requires_grad=False)
+        return torch.Tensor._make_wrapper_subclass(cls, qdata.shape, **kwargs)
+
+    def __init__(self, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None):
+        self.qdata = qdata
+        self.scale = scale
+        self.block_size = list(block_size)
+        self.dtype_ = dtype_
+        self.act_quant_kwargs = act_quant_kwargs
+        self.act_pre_scale = act_pre_scale
+
+    def _quantization_type(self):
+        return (f"act_quant_kwargs={self.act_quant_kwargs}, block_size={self.block_size}, "
+                f"shape={tuple(self.shape)}, device={self.device}, dtype={self.dtype}")
+
+    @classmethod
+    def from_hp(cls, hp_tensor: torch.Tensor, float8_dtype: torch.dtype = torch.float8_e4m3fn,
+                granularity: Granularity = None, act_quant_kwargs: Optional[QuantizeTensorToFloat8Kwargs] = None):
+        """reference from_hp (:167-253), kernel_choice "torch": scale = amax / 448 in the input dtype
+        (no eps clamp: an all-zero row gives scale 0 and NaN data, like the reference), data =
+        saturating e4m3 cast of x / scale."""
+        granularity = PerRow() if granularity is None else granularity
+        _check(granularity, float8_dtype)
+        if hp_tensor.dtype != torch.bfloat16:
+            # reference quant_api.py:1211-1216: PerRow quantization only works for bfloat16 precision
+            raise AssertionError("PerRow quantization only works for bfloat16 precision input weight")
+        if hp_tensor.dim() != 2:
+            raise NotImplementedError("Float8Tensor.from_hp on MI355X takes 2-D tensors")
+        qdata, scale = ops.fp8_quantize_rowwise(hp_tensor.contiguous())
+        return cls(qdata, scale, [1, hp_tensor.shape[-1]], hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs)
+
+    def dequantize(self, output_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """reference :255-275: fp8 -> fp32 * scale, then cast"""
+        return (self.qdata.to(torch.float32) * self.scale.to(torch.float32)).to(output_dtype or self.dtype)
+
+
+implements = Float8Tensor.implements
+implements_torch_function = Float8Tensor.implements_torch_function
+
+
+@implements(aten.linear.default)
+@implements_torch_function(F.linear)
+def _(func, types, args, kwargs):
+    """reference :278-469 -> preprocess_data / preprocess_scale -> _scaled_mm(A row-major,
+    B = W.t() column-major, scale_a [M,1], scale_b [1,N], bias, out_dtype, use_fast_accum)."""
+    x, w = args[0], args[1]
+    bias = args[2] if len(args) > 2 else kwargs.get("bias", None)
+    assert isinstance(w, Float8Tensor), f"Expected weight to be Float8Tensor, got {type(w)}"
+    out_dtype = x.dtype
+    if w.act_pre_scale is not None:
+        x = x * w.act_pre_scale
+    if w.act_quant_kwargs is None:
+        raise NotImplementedError(
+            "Float8Tensor weight-only linear is not on the MI355X hot path (SURVEY.md section 8): "
+            "use Float8DynamicActivationFloat8WeightConfig"
+        )
+    _check(w.act_quant_kwargs.granularity, w.act_quant_kwargs.float8_dtype)
+    x2 = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
+    n = w.qdata.shape[0]
+    if x2.shape[0] == 0:
+        y = x2.new_zeros((0, n))
+    else:
+        xq, xs = ops.fp8_quantize_rowwise(x2)
+        y = ops.fp8_scaled_mm(xq, w.qdata.t(), xs, w.scale.t(), bias)
+        bias = None
+    y = y.reshape(*x.shape[:-1], n)
+    if bias is not None:
+        y = y + bias.to(y.dtype)
+    return y.to(out_dtype)
+
+
+@implements(aten.slice.Tensor)
+def _(func, types, args, kwargs):
+    """reference :732-790: rows slice qdata and scale; columns slice qdata only (rowwise scales are
+    over the full K -- what a row-parallel TP shard needs)"""
+    self, dim = args[0], args[1] if len(args) > 1 else 0
+    start = args[2] if len(args) > 2 and args[2] is not None else 0
+    end = args[3] if len(args) > 3 and args[3] is not None else self.shape[dim]
+    step = args[4] if len(args) > 4 else 1
+    assert step == 1 and dim in (0, 1)
+    end = min(end, self.shape[dim])
+    if dim == 0:
+        q, s = self.qdata[start:end].contiguous(), self.scale[start:end].contiguous()
+    else:
+        q, s = self.qdata[:, start:end].contiguous(), self.scale
+    return Float8Tensor(q, s, [1, q.shape[1]], self.dtype_, self.act_quant_kwargs, self.act_pre_scale)
+
+
+torch.serialization.add_safe_globals([Float8Tensor, QuantizeTensorToFloat8Kwargs])

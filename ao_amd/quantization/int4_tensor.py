@@ -111,7 +111,10 @@ def _(func, types, args, kwargs):
     orig_act_size = input_tensor.size()
     orig_dtype = input_tensor.dtype
     act_mat = input_tensor.reshape(-1, input_tensor.shape[-1]).to(torch.bfloat16)
-    pad_size = find_multiple(act_mat.shape[-1], 1024)
+    # the reference pads to a multiple of 1024 (what from_hp padded the weight to); a K-sliced
+    # shard keeps its own (128-aligned) extent, so pad to what the packed weight actually holds
+    pad_size = weight_tensor.qdata.shape[1] * 128
+    assert pad_size >= act_mat.shape[-1], "activation is wider than the packed weight"
     if pad_size != act_mat.shape[-1]:
         act_mat = F.pad(act_mat, (0, pad_size - act_mat.shape[-1]))
     groupsize = weight_tensor.block_size[-1]

@@ -106,3 +106,55 @@ def _int4_weight_only_transform(module, config, *, parameter_name="weight"):
     new_weight = _int4_weight_only_quantize_tensor(getattr(module, parameter_name), config)
     setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
     return module
+
+
+@register_quantize_module_handler(Int8DynamicActivationInt8WeightConfig)
+def _int8_dynamic_activation_int8_weight_transform(module, config, *, parameter_name="weight"):
+    """reference quant_api.py:885-960: per-row symmetric int8 weight, per-token symmetric dynamic
+    int8 activation (version 2 -> Int8Tensor)."""
+    from .int8_tensor import Int8Tensor, QuantizeTensorToInt8Kwargs
+
+    assert hasattr(module, parameter_name), (
+        f"applying int8 dynamic activation int8 weight quant requires module to have {parameter_name} attribute"
+    )
+    weight = getattr(module, parameter_name)
+    new_weight = Int8Tensor.from_hp(
+        weight,
+        granularity=config.granularity,
+        act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=config.granularity),
+    )
+    setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
+    return module
+
+
+def _fp8_mm_compat(weight: torch.Tensor) -> bool:
+    """reference quantization/utils.py:663-687: _scaled_mm needs both dims divisible by 16"""
+    assert weight.dim() in [2, 3], f"float8 quantization only works for 2/3-D tensors, got {weight.dim()}D tensor"
+    out_dim, in_dim = weight.shape[-2], weight.shape[-1]
+    if (in_dim % 16 != 0) or (out_dim % 16 != 0):
+        logger.info(
+            f"Skipping float8 quantization: weight shape {weight.shape} is not compatible with _scaled_mm. "
+            f"Both input dimension ({in_dim}) and output dimension ({out_dim}) must be multiples of 16. "
+        )
+        return False
+    return True
+
+
+@register_quantize_module_handler(Float8DynamicActivationFloat8WeightConfig)
+def _float8_dynamic_activation_float8_weight_transform(module, config, *, parameter_name="weight"):
+    """reference quant_api.py:1196-1297 (PerRow branch): unsupported shapes are left unquantized."""
+    from .float8_tensor import Float8Tensor, QuantizeTensorToFloat8Kwargs
+
+    assert hasattr(module, parameter_name), (
+        f"applying float8 dynamic activation quant requires module to have {parameter_name} attribute"
+    )
+    weight = getattr(module, parameter_name)
+    if not _fp8_mm_compat(weight):
+        return module
+    new_weight = Float8Tensor.from_hp(
+        weight,
+        granularity=config.granularity,
+        act_quant_kwargs=QuantizeTensorToFloat8Kwargs(granularity=config.granularity),
+    )
+    setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
+    return module

@@ -67,3 +67,51 @@ def test_ops_refuse_cpu_tensors():
             128,
             torch.zeros(1, 16, 2, dtype=torch.bfloat16),
         )
+
+
+def test_8bit_configs_are_registered_and_need_a_gpu():
+    from ao_amd.quantization import (
+        Float8DynamicActivationFloat8WeightConfig,
+        Int8DynamicActivationInt8WeightConfig,
+    )
+
+    for cfg in (Int8DynamicActivationInt8WeightConfig(), Float8DynamicActivationFloat8WeightConfig()):
+        m = torch.nn.Sequential(torch.nn.Linear(64, 32, bias=False)).to(torch.bfloat16)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            quantize_(m, cfg)
+
+
+def test_fp8_skips_shapes_scaled_mm_cannot_take():
+    # reference quantization/utils.py:678-687: N or K not a multiple of 16 -> weight left unquantized
+    from ao_amd.quantization import Float8DynamicActivationFloat8WeightConfig
+
+    m = torch.nn.Sequential(torch.nn.Linear(40, 32, bias=False)).to(torch.bfloat16)
+    quantize_(m, Float8DynamicActivationFloat8WeightConfig())
+    assert type(m[0].weight.data) is torch.Tensor
+
+
+def test_8bit_granularity_checks():
+    from ao_amd.quantization import Float8Tensor, Int8Tensor, PerTensor
+
+    w = torch.zeros(32, 64, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        Int8Tensor.from_hp(w, PerTensor())
+    with pytest.raises(NotImplementedError):
+        Float8Tensor.from_hp(w, granularity=PerTensor())
+    with pytest.raises(AssertionError):
+        Float8Tensor.from_hp(w.float())  # PerRow needs bf16 (reference quant_api.py:1211-1216)
+
+
+def test_mx_argument_checks():
+    from ao_amd.prototype.mx import _to_mxfp8_then_scaled_grouped_mm, to_mx
+
+    with pytest.raises(AssertionError):
+        to_mx(torch.zeros(4, 33, dtype=torch.bfloat16))
+    with pytest.raises(NotImplementedError):
+        to_mx(torch.zeros(4, 64, dtype=torch.bfloat16), torch.float8_e5m2)
+    a = torch.zeros(8, 64, dtype=torch.bfloat16)
+    b = torch.zeros(2, 64, 32, dtype=torch.bfloat16)
+    with pytest.raises(AssertionError):
+        _to_mxfp8_then_scaled_grouped_mm(a, b, offs=None)
+    with pytest.raises(AssertionError):
+        _to_mxfp8_then_scaled_grouped_mm(a, b[0], offs=torch.zeros(2, dtype=torch.int32))

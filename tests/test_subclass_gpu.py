@@ -1,0 +1,182 @@
+"""GPU: quantize_() + tensor subclasses for the 8-bit paths and the MXFP8 MoE forward, end to end
+through nn.Linear / the reference-named entry points, against the CPU oracle pipelines and the
+reference's own SQNR bars (test_int8_tensor.py:162, test_float8_tensor.py:402-405,
+test_mxfp8_grouped_mm.py:120-122)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import np_from_torch_bf16
+from oracle import fp8_ref as F8, int8_ref as I8, mx_ref as MX
+
+pytestmark = pytest.mark.gpu
+
+from ao_amd.prototype.mx import ScaleCalculationMode, _to_mxfp8_then_scaled_grouped_mm, mx_dequantize, to_mx  # noqa: E402
+from ao_amd.quantization import (  # noqa: E402
+    Float8DynamicActivationFloat8WeightConfig,
+    Float8Tensor,
+    Int8DynamicActivationInt8WeightConfig,
+    Int8Tensor,
+    quantize_,
+)
+
+DEV = "cuda"
+
+
+def _sqnr(x, y):
+    """torchao/quantization/utils.py:59-62 compute_error"""
+    x, y = x.double(), y.double()
+    return float(20 * torch.log10(torch.linalg.norm(x) / torch.linalg.norm(x - y)))
+
+
+def _rel(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _linear(n, k, bias, seed):
+    torch.manual_seed(seed)
+    lin = torch.nn.Linear(k, n, bias=bias).to(torch.bfloat16)
+    x = torch.randn(3, 5, k).to(torch.bfloat16)
+    return lin, x
+
+
+@pytest.mark.parametrize("n,k,bias", [(256, 512, False), (96, 1024, True)])
+def test_int8_dynamic_linear(n, k, bias):
+    lin, x = _linear(n, k, bias, n + k)
+    w = lin.weight.detach().float().numpy()
+    b = lin.bias.detach().float().numpy() if bias else None
+    y_bf16 = lin(x)
+    lin = lin.to(DEV)
+    quantize_(lin, Int8DynamicActivationInt8WeightConfig())
+    assert isinstance(lin.weight, Int8Tensor) and lin.weight.qdata.dtype == torch.int8
+    assert tuple(lin.weight.scale.shape) == (n, 1)
+    y = lin(x.to(DEV))
+    assert y.shape == (3, 5, n) and y.dtype == torch.bfloat16
+    y_ref = I8.linear(x.reshape(-1, k).float().numpy(), w, b)
+    # two bf16 roundings in the epilogue replayed exactly: at most one bf16 ulp from the oracle
+    got = np_from_torch_bf16(y).reshape(-1, n)
+    assert _rel(got, y_ref) <= 1e-3
+    assert _sqnr(y_bf16, y.cpu()) > 20  # reference bar
+    assert _sqnr(lin.weight.dequantize().cpu(), torch.from_numpy(w)) > 30
+
+
+@pytest.mark.parametrize("n,k,bias", [(256, 512, False), (96, 1024, True)])
+def test_float8_dynamic_linear(n, k, bias):
+    lin, x = _linear(n, k, bias, 3 * n + k)
+    w = lin.weight.detach().float().numpy()
+    b = lin.bias.detach().float().numpy() if bias else None
+    y_bf16 = lin(x)
+    lin = lin.to(DEV)
+    quantize_(lin, Float8DynamicActivationFloat8WeightConfig())
+    assert isinstance(lin.weight, Float8Tensor) and lin.weight.qdata.dtype == torch.float8_e4m3fn
+    y = lin(x.to(DEV))
+    y_ref = F8.linear(x.reshape(-1, k).float().numpy(), w, b)
+    assert _rel(np_from_torch_bf16(y).reshape(-1, n), y_ref) <= 1e-3  # BASELINE.json tolerance
+    assert _sqnr(y_bf16, y.cpu()) > 20  # reference bar
+
+
+def test_subclass_slices_match_full_tensor():
+    """what a TP caller does (reference testing/utils.py:471-519): N and K slices of the quantized
+    weight equal the slices of the full quantized tensor bit for bit"""
+    torch.manual_seed(0)
+    w = torch.randn(128, 512).to(torch.bfloat16).to(DEV)
+    for cls in (Int8Tensor, Float8Tensor):
+        t = cls.from_hp(w)
+        r = t[32:96]
+        assert torch.equal(r.qdata.view(torch.uint8), t.qdata[32:96].view(torch.uint8)) and torch.equal(r.scale, t.scale[32:96])
+        c = t[:, 128:384]
+        assert torch.equal(c.qdata.view(torch.uint8), t.qdata[:, 128:384].view(torch.uint8)) and torch.equal(c.scale, t.scale)
+        assert tuple(c.shape) == (128, 256)
+
+
+def test_state_dict_roundtrip():
+    import io
+
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(256, 64, bias=False).to(torch.bfloat16).to(DEV)
+    quantize_(lin, Int8DynamicActivationInt8WeightConfig())
+    buf = io.BytesIO()
+    torch.save(lin.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, weights_only=True)
+    assert isinstance(sd["weight"], Int8Tensor)
+    assert torch.equal(sd["weight"].qdata, lin.weight.qdata) and torch.equal(sd["weight"].scale, lin.weight.scale)
+
+
+@pytest.mark.parametrize("mode", [ScaleCalculationMode.FLOOR, ScaleCalculationMode.RCEIL])
+def test_to_mx_roundtrip(mode):
+    torch.manual_seed(2)
+    x = (torch.randn(64, 256) * 3).to(torch.bfloat16).to(DEV)
+    s, q = to_mx(x, torch.float8_e4m3fn, 32, mode)
+    assert s.dtype == torch.float8_e8m0fnu and q.dtype == torch.float8_e4m3fn and tuple(s.shape) == (64, 8)
+    q_ref, s_ref = MX.to_mx(x.float().cpu().numpy(), mode=(MX.RCEIL if mode == ScaleCalculationMode.RCEIL else MX.FLOOR))
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), q_ref) and np.array_equal(s.view(torch.uint8).cpu().numpy(), s_ref)
+    assert _sqnr(x.cpu(), mx_dequantize(s, q).cpu()) > 25
+
+
+def test_mxfp8_moe_grouped_forward():
+    """Mixtral-like expert GEMM at reduced size: E experts, ragged groups (multiples of 32)."""
+    torch.manual_seed(3)
+    E, K, N = 4, 512, 256
+    sizes = [32, 0, 96, 64]
+    M = sum(sizes)
+    A = torch.randn(M, K).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(E, N, K) * 0.05).to(torch.bfloat16).to(DEV)
+    B_t = W.transpose(-2, -1)  # [E, K, N] view, strides (N*K, 1, K) -- what the reference passes
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device=DEV)
+    out = _to_mxfp8_then_scaled_grouped_mm(A, B_t, offs)
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16
+    # oracle: cast both operands with the CPU restatement, emulated grouped mm
+    a_q, a_s = MX.to_mx(A.float().cpu().numpy(), mode=MX.RCEIL)
+    w_q, w_s = MX.to_mx(W.float().cpu().numpy().reshape(E * N, K), mode=MX.RCEIL)
+    ref, mag = MX.grouped_mm(a_q, a_s, w_q.reshape(E, N, K), w_s.reshape(E, N, K // 32), offs.cpu().numpy(), return_abs=True)
+    got = np_from_torch_bf16(out)
+    assert np.all(np.abs(got - ref) <= 1e-3 * mag + 1e-6)
+    # reference bar (test_mxfp8_grouped_mm.py:120-122): SQNR >= 27 dB vs the bf16 grouped mm
+    bf = torch.zeros(M, N)
+    start = 0
+    for e, sz in enumerate(sizes):
+        bf[start:start + sz] = A[start:start + sz].float().cpu() @ W[e].float().cpu().t()
+        start += sz
+    assert _sqnr(bf, out.float().cpu()) >= 27
+
+
+@pytest.mark.parametrize("kind", ["int4", "int8", "fp8"])
+def test_tp_shards_sum_to_the_unsharded_linear(kind):
+    """Row-parallel (K split) and column-parallel (N split) shards of a quantized weight, computed on
+    one GPU for every rank of a world of 2 and combined the way the collective would (sum / concat),
+    against the unsharded linear."""
+    from ao_amd.parallel import shard_bounds, shard_unit
+    from ao_amd.quantization import Int4TilePackedTo4dTensor
+
+    torch.manual_seed(4)
+    n, k, world = 256, 3584, 2  # 3584 = 28 k-blocks: K shards of 1792, not a multiple of 1024
+    w = (torch.randn(n, k) * 0.05).to(torch.bfloat16).to(DEV)
+    x = torch.randn(4, k).to(torch.bfloat16).to(DEV)
+    if kind == "int4":
+        t = Int4TilePackedTo4dTensor.from_hp(w, [1, 128])
+        t = t[:, : k]  # drop from_hp's padding to 4096 so that K shards are real columns
+    elif kind == "int8":
+        from ao_amd.quantization.int8_tensor import QuantizeTensorToInt8Kwargs
+        t = Int8Tensor.from_hp(w, act_quant_kwargs=QuantizeTensorToInt8Kwargs())
+    else:
+        from ao_amd.quantization.float8_tensor import QuantizeTensorToFloat8Kwargs
+        t = Float8Tensor.from_hp(w, act_quant_kwargs=QuantizeTensorToFloat8Kwargs())
+    y_full = torch.nn.functional.linear(x, t).float()
+    # column parallel: concat of row shards == full
+    parts = []
+    for r in range(world):
+        n0, n1 = shard_bounds(n, world, r, shard_unit(t, 0))
+        parts.append(torch.nn.functional.linear(x, t[n0:n1]).float())
+    assert torch.equal(torch.cat(parts, dim=-1), y_full)
+    # row parallel: sum of K-shard partials ~= full (activation shards are quantized locally for the
+    # 8-bit paths, so this is a different -- finer -- quantization: compare at the SQNR level)
+    acc = torch.zeros_like(y_full)
+    for r in range(world):
+        k0, k1 = shard_bounds(k, world, r, shard_unit(t, 1))
+        acc += torch.nn.functional.linear(x[:, k0:k1].contiguous(), t[:, k0:k1]).float()
+    if kind == "int4":
+        assert _rel(acc.cpu().numpy(), y_full.cpu().numpy()) <= 1e-2  # two bf16 roundings of the partials
+    else:
+        assert _sqnr(y_full.cpu(), acc.cpu()) > 25
