@@ -35,3 +35,9 @@ def get_block_size(shape, granularity):
         assert shape[-1] % granularity.group_size == 0
         return tuple([1] * (len(shape) - 1) + [granularity.group_size])
     raise ValueError(f"Unsupported Granularity: {granularity}")
+
+
+import torch as _torch  # noqa: E402
+
+# granularities ride along in the quantized tensors' attributes: allow them under torch.load(weights_only=True)
+_torch.serialization.add_safe_globals([Granularity, PerTensor, PerRow, PerGroup])
