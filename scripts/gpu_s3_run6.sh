@@ -4,5 +4,5 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-echo "== pytest subclass ==" ; timeout 600 python -m pytest tests/test_subclass_gpu.py -m gpu -q --timeout 200 2>&1 | tail -15
-echo "== 8bit bench ==" ; timeout 600 python tools/bench_8bit.py 2>&1 | grep -v amdgpu.ids | tee $O/bench_8bit_r01.jsonl
+echo "== pytest 8bit+subclass ==" ; timeout 600 python -m pytest tests/test_subclass_gpu.py tests/test_8bit_gpu.py -m gpu -q --timeout 200 2>&1 | tail -12
+echo "== 8bit bench ==" ; timeout 600 python tools/bench_8bit.py --which mx 2>&1 | grep -v amdgpu.ids | tee $O/bench_8bit_r01b.jsonl | cut -c1-250

@@ -182,3 +182,29 @@ def test_tp_shards_sum_to_the_unsharded_linear(kind):
         assert _rel(acc.cpu().numpy(), y_full.cpu().numpy()) <= 1e-2  # two bf16 roundings of the partials
     else:
         assert _sqnr(y_full.cpu(), acc.cpu()) > 25
+
+
+def test_dispatcher_ops_and_aten_override():
+    """ao_mi355::* ops run through the dispatcher; after install_aten_overrides() the EXISTING ATen op
+    names torchao calls reach the MI355X kernels (proved by the library's own launch counter)."""
+    import ctypes
+
+    from ao_amd import _lib, ops, torch_ops
+
+    torch.manual_seed(5)
+    n, k, g = 256, 1024, 128
+    w = (torch.randn(n, k) * 0.05).to(torch.bfloat16).to(DEV)
+    x = torch.randn(2, k).to(torch.bfloat16).to(DEV)
+    qdata, sz = ops.int4_quantize_tinygemm(w, g)
+    y = ops.weight_int4pack_mm(x, qdata, g, sz)
+    assert torch.equal(torch.ops.ao_mi355.weight_int4pack_mm(x, qdata, g, sz), y)
+    torch_ops.install_aten_overrides()
+    lib = _lib.lib()
+    _lib.check(lib.ao_prof_enable(4))
+    y2 = torch.ops.aten._weight_int4pack_mm(x, qdata, g, sz)
+    w_u8 = ops.unpack_int4pack(qdata)
+    q2 = torch.ops.aten._convert_weight_to_int4pack(w_u8, 8)
+    buf, cnt = (ctypes.c_float * 4)(), ctypes.c_int(0)
+    _lib.check(lib.ao_prof_collect(buf, 4, ctypes.byref(cnt)))
+    assert cnt.value == 3  # mm + unpack + pack all went through ao_amd/_C_mi355.so
+    assert torch.equal(y2, y) and torch.equal(q2, qdata)
