@@ -13,6 +13,8 @@
 // and no separate dequant pass exist.  One barrier for the split-K reduction.
 #include "common.h"
 
+#include <type_traits>
+
 namespace ao {
 namespace {
 
@@ -126,6 +128,219 @@ __global__ __launch_bounds__(512) void stream8_kernel(Stream8Args p) {
   }
 }
 
+// Buffer addressing: SGPR descriptor + SGPR offset + ONE 32-bit VGPR offset per lane, so a dozen
+// streams (TN weight tiles, MT activation rows, their scales) cost no 64-bit VGPR pointers; reads
+// past num_records return 0 (tiles past N need no clamp).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+constexpr int kAuxNT = 2;  // non-temporal: streamed once
+template <int AUX>
+__device__ __forceinline__ u32x4 buf_load_b128(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ uint32_t buf_load_b32(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MXFP8 grouped GEMM, A-stationary form (the MoE decode/prefill-at-small-batch case of BASELINE
+// config 5: a few dozen token rows per expert against 58.7 MB of expert weights).
+//
+// stream8_kernel above re-reads the expert's A rows [rows][K] from L2 for EVERY 16-wide n-tile
+// (2-4x the weight bytes per workgroup): it runs at 2.2 TB/s.  Here a workgroup owns TN n-tiles of
+// one expert, its 8 waves split each 2048-k chunk (2 k-steps of 128 per wave), a wave loads its A
+// fragments for the chunk ONCE into registers and streams the TN weight tiles past them through a
+// 4-deep register ring that runs on across chunks; per-tile accumulators stay in registers for the
+// whole K loop and meet the other waves' once, at the end (LDS, rounds of 4 tiles).
+// ---------------------------------------------------------------------------------------------
+template <int MT, int TN>
+__global__ __launch_bounds__(256) void mx_grouped_kernel(Stream8Args p) {
+  constexpr int W = 4, S = 2;                          // waves, k-steps per wave per chunk (4-wave workgroups: three fit a CU at ~150 VGPRs, so one's prologue/reduction overlaps the others' streaming)
+  constexpr int R = TN < 4 ? TN : 4;                   // tiles per reduction round
+  constexpr int D = 2;                                 // ring depth in tiles (18 VGPRs per stage; the A double buffer takes the rest)
+  static_assert(TN % D == 0 && TN % R == 0, "ring and reduction rounds must divide the tile group");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [W][R][MT][256]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int e = blockIdx.y;
+  const int row_begin = (e > 0) ? p.offs[e - 1] : 0;
+  const int rows_total = p.offs[e] - row_begin;
+  if (rows_total <= 0) return;  // uniform: empty group
+
+  const int ntiles = p.N >> 4;
+  const int tile0 = blockIdx.x * TN;
+  const int kq = lane >> 4, nl = lane & 15;
+  const int kblocks = p.K >> 5;
+  const int chunks = p.K / (W * S * 128);  // 1024 k per chunk
+
+  // this expert's weights and scales as buffers; lane offset inside a 16-row tile
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.b + (size_t)e * p.N * p.K, (uint32_t)((size_t)p.N * p.K));
+  const __amdgpu_buffer_rsrc_t rbs = make_rsrc(p.b_scale + (size_t)e * p.N * kblocks, (uint32_t)((size_t)p.N * kblocks));
+  const uint32_t b_off = (uint32_t)nl * (uint32_t)p.K + kq * 16;
+  const uint32_t bs_off = (uint32_t)nl * (uint32_t)kblocks;
+
+  for (int m_base = 0; m_base < rows_total; m_base += 16 * MT) {
+    const int rows = min(16 * MT, rows_total - m_base);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.a + (size_t)(row_begin + m_base) * p.K, (uint32_t)((size_t)rows * p.K));
+    const __amdgpu_buffer_rsrc_t ras = make_rsrc(p.a_scale + (size_t)(row_begin + m_base) * kblocks, (uint32_t)((size_t)rows * kblocks));
+    uint32_t a_off[MT], as_off[MT];
+    bool valid[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int r = t * 16 + nl;
+      valid[t] = r < rows;
+      const uint32_t rr = (uint32_t)min(r, rows - 1);
+      a_off[t] = rr * (uint32_t)p.K + kq * 16;
+      as_off[t] = rr * (uint32_t)kblocks;
+    }
+    f32x4 acc[TN][MT];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Stage {
+      u32x4 b[S][2];
+      uint32_t sb[S];
+    };
+    Stage st[D];
+    // k-step s of this wave in chunk c
+    auto kstep = [&](int c, int s) { return c * (W * S) + wave * S + s; };
+    auto issue = [&](Stage& sg, int j, int c) {
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int ks = kstep(c, s);
+        const uint32_t trow = (uint32_t)(tile0 + j) * 16u;  // tiles past N read zeros (buffer bounds)
+        sg.b[s][0] = buf_load_b128<kAuxNT>(rb, b_off, trow * (uint32_t)p.K + ks * 128);
+        sg.b[s][1] = buf_load_b128<kAuxNT>(rb, b_off + 64, trow * (uint32_t)p.K + ks * 128);
+        sg.sb[s] = buf_load_b32<0>(rbs, bs_off, trow * (uint32_t)kblocks + ks * 4);
+      }
+    };
+    // this wave's A fragments of a chunk (L2-resident).  Loads return in order, so they must be OLDER
+    // than the weight stages whose MFMAs need them: chunk 0's go out before the ring prologue, chunk
+    // c+1's at the top of chunk c (double buffer) -- fetching them at the top of their own chunk
+    // meant waiting behind every weight stage in flight, i.e. draining the ring once per chunk.
+    struct AFrag {
+      u32x4 a[S][MT][2];
+      uint32_t sa[S][MT];
+    };
+    auto load_a = [&](AFrag& f, int c) {
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int ks = kstep(c, s);
+          f.a[s][t][0] = buf_load_b128<0>(ra, a_off[t], ks * 128);
+          f.a[s][t][1] = buf_load_b128<0>(ra, a_off[t] + 64, ks * 128);
+          f.sa[s][t] = buf_load_b32<0>(ras, as_off[t], ks * 4);
+        }
+    };
+    AFrag cur, nxt;
+    load_a(cur, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ring prologue: tiles 0..D-1 of chunk 0
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(st[d], d, 0);
+
+    // One chunk: build the MFMA operands from `cur`, prefetch the next chunk's A, stream the TN tiles.
+    // No branch inside (rows beyond the group carry zero A fragments instead of skipping their MFMAs,
+    // the last chunk is a separate instantiation): any wave-uniform branch between a load and its use
+    // makes the compiler wait vmcnt(0), which drains the ring (11 GB/s per CU instead of 25).
+    auto chunk_body = [&](int c, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      i32x8 af[S][MT];
+      int sa[S][MT];
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          u32x4 a0 = cur.a[s][t][0], a1 = cur.a[s][t][1];
+          int sc = (int)(cur.sa[s][t] >> (8 * kq)) & 0xff;
+          if (!valid[t]) { a0 = u32x4{0, 0, 0, 0}; a1 = u32x4{0, 0, 0, 0}; sc = 127; }  // v_cndmask, not a branch
+          af[s][t] = i32x8{(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+          sa[s][t] = sc;
+        }
+      if (!LAST) {
+        load_a(nxt, c + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep these loads OLDER than the weight stages issued below
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const Stage& sg = st[j % D];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const int sb = (int)(sg.sb[s] >> (8 * kq)) & 0xff;
+          const i32x8 bf = {(int)sg.b[s][0].x, (int)sg.b[s][0].y, (int)sg.b[s][0].z, (int)sg.b[s][0].w,
+                            (int)sg.b[s][1].x, (int)sg.b[s][1].y, (int)sg.b[s][1].z, (int)sg.b[s][1].w};
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+            acc[j][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[s][t], bf, acc[j][t], 0, 0, 0, sa[s][t], 0, sb);
+        }
+        if (!LAST) issue(st[j % D], (j + D) % TN, c + (j + D) / TN);
+        else if (j + D < TN) issue(st[j % D], j + D, c);
+      }
+      if (!LAST) cur = nxt;
+    };
+    for (int c = 0; c + 1 < chunks; ++c) chunk_body(c, std::false_type{});
+    chunk_body(chunks - 1, std::true_type{});
+
+    // cross-wave (split-K) reduction, R tiles per round: red[wave][r][t][row 16][col 16]
+#pragma unroll
+    for (int j0 = 0; j0 < TN; j0 += R) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          float* q = red + (((size_t)wave * R + r) * MT + t) * 256 + (kq * 4) * 16 + nl;
+          q[0] = acc[j0 + r][t].x; q[16] = acc[j0 + r][t].y; q[32] = acc[j0 + r][t].z; q[48] = acc[j0 + r][t].w;
+        }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < R * MT * 256; idx += W * 64) {
+        const int r = idx / (MT * 256), t = (idx / 256) % MT, rc = idx & 255;
+        const int row = t * 16 + (rc >> 4), col = rc & 15;
+        const int tile = tile0 + j0 + r;
+        if (row < rows && tile < ntiles) {
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < W; ++w) sum += red[(((size_t)w * R + r) * MT + t) * 256 + rc];
+          p.out[(size_t)(row_begin + m_base + row) * p.N + tile * 16 + col] = f32_to_bf16_bits(sum);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int MT, int TN>
+int launch_mx_grouped_tn(const Stream8Args& p, hipStream_t stream) {
+  const int ntiles = p.N >> 4;
+  constexpr int R = TN < 4 ? TN : 4;
+  const size_t smem = (size_t)4 * R * MT * 256 * sizeof(float);
+  auto kern = mx_grouped_kernel<MT, TN>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(mx_grouped_kernel)");
+  }
+  ao::launch(kern, dim3((unsigned)((ntiles + TN - 1) / TN), (unsigned)p.E), dim3(256), smem, stream, p);
+  AO_LAUNCH_CHECK("mx_grouped_kernel launch");
+  return AO_OK;
+}
+
+// n-tiles per workgroup: as many as the accumulators allow (A is fetched once per workgroup) while
+// the grid still has >= 1024 workgroups -- only experts that received tokens do any work
+template <int MT>
+int launch_mx_grouped(const Stream8Args& p, hipStream_t stream) {
+  const int64_t ntiles = p.N >> 4;
+  auto enough = [&](int tn) { return ((ntiles + tn - 1) / tn) * p.E >= 1024; };
+  if (MT == 1 && enough(8)) return launch_mx_grouped_tn<1, 8>(p, stream);
+  if (enough(4)) return launch_mx_grouped_tn<MT, 4>(p, stream);
+  return launch_mx_grouped_tn<MT, 2>(p, stream);
+}
+
 template <bool MX>
 int launch_stream8(const Stream8Args& p, int max_rows_per_group, hipStream_t stream) {
   const int ksteps = p.K >> 7;
@@ -177,7 +392,15 @@ extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, con
   Stream8Args p{};
   p.a = a; p.a_scale = a_scale; p.b = b; p.b_scale = b_scale; p.offs = offs; p.out = out;
   p.M_total = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
-  // group sizes live on the device; size the m-tiling for the worst case the
-  // caller can have (a group cannot exceed M_total rows)
+  if (offs != nullptr && K % 2048 == 0) {
+    // Group sizes live on the device.  Size the m-tiling for twice the AVERAGE group: a larger group
+    // takes another pass over its expert's weights (correct, slower), while sizing for the worst
+    // case (one group of M_total rows) would carry 4 m-tiles of A and accumulators everywhere.
+    const int64_t guess = (2 * M_total + E - 1) / E;
+    if (guess <= 16) return launch_mx_grouped<1>(p, (hipStream_t)stream);
+    if (guess <= 32) return launch_mx_grouped<2>(p, (hipStream_t)stream);
+    return launch_mx_grouped<4>(p, (hipStream_t)stream);
+  }
+  // other K: the per-tile kernel, m-tiling for the worst case (a group cannot exceed M_total rows)
   return launch_stream8<true>(p, (int)M_total, (hipStream_t)stream);
 }

@@ -229,3 +229,28 @@ def test_mxfp8_grouped_mm_vs_oracle(sizes):
         st += sz
     sqnr = 20 * np.log10(np.linalg.norm(full) / np.linalg.norm(full - yn))
     assert sqnr >= 27, sqnr
+
+
+@pytest.mark.parametrize(
+    "sizes,n,k",
+    [([8, 8, 8, 8], 80, 2048), ([16, 16, 16, 16], 256, 4096), ([40, 0, 5, 27], 80, 2048), ([70, 1, 3, 0], 144, 4096),
+     ([3, 0, 0, 1], 2048, 2048), ([32, 32, 32, 32, 0, 0, 0, 0], 192, 6144)],
+)
+def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
+    """K % 2048 == 0 takes the A-stationary kernel (mx_grouped_kernel): every m-tiling (avg group <= 8,
+    <= 16, larger), groups larger than one pass, empty experts, N not a multiple of the tile group."""
+    E = len(sizes)
+    M = sum(sizes)
+    a = _randn_bf16((M, k), 31 + n)
+    w = _randn_bf16((E, n, k), 32 + k, 0.1)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32)
+    a_d, a_s = ops.mxfp8_quantize(a.to(DEV), "rceil")
+    w_d, w_s = ops.mxfp8_quantize(w.to(DEV), "rceil")
+    y = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+    y_ref, mag = MX.grouped_mm(
+        a_d.view(torch.uint8).cpu().numpy(), a_s.view(torch.uint8).cpu().numpy(),
+        w_d.view(torch.uint8).cpu().numpy(), w_s.view(torch.uint8).cpu().numpy(), offs.numpy(), return_abs=True,
+    )
+    yn = np_from_torch_bf16(y)
+    assert _rel(yn, y_ref) <= 1e-3
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
