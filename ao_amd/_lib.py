@@ -37,6 +37,7 @@ _SIGNATURES = {
     "ao_int4_quantize_tinygemm": [_P, _P, _P, _I64, _I64, _INT, _P],
     "ao_int4_set_tuning": [_INT, _INT],
     "ao_int4_set_trace": [_P],
+    "ao_gemm8_set_variant": [_INT],
     "ao_int4_mm_kernel_name": [_I64, _I64, _I64, _INT],
     "ao_int8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _P],
     "ao_int8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],

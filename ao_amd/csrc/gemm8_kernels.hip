@@ -184,8 +184,196 @@ __global__ __launch_bounds__(THREADS) void gemm8_kernel(Gemm8Args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same GEMM with LDS-DMA staging (global_load_lds_dwordx4: 1 KiB per wave instruction straight
+// into LDS, no VGPR round trip, no ds_write pass) -- the single biggest step of the CDNA4 GEMM ladder
+// for this two-barrier structure.  LDS-DMA writes lane-linear, so rows cannot be padded; bank
+// conflicts of the fragment reads are removed by a swizzle applied on the SOURCE address instead:
+// LDS[row][chunk'] holds global 16-byte chunk  chunk' ^ f(row),  f(row) = (row & 7) ^ ((row >> 3) & 7)
+// (within the 16 rows of every ds_read_b128 lane group, f is a bijection per row parity -> 16
+// distinct 16-byte bank slots).  Needs K % 128 == 0; ragged M/N rows are clamped (never stored).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 3) & 7); }
+
+// TM = 32-row MFMA tiles per wave along M: wave tile (TM*32) x 64, workgroup tile (TM*64) x 128.
+// At TM = 2 every K step moves 64 KiB from LDS per CU for 512 MFMA cycles per SIMD -- LDS time equals
+// MFMA time; TM = 4 (256 x 128 workgroup tile, 128 accumulator registers per lane) does 1024 MFMA
+// cycles per 96 KiB of LDS reads.
+template <int EPI, int TM>
+__global__ __launch_bounds__(THREADS) void gemm8_dma_kernel(Gemm8Args p) {
+  constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE);
+  constexpr int WGM = TM * 64;            // workgroup rows
+  constexpr int A_TILE = WGM * BK;        // bytes, unpadded
+  constexpr int B_TILE = BN * BK;
+  constexpr int A_DMAS = WGM / 32;        // 1 KiB DMA instructions per wave for the A tile (8 rows each, 4 waves)
+  using acc_t = typename Acc<EPI>::type;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 bufs][A tile | B tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * WGM, n0 = blockIdx.x * BN;
+  const int ktiles = p.K / BK;
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem));
+
+  // DMA sources: wave w fills rows (w*A_DMAS + i)*8 .. +7 of the A tile (and (w*4 + i)*8 of the B tile);
+  // lane l lands at row r0 + (l >> 3), position l & 7 -> it must fetch chunk (l & 7) ^ f(row)
+  const uint8_t* asrc[A_DMAS];
+  const uint8_t* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < A_DMAS; ++i) {
+    const int row = (wave * A_DMAS + i) * 8 + (lane >> 3);
+    asrc[i] = p.a + (size_t)min(m0 + row, p.M - 1) * p.K + (((lane & 7) ^ swz(row)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+    bsrc[i] = p.b + (size_t)min(n0 + row, p.N - 1) * p.K + (((lane & 7) ^ swz(row)) << 4);
+  }
+  auto stage = [&](int kt, int buf) {
+    const uint32_t abase = lds0 + buf * (A_TILE + B_TILE);
+#pragma unroll
+    for (int i = 0; i < A_DMAS; ++i) dma16(asrc[i] + (size_t)kt * BK, abase + (wave * A_DMAS + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(bsrc[i] + (size_t)kt * BK, abase + A_TILE + (wave * 4 + i) * 1024);
+  };
+
+  acc_t acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+  // fragment addressing: row = lane & 31 of the 32-row MFMA tile, logical chunks (lane >> 5) * 2 + {0, 1} of each
+  // 64-byte k-slice; physical chunk = logical ^ f(row)
+  const int frow = lane & 31, fc = (lane >> 5) * 2;
+  int arow_off[TM], asw[TM], brow_off[2], bsw[2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int ra = wm * (TM * 32) + i * 32 + frow;
+    arow_off[i] = ra * BK; asw[i] = swz(ra);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb = wn * 64 + j * 32 + frow;
+    brow_off[j] = rb * BK; bsw[j] = swz(rb);
+  }
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ktiles) stage(kt + 1, buf ^ 1);
+    const char* abase = smem + buf * (A_TILE + B_TILE);
+    const char* bbase = abase + A_TILE;
+#pragma unroll
+    for (int kc = 0; kc < BK / 64; ++kc) {
+      u32x4 af[TM][2], bf[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = kc * 4 + fc + h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i][h] = *reinterpret_cast<const u32x4*>(abase + arow_off[i] + ((c ^ asw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j][h] = *reinterpret_cast<const u32x4*>(bbase + brow_off[j] + ((c ^ bsw[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (IS_INT) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const i32x4 av = {(int)af[i][h].x, (int)af[i][h].y, (int)af[i][h].z, (int)af[i][h].w};
+              const i32x4 bv = {(int)bf[j][h].x, (int)bf[j][h].y, (int)bf[j][h].z, (int)bf[j][h].w};
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, bv, acc[i][j], 0, 0, 0);
+            }
+          } else {
+            const i32x8 av = {(int)af[i][0].x, (int)af[i][0].y, (int)af[i][0].z, (int)af[i][0].w,
+                              (int)af[i][1].x, (int)af[i][1].y, (int)af[i][1].z, (int)af[i][1].w};
+            const i32x8 bv = {(int)bf[j][0].x, (int)bf[j][0].y, (int)bf[j][0].z, (int)bf[j][0].w,
+                              (int)bf[j][1].x, (int)bf[j][1].y, (int)bf[j][1].z, (int)bf[j][1].w};
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 0, 0, 0, 127, 0, 127);
+          }
+        }
+    }
+    // next tile landed (this wave's DMAs) and everybody is done reading `buf`
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+
+  // epilogue: C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gn = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (gn >= p.N) continue;
+      float cs = 1.f, bias = 0.f;
+      if (EPI != EPI_INT32) {
+        cs = p.col_scale[gn];
+        if (p.bias != nullptr) bias = bf16_lo_to_f32(p.bias[gn]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm >= p.M) continue;
+        if (EPI == EPI_INT32) {
+          reinterpret_cast<int32_t*>(p.out)[(size_t)gm * p.N + gn] = (int32_t)acc[i][j][r];
+        } else if (EPI == EPI_INT8_SCALED) {
+          const float t = round_bf16((float)acc[i][j][r] * p.row_scale[gm]);
+          float y = t * cs;
+          if (p.bias != nullptr) y += bias;
+          reinterpret_cast<uint16_t*>(p.out)[(size_t)gm * p.N + gn] = f32_to_bf16_bits(y);
+        } else {
+          float y = (float)acc[i][j][r] * p.row_scale[gm] * cs;
+          if (p.bias != nullptr) y += bias;
+          reinterpret_cast<uint16_t*>(p.out)[(size_t)gm * p.N + gn] = f32_to_bf16_bits(y);
+        }
+      }
+    }
+}
+
+bool g_gemm8_force_regstage = false;  // profiling: ao_gemm8_set_variant(1)
+
+int g_gemm8_tm = 0;  // profiling: 0 = by shape, 2 / 4 = force
+
+template <int EPI, int TM>
+int launch_gemm8_dma_tm(const Gemm8Args& p, hipStream_t stream) {
+  constexpr int WGM = TM * 64;
+  dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + WGM - 1) / WGM)), block(THREADS);
+  const size_t smem = 2 * (size_t)(WGM + BN) * BK;  // 64 KiB (TM = 2) / 96 KiB (TM = 4)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_dma_kernel<EPI, TM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(gemm8_dma_kernel)");
+    attr_set = true;
+  }
+  ao::launch(gemm8_dma_kernel<EPI, TM>, grid, block, smem, stream, p);
+  AO_LAUNCH_CHECK("gemm8_dma_kernel launch");
+  return AO_OK;
+}
+
+template <int EPI>
+int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
+  // Product: 128-row tiles (2 workgroups per CU).  The 256-row tile halves LDS traffic per MFMA but runs one
+  // wave per SIMD, and with this two-barrier loop nothing hides its ds_read -> MFMA latency: measured 0.75-0.95x
+  // (profiles/bench_8bit_r01_gemm.txt).  It needs the multi-phase schedule first; kept as a profiling variant.
+  return g_gemm8_tm == 4 ? launch_gemm8_dma_tm<EPI, 4>(p, stream) : launch_gemm8_dma_tm<EPI, 2>(p, stream);
+}
+
 template <int EPI>
 int launch_gemm8(const Gemm8Args& p, hipStream_t stream) {
+  if (p.K % BK == 0 && !g_gemm8_force_regstage) return launch_gemm8_dma<EPI>(p, stream);
   dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM)), block(THREADS);
   const size_t smem = 2 * 2 * TILE_BYTES;  // 73,728 B
   static bool attr_set = false;
@@ -212,6 +400,12 @@ int check_gemm_shape(const char* fn, int64_t M, int64_t N, int64_t K) {
 }  // namespace ao
 
 using namespace ao;
+
+extern "C" int ao_gemm8_set_variant(int variant) {
+  g_gemm8_force_regstage = (variant == 1);
+  g_gemm8_tm = (variant == 2 || variant == 4) ? variant : 0;
+  return AO_OK;
+}
 
 extern "C" int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const int8_t* wq, const float* w_scale,
                                  const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K, void* stream) {

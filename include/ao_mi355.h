@@ -105,6 +105,9 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
  * workgroup (0 = heuristic) and a profiling mode (0 = product kernel; 1/2 =
  * ablation builds, 12/18 = prefetch depth 2/8) of the int4 mm. */
 int ao_int4_set_tuning(int waves_per_block, int mode);
+/* Profiling only: 0 = product dispatch of the 8-bit GEMMs (LDS-DMA staged kernel when K % 128 == 0),
+ * 1 = force the register-staged kernel, 2 / 4 = force the LDS-DMA kernel with 128- / 256-row tiles. */
+int ao_gemm8_set_variant(int variant);
 /* Name of the kernel ao_int4_weight_int4pack_mm launches for this problem (product dispatch, no
  * tuning override): what a profiler's kernel table should be matched against.  Static string. */
 const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size);
