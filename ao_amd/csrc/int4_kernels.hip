@@ -59,31 +59,21 @@ __device__ __forceinline__ void dequant_word(uint32_t p, float s, float neg8s, f
 }
 
 // ---------------------------------------------------------------------------
-// MFMA-assisted variants of the same exact sequence.  The VALU issue rates
-// measured on gfx950 (profiles/ubench_valu_r01.txt: ~4.4 cycles for cvt/shift/
-// VOP3, ~2.2 per value for packed-fp32 and plain VOP2) make the all-VALU replay
-// ~18 cycles per weight; the matrix pipe is idle in a GEMV, so the steps that
-// are pure data movement + one IEEE add are moved onto it with an identity
-// A-operand:   D = I * B + C   returns each lane's own four bf16 values widened
-// to fp32 plus C (one product per output, so the fp32 result is the correctly
-// rounded b + c):
-//   #1  B = bf16(128 + q) built with one v_perm per pair, C = -136  ->  q - 8
-//   #2  B = t = bf16((q-8)*s),                          C = z      ->  fl32(t + z)
-// DQ: 0 = all VALU, 1 = #2 on a 16x16x16 MFMA, 2 = #1 and #2 on 4x4x4 MFMAs,
-//     3 = #1 and #2 on 16x16x16 MFMAs.
+// The product form of the same exact sequence (DQ = 4; DQ = 0 is the all-VALU form above, kept
+// for A/B profiling).  All VALU instructions cost ~4.4 issue cycles per wave64 on gfx950
+// (profiles/ubench_valu_r01.txt) and the matrix pipe is idle in a GEMV, so:
+//   * q -> fp32: a byte holding q (0..15) read as OCP e4m3 is q * 2^-9, so
+//     v_cvt_scalef32_pk_f32_fp8 with scale 2^9 converts two nibbles per instruction, exactly;
+//   * the IEEE add t + z runs on the matrix pipe:  D = I * B + C  with an identity A operand
+//     returns each lane's own four bf16 values widened to fp32 plus C (one product per output, so
+//     the fp32 result is the correctly rounded sum).
 // ---------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 template <int DQ>
 __device__ __forceinline__ s16x4 identity_fragment(int lane) {
-  // row `i` of the identity held by this lane as an A operand (4 bf16, k' = base..base+3)
-  int hot;  // which of the 4 elements is 1.0 (or -1 for none)
-  if (DQ == 2 || DQ == 4) {
-    hot = lane & 3;  // 4x4x4: lane holds row (lane & 3), k = 0..3
-  } else {
-    const int i = lane & 15, base = (lane >> 4) * 4;  // 16x16x16: k' = base..base+3
-    hot = (i >= base && i < base + 4) ? (i - base) : -1;
-  }
+  // row (lane & 3) of the 4x4 identity as a 4x4x4 A operand (4 bf16, k = 0..3)
+  const int hot = lane & 3;
   s16x4 f;
   f.x = hot == 0 ? (short)0x3F80 : (short)0;
   f.y = hot == 1 ? (short)0x3F80 : (short)0;
@@ -95,59 +85,26 @@ __device__ __forceinline__ s16x4 identity_fragment(int lane) {
 template <int DQ>
 __device__ __forceinline__ f32x4 widen_add(s16x4 ident, uint32_t lo_pair, uint32_t hi_pair, f32x4 c) {
   const u32x2 bb = {lo_pair, hi_pair};
-  const s16x4 b = __builtin_bit_cast(s16x4, bb);
-  if (DQ == 2 || DQ == 4) return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ident, b, c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ident, b, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ident, __builtin_bit_cast(s16x4, bb), c, 0, 0, 0);
 }
 
 template <int DQ>
 __device__ __forceinline__ void dequant_word_mfma(uint32_t p, float s, float neg8s, float z, s16x4 ident,
                                                   uint32_t (&out)[4]) {
-  uint32_t lo = p & 0x0F0F0F0Fu;         // bytes: v0, v4, v1, v5
-  uint32_t hi = (p >> 4) & 0x0F0F0F0Fu;  // bytes: v2, v6, v3, v7
-  uint32_t tp[4];                        // t = bf16((q-8)*s) as packed pairs 01,23,45,67
-  if (DQ == 4) {
-    // a byte holding q (0..15) read as OCP e4m3 is q * 2^-9 (subnormal spacing ==
-    // first-binade spacing), so v_cvt_scalef32_pk_f32_fp8 with scale 2^9 converts
-    // two nibbles per instruction, exactly.
-    const f32x2 r0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, false);  // q0, q4
-    const f32x2 r1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, true);   // q1, q5
-    const f32x2 r2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, false);  // q2, q6
-    const f32x2 r3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, true);   // q3, q7
-    const f32x2 t0 = r0 * s + neg8s, t1 = r1 * s + neg8s, t2 = r2 * s + neg8s, t3 = r3 * s + neg8s;
-    tp[0] = pack_bf16x2(t0.x, t1.x); tp[1] = pack_bf16x2(t2.x, t3.x);
-    tp[2] = pack_bf16x2(t0.y, t1.y); tp[3] = pack_bf16x2(t2.y, t3.y);
-  } else if (DQ >= 2) {
-    const uint32_t k43 = 0x43434343u;    // bf16 0x43xx = 128 + xx
-    const uint32_t q01 = __builtin_amdgcn_perm(k43, lo, 0x04020400u);
-    const uint32_t q45 = __builtin_amdgcn_perm(k43, lo, 0x04030401u);
-    const uint32_t q23 = __builtin_amdgcn_perm(k43, hi, 0x04020400u);
-    const uint32_t q67 = __builtin_amdgcn_perm(k43, hi, 0x04030401u);
-    const f32x4 m136 = {-136.f, -136.f, -136.f, -136.f};
-    const f32x4 u0 = widen_add<DQ>(ident, q01, q23, m136);  // q0..q3 - 8, exact
-    const f32x4 u1 = widen_add<DQ>(ident, q45, q67, m136);  // q4..q7 - 8
-    const f32x2 a = f32x2{u0.x, u0.y} * s, b = f32x2{u0.z, u0.w} * s;
-    const f32x2 c = f32x2{u1.x, u1.y} * s, d = f32x2{u1.z, u1.w} * s;
-    tp[0] = pack_bf16x2(a.x, a.y); tp[1] = pack_bf16x2(b.x, b.y);
-    tp[2] = pack_bf16x2(c.x, c.y); tp[3] = pack_bf16x2(d.x, d.y);
-  } else {
-    asm("" : "+v"(lo));
-    asm("" : "+v"(hi));
-    const float f0 = (float)(lo & 0xffu), f4 = (float)((lo >> 8) & 0xffu);
-    const float f1 = (float)((lo >> 16) & 0xffu), f5 = (float)(lo >> 24);
-    const float f2 = (float)(hi & 0xffu), f6 = (float)((hi >> 8) & 0xffu);
-    const float f3 = (float)((hi >> 16) & 0xffu), f7 = (float)(hi >> 24);
-    const f32x2 q[4] = {{f0, f1}, {f2, f3}, {f4, f5}, {f6, f7}};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x2 t = q[i] * s + neg8s;
-      tp[i] = pack_bf16x2(t.x, t.y);
-    }
-  }
+  static_assert(DQ == 4, "DQ: 0 (all VALU, dequant_word) or 4 (this)");
+  const uint32_t lo = p & 0x0F0F0F0Fu;         // bytes: v0, v4, v1, v5
+  const uint32_t hi = (p >> 4) & 0x0F0F0F0Fu;  // bytes: v2, v6, v3, v7
+  const f32x2 r0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, false);  // q0, q4
+  const f32x2 r1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, true);   // q1, q5
+  const f32x2 r2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, false);  // q2, q6
+  const f32x2 r3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, true);   // q3, q7
+  const f32x2 t0 = r0 * s + neg8s, t1 = r1 * s + neg8s, t2 = r2 * s + neg8s, t3 = r3 * s + neg8s;
+  const uint32_t tp0 = pack_bf16x2(t0.x, t1.x), tp1 = pack_bf16x2(t2.x, t3.x);  // t = bf16((q-8)*s): rounding #1
+  const uint32_t tp2 = pack_bf16x2(t0.y, t1.y), tp3 = pack_bf16x2(t2.y, t3.y);
   const f32x4 zz = {z, z, z, z};
-  const f32x4 w0 = widen_add<DQ>(ident, tp[0], tp[1], zz);  // fl32(t + z), lanes' own values
-  const f32x4 w1 = widen_add<DQ>(ident, tp[2], tp[3], zz);
-  out[0] = pack_bf16x2(w0.x, w0.y); out[1] = pack_bf16x2(w0.z, w0.w);
+  const f32x4 w0 = widen_add<DQ>(ident, tp0, tp1, zz);  // fl32(t + z), lanes' own values
+  const f32x4 w1 = widen_add<DQ>(ident, tp2, tp3, zz);
+  out[0] = pack_bf16x2(w0.x, w0.y); out[1] = pack_bf16x2(w0.z, w0.w);  // rounding #2
   out[2] = pack_bf16x2(w1.x, w1.y); out[3] = pack_bf16x2(w1.z, w1.w);
 }
 
@@ -171,7 +128,7 @@ struct XRegs {
 };
 
 // ABL: ablation builds for profiling only (0 = product kernel; 1 = loads but no
-// dequant/MFMA; 2 = dequant/MFMA but no weight loads)
+// dequant/MFMA)
 template <int G, int MAXM, int DEPTH, int ABL = 0, int DQ = 4>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
@@ -285,7 +242,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
       const float sc = bf16_lo_to_f32(s.sz[gi]);
       const float zp = bf16_hi_to_f32(s.sz[gi]);
       uint32_t b[4];
-      if (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
+      if constexpr (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
       else dequant_word_mfma<DQ>(wds[j], sc, -8.0f * sc, zp, ident, b);
       const u32x4 bv = {b[0], b[1], b[2], b[3]};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
@@ -453,7 +410,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
       const float sc = bf16_lo_to_f32(s.sz[gi]);
       const float zp = bf16_hi_to_f32(s.sz[gi]);
       uint32_t b[4];
-      if (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
+      if constexpr (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
       else dequant_word_mfma<DQ>(wds[j], sc, -8.0f * sc, zp, ident, b);
       const u32x4 bv = {b[0], b[1], b[2], b[3]};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
@@ -483,197 +440,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
   }
 
   // ---- 4. split-K reduction: row 0 of the tile lives in acc.x of lanes 0..15
-  if (lane < 16) red[wave * 16 + lane] = acc.x;
-  __syncthreads();
-  if (tid < 16) {
-    float sum = 0.f;
-    for (int w = 0; w < nwaves; ++w) sum += red[w * 16 + tid];
-    y[ntile * 16 + tid] = f32_to_bf16_bits(sum);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// M == 1 GEMV, wave-private variant (no workgroup barrier before the reduction):
-// each wave stages only the x slice of ITS k-range into a private LDS slab in
-// A-fragment order (one 16-byte global load + two ds_write_b64 per lane per 4
-// weight blocks), then streams its weight blocks.  The dequant chain of word
-// j+1 (VALU) is software-pipelined against the MFMAs of word j.
-// ---------------------------------------------------------------------------
-struct DqA { uint32_t tp[4]; };  // t = bf16((q-8)*s), packed pairs 01,23,45,67
-
-// FMA: 0 = v_pk_fma_f32 (2 values / op), 1 = scalar v_fma_f32, 2 = v_mul_f32 + v_add_f32 (VOP2 pairs)
-__device__ __forceinline__ float fma_asm(float a, float b, float c) {
-  float r;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-__device__ __forceinline__ float mul_add_asm(float a, float b, float c) {
-  float r;
-  asm("v_mul_f32 %0, %1, %2\n\tv_add_f32 %0, %0, %3" : "=&v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-template <int FMA>
-__device__ __forceinline__ f32x2 scale_shift(f32x2 q, float s, float neg8s) {
-  if (FMA == 1) return f32x2{fma_asm(q.x, s, neg8s), fma_asm(q.y, s, neg8s)};
-  if (FMA == 2) return f32x2{mul_add_asm(q.x, s, neg8s), mul_add_asm(q.y, s, neg8s)};
-  return q * s + neg8s;
-}
-
-template <int FMA = 0>
-__device__ __forceinline__ DqA dq_stage_a(uint32_t p, float s, float neg8s) {
-  const uint32_t lo = p & 0x0F0F0F0Fu;         // bytes: v0, v4, v1, v5
-  const uint32_t hi = (p >> 4) & 0x0F0F0F0Fu;  // bytes: v2, v6, v3, v7
-  const f32x2 r0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, false);  // q0, q4
-  const f32x2 r1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, true);   // q1, q5
-  const f32x2 r2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, false);  // q2, q6
-  const f32x2 r3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, true);   // q3, q7
-  const f32x2 t0 = scale_shift<FMA>(r0, s, neg8s), t1 = scale_shift<FMA>(r1, s, neg8s);
-  const f32x2 t2 = scale_shift<FMA>(r2, s, neg8s), t3 = scale_shift<FMA>(r3, s, neg8s);
-  DqA a;
-  a.tp[0] = pack_bf16x2(t0.x, t1.x); a.tp[1] = pack_bf16x2(t2.x, t3.x);
-  a.tp[2] = pack_bf16x2(t0.y, t1.y); a.tp[3] = pack_bf16x2(t2.y, t3.y);
-  return a;
-}
-
-template <int G, int SCHED, int WPE, int ABL = 0, int FMA = 0>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void int4_gemv3_kernel(
-    const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz,
-    uint16_t* __restrict__ y, int N, int K, int slab_bytes) {
-  constexpr int NG = (G >= 128) ? 1 : (128 / G);
-  constexpr int DEPTH = 4;
-  constexpr int MAXCH = 4;  // x chunks (4 blocks each) per wave: <= 16 weight blocks per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [nwaves][slab_bytes] + [nwaves*16 f32]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwaves = blockDim.x >> 6;
-  const int ntile = blockIdx.x;
-  const int kblocks = K >> 7;
-  const int kb0 = (kblocks * wave) / nwaves;
-  const int kb1 = (kblocks * (wave + 1)) / nwaves;
-  const int nb = kb1 - kb0;
-  const int n = ntile * 16 + (lane & 15);
-  const int kq = lane >> 4;
-
-  char* slab = smem + (size_t)wave * slab_bytes;  // [nb][4 kq][4 j][16 B] then a 64-byte zero row
-  char* zero_row = slab + slab_bytes - 64;
-  float* red = reinterpret_cast<float*>(smem + (size_t)nwaves * slab_bytes);
-
-  // x slice loads: chunk c covers blocks kb0 + 4c .. +3, lane owns 8 consecutive k
-  u32x4 xc[MAXCH];
-#pragma unroll
-  for (int c = 0; c < MAXCH; ++c) {
-    const int blk = 4 * c + (lane >> 4);
-    if (blk < nb) xc[c] = *reinterpret_cast<const u32x4*>(x + (size_t)(kb0 + blk) * 128 + (lane & 15) * 8);
-  }
-
-  struct Stage {
-    u32x4 w;
-    uint32_t sz[NG];
-  };
-  Stage st[DEPTH];
-  const u32x4* wp = qdata + ((size_t)ntile * kblocks) * 64 + lane;
-  auto issue = [&](Stage& s, int kb) {
-    if (ABL == 2) {
-      s.w = u32x4{(uint32_t)lane * 0x01010101u, (uint32_t)kb, 0x12345678u, (uint32_t)lane};
-    } else {
-      s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
-    }
-    const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
-#pragma unroll
-    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
-  };
-  const int kb_last = max(kb1 - 1, kb0);
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
-
-  // x -> private slab.  Lane's 8 k's of block `blk`: offset o = (lane & 15) * 8 inside the block,
-  // j = o >> 5, h = (o >> 4) & 1, and the two 4-k halves belong to kq = 2*(lane&1) and 2*(lane&1)+1.
-  {
-    const int l15 = lane & 15;
-    const int j = l15 >> 2, h = (l15 >> 1) & 1, kq_lo = (l15 & 1) * 2;
-    const int in_blk = kq_lo * 64 + j * 16 + h * 8;
-#pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-      const int blk = 4 * c + (lane >> 4);
-      if (blk < nb) {
-        char* d = slab + blk * 256 + in_blk;
-        *reinterpret_cast<u32x2*>(d) = u32x2{xc[c].x, xc[c].y};
-        *reinterpret_cast<u32x2*>(d + 64) = u32x2{xc[c].z, xc[c].w};
-      }
-    }
-    if (lane < 16) reinterpret_cast<uint32_t*>(zero_row)[lane] = 0u;
-  }
-
-  const bool row0 = (lane & 15) == 0;
-  const char* a_ptr = row0 ? (slab + kq * 64) : zero_row;
-  const int a_step = row0 ? 256 : 0;
-
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const s16x4 ident = identity_fragment<4>(lane);
-
-  auto consume = [&](const Stage& s) {
-    if (ABL == 1) {
-      acc.x += bits_to_f32((s.w.x ^ s.w.y ^ s.w.z ^ s.w.w ^ s.sz[0]) & 0x3f800000u);
-      return;
-    }
-    u32x4 a[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_ptr + j * 16);
-    a_ptr += a_step;
-    const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
-    float sc[4], zp[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
-      sc[j] = bf16_lo_to_f32(s.sz[gi]);
-      zp[j] = bf16_hi_to_f32(s.sz[gi]);
-    }
-    DqA ta = dq_stage_a<FMA>(wds[0], sc[0], -8.0f * sc[0]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 zz = {zp[j], zp[j], zp[j], zp[j]};
-      const f32x4 w0 = widen_add<4>(ident, ta.tp[0], ta.tp[1], zz);  // MFMA 4x4x4: fl32(t + z)
-      const f32x4 w1 = widen_add<4>(ident, ta.tp[2], ta.tp[3], zz);
-      if (j < 3) ta = dq_stage_a<FMA>(wds[j + 1], sc[j + 1], -8.0f * sc[j + 1]);  // next word's VALU under the MFMAs
-      const u32x4 bv = {pack_bf16x2(w0.x, w0.y), pack_bf16x2(w0.z, w0.w), pack_bf16x2(w1.x, w1.y),
-                        pack_bf16x2(w1.z, w1.w)};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
-                                                    __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
-      if (SCHED == 1) {
-        // per word: MFMA4, 6 VALU, MFMA4, 6 VALU (stage A of the next word), 4 VALU (cvt_pk), MFMA16, 3 VALU
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x2, 10, 0);
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
-      }
-    }
-  };
-
-  int kb = kb0;
-  for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      consume(st[d]);
-      issue(st[d], kb + d + DEPTH);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (kb + d < kb1) {
-      consume(st[d]);
-      if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
-    }
-  }
-  kb += DEPTH;
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (kb + d < kb1) consume(st[d]);
-  }
-
   if (lane < 16) red[wave * 16 + lane] = acc.x;
   __syncthreads();
   if (tid < 16) {
@@ -844,7 +610,7 @@ __global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __res
 }
 
 int g_tune_wpb = 0;
-int g_tune_mode = 0;  // profiling only: 1/2 = ablations, 12/18 = prefetch depth 2/8, 21/22/23 = dequant variant DQ (G=128, M=1)
+int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 100/101/110 per-tile M = 1 kernel (product / loads only / all-VALU dequant), 400-403 streaming kernel
 
 template <int G, int MAXM>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
@@ -865,26 +631,6 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
   const size_t smem = (size_t)wpb * (SLAB + 1024);
   dim3 grid((unsigned)ntiles, (unsigned)mslabs), block(wpb * 64);
-  if (G == 128 && MAXM == 1 && g_tune_mode != 0 && g_tune_mode != 99) {
-    const u32x4* q4 = reinterpret_cast<const u32x4*>(qdata);
-    const uint32_t* sz4 = reinterpret_cast<const uint32_t*>(sz);
-    switch (g_tune_mode) {
-      case 1: ao::launch((int4_mm_kernel<128, 1, 4, 1, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 2: ao::launch((int4_mm_kernel<128, 1, 4, 2, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 12: ao::launch((int4_mm_kernel<128, 1, 2, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 18: ao::launch((int4_mm_kernel<128, 1, 8, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 20: ao::launch((int4_mm_kernel<128, 1, 4, 0, 0>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 21: ao::launch((int4_mm_kernel<128, 1, 4, 0, 1>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 22: ao::launch((int4_mm_kernel<128, 1, 4, 0, 2>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 24: ao::launch((int4_mm_kernel<128, 1, 4, 0, 4>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 34: ao::launch((int4_mm_kernel<128, 1, 4, 2, 4>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 32: ao::launch((int4_mm_kernel<128, 1, 4, 2, 2>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      case 23: ao::launch((int4_mm_kernel<128, 1, 4, 0, 3>), grid, block, smem, stream, x, q4, sz4, y, (int)M, (int)N, (int)K); break;
-      default: ao::set_error("bad tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
-    }
-    AO_LAUNCH_CHECK("int4_mm_kernel (tuning variant) launch");
-    return AO_OK;
-  }
   ao::launch((int4_mm_kernel<G, MAXM, DEPTH>), grid, block, smem, stream, x,
                      reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
                      (int)M, (int)N, (int)K);
@@ -911,19 +657,6 @@ int launch_gemv_variant(const uint16_t* x, const int32_t* qdata, const uint16_t*
   return AO_OK;
 }
 
-template <int G, int SCHED, int WPE, int ABL, int FMA = 0>
-int launch_gemv3_variant(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N,
-                         int64_t K, int wpb, hipStream_t stream) {
-  const int kblocks = (int)(K >> 7);
-  const int nb_max = (kblocks + wpb - 1) / wpb;
-  const int slab = nb_max * 256 + 64;
-  const size_t smem = (size_t)wpb * slab + (size_t)wpb * 16 * sizeof(float);
-  ao::launch(int4_gemv3_kernel<G, SCHED, WPE, ABL, FMA>, dim3((unsigned)(N >> 4)), dim3(wpb * 64), smem, stream, x,
-             reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)N, (int)K, slab);
-  AO_LAUNCH_CHECK("int4_gemv3_kernel launch");
-  return AO_OK;
-}
-
 constexpr int64_t kManyTiles = 1024;  // n-tiles from which the per-tile grid beats the persistent one
 constexpr int64_t kGemvMaxK = 65536;  // x (2 B/k) must fit LDS next to the reduction scratch
 
@@ -938,38 +671,10 @@ int launch_gemv(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   if (ntiles * wpb > 256 * 32 && wpb > 4) wpb /= 2;
   if (g_tune_wpb >= 1 && g_tune_wpb <= 16) wpb = g_tune_wpb;
   if (wpb > kblocks) wpb = kblocks;
-  if (g_tune_mode >= 300 && g_tune_mode < 400) {
-    while (kblocks > 16 * wpb) wpb *= 2;  // <= 16 blocks per wave
-    if (wpb > 16) { ao::set_error("gemv3: K too large"); return AO_ERR_INVALID_ARGUMENT; }
-    switch (g_tune_mode) {
-      case 300: return launch_gemv3_variant<G, 0, 6, 0>(x, qdata, sz, y, N, K, wpb, stream);
-      case 301: return launch_gemv3_variant<G, 1, 6, 0>(x, qdata, sz, y, N, K, wpb, stream);
-      case 304: return launch_gemv3_variant<G, 0, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
-      case 305: return launch_gemv3_variant<G, 1, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
-      case 308: return launch_gemv3_variant<G, 0, 8, 0>(x, qdata, sz, y, N, K, wpb, stream);
-      case 309: return launch_gemv3_variant<G, 1, 8, 0>(x, qdata, sz, y, N, K, wpb, stream);
-      case 311: return launch_gemv3_variant<G, 0, 6, 1>(x, qdata, sz, y, N, K, wpb, stream);
-      case 312: return launch_gemv3_variant<G, 0, 6, 2>(x, qdata, sz, y, N, K, wpb, stream);
-      case 313: return launch_gemv3_variant<G, 1, 6, 2>(x, qdata, sz, y, N, K, wpb, stream);
-      case 320: return launch_gemv3_variant<G, 0, 6, 0, 1>(x, qdata, sz, y, N, K, wpb, stream);
-      case 321: return launch_gemv3_variant<G, 1, 6, 0, 1>(x, qdata, sz, y, N, K, wpb, stream);
-      case 322: return launch_gemv3_variant<G, 0, 6, 2, 1>(x, qdata, sz, y, N, K, wpb, stream);
-      case 330: return launch_gemv3_variant<G, 0, 6, 0, 2>(x, qdata, sz, y, N, K, wpb, stream);
-      case 331: return launch_gemv3_variant<G, 1, 6, 0, 2>(x, qdata, sz, y, N, K, wpb, stream);
-      case 332: return launch_gemv3_variant<G, 0, 6, 2, 2>(x, qdata, sz, y, N, K, wpb, stream);
-      default: ao::set_error("bad gemv3 tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
-    }
-  }
   switch (g_tune_mode) {
     case 0: case 100: return launch_gemv_variant<G, 4, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
-    case 101: return launch_gemv_variant<G, 4, 4, 1>(x, qdata, sz, y, N, K, wpb, stream);
-    case 102: return launch_gemv_variant<G, 4, 4, 2>(x, qdata, sz, y, N, K, wpb, stream);
-    case 110: return launch_gemv_variant<G, 4, 0, 0>(x, qdata, sz, y, N, K, wpb, stream);
-    case 112: return launch_gemv_variant<G, 4, 2, 0>(x, qdata, sz, y, N, K, wpb, stream);
-    case 120: return launch_gemv_variant<G, 2, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
-    case 180: return launch_gemv_variant<G, 8, 4, 0, 4>(x, qdata, sz, y, N, K, wpb, stream);
-    case 104: return launch_gemv_variant<G, 4, 4, 0, 4>(x, qdata, sz, y, N, K, wpb, stream);
-    case 106: return launch_gemv_variant<G, 4, 4, 0, 6>(x, qdata, sz, y, N, K, wpb, stream);
+    case 101: return launch_gemv_variant<G, 4, 4, 1>(x, qdata, sz, y, N, K, wpb, stream);  // loads only
+    case 110: return launch_gemv_variant<G, 4, 0, 0>(x, qdata, sz, y, N, K, wpb, stream);  // all-VALU dequant
     default: ao::set_error("bad gemv tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
   }
 }
@@ -977,7 +682,7 @@ int launch_gemv(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
 template <int G>
 int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
                 int64_t N, int64_t K, hipStream_t stream) {
-  // M == 1 product dispatch (mode 0), measured in-graph on cold weights (profiles/int4_lab_r01.txt):
+  // M == 1 product dispatch (mode 0), measured in-graph on cold weights (profiles/int4_lab_trace_r01.txt):
   //   * fewer than kManyTiles n-tiles: the balanced streaming kernel (one workgroup per CU) -- start-up
   //     and tile imbalance dominate there;
   //   * more (merged gate_up_proj: 1792 tiles): one small workgroup per tile, scheduled by the

@@ -161,8 +161,8 @@ __global__ __launch_bounds__(64 << LOGW) void int4_gemv_stream_kernel(
   constexpr int STAGE = 1024 + NG * 256;          // bytes: one 1 KiB weight block + NG x 64 scale/zero words
   static_assert(kRing == 4 && kRedBufs == 4, "wait_ring and the buffer index are written for 4");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS: [K*2 x in A-fragment order][64 B zero row][W][kRing][STAGE] ring
-  //      [kRedBufs][W][16] f32 partials, arrival counters, generations, [2][64] granule landing pad
+  // LDS: [W][ring | x slices | zero row], [kRedBufs][W][16] f32 partials, arrival counters, generations,
+  //      [64] granule landing pad
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -172,10 +172,13 @@ __global__ __launch_bounds__(64 << LOGW) void int4_gemv_stream_kernel(
   const int nl = lane & 15;
   const int S1 = (1 << plan.log_split) - 1;
 
-  char* xs = smem;
-  char* zero_row = smem + (size_t)K * 2;
-  char* ring = zero_row + 64 + wave * (kRing * STAGE);  // this wave's ring
-  float* red = reinterpret_cast<float*>(zero_row + 64 + W * (kRing * STAGE));
+  // per wave: [kRing stages][x slices of this wave's k-ranges, A-fragment order][64 B of zeros]
+  const int xw_blocks = 2 * ((plan.kblocks + W - 1) / W) + 2;  // full-tile range + remainder range, upper bound (host uses the same)
+  const int wave_bytes = kRing * STAGE + xw_blocks * 256 + 64;
+  char* ring = smem + wave * wave_bytes;
+  char* xw = ring + kRing * STAGE;
+  char* zero_row = xw + xw_blocks * 256;
+  float* red = reinterpret_cast<float*>(smem + W * wave_bytes);
   uint32_t* arrive = reinterpret_cast<uint32_t*>(red + kRedBufs * W * 16);
   uint32_t* gen = arrive + kRedBufs;
   u32x4* pad = reinterpret_cast<u32x4*>(gen + kRedBufs);  // [64] granules {partial bits, tag, 0, 0} of the owned K-split tile (16-byte aligned: all sizes before it are)
@@ -205,24 +208,38 @@ __global__ __launch_bounds__(64 << LOGW) void int4_gemv_stream_kernel(
     b1 = u0 + ((len * (wave + 1)) >> LOGW);
   };
 
-  // ---- 1a. x staging: LDS-DMA in 4-byte units, dest unit e (lane-linear) <- the source unit that
-  // belongs there.  LDS order xs[kb][kq][j][8]: k = 128 kb + 32 j + 16 h + 4 kq + i sits at slot
-  // 4 h + i, so the A operand of MFMA j of block kb is one ds_read_b128 at xs + kb*256 + kq*64 + j*16.
+  // ---- 1a. counters and zero row; the only workgroup barrier of the kernel (nothing is in flight yet)
+  if (tid < 2 * kRedBufs) arrive[tid] = 0u;  // arrive[] and gen[] are contiguous
+  if (lane < 16) reinterpret_cast<uint32_t*>(zero_row)[lane] = 0u;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ---- 1b. x staging, wave-private: each wave DMAs exactly the x slices of ITS k-ranges (one for
+  // the full tiles, one for its remainder unit) -- 256 B per 128-k block, one 4-byte-per-lane DMA
+  // each -- AHEAD of its own weight ring.  Loads return in order, so when the first weight stage
+  // has landed x has too: no staging barrier, no wave waits for another wave's x, and the waves'
+  // first blocks start staggered instead of all at once.  (A workgroup-wide staging needed two
+  // barriers: one so that no wave's 4 KiB ring prologue queued ahead of another wave's x request
+  // in the CU's in-order memory pipe, one for the hand-over; trace: 0.7 us from x landed to barrier.)
+  // LDS order per block [kq][j][8]: k = 32 j + 16 h + 4 kq + i sits at slot 4 h + i, so the A operand
+  // of MFMA j is one ds_read_b128 at block + kq*64 + j*16.
+  int fb0, fb1, rb0 = 0, rb1 = 0;  // this wave's block ranges: full tiles, remainder unit
   {
-    const uint32_t xs_lds = __builtin_amdgcn_readfirstlane(lds_offset(xs));
-    const int units4 = K >> 1;  // multiple of 64: whole waves
-#pragma nounroll
-    for (int e0 = wave * 64; e0 < units4; e0 += W * 64) {
-      const int e = e0 + lane;
-      const int d = e >> 1, du = d & 31;  // 8-byte dest unit within its block: kq*8 + j*2 + h
-      const int src8 = (d & ~31) + 8 * ((du >> 1) & 3) + 4 * (du & 1) + (du >> 3);
-      dma_b32(x + (size_t)(2 * src8 + (e & 1)) * 2, xs_lds + e0 * 4);
+    fb0 = (plan.kblocks * wave) >> LOGW;
+    fb1 = (plan.kblocks * (wave + 1)) >> LOGW;
+    if (plan.full == 0) fb1 = fb0;
+    if (nrem > 0) {
+      int t;
+      unit_range(0, t, rb0, rb1);
     }
+    const uint32_t xw_lds = __builtin_amdgcn_readfirstlane(lds_offset(xw));
+    const int d = lane >> 1;  // 8-byte dest unit within the block: kq*8 + j*2 + h
+    const int src4 = 2 * (8 * ((d >> 1) & 3) + 4 * (d & 1) + (d >> 3)) + (lane & 1);  // source 4-byte unit within the block
+    const uint16_t* xl = x + src4 * 2;
+#pragma nounroll
+    for (int kb = fb0; kb < fb1; ++kb) dma_b32(xl + (size_t)kb * 128, xw_lds + (kb - fb0) * 256);
+#pragma nounroll
+    for (int kb = rb0; kb < rb1; ++kb) dma_b32(xl + (size_t)kb * 128, xw_lds + (fb1 - fb0 + kb - rb0) * 256);
   }
-  // The CU's vector-memory pipe serves requests in issue order ACROSS waves: without this barrier
-  // the x loads of the later waves queue behind the 4 KiB ring prologues of the earlier ones
-  // (60 KiB per CU, ~2.5 us at a CU's share of HBM bandwidth) and the staging barrier waits for it.
-  asm volatile("s_barrier" ::: "memory");
 
   // ---- 1b. weight ring prologue: prefetch cursor over this wave's block stream
   int pf_ui = -1, pf_kb = 0, pf_b1 = 0, pf_tile = 0;
@@ -256,19 +273,9 @@ __global__ __launch_bounds__(64 << LOGW) void int4_gemv_stream_kernel(
     }
   }
 
-  // ---- 2. x landed (everything issued after it may stay in flight), zero row, counters, barrier.
-  // (Deferring this barrier until after the first block's dequant -- which needs no x -- was tried:
-  // no gain, the barrier then waits for the slowest wave's dequant instead of its x.)
-  wait_ring<LPS>(inflight);
-  if (MODE == 3) ts[1] = __builtin_amdgcn_s_memrealtime();
-  if (tid < 16) reinterpret_cast<uint32_t*>(zero_row)[tid] = 0u;
-  if (tid < 2 * kRedBufs) arrive[tid] = 0u;  // arrive[] and gen[] are contiguous
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  if (MODE == 3) ts[2] = __builtin_amdgcn_s_memrealtime();
-
   // ---- 3. main loop
   const bool row0 = nl == 0;  // lanes holding row 0 (= x) of the 16x16 MFMA tile; the rest read zeros
-  const int a_off = row0 ? kq * 64 : K * 2;
+  const char* a_lane = row0 ? xw + kq * 64 : zero_row;  // + block slot * a_stride
   const int a_stride = row0 ? 256 : 0;
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -287,10 +294,12 @@ __global__ __launch_bounds__(64 << LOGW) void int4_gemv_stream_kernel(
   for (int ui = 0; ui < nunits; ++ui) {
     int tile, b0, b1;
     unit_range(ui, tile, b0, b1);
+    const int xbase = (ui < nrem) ? rb0 - (fb1 - fb0) : fb0;  // block kb's x sits at slot kb - xbase
     if (owner && wave == W - 1 && ui == nunits - 1) fetch_granules();
 #pragma nounroll
     for (int kb = b0; kb < b1; ++kb) {
-      wait_ring<LPS>(inflight - 1);  // the oldest stage has landed; the younger ones may be in flight
+      wait_ring<LPS>(inflight - 1);  // the oldest stage has landed (and with it this wave's x); the younger ones may be in flight
+      if (MODE == 3 && first) ts[1] = ts[2] = __builtin_amdgcn_s_memrealtime();
       const char* sb = ring + slot * STAGE;
       const u32x4 wv = *reinterpret_cast<const u32x4*>(sb + lane * 16);
       uint32_t szv[NG];
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(64 << LOGW) void int4_gemv_stream_kernel(
           dequant_word_exact(wds[j], sc, -8.0f * sc, f32x4{zp, zp, zp, zp}, ident, b);
           bw[j] = u32x4{b[0], b[1], b[2], b[3]};
         }
-        const char* a_ptr = xs + a_off + kb * a_stride;
+        const char* a_ptr = a_lane + (kb - xbase) * a_stride;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const u32x4 a = *reinterpret_cast<const u32x4*>(a_ptr + j * 16);
@@ -477,7 +486,8 @@ int launch_stream_impl(const uint16_t* x, const int32_t* qdata, const uint16_t* 
   const StreamPlan p = make_plan((int)(N >> 4), (int)(K >> 7), d->cus);
   constexpr int wpb = 1 << LOGW;
   constexpr int stage = 1024 + ((G >= 128) ? 1 : (128 / G)) * 256;
-  const size_t smem = (size_t)K * 2 + 64 + (size_t)wpb * kRing * stage + (size_t)kRedBufs * wpb * 16 * sizeof(float) +
+  const int xw_blocks = 2 * ((p.kblocks + wpb - 1) / wpb) + 2;
+  const size_t smem = (size_t)wpb * (kRing * stage + xw_blocks * 256 + 64) + (size_t)kRedBufs * wpb * 16 * sizeof(float) +
                       2 * kRedBufs * sizeof(uint32_t) + 64 * sizeof(u32x4);
   auto kern = int4_gemv_stream_kernel<G, LOGW, MODE>;
   if (smem > 48 * 1024) {
@@ -496,9 +506,9 @@ int launch_stream_impl(const uint16_t* x, const int32_t* qdata, const uint16_t* 
 
 }  // namespace
 
-// x (2 B per k) + the ring (80 KiB at 16 waves, g >= 128; 64 KiB at 8 waves, g = 32) + scratch must fit
-// the 160 KiB LDS of a CU
-bool int4_gemv_stream_supported(int64_t K) { return K * 2 <= 64 * 1024; }
+// per wave: the ring (5 KiB at g >= 128, 8 KiB at g = 32) + its x slices (2 * ceil(K/128/W) + 2 blocks of
+// 256 B); 16 (8 at g < 128) waves + 5 KiB of scratch must fit the 160 KiB LDS of a CU
+bool int4_gemv_stream_supported(int64_t K) { return K <= 16384; }
 
 void int4_gemv_stream_set_trace(unsigned long long* p) { g_trace = p; }
 
