@@ -450,6 +450,198 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
 }
 
 // ---------------------------------------------------------------------------
+// 16 < M: int4 weight-only GEMM for batched decode / small prefill (the "bs = 128" half of the
+// BASELINE metric).  int4_mm_kernel re-dequantises the weights for every 16-row slab of x and
+// re-reads x from L2 for every 16-wide n-tile.  Here a workgroup (8 waves) owns a 128 (m) x 128 (n)
+// output tile and walks K one packed k-block (128 k) at a time:
+//   * wave w dequantises the block of n-tile w (exact oracle rounding, as everywhere) into an LDS
+//     tile of bf16 [128 n][128 k] rows, k contiguous;
+//   * all threads stage x[128 m][128 k] next to it;
+//   * wave (wm, wn) = (w >> 1, w & 1) multiplies its 32 x 64 sub-tile: 8 MFMAs 16x16x32 per 32-k slice.
+// Dequant work per weight is done once and is split over the 8 waves; 128 rows amortise it.  LDS
+// tiles are double buffered (one barrier per k-block), operands for block kb+2 are in registers
+// while block kb is multiplied.  Rows are 272 B apart (256 + 16 pad) so that the 16 rows of a
+// fragment read start on different banks.
+// ---------------------------------------------------------------------------
+constexpr int kTiledStride = 256 + 16;             // bytes per row of 128 bf16
+constexpr int kTiledA = 128 * kTiledStride;         // x tile: 34,816 B
+
+// TNW = n-tiles (16 columns each) per workgroup: 8, 4 or 2 -- fewer for narrow N so that the grid still
+// covers the chip.  The 8 waves always split the dequant evenly: 8 / TNW waves share one packed block,
+// 4 * TNW / 8 of its 4 words each.
+template <int G, int TNW>
+__global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qdata,
+                                                            const uint32_t* __restrict__ sz, uint16_t* __restrict__ y,
+                                                            int M, int N, int K) {
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);
+  constexpr int WPT = 8 / TNW;          // waves per n-tile
+  constexpr int WPW = 4 / WPT;          // packed words per lane per wave
+  constexpr int NJ = TNW / 2;           // 16-column MFMA tiles per wave (waves: 4 along m x 2 along n)
+  constexpr int BUF = kTiledA + TNW * 16 * kTiledStride;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][A 128 rows | B TNW*16 rows], 272 B per row
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * (TNW * 16);
+  const int kblocks = K >> 7;
+  const int ntiles = N >> 4;
+  const int nl = lane & 15, kq = lane >> 4;
+  const s16x4 ident = identity_fragment<4>(lane);
+
+  // weights: this wave dequantises words w0 .. w0 + WPW - 1 of n-tile n0/16 + wt (tiles past N alias the last one;
+  // their columns are never stored)
+  const int wt = wave / WPT, w0 = (wave % WPT) * WPW;
+  const int wtile = min((n0 >> 4) + wt, ntiles - 1);
+  const uint32_t* wp = qdata + ((size_t)wtile * kblocks * 64 + lane) * 4 + w0;
+  const uint32_t* szp = sz + wtile * 16 + nl;
+  // activations: thread t stages chunks t + 512 i (i < 4) of the 128 x 16 chunk grid (16 B each)
+  const uint16_t* xsrc[4];
+  int xdst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 512 * i, row = c >> 4, col = c & 15;
+    xsrc[i] = x + (size_t)min(m0 + row, M - 1) * K + col * 8;
+    xdst[i] = row * kTiledStride + col * 16;
+  }
+
+  struct Regs {
+    uint32_t w[WPW];
+    uint32_t sz[NG];
+    u32x4 a[4];
+  };
+  auto fetch = [&](Regs& r, int kb) {  // kb clamped: the prefetch past the end re-reads the last block (unused)
+    const int k = min(kb, kblocks - 1);
+    const uint32_t* p = wp + (size_t)k * 256;
+    if constexpr (WPW == 4) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+      r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else if constexpr (WPW == 2) {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+      r.w[0] = v.x; r.w[1] = v.y;
+    } else {
+      r.w[0] = *p;
+    }
+    const int kg0 = (G >= 128) ? ((k * 128) / G) : (k * NG);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) r.sz[i] = szp[(size_t)(kg0 + i) * N];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.a[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + (size_t)k * 128);
+  };
+  auto stage = [&](const Regs& r, char* buf) {
+    // B: lane (n, kq) owns, per word j, k = 32j + 4kq + {0..3} and 32j + 16 + 4kq + {0..3}
+    char* brow = buf + kTiledA + (wt * 16 + nl) * kTiledStride + kq * 8;
+#pragma unroll
+    for (int jj = 0; jj < WPW; ++jj) {
+      const int j = w0 + jj;
+      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
+      const float sc = bf16_lo_to_f32(r.sz[gi]);
+      const float zp = bf16_hi_to_f32(r.sz[gi]);
+      uint32_t b[4];
+      dequant_word_mfma<4>(r.w[jj], sc, -8.0f * sc, zp, ident, b);
+      *reinterpret_cast<u32x2*>(brow + j * 64) = u32x2{b[0], b[1]};       // k = 32j + 4kq .. +3
+      *reinterpret_cast<u32x2*>(brow + j * 64 + 32) = u32x2{b[2], b[3]};  // k = 32j + 16 + 4kq .. +3
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(buf + xdst[i]) = r.a[i];
+  };
+
+  f32x4 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: lane (row nl of a 16-row tile, kq) reads the 8 contiguous k at 8 kq of each 32-k slice
+  const int a_off = (wm * 32 + nl) * kTiledStride + kq * 16;
+  const int b_off = kTiledA + (wn * NJ * 16 + nl) * kTiledStride + kq * 16;
+  auto multiply = [&](const char* buf) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 af[2], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(buf + a_off + i * 16 * kTiledStride + ks * 64);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const u32x4*>(buf + b_off + j * 16 * kTiledStride + ks * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  };
+  // LDS-only barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. for the operand prefetch
+  // issued just before it -- a full memory latency per k-block (measured: 0.94 us per block)
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // Operands are fetched FOUR k-blocks ahead into a static ring of register sets (the loop is unrolled by 4 so
+  // that every set has a fixed name): block b+1 is dequantised/staged into the other LDS buffer while block b
+  // is multiplied.  The steady-state body has no branch (a branch between a load and its use costs vmcnt(0)).
+  Regs r0, r1, r2, r3;
+  fetch(r0, 0); fetch(r1, 1); fetch(r2, 2); fetch(r3, 3);
+  stage(r0, smem);
+  fetch(r0, 4);
+  lds_barrier();
+  char* const buf0 = smem;
+  char* const buf1 = smem + BUF;
+  int kb = 0;
+  for (; kb + 8 <= kblocks; kb += 4) {
+    stage(r1, buf1); fetch(r1, kb + 5); multiply(buf0); lds_barrier();
+    stage(r2, buf0); fetch(r2, kb + 6); multiply(buf1); lds_barrier();
+    stage(r3, buf1); fetch(r3, kb + 7); multiply(buf0); lds_barrier();
+    stage(r0, buf0); fetch(r0, kb + 8); multiply(buf1); lds_barrier();
+  }
+  // tail (< 8 blocks): same schedule with bounds checks (fetch clamps its index)
+  for (; kb < kblocks; kb += 4) {
+    if (kb + 1 < kblocks) stage(r1, buf1);
+    fetch(r1, kb + 5); multiply(buf0); lds_barrier();
+    if (kb + 1 >= kblocks) break;
+    if (kb + 2 < kblocks) stage(r2, buf0);
+    fetch(r2, kb + 6); multiply(buf1); lds_barrier();
+    if (kb + 2 >= kblocks) break;
+    if (kb + 3 < kblocks) stage(r3, buf1);
+    fetch(r3, kb + 7); multiply(buf0); lds_barrier();
+    if (kb + 3 >= kblocks) break;
+    if (kb + 4 < kblocks) stage(r0, buf0);
+    fetch(r0, kb + 8); multiply(buf1); lds_barrier();
+  }
+
+  // D layout of the 16x16 tile: lane (col = nl, kq) holds rows 4 kq + {0..3}
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nn = n0 + (wn * NJ + j) * 16 + nl;
+      if (nn >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + kq * 4 + r;
+        if (m < M) y[(size_t)m * N + nn] = f32_to_bf16_bits(acc[i][j][r]);
+      }
+    }
+}
+
+template <int G, int TNW>
+int launch_mm_tiled(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K,
+                    hipStream_t stream) {
+  dim3 grid((unsigned)((N + TNW * 16 - 1) / (TNW * 16)), (unsigned)((M + 127) / 128)), block(512);
+  const size_t smem = 2 * (size_t)(kTiledA + TNW * 16 * kTiledStride);
+  auto kern = int4_mm_tiled_kernel<G, TNW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(int4_mm_tiled_kernel)");
+    attr_set = true;
+  }
+  ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const uint32_t*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
+             (int)M, (int)N, (int)K);
+  AO_LAUNCH_CHECK("int4_mm_tiled_kernel launch");
+  return AO_OK;
+}
+
+// ---------------------------------------------------------------------------
 // pack / unpack / dequantize / fused quantize
 // ---------------------------------------------------------------------------
 
@@ -696,7 +888,13 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   if (M == 1 && K <= kGemvMaxK && (g_tune_mode == 0 || g_tune_mode >= 100)) return launch_gemv<G>(x, qdata, sz, y, N, K, stream);
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
-  return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+  if (M <= 16 || g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+  // 16 < M: dequantise each weight block once per workgroup (int4_mm_tiled_kernel); as many n-tiles per
+  // workgroup as still leave >= ~200 workgroups (x is re-staged by every workgroup of a row slab)
+  const int64_t slabs = (M + 127) / 128, ntiles = N >> 4;
+  if (g_tune_wpb == 8 || (g_tune_wpb == 0 && ((ntiles + 7) / 8) * slabs >= 200)) return launch_mm_tiled<G, 8>(x, qdata, sz, y, M, N, K, stream);
+  if (g_tune_wpb == 4 || (g_tune_wpb == 0 && ((ntiles + 3) / 4) * slabs >= 200)) return launch_mm_tiled<G, 4>(x, qdata, sz, y, M, N, K, stream);
+  return launch_mm_tiled<G, 2>(x, qdata, sz, y, M, N, K, stream);
 }
 
 int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
@@ -721,6 +919,7 @@ extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, i
   (void)group_size;
   if (M == 1 && int4_gemv_stream_supported(K) && (N >> 4) < kManyTiles) return "int4_gemv_stream_kernel";
   if (M == 1 && K <= kGemvMaxK) return "int4_gemv_kernel";
+  if (M > 16) return "int4_mm_tiled_kernel";
   return "int4_mm_kernel";
 }
 

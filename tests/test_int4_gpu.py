@@ -156,6 +156,21 @@ def test_mm_bs1_repeatable_and_workspace_reuse():
     assert _rel(a, b) <= 1e-3 and np.mean(a == b) > 0.99
 
 
+# 16 < M takes the M-tiled kernel (dequantise once per workgroup, 8 m-tiles share it through LDS)
+@pytest.mark.parametrize(
+    "m,n,k,g",
+    [(17, 64, 1024, 128), (128, 6144, 4096, 128), (100, 256, 2048, 32), (200, 128, 3584, 64), (64, 48, 1152 * 2, 256),
+     (129, 4096, 14336, 128), (40, 28672, 256, 128), (33, 12800, 384, 64)],  # the last two: 8 and 4 n-tiles per workgroup
+)
+def test_mm_tiled_batched(m, n, k, g):
+    y, y_ref = _mm_case(m, n, k, g, 7 * m + n + k)
+    assert y.shape == y_ref.shape
+    assert _rel(y, y_ref) <= 1e-3  # BASELINE.json tolerance
+    # exact dequant: one bf16 ulp, plus fp32 accumulation-order noise on cancelling outputs
+    assert np.all(np.abs(y - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + 1e-3 * np.abs(y_ref).max())
+    assert np.mean(y == y_ref) > 0.97
+
+
 def test_mm_golden(golden_int4):
     d = golden_int4
     for case in ["g32", "g64", "g128", "g256"]:
