@@ -204,36 +204,41 @@ __device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 3) & 7
 // At TM = 2 every K step moves 64 KiB from LDS per CU for 512 MFMA cycles per SIMD -- LDS time equals
 // MFMA time; TM = 4 (256 x 128 workgroup tile, 128 accumulator registers per lane) does 1024 MFMA
 // cycles per 96 KiB of LDS reads.
-template <int EPI, int TM>
-__global__ __launch_bounds__(THREADS) void gemm8_dma_kernel(Gemm8Args p) {
+// WN = waves along n (2: 4-wave workgroup, 128 columns; 4: 8-wave workgroup, 256 columns -- with TM = 4 the
+// 256 x 256 tile whose wave tile is 128 x 64 (LDS reads 24 B per MFMA cycle instead of 32) at two waves per SIMD).
+template <int EPI, int TM, int WN>
+__global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
   constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE);
+  constexpr int NWAVES = 2 * WN;
   constexpr int WGM = TM * 64;            // workgroup rows
+  constexpr int WGN = WN * 64;            // workgroup columns
   constexpr int A_TILE = WGM * BK;        // bytes, unpadded
-  constexpr int B_TILE = BN * BK;
-  constexpr int A_DMAS = WGM / 32;        // 1 KiB DMA instructions per wave for the A tile (8 rows each, 4 waves)
+  constexpr int B_TILE = WGN * BK;
+  constexpr int A_DMAS = WGM / 8 / NWAVES;  // 1 KiB DMA instructions (8 rows each) per wave for the A tile
+  constexpr int B_DMAS = WGN / 8 / NWAVES;
   using acc_t = typename Acc<EPI>::type;
   extern __shared__ __attribute__((aligned(1024))) char smem[];  // [2 bufs][A tile | B tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * WGM, n0 = blockIdx.x * BN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * WGM, n0 = blockIdx.x * WGN;
   const int ktiles = p.K / BK;
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem));
 
-  // DMA sources: wave w fills rows (w*A_DMAS + i)*8 .. +7 of the A tile (and (w*4 + i)*8 of the B tile);
+  // DMA sources: wave w fills rows (w*A_DMAS + i)*8 .. +7 of the A tile (and (w*B_DMAS + i)*8 of the B tile);
   // lane l lands at row r0 + (l >> 3), position l & 7 -> it must fetch chunk (l & 7) ^ f(row)
   const uint8_t* asrc[A_DMAS];
-  const uint8_t* bsrc[4];
+  const uint8_t* bsrc[B_DMAS];
 #pragma unroll
   for (int i = 0; i < A_DMAS; ++i) {
     const int row = (wave * A_DMAS + i) * 8 + (lane >> 3);
     asrc[i] = p.a + (size_t)min(m0 + row, p.M - 1) * p.K + (((lane & 7) ^ swz(row)) << 4);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + (lane >> 3);
+  for (int i = 0; i < B_DMAS; ++i) {
+    const int row = (wave * B_DMAS + i) * 8 + (lane >> 3);
     bsrc[i] = p.b + (size_t)min(n0 + row, p.N - 1) * p.K + (((lane & 7) ^ swz(row)) << 4);
   }
   auto stage = [&](int kt, int buf) {
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void gemm8_dma_kernel(Gemm8Args p) {
 #pragma unroll
     for (int i = 0; i < A_DMAS; ++i) dma16(asrc[i] + (size_t)kt * BK, abase + (wave * A_DMAS + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16(bsrc[i] + (size_t)kt * BK, abase + A_TILE + (wave * 4 + i) * 1024);
+    for (int i = 0; i < B_DMAS; ++i) dma16(bsrc[i] + (size_t)kt * BK, abase + A_TILE + (wave * B_DMAS + i) * 1024);
   };
 
   acc_t acc[TM][2];
@@ -346,29 +351,31 @@ bool g_gemm8_force_regstage = false;  // profiling: ao_gemm8_set_variant(1)
 
 int g_gemm8_tm = 0;  // profiling: 0 = by shape, 2 / 4 = force
 
-template <int EPI, int TM>
+template <int EPI, int TM, int WN>
 int launch_gemm8_dma_tm(const Gemm8Args& p, hipStream_t stream) {
-  constexpr int WGM = TM * 64;
-  dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + WGM - 1) / WGM)), block(THREADS);
-  const size_t smem = 2 * (size_t)(WGM + BN) * BK;  // 64 KiB (TM = 2) / 96 KiB (TM = 4)
+  constexpr int WGM = TM * 64, WGN = WN * 64;
+  dim3 grid((unsigned)((p.N + WGN - 1) / WGN), (unsigned)((p.M + WGM - 1) / WGM)), block(128 * WN);
+  const size_t smem = 2 * (size_t)(WGM + WGN) * BK;  // 64 KiB (128 x 128) ... 128 KiB (256 x 256)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_dma_kernel<EPI, TM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_dma_kernel<EPI, TM, WN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(gemm8_dma_kernel)");
     attr_set = true;
   }
-  ao::launch(gemm8_dma_kernel<EPI, TM>, grid, block, smem, stream, p);
+  ao::launch(gemm8_dma_kernel<EPI, TM, WN>, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("gemm8_dma_kernel launch");
   return AO_OK;
 }
 
 template <int EPI>
 int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
-  // Product: 128-row tiles (2 workgroups per CU).  The 256-row tile halves LDS traffic per MFMA but runs one
-  // wave per SIMD, and with this two-barrier loop nothing hides its ds_read -> MFMA latency: measured 0.75-0.95x
-  // (profiles/bench_8bit_r01_gemm.txt).  It needs the multi-phase schedule first; kept as a profiling variant.
-  return g_gemm8_tm == 4 ? launch_gemm8_dma_tm<EPI, 4>(p, stream) : launch_gemm8_dma_tm<EPI, 2>(p, stream);
+  // variants (ao_gemm8_set_variant): 2 = 128 x 128 tile / 4 waves; 4 = 256 x 128 / 4 waves (one wave per SIMD:
+  // measured 0.75-0.95x, nothing hides its ds_read -> MFMA latency); 8 = 256 x 256 / 8 waves.
+  if (g_gemm8_tm == 4) return launch_gemm8_dma_tm<EPI, 4, 2>(p, stream);
+  const int64_t big = (int64_t)((p.N + 255) / 256) * ((p.M + 255) / 256);
+  if (g_gemm8_tm == 8 || (g_gemm8_tm == 0 && big >= 512)) return launch_gemm8_dma_tm<EPI, 4, 4>(p, stream);
+  return launch_gemm8_dma_tm<EPI, 2, 2>(p, stream);
 }
 
 template <int EPI>
@@ -403,7 +410,7 @@ using namespace ao;
 
 extern "C" int ao_gemm8_set_variant(int variant) {
   g_gemm8_force_regstage = (variant == 1);
-  g_gemm8_tm = (variant == 2 || variant == 4) ? variant : 0;
+  g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8) ? variant : 0;
   return AO_OK;
 }
 

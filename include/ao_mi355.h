@@ -106,7 +106,7 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
  * ablation builds, 12/18 = prefetch depth 2/8) of the int4 mm. */
 int ao_int4_set_tuning(int waves_per_block, int mode);
 /* Profiling only: 0 = product dispatch of the 8-bit GEMMs (LDS-DMA staged kernel when K % 128 == 0),
- * 1 = force the register-staged kernel, 2 / 4 = force the LDS-DMA kernel with 128- / 256-row tiles. */
+ * 1 = force the register-staged kernel, 2 / 4 / 8 = force the LDS-DMA kernel with 128x128, 256x128 (4 waves), 256x256 (8 waves) tiles. */
 int ao_gemm8_set_variant(int variant);
 /* Name of the kernel ao_int4_weight_int4pack_mm launches for this problem (product dispatch, no
  * tuning override): what a profiler's kernel table should be matched against.  Static string. */

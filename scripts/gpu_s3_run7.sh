@@ -5,9 +5,3 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 echo "== pytest 8bit+subclass ==" ; timeout 600 python -m pytest tests/test_subclass_gpu.py tests/test_8bit_gpu.py -m gpu -q --timeout 200 2>&1 | tail -8
-echo "== 8bit bench ==" ; timeout 600 python tools/bench_8bit.py --which int8,fp8 2>&1 | grep -v amdgpu.ids | tee $O/bench_8bit_r01c.jsonl | python -c "
-import sys, json
-for l in sys.stdin:
-    try: d = json.loads(l)
-    except Exception: print(l.strip()); continue
-    print(d['kernel'], d.get('shape'), 'M', d['M'], 'us', round(d['us'],1), 'frac_mfma', round(d.get('frac_mfma',0),3), 'T', round(d.get('TOPs', d.get('TFLOPs',0)),0))"

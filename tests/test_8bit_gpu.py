@@ -254,3 +254,30 @@ def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
     yn = np_from_torch_bf16(y)
     assert _rel(yn, y_ref) <= 1e-3
     assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4, 8])
+@pytest.mark.parametrize("m,n,k", [(130, 208, 1152), (300, 528, 256), (513, 384, 4096)])  # N % 16 == 0 (fp8 requirement)
+def test_gemm8_every_kernel_variant(variant, m, n, k):
+    """register-staged, 128x128 / 256x128 / 256x256 LDS-DMA kernels: same bits for int8 (integer GEMM + the
+    reference's rounding sequence), <= 1e-3 for fp8; ragged M and N against every tile shape."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    x = _randn_bf16((m, k), 3 * m + k)
+    w = _randn_bf16((n, k), 5 * n + k, 0.05)
+    b = _randn_bf16((n,), 9)
+    try:
+        lib.ao_gemm8_set_variant(variant)
+        xq, xs = ops.int8_quantize_rowwise(x.to(DEV))
+        wq, ws = ops.int8_quantize_rowwise(w.to(DEV))
+        y8 = ops.int8_scaled_mm(xq, xs, wq, ws, b.to(DEV))
+        c = ops.int_mm(xq, wq.t())
+        fq, fs = ops.fp8_quantize_rowwise(x.to(DEV))
+        gq, gs = ops.fp8_quantize_rowwise(w.to(DEV))
+        yf = ops.fp8_scaled_mm(fq, gq.t(), fs, gs.t(), b.to(DEV))
+    finally:
+        lib.ao_gemm8_set_variant(0)
+    assert np.array_equal(np_from_torch_bf16(y8), I.linear(x.float().numpy(), w.float().numpy(), b.float().numpy()))
+    assert np.array_equal(c.cpu().numpy(), I.int_mm(xq.cpu().numpy(), wq.cpu().numpy()))
+    assert _rel(np_from_torch_bf16(yf), F.linear(x.float().numpy(), w.float().numpy(), b.float().numpy())) <= 1e-3

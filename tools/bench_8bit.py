@@ -42,9 +42,12 @@ def main():
     ap.add_argument("--m", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--which", default="int8,fp8,mx,quant")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="ao_gemm8_set_variant (0 product, 1 reg-staged, 2/4/8 tile shapes)")
     args = ap.parse_args()
     which = set(args.which.split(","))
     dev = torch.device("cuda", 0)
+    from ao_amd import _lib
+    _lib.lib().ao_gemm8_set_variant(args.gemm_variant)
     torch.manual_seed(0)
     out = []
 
