@@ -373,6 +373,8 @@ int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
   // variants (ao_gemm8_set_variant): 2 = 128 x 128 tile / 4 waves; 4 = 256 x 128 / 4 waves (one wave per SIMD:
   // measured 0.75-0.95x, nothing hides its ds_read -> MFMA latency); 8 = 256 x 256 / 8 waves.
   if (g_gemm8_tm == 4) return launch_gemm8_dma_tm<EPI, 4, 2>(p, stream);
+  // (A 4-stage, 64-byte-K-step pipeline with hand-counted vmcnt was measured at 0.94-0.97x of these two-stage
+  // kernels at both tile shapes, profiles/bench_8bit_r01_gemm.txt: the loop is LDS-read bound, not latency bound.)
   const int64_t big = (int64_t)((p.N + 255) / 256) * ((p.M + 255) / 256);
   if (g_gemm8_tm == 8 || (g_gemm8_tm == 0 && big >= 512)) return launch_gemm8_dma_tm<EPI, 4, 4>(p, stream);
   return launch_gemm8_dma_tm<EPI, 2, 2>(p, stream);
@@ -380,7 +382,7 @@ int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
 
 template <int EPI>
 int launch_gemm8(const Gemm8Args& p, hipStream_t stream) {
-  if (p.K % BK == 0 && !g_gemm8_force_regstage) return launch_gemm8_dma<EPI>(p, stream);
+  if (p.K % BK == 0 && !g_gemm8_force_regstage) return launch_gemm8_dma<EPI>(p, stream);  // K % 128 == 0 (the pipelined kernels need K % 64)
   dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM)), block(THREADS);
   const size_t smem = 2 * 2 * TILE_BYTES;  // 73,728 B
   static bool attr_set = false;
