@@ -206,12 +206,13 @@ __device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 3) & 7
 // cycles per 96 KiB of LDS reads.
 // WN = waves along n (2: 4-wave workgroup, 128 columns; 4: 8-wave workgroup, 256 columns -- with TM = 4 the
 // 256 x 256 tile whose wave tile is 128 x 64 (LDS reads 24 B per MFMA cycle instead of 32) at two waves per SIMD).
-template <int EPI, int TM, int WN>
+// TNJ = 32-column MFMA tiles per wave along N (2 or 4).
+template <int EPI, int TM, int WN, int TNJ = 2>
 __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
   constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE);
   constexpr int NWAVES = 2 * WN;
   constexpr int WGM = TM * 64;            // workgroup rows
-  constexpr int WGN = WN * 64;            // workgroup columns
+  constexpr int WGN = WN * TNJ * 32;      // workgroup columns
   constexpr int A_TILE = WGM * BK;        // bytes, unpadded
   constexpr int B_TILE = WGN * BK;
   constexpr int A_DMAS = WGM / 8 / NWAVES;  // 1 KiB DMA instructions (8 rows each) per wave for the A tile
@@ -249,26 +250,26 @@ __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
     for (int i = 0; i < B_DMAS; ++i) dma16(bsrc[i] + (size_t)kt * BK, abase + A_TILE + (wave * B_DMAS + i) * 1024);
   };
 
-  acc_t acc[TM][2];
+  acc_t acc[TM][TNJ];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TNJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
   // fragment addressing: row = lane & 31 of the 32-row MFMA tile, logical chunks (lane >> 5) * 2 + {0, 1} of each
   // 64-byte k-slice; physical chunk = logical ^ f(row)
   const int frow = lane & 31, fc = (lane >> 5) * 2;
-  int arow_off[TM], asw[TM], brow_off[2], bsw[2];
+  int arow_off[TM], asw[TM], brow_off[TNJ], bsw[TNJ];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int ra = wm * (TM * 32) + i * 32 + frow;
     arow_off[i] = ra * BK; asw[i] = swz(ra);
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int rb = wn * 64 + j * 32 + frow;
+  for (int j = 0; j < TNJ; ++j) {
+    const int rb = wn * (TNJ * 32) + j * 32 + frow;
     brow_off[j] = rb * BK; bsw[j] = swz(rb);
   }
 
@@ -282,19 +283,19 @@ __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
     const char* bbase = abase + A_TILE;
 #pragma unroll
     for (int kc = 0; kc < BK / 64; ++kc) {
-      u32x4 af[TM][2], bf[2][2];
+      u32x4 af[TM][2], bf[TNJ][2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int c = kc * 4 + fc + h;
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i][h] = *reinterpret_cast<const u32x4*>(abase + arow_off[i] + ((c ^ asw[i]) << 4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j][h] = *reinterpret_cast<const u32x4*>(bbase + brow_off[j] + ((c ^ bsw[j]) << 4));
+        for (int j = 0; j < TNJ; ++j) bf[j][h] = *reinterpret_cast<const u32x4*>(bbase + brow_off[j] + ((c ^ bsw[j]) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TNJ; ++j) {
           if constexpr (IS_INT) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int gn = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < TNJ; ++j) {
+      const int gn = n0 + wn * (TNJ * 32) + j * 32 + (lane & 31);
       if (gn >= p.N) continue;
       float cs = 1.f, bias = 0.f;
       if (EPI != EPI_INT32) {
@@ -351,19 +352,19 @@ bool g_gemm8_force_regstage = false;  // profiling: ao_gemm8_set_variant(1)
 
 int g_gemm8_tm = 0;  // profiling: 0 = by shape, 2 / 4 = force
 
-template <int EPI, int TM, int WN>
+template <int EPI, int TM, int WN, int TNJ = 2>
 int launch_gemm8_dma_tm(const Gemm8Args& p, hipStream_t stream) {
-  constexpr int WGM = TM * 64, WGN = WN * 64;
+  constexpr int WGM = TM * 64, WGN = WN * TNJ * 32;
   dim3 grid((unsigned)((p.N + WGN - 1) / WGN), (unsigned)((p.M + WGM - 1) / WGM)), block(128 * WN);
   const size_t smem = 2 * (size_t)(WGM + WGN) * BK;  // 64 KiB (128 x 128) ... 128 KiB (256 x 256)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_dma_kernel<EPI, TM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_dma_kernel<EPI, TM, WN, TNJ>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(gemm8_dma_kernel)");
     attr_set = true;
   }
-  ao::launch(gemm8_dma_kernel<EPI, TM, WN>, grid, block, smem, stream, p);
+  ao::launch(gemm8_dma_kernel<EPI, TM, WN, TNJ>, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("gemm8_dma_kernel launch");
   return AO_OK;
 }
@@ -373,6 +374,7 @@ int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
   // variants (ao_gemm8_set_variant): 2 = 128 x 128 tile / 4 waves; 4 = 256 x 128 / 4 waves (one wave per SIMD:
   // measured 0.75-0.95x, nothing hides its ds_read -> MFMA latency); 8 = 256 x 256 / 8 waves.
   if (g_gemm8_tm == 4) return launch_gemm8_dma_tm<EPI, 4, 2>(p, stream);
+  if (g_gemm8_tm == 16) return launch_gemm8_dma_tm<EPI, 4, 2, 4>(p, stream);  // 256 x 256, 4 waves of 128 x 128
   // (A 4-stage, 64-byte-K-step pipeline with hand-counted vmcnt was measured at 0.94-0.97x of these two-stage
   // kernels at both tile shapes, profiles/bench_8bit_r01_gemm.txt: the loop is LDS-read bound, not latency bound.)
   const int64_t big = (int64_t)((p.N + 255) / 256) * ((p.M + 255) / 256);
@@ -412,7 +414,7 @@ using namespace ao;
 
 extern "C" int ao_gemm8_set_variant(int variant) {
   g_gemm8_force_regstage = (variant == 1);
-  g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8) ? variant : 0;
+  g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16) ? variant : 0;
   return AO_OK;
 }
 

@@ -256,7 +256,7 @@ def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
     assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 8])
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("m,n,k", [(130, 208, 1152), (300, 528, 256), (513, 384, 4096)])  # N % 16 == 0 (fp8 requirement)
 def test_gemm8_every_kernel_variant(variant, m, n, k):
     """register-staged, 128x128 / 256x128 / 256x256 LDS-DMA kernels: same bits for int8 (integer GEMM + the
