@@ -16,6 +16,9 @@
 //   int4_tile_packed_to_4d_tensor.py:287  aten::_weight_int4pack_mm
 //   quant_primitives.py:999-1007          dequant rounding sequence (the oracle)
 //   quant_primitives.py:1299-1335,577-599 tinygemm qparams / quantize
+#include <algorithm>
+#include <mutex>
+
 #include "common.h"
 
 namespace ao {
@@ -472,7 +475,8 @@ constexpr int kTiledA = 128 * kTiledStride;         // x tile: 34,816 B
 template <int G, int TNW>
 __global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qdata,
                                                             const uint32_t* __restrict__ sz, uint16_t* __restrict__ y,
-                                                            int M, int N, int K) {
+                                                            int M, int N, int K, float* __restrict__ ws,
+                                                            unsigned* __restrict__ tickets) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
   constexpr int WPT = 8 / TNW;          // waves per n-tile
   constexpr int WPW = 4 / WPT;          // packed words per lane per wave
@@ -485,7 +489,10 @@ __global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __re
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * (TNW * 16);
-  const int kblocks = K >> 7;
+  // split-K: workgroup z of S walks packed k-blocks [kb0, kb0 + kblocks) of the K / 128 (balanced cut)
+  const int S = gridDim.z, ks = blockIdx.z;
+  const int kb0 = (int)(((long long)(K >> 7) * ks) / S);
+  const int kblocks = (int)(((long long)(K >> 7) * (ks + 1)) / S) - kb0;
   const int ntiles = N >> 4;
   const int nl = lane & 15, kq = lane >> 4;
   const s16x4 ident = identity_fragment<4>(lane);
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __re
   // their columns are never stored)
   const int wt = wave / WPT, w0 = (wave % WPT) * WPW;
   const int wtile = min((n0 >> 4) + wt, ntiles - 1);
-  const uint32_t* wp = qdata + ((size_t)wtile * kblocks * 64 + lane) * 4 + w0;
+  const uint32_t* wp = qdata + ((size_t)wtile * (K >> 7) * 64 + lane) * 4 + w0;
   const uint32_t* szp = sz + wtile * 16 + nl;
   // activations: thread t stages chunks t + 512 i (i < 4) of the 128 x 16 chunk grid (16 B each)
   const uint16_t* xsrc[4];
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __re
     u32x4 a[4];
   };
   auto fetch = [&](Regs& r, int kb) {  // kb clamped: the prefetch past the end re-reads the last block (unused)
-    const int k = min(kb, kblocks - 1);
+    const int k = kb0 + min(kb, kblocks - 1);
     const uint32_t* p = wp + (size_t)k * 256;
     if constexpr (WPW == 4) {
       const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
@@ -608,6 +615,69 @@ __global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __re
     fetch(r0, kb + 8); multiply(buf1); lds_barrier();
   }
 
+  // split-K meeting: every part parks its fp32 tile in the workspace ([tile][part][reg][thread], 16 B per
+  // thread and register: coalesced), takes a ticket, and the last one to arrive adds the parts in part
+  // order (so the sum does not depend on arrival order) and stores the tile.  The parts sit on different
+  // XCDs (non-coherent L2s): the tiles are written through and read with agent-scope (sc1) accesses
+  // instead of device fences -- a fence writes back / invalidates the whole L2 and cost ~60 us per launch.
+  if (S > 1) {
+    constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    constexpr int kPartBytes = 2 * NJ * 512 * 16;
+    const __amdgpu_buffer_rsrc_t rws =
+        __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * S * (kPartBytes / 4), 0, S * kPartBytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rws, tid * 16 + (i * NJ + j) * 8192,
+                                               ks * kPartBytes, kSc1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
+    __syncthreads();
+    int* last = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *last = (t == (unsigned)S - 1);
+      // everyone has arrived: leave the ticket ready for the next launch
+      if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!*last) return;
+    // parts are read four at a time (32 loads in flight per thread; indices past S re-read the last part and
+    // are not added), summed in part order
+    f32x4 sum[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sum[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < S; q0 += 4) {
+      f32x4 v[4][2][NJ];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            v[u][i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + (i * NJ + j) * 8192,
+                                                                                        min(q0 + u, S - 1) * kPartBytes, kSc1));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool keep = q0 + u < S;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            sum[i][j].x += keep ? v[u][i][j].x : 0.f; sum[i][j].y += keep ? v[u][i][j].y : 0.f;
+            sum[i][j].z += keep ? v[u][i][j].z : 0.f; sum[i][j].w += keep ? v[u][i][j].w : 0.f;
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = sum[i][j];
+  }
+
   // D layout of the 16x16 tile: lane (col = nl, kq) holds rows 4 kq + {0..3}
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -623,11 +693,58 @@ __global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __re
     }
 }
 
+// Split-K workspace of the tiled kernel: kTiledSlots rotating slots (launches in flight per device) of
+// kTiledMaxWgs fp32 tiles (128 x 128) + one ticket per output tile.  Allocated on first use.
+constexpr int kTiledSlots = 4;
+constexpr int kTiledMaxWgs = 256;
+constexpr size_t kTiledSlotFloats = (size_t)kTiledMaxWgs * 128 * 128;
+struct TiledWs {
+  float* part = nullptr;
+  unsigned* tickets = nullptr;
+  unsigned next_slot = 0;
+};
+std::mutex g_tiled_mu;
+TiledWs g_tiled_ws[64];
+
+int tiled_workspace(float** part, unsigned** tickets) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_failed(e, "hipGetDevice");
+  AO_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_tiled_mu);
+  TiledWs& w = g_tiled_ws[dev];
+  if (w.part == nullptr) {
+    const size_t bytes = kTiledSlots * (kTiledSlotFloats * sizeof(float) + kTiledMaxWgs * sizeof(unsigned));
+    char* p = nullptr;
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+      return hip_failed(e, "hipMalloc(int4 tiled split-K workspace); call ao_int4_weight_int4pack_mm with this M once "
+                           "outside stream capture before capturing it into a graph");
+    unsigned* t = reinterpret_cast<unsigned*>(p + kTiledSlots * kTiledSlotFloats * sizeof(float));
+    e = hipMemset(t, 0, kTiledSlots * kTiledMaxWgs * sizeof(unsigned));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(int4 tiled split-K tickets)"); }
+    w.part = reinterpret_cast<float*>(p);
+    w.tickets = t;
+  }
+  const unsigned slot = w.next_slot++ % kTiledSlots;
+  *part = w.part + slot * kTiledSlotFloats;
+  *tickets = w.tickets + slot * kTiledMaxWgs;
+  return AO_OK;
+}
+
 template <int G, int TNW>
 int launch_mm_tiled(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K,
-                    hipStream_t stream) {
-  dim3 grid((unsigned)((N + TNW * 16 - 1) / (TNW * 16)), (unsigned)((M + 127) / 128)), block(512);
+                    int split, hipStream_t stream) {
+  dim3 grid((unsigned)((N + TNW * 16 - 1) / (TNW * 16)), (unsigned)((M + 127) / 128), (unsigned)split), block(512);
   const size_t smem = 2 * (size_t)(kTiledA + TNW * 16 * kTiledStride);
+  float* ws = nullptr;
+  unsigned* tickets = nullptr;
+  if (split > 1) {
+    AO_REQUIRE((int64_t)grid.x * grid.y * split <= kTiledMaxWgs, "int4_mm_tiled: %u x %u tiles x %d parts exceed the split-K workspace",
+               grid.x, grid.y, split);
+    if (int rc = tiled_workspace(&ws, &tickets)) return rc;
+  }
   auto kern = int4_mm_tiled_kernel<G, TNW>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -636,7 +753,7 @@ int launch_mm_tiled(const uint16_t* x, const int32_t* qdata, const uint16_t* sz,
     attr_set = true;
   }
   ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const uint32_t*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
-             (int)M, (int)N, (int)K);
+             (int)M, (int)N, (int)K, ws, tickets);
   AO_LAUNCH_CHECK("int4_mm_tiled_kernel launch");
   return AO_OK;
 }
@@ -889,12 +1006,26 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 16 || g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
-  // 16 < M: dequantise each weight block once per workgroup (int4_mm_tiled_kernel); as many n-tiles per
-  // workgroup as still leave >= ~200 workgroups (x is re-staged by every workgroup of a row slab)
-  const int64_t slabs = (M + 127) / 128, ntiles = N >> 4;
-  if (g_tune_wpb == 8 || (g_tune_wpb == 0 && ((ntiles + 7) / 8) * slabs >= 200)) return launch_mm_tiled<G, 8>(x, qdata, sz, y, M, N, K, stream);
-  if (g_tune_wpb == 4 || (g_tune_wpb == 0 && ((ntiles + 3) / 4) * slabs >= 200)) return launch_mm_tiled<G, 4>(x, qdata, sz, y, M, N, K, stream);
-  return launch_mm_tiled<G, 2>(x, qdata, sz, y, M, N, K, stream);
+  // 16 < M: dequantise each weight block once per workgroup (int4_mm_tiled_kernel).  Widest tile (least
+  // re-staging of x) whose grid, cut along K into at most 8 parts of >= 8 k-blocks, still has ~200
+  // workgroups; modes 500 + S force the number of parts, wpb the tile width.
+  const int64_t slabs = (M + 127) / 128, ntiles = N >> 4, kblocks = K >> 7;
+  int tnw = 2, split = 1;
+  for (int t : {8, 4, 2}) {
+    const int64_t base = ((ntiles + t - 1) / t) * slabs;
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>({(int64_t)kTiledMaxWgs / std::max<int64_t>(base, 1), 8, kblocks / 8}));
+    if (base >= 200) s = 1;
+    tnw = t;
+    split = (int)s;
+    if (g_tune_wpb == t || (g_tune_wpb == 0 && base * s >= 190)) break;
+  }
+  if (g_tune_mode >= 500 && g_tune_mode < 600) {  // forced number of parts (clamped to what fits)
+    const int64_t base = ((ntiles + tnw - 1) / tnw) * slabs;
+    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)g_tune_mode - 500, kblocks, kTiledMaxWgs / std::max<int64_t>(base, 1)}));
+  }
+  if (tnw == 8) return launch_mm_tiled<G, 8>(x, qdata, sz, y, M, N, K, split, stream);
+  if (tnw == 4) return launch_mm_tiled<G, 4>(x, qdata, sz, y, M, N, K, split, stream);
+  return launch_mm_tiled<G, 2>(x, qdata, sz, y, M, N, K, split, stream);
 }
 
 int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {

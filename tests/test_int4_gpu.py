@@ -171,6 +171,20 @@ def test_mm_tiled_batched(m, n, k, g):
     assert np.mean(y == y_ref) > 0.97
 
 
+def test_mm_tiled_split_k_is_deterministic_and_reusable():
+    """Narrow N at bs = 128 cuts K into parts that meet through a workspace + ticket: the sum is taken in
+    part order, so repeated launches (which also rotate workspace slots and reuse tickets) agree bit for bit."""
+    m, n, k, g = 128, 4096, 14336, 128
+    w = _rand_weight(n, k, 5).to(DEV)
+    qdata, sz = ops.int4_quantize_tinygemm(w, g)
+    x = torch.randn(m, k, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    first = ops.weight_int4pack_mm(x, qdata, g, sz)
+    for _ in range(9):
+        assert torch.equal(ops.weight_int4pack_mm(x, qdata, g, sz), first)
+    ref = (x.float() @ ops.int4_dequantize(qdata, sz, g).float().t()).to(torch.bfloat16)
+    assert _rel(np_from_torch_bf16(first), np_from_torch_bf16(ref)) <= 1e-3
+
+
 def test_mm_golden(golden_int4):
     d = golden_int4
     for case in ["g32", "g64", "g128", "g256"]:
