@@ -18,8 +18,11 @@
 //   quant_primitives.py:1299-1335,577-599 tinygemm qparams / quantize
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
+#include <utility>
 
 #include "common.h"
+#include "lds_dma.h"
 
 namespace ao {
 // int4_stream_kernels.hip: the balanced streaming M = 1 kernel (the product decode path)
@@ -109,6 +112,36 @@ __device__ __forceinline__ void dequant_word_mfma(uint32_t p, float s, float neg
   const f32x4 w1 = widen_add<DQ>(ident, tp2, tp3, zz);
   out[0] = pack_bf16x2(w0.x, w0.y); out[1] = pack_bf16x2(w0.z, w0.w);  // rounding #2
   out[2] = pack_bf16x2(w1.x, w1.y); out[3] = pack_bf16x2(w1.z, w1.w);
+}
+
+// dequant_word_mfma cut into four stages so that a caller can slot them between independent MFMAs
+// (the batched register-B kernel: one wave per SIMD, nothing else hides the VALU work)
+struct DequantPipe {
+  f32x2 r0, r1, r2, r3;
+  uint32_t tp0, tp1, tp2, tp3;
+  f32x4 w0, w1;
+  uint32_t out[4];
+};
+template <int STAGE>
+__device__ __forceinline__ void dequant_stage(DequantPipe& d, uint32_t p, float s, float neg8s, float z, s16x4 ident) {
+  if constexpr (STAGE == 0) {
+    const uint32_t lo = p & 0x0F0F0F0Fu, hi = (p >> 4) & 0x0F0F0F0Fu;
+    d.r0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, false);
+    d.r1 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, true);
+    d.r2 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, false);
+    d.r3 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(hi, 512.0f, true);
+  } else if constexpr (STAGE == 1) {
+    const f32x2 t0 = d.r0 * s + neg8s, t1 = d.r1 * s + neg8s, t2 = d.r2 * s + neg8s, t3 = d.r3 * s + neg8s;
+    d.tp0 = pack_bf16x2(t0.x, t1.x); d.tp1 = pack_bf16x2(t2.x, t3.x);  // rounding #1
+    d.tp2 = pack_bf16x2(t0.y, t1.y); d.tp3 = pack_bf16x2(t2.y, t3.y);
+  } else if constexpr (STAGE == 2) {
+    const f32x4 zz = {z, z, z, z};
+    d.w0 = widen_add<4>(ident, d.tp0, d.tp1, zz);
+    d.w1 = widen_add<4>(ident, d.tp2, d.tp3, zz);
+  } else {
+    d.out[0] = pack_bf16x2(d.w0.x, d.w0.y); d.out[1] = pack_bf16x2(d.w0.z, d.w0.w);  // rounding #2
+    d.out[2] = pack_bf16x2(d.w1.x, d.w1.y); d.out[3] = pack_bf16x2(d.w1.z, d.w1.w);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -453,247 +486,303 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) 
 }
 
 // ---------------------------------------------------------------------------
-// 16 < M: int4 weight-only GEMM for batched decode / small prefill (the "bs = 128" half of the
-// BASELINE metric).  int4_mm_kernel re-dequantises the weights for every 16-row slab of x and
-// re-reads x from L2 for every 16-wide n-tile.  Here a workgroup (8 waves) owns a 128 (m) x 128 (n)
-// output tile and walks K one packed k-block (128 k) at a time:
-//   * wave w dequantises the block of n-tile w (exact oracle rounding, as everywhere) into an LDS
-//     tile of bf16 [128 n][128 k] rows, k contiguous;
-//   * all threads stage x[128 m][128 k] next to it;
-//   * wave (wm, wn) = (w >> 1, w & 1) multiplies its 32 x 64 sub-tile: 8 MFMAs 16x16x32 per 32-k slice.
-// Dequant work per weight is done once and is split over the 8 waves; 128 rows amortise it.  LDS
-// tiles are double buffered (one barrier per k-block), operands for block kb+2 are in registers
-// while block kb is multiplied.  Rows are 272 B apart (256 + 16 pad) so that the 16 rows of a
-// fragment read start on different banks.
+// Split-K meeting of the batched kernels: every part parks its fp32 tile in the workspace
+// ([tile][part][reg][thread], 16 B per thread and register: coalesced), takes a ticket, and the last one
+// to arrive adds the parts in part order (so the sum does not depend on arrival order) and returns true:
+// it stores the tile.  The parts sit on different XCDs (non-coherent L2s): the tiles are written through
+// and read with agent-scope (sc1) accesses instead of device fences -- a fence writes back / invalidates
+// the whole L2 and cost ~60 us per launch.  `flag` is any LDS word no wave is still using.
 // ---------------------------------------------------------------------------
-constexpr int kTiledStride = 256 + 16;             // bytes per row of 128 bf16
-constexpr int kTiledA = 128 * kTiledStride;         // x tile: 34,816 B
+template <int NREG, int NTHR>
+__device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
+  constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
+  constexpr int kRegBytes = NTHR * 16;
+  constexpr int kPartBytes = NREG * kRegBytes;
+  const __amdgpu_buffer_rsrc_t rws =
+      __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * S * (kPartBytes / 4), 0, S * kPartBytes, 0x00020000);
+#pragma unroll
+  for (int r = 0; r < NREG; ++r)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kSc1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == (unsigned)S - 1);
+    // everyone has arrived: leave the ticket ready for the next launch
+    if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!*flag) return false;
+  // parts are read in batches (<= 32 loads in flight per thread; indices past S re-read the last part and are
+  // not added), summed in part order
+  constexpr int U = (NREG >= 16) ? 2 : 4;
+  f32x4 sum[NREG];
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) sum[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < S; q0 += U) {
+    f32x4 v[U][NREG];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < NREG; ++r)
+        v[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, min(q0 + u, S - 1) * kPartBytes, kSc1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool keep = q0 + u < S;
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        sum[r].x += keep ? v[u][r].x : 0.f; sum[r].y += keep ? v[u][r].y : 0.f;
+        sum[r].z += keep ? v[u][r].z : 0.f; sum[r].w += keep ? v[u][r].w : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) acc[r] = sum[r];
+  return true;
+}
 
-// TNW = n-tiles (16 columns each) per workgroup: 8, 4 or 2 -- fewer for narrow N so that the grid still
-// covers the chip.  The 8 waves always split the dequant evenly: 8 / TNW waves share one packed block,
-// 4 * TNW / 8 of its 4 words each.
-template <int G, int TNW>
-__global__ __launch_bounds__(512) void int4_mm_tiled_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ qdata,
-                                                            const uint32_t* __restrict__ sz, uint16_t* __restrict__ y,
-                                                            int M, int N, int K, float* __restrict__ ws,
-                                                            unsigned* __restrict__ tickets) {
+// ---------------------------------------------------------------------------
+// 16 < M (batched decode / small prefill, the "bs = 128" half of the BASELINE metric), "register-B" form: each packed
+// block is dequantised once per 128-row slab and the dequantised weights never touch LDS -- a wave that owns NT n-tiles
+// dequantises their packed words straight into B operands of v_mfma_f32_16x16x32_bf16 and multiplies all 128 rows
+// of the slab against them; only x goes through LDS, once per workgroup and k-block.
+//
+// Operand shapes.  In the packed block lane (n, kq) owns, per word j, the runs k = 32j + 16h + 4kq + {0..3}
+// (h = 0, 1): never 8 contiguous k, so an A operand matching "one lane = one packed lane" would be two 8-byte
+// pieces of x (ds_read2_b64: half the LDS rate, and LDS-DMA cannot scatter 8-byte pieces).  The weights sit in
+// LDS anyway (ring below), so a lane reads a different 16 bytes of the block instead: lane (n, g), g = 2a + t,
+// takes words {2a, 2a + 1} of packed lanes (n, kq = 2t) and (n, kq = 2t + 1).  For e, h in {0, 1} its runs
+// (j = 2a + e, h) of the two kq are adjacent: k = 64a + 32e + 16h + 8t + {0..7}.  The MFMA of phase p = 2e + h
+// sums the 4 lane groups' 8 k = all (a, t): 32 distinct k; four phases cover the 128.  The matching A operand is
+// one aligned 16-byte chunk of x: chunk c = 8a + 4e + 2h + t = 2p ^ (8a | t)  ->  one ds_read_b128.
+//   * workgroup = WAVES waves, tile 128 (m) x WAVES NT 16 (n), grid.z = split-K parts;
+//   * x tile [128 rows][256 B] by LDS-DMA (16 B per lane, 4 rows per instruction).  DMA writes lane-linear, so rows
+//     cannot be padded; the SOURCE is swizzled instead: LDS chunk position c' of row r holds global chunk c' ^ (r & 15),
+//     which makes every 16-lane service group of the b128 fragment reads hit 16 different bank windows;
+//   * packed weights + scale/zero words by LDS-DMA into a wave-private ring (as in the M = 1 kernel);
+//   * one ring of 3 stages for everything, filled two k-blocks ahead, one s_waitcnt vmcnt(LPS) + one LDS-only
+//     barrier per k-block (all loads are DMAs issued from asm: the compiler's own counting never sees them);
+//   * the k-block is scheduled by hand in slots of two MFMAs: next A operands are read, the next two words are
+//     dequantised (four VALU stages per word) and the ring's DMAs are dealt one per slot (issued back to back they
+//     queue in the texture path and hold the wave ~120 cycles each; spreading them further or staggering them
+//     between waves measured 7 % slower).
+// ---------------------------------------------------------------------------
+constexpr int kRbABuf = 128 * 256;  // one x stage: 32 KiB
+constexpr int kRbStages = 3;
+
+// ABL (profiling builds only): 1 no 16x16x32 MFMAs, 2 no dequant, 3 no A reads, 4 no DMAs, 5 product + s_memtime stamps of wave 0
+// (16 u64 per workgroup: entry, ring primed, barrier of k-blocks 0..7 passed, loop done, meeting done, exit)
+template <int G, int WAVES, int NT, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_kernel(
+    const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M,
+    int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets, unsigned long long* __restrict__ trace) {
+  unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (ABL == 5) ts[0] = __builtin_amdgcn_s_memtime();
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
-  constexpr int WPT = 8 / TNW;          // waves per n-tile
-  constexpr int WPW = 4 / WPT;          // packed words per lane per wave
-  constexpr int NJ = TNW / 2;           // 16-column MFMA tiles per wave (waves: 4 along m x 2 along n)
-  constexpr int BUF = kTiledA + TNW * 16 * kTiledStride;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][A 128 rows | B TNW*16 rows], 272 B per row
+  constexpr int WBLK = 1024 + NG * 256;   // one n-tile's share of a ring stage: packed block + NG x 64 scale/zero words
+  constexpr int WST = NT * WBLK;
+  constexpr int ADMA = 32 / WAVES;        // x DMAs per wave and stage (4 rows each)
+  constexpr int LPS = ADMA + NT * (1 + NG);  // DMAs per wave and stage
+  constexpr int SLOTS = 16 * NT;          // MFMA pairs per k-block
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][128 rows][256 B] x | [WAVES][3][WST]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * (TNW * 16);
-  // split-K: workgroup z of S walks packed k-blocks [kb0, kb0 + kblocks) of the K / 128 (balanced cut)
-  const int S = gridDim.z, ks = blockIdx.z;
-  const int kb0 = (int)(((long long)(K >> 7) * ks) / S);
-  const int kblocks = (int)(((long long)(K >> 7) * (ks + 1)) / S) - kb0;
+  const int nl = lane & 15, grp = lane >> 4;
+  const int m0 = blockIdx.y * 128;
   const int ntiles = N >> 4;
-  const int nl = lane & 15, kq = lane >> 4;
+  const int kblocks = K >> 7;
+  const int tile0 = blockIdx.x * (WAVES * NT) + wave * NT;  // this wave's first n-tile
+  const int S = gridDim.z, ks = blockIdx.z;
+  const int kb0 = (int)(((long long)kblocks * ks) / S);
+  const int nkb = (int)(((long long)kblocks * (ks + 1)) / S) - kb0;
   const s16x4 ident = identity_fragment<4>(lane);
 
-  // weights: this wave dequantises words w0 .. w0 + WPW - 1 of n-tile n0/16 + wt (tiles past N alias the last one;
-  // their columns are never stored)
-  const int wt = wave / WPT, w0 = (wave % WPT) * WPW;
-  const int wtile = min((n0 >> 4) + wt, ntiles - 1);
-  const uint32_t* wp = qdata + ((size_t)wtile * (K >> 7) * 64 + lane) * 4 + w0;
-  const uint32_t* szp = sz + wtile * 16 + nl;
-  // activations: thread t stages chunks t + 512 i (i < 4) of the 128 x 16 chunk grid (16 B each)
-  const uint16_t* xsrc[4];
-  int xdst[4];
+  // x DMA i of this wave fills rows 4 (ADMA wave + i) + (lane >> 4), chunk position lane & 15
+  uint32_t aoff[ADMA];  // byte offsets from x + k * 128 (rows past M alias row M - 1; never stored)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 512 * i, row = c >> 4, col = c & 15;
-    xsrc[i] = x + (size_t)min(m0 + row, M - 1) * K + col * 8;
-    xdst[i] = row * kTiledStride + col * 16;
+  for (int i = 0; i < ADMA; ++i) {
+    const int row = 4 * (ADMA * wave + i) + (lane >> 4);
+    aoff[i] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)K * 2u + (((lane & 15) ^ (row & 15)) << 4);
   }
-
-  struct Regs {
-    uint32_t w[WPW];
-    uint32_t sz[NG];
-    u32x4 a[4];
-  };
-  auto fetch = [&](Regs& r, int kb) {  // kb clamped: the prefetch past the end re-reads the last block (unused)
-    const int k = kb0 + min(kb, kblocks - 1);
-    const uint32_t* p = wp + (size_t)k * 256;
-    if constexpr (WPW == 4) {
-      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-      r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
-    } else if constexpr (WPW == 2) {
-      const u32x2 v = *reinterpret_cast<const u32x2*>(p);
-      r.w[0] = v.x; r.w[1] = v.y;
+  const uint32_t a_lds = lds_offset(smem);
+  const uint32_t w_lds = a_lds + kRbStages * kRbABuf + wave * (kRbStages * WST);
+  // One DMA of the stage's LPS (compile-time index): the x rows first, then per n-tile the packed block and its
+  // scale/zero words.  kb clamped: the fill past the end re-reads the last block (unused)
+  auto issue_one = [&](auto idx_c, int stage, int kb) {
+    constexpr int idx = decltype(idx_c)::value;
+    if (ABL == 4) return;
+    const int k = kb0 + min(kb, nkb - 1);
+    if constexpr (idx < ADMA) {
+      dma_b128_s(x + (size_t)k * 128, aoff[idx], a_lds + stage * kRbABuf + (ADMA * wave + idx) * 1024);
     } else {
-      r.w[0] = *p;
-    }
-    const int kg0 = (G >= 128) ? ((k * 128) / G) : (k * NG);
-#pragma unroll
-    for (int i = 0; i < NG; ++i) r.sz[i] = szp[(size_t)(kg0 + i) * N];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.a[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + (size_t)k * 128);
-  };
-  auto stage = [&](const Regs& r, char* buf) {
-    // B: lane (n, kq) owns, per word j, k = 32j + 4kq + {0..3} and 32j + 16 + 4kq + {0..3}
-    char* brow = buf + kTiledA + (wt * 16 + nl) * kTiledStride + kq * 8;
-#pragma unroll
-    for (int jj = 0; jj < WPW; ++jj) {
-      const int j = w0 + jj;
-      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
-      const float sc = bf16_lo_to_f32(r.sz[gi]);
-      const float zp = bf16_hi_to_f32(r.sz[gi]);
-      uint32_t b[4];
-      dequant_word_mfma<4>(r.w[jj], sc, -8.0f * sc, zp, ident, b);
-      *reinterpret_cast<u32x2*>(brow + j * 64) = u32x2{b[0], b[1]};       // k = 32j + 4kq .. +3
-      *reinterpret_cast<u32x2*>(brow + j * 64 + 32) = u32x2{b[2], b[3]};  // k = 32j + 16 + 4kq .. +3
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(buf + xdst[i]) = r.a[i];
-  };
-
-  f32x4 acc[2][NJ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment reads: lane (row nl of a 16-row tile, kq) reads the 8 contiguous k at 8 kq of each 32-k slice
-  const int a_off = (wm * 32 + nl) * kTiledStride + kq * 16;
-  const int b_off = kTiledA + (wn * NJ * 16 + nl) * kTiledStride + kq * 16;
-  auto multiply = [&](const char* buf) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 af[2], bf[NJ];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const u32x4*>(buf + a_off + i * 16 * kTiledStride + ks * 64);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const u32x4*>(buf + b_off + j * 16 * kTiledStride + ks * 64);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
-                                                              acc[i][j], 0, 0, 0);
-    }
-  };
-  // LDS-only barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. for the operand prefetch
-  // issued just before it -- a full memory latency per k-block (measured: 0.94 us per block)
-  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  // Operands are fetched FOUR k-blocks ahead into a static ring of register sets (the loop is unrolled by 4 so
-  // that every set has a fixed name): block b+1 is dequantised/staged into the other LDS buffer while block b
-  // is multiplied.  The steady-state body has no branch (a branch between a load and its use costs vmcnt(0)).
-  Regs r0, r1, r2, r3;
-  fetch(r0, 0); fetch(r1, 1); fetch(r2, 2); fetch(r3, 3);
-  stage(r0, smem);
-  fetch(r0, 4);
-  lds_barrier();
-  char* const buf0 = smem;
-  char* const buf1 = smem + BUF;
-  int kb = 0;
-  for (; kb + 8 <= kblocks; kb += 4) {
-    stage(r1, buf1); fetch(r1, kb + 5); multiply(buf0); lds_barrier();
-    stage(r2, buf0); fetch(r2, kb + 6); multiply(buf1); lds_barrier();
-    stage(r3, buf1); fetch(r3, kb + 7); multiply(buf0); lds_barrier();
-    stage(r0, buf0); fetch(r0, kb + 8); multiply(buf1); lds_barrier();
-  }
-  // tail (< 8 blocks): same schedule with bounds checks (fetch clamps its index)
-  for (; kb < kblocks; kb += 4) {
-    if (kb + 1 < kblocks) stage(r1, buf1);
-    fetch(r1, kb + 5); multiply(buf0); lds_barrier();
-    if (kb + 1 >= kblocks) break;
-    if (kb + 2 < kblocks) stage(r2, buf0);
-    fetch(r2, kb + 6); multiply(buf1); lds_barrier();
-    if (kb + 2 >= kblocks) break;
-    if (kb + 3 < kblocks) stage(r3, buf1);
-    fetch(r3, kb + 7); multiply(buf0); lds_barrier();
-    if (kb + 3 >= kblocks) break;
-    if (kb + 4 < kblocks) stage(r0, buf0);
-    fetch(r0, kb + 8); multiply(buf1); lds_barrier();
-  }
-
-  // split-K meeting: every part parks its fp32 tile in the workspace ([tile][part][reg][thread], 16 B per
-  // thread and register: coalesced), takes a ticket, and the last one to arrive adds the parts in part
-  // order (so the sum does not depend on arrival order) and stores the tile.  The parts sit on different
-  // XCDs (non-coherent L2s): the tiles are written through and read with agent-scope (sc1) accesses
-  // instead of device fences -- a fence writes back / invalidates the whole L2 and cost ~60 us per launch.
-  if (S > 1) {
-    constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    constexpr int kPartBytes = 2 * NJ * 512 * 16;
-    const __amdgpu_buffer_rsrc_t rws =
-        __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * S * (kPartBytes / 4), 0, S * kPartBytes, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rws, tid * 16 + (i * NJ + j) * 8192,
-                                               ks * kPartBytes, kSc1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
-    __syncthreads();
-    int* last = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *last = (t == (unsigned)S - 1);
-      // everyone has arrived: leave the ticket ready for the next launch
-      if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!*last) return;
-    // parts are read four at a time (32 loads in flight per thread; indices past S re-read the last part and
-    // are not added), summed in part order
-    f32x4 sum[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) sum[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int q0 = 0; q0 < S; q0 += 4) {
-      f32x4 v[4][2][NJ];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            v[u][i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + (i * NJ + j) * 8192,
-                                                                                        min(q0 + u, S - 1) * kPartBytes, kSc1));
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool keep = q0 + u < S;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            sum[i][j].x += keep ? v[u][i][j].x : 0.f; sum[i][j].y += keep ? v[u][i][j].y : 0.f;
-            sum[i][j].z += keep ? v[u][i][j].z : 0.f; sum[i][j].w += keep ? v[u][i][j].w : 0.f;
-          }
+      constexpr int t = (idx - ADMA) / (1 + NG), part = (idx - ADMA) % (1 + NG);
+      const int tile = min(tile0 + t, ntiles - 1);  // tiles past N alias the last one; their columns are never stored
+      const uint32_t dst = w_lds + stage * WST + t * WBLK;
+      if constexpr (part == 0) {
+        dma_b128_nt_s(qdata + ((size_t)tile * kblocks + k) * 64, lane * 16, dst);
+      } else {
+        const int kg0 = (G >= 128) ? ((k * 128) / G) : (k * NG);
+        dma_b32_s(sz + (size_t)(kg0 + part - 1) * N + tile * 16, nl * 4, dst + 1024 + (part - 1) * 256);
       }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = sum[i][j];
-  }
+  };
+  auto issue_all = [&](int stage, int kb) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, I>{}, stage, kb), ...); }
+    (std::make_integer_sequence<int, LPS>{});
+  };
 
-  // D layout of the 16x16 tile: lane (col = nl, kq) holds rows 4 kq + {0..3}
+  f32x4 acc[8 * NT];  // [n-tile][m-tile]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 8 * NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane (row r = nl, group g = 2a + t): A operand of phase p = chunk 2p ^ (8a | t) of row r, at position chunk ^ r
+  const int ga = grp >> 1, gt = grp & 1;
+  const int pbase = nl * 256 + ((((ga << 3) | gt) ^ nl) << 4);  // ^ (p << 5) per phase, + 4096 per m-tile
+  // its weight words: words {2a, 2a + 1} of packed lanes (n, kq = 2t) and (n, kq = 2t + 1)
+  const int wbase = ((2 * gt) * 16 + nl) * 16 + 8 * ga;        // second piece: + 256
+  // scale/zero word of word j = 2a + e
+  const int zg0 = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga, zg1 = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga + 1;
+
+  auto kblock = [&](int stage, int refill, int kb) {
+    const char* A = smem + stage * kRbABuf;
+    const char* Wst = smem + kRbStages * kRbABuf + (wave * kRbStages + stage) * WST;
+    uint32_t word[NT][2][2];  // [tile][e][which packed lane]
+    float sc[NT][2], zp[NT][2];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int nn = n0 + (wn * NJ + j) * 16 + nl;
-      if (nn >= N) continue;
+    for (int t = 0; t < NT; ++t) {
+      const u32x2 pa = *reinterpret_cast<const u32x2*>(Wst + t * WBLK + wbase);
+      const u32x2 pb = *reinterpret_cast<const u32x2*>(Wst + t * WBLK + wbase + 256);
+      word[t][0][0] = pa.x; word[t][1][0] = pa.y; word[t][0][1] = pb.x; word[t][1][1] = pb.y;
+      const uint32_t z0 = *reinterpret_cast<const uint32_t*>(Wst + t * WBLK + 1024 + zg0 * 256 + nl * 4);
+      const uint32_t z1 = (G >= 64) ? z0 : *reinterpret_cast<const uint32_t*>(Wst + t * WBLK + 1024 + zg1 * 256 + nl * 4);
+      sc[t][0] = bf16_lo_to_f32(z0); zp[t][0] = bf16_hi_to_f32(z0);
+      sc[t][1] = bf16_lo_to_f32(z1); zp[t][1] = bf16_hi_to_f32(z1);
+    }
+    auto read_a = [&](u32x4 (&a)[8], int p) {
+      const char* ap = A + (pbase ^ (p << 5));
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        if (ABL == 3) { a[mt] = u32x4{(uint32_t)pbase, (uint32_t)mt, (uint32_t)p, word[0][0][0]}; continue; }
+        a[mt] = *reinterpret_cast<const u32x4*>(ap + mt * 4096);
+      }
+    };
+    // dequant stage st of word (tile t, e, which)
+    auto stage_of = [&](auto st_c, DequantPipe& d, int t, int e, int which) {
+      if (ABL == 2) {
+        if constexpr (decltype(st_c)::value == 3) { d.out[0] = word[t][e][which]; d.out[1] = d.out[0] + 1; d.out[2] = d.out[0] ^ 5; d.out[3] = d.out[0] + 7; }
+        return;
+      }
+      dequant_stage<decltype(st_c)::value>(d, word[t][e][which], sc[t][e], -8.0f * sc[t][e], zp[t][e], ident);
+    };
+    DequantPipe dq[NT][2];
+    u32x4 a[8], an[8];
+    u32x4 bv[NT][2];  // [tile][h] B operands of the current e
+    auto take_b = [&] {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        bv[t][0] = u32x4{dq[t][0].out[0], dq[t][0].out[1], dq[t][1].out[0], dq[t][1].out[1]};
+        bv[t][1] = u32x4{dq[t][0].out[2], dq[t][0].out[3], dq[t][1].out[2], dq[t][1].out[3]};
+      }
+    };
+    read_a(a, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int wh = 0; wh < 2; ++wh) {
+        stage_of(std::integral_constant<int, 0>{}, dq[t][wh], t, 0, wh);
+        stage_of(std::integral_constant<int, 1>{}, dq[t][wh], t, 0, wh);
+        stage_of(std::integral_constant<int, 2>{}, dq[t][wh], t, 0, wh);
+        stage_of(std::integral_constant<int, 3>{}, dq[t][wh], t, 0, wh);
+      }
+    take_b();
+    [&]<int... P>(std::integer_sequence<int, P...>) {
+      (([&] {
+         constexpr int p = P, e = p >> 1, h = p & 1;
+         if (p < 3) read_a(an, p + 1);
+         [&]<int... C>(std::integer_sequence<int, C...>) {
+           (([&] {
+              constexpr int c = C, t = c / 4, slot = p * 4 * NT + c;
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (slot < LPS) issue_one(std::integral_constant<int, slot>{}, refill, kb + 2);
+              if constexpr (e == 0) {  // the 8 NT slots of phases 0, 1 carry the 2 NT words of e = 1, four stages each
+                constexpr int q = h * 4 * NT + c, w = q / 4;
+                stage_of(std::integral_constant<int, q % 4>{}, dq[w / 2][w % 2], w / 2, 1, w % 2);
+              }
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int mt = (c % 4) * 2 + u;
+                if (ABL == 1) { acc[t * 8 + mt].x += bits_to_f32(a[mt].x ^ bv[t][h].x ^ a[mt].y ^ a[mt].z ^ a[mt].w ^ bv[t][h].y ^ bv[t][h].z ^ bv[t][h].w); continue; }
+                acc[t * 8 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
+                                                                         __builtin_bit_cast(bf16x8, bv[t][h]), acc[t * 8 + mt], 0, 0, 0);
+              }
+            }()),
+            ...);
+         }(std::make_integer_sequence<int, 4 * NT>{});
+         __builtin_amdgcn_sched_barrier(0);
+         if constexpr (p == 1) take_b();
+         if constexpr (p < 3) {
+#pragma unroll
+           for (int mt = 0; mt < 8; ++mt) a[mt] = an[mt];
+         }
+       }()),
+       ...);
+    }(std::make_integer_sequence<int, 4>{});
+    // DMAs left over when a stage has more of them than the k-block has slots
+    if constexpr (LPS > SLOTS) {
+      [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, SLOTS + I>{}, refill, kb + 2), ...); }
+      (std::make_integer_sequence<int, LPS - SLOTS>{});
+    }
+  };
+
+  issue_all(0, 0);
+  issue_all(1, 1);
+  if (ABL == 5) ts[1] = __builtin_amdgcn_s_memtime();
+  int stage = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (ABL != 4) wait_vmcnt<LPS>();  // this wave's share of stage kb has landed (stage kb + 1 may still be in flight)
+    // everyone's share has landed, and everyone has finished reading stage kb - 1 (its LDS reads have returned)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ABL == 5 && kb < 8) ts[2 + kb] = __builtin_amdgcn_s_memtime();
+    const int refill = (stage == 0) ? 2 : stage - 1;  // (kb + 2) % 3 == (kb - 1) % 3
+    kblock(stage, refill, kb);
+    stage = (stage == 2) ? 0 : stage + 1;
+  }
+  wait_vmcnt<0>();  // the clamped fills past the end still write LDS
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (ABL == 5) ts[10] = __builtin_amdgcn_s_memtime();
+  auto dump = [&] {
+    if (ABL == 5 && trace != nullptr && tid == 0) {
+      ts[12] = __builtin_amdgcn_s_memtime();
+      unsigned long long* t = trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
+      for (int i = 0; i < 13; ++i) t[i] = ts[i];
+    }
+  };
+
+  if (S > 1 && !split_k_meet<8 * NT, 64 * WAVES>(acc, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
+    dump();
+    return;
+  }
+  if (ABL == 5) ts[11] = __builtin_amdgcn_s_memtime();
+
+  // D layout of the 16x16 tile: lane (col = nl, group g) holds rows 4 g + {0..3}
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (tile0 + t >= ntiles) continue;
+    const int nn = (tile0 + t) * 16 + nl;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + i * 16 + kq * 4 + r;
-        if (m < M) y[(size_t)m * N + nn] = f32_to_bf16_bits(acc[i][j][r]);
+        const int m = m0 + mt * 16 + grp * 4 + r;
+        if (m < M) y[(size_t)m * N + nn] = f32_to_bf16_bits(acc[t * 8 + mt][r]);
       }
-    }
+  }
+  dump();
 }
 
-// Split-K workspace of the tiled kernel: kTiledSlots rotating slots (launches in flight per device) of
+// Split-K workspace of the batched kernel: kTiledSlots rotating slots (launches in flight per device) of
 // kTiledMaxWgs fp32 tiles (128 x 128) + one ticket per output tile.  Allocated on first use.
 constexpr int kTiledSlots = 4;
 constexpr int kTiledMaxWgs = 256;
@@ -733,28 +822,33 @@ int tiled_workspace(float** part, unsigned** tickets) {
   return AO_OK;
 }
 
-template <int G, int TNW>
-int launch_mm_tiled(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K,
-                    int split, hipStream_t stream) {
-  dim3 grid((unsigned)((N + TNW * 16 - 1) / (TNW * 16)), (unsigned)((M + 127) / 128), (unsigned)split), block(512);
-  const size_t smem = 2 * (size_t)(kTiledA + TNW * 16 * kTiledStride);
+unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
+
+template <int G, int WAVES, int NT, int ABL = 0>
+int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
+                 hipStream_t stream) {
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);
+  constexpr int BN = WAVES * NT * 16;
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + 127) / 128), (unsigned)split), block(64 * WAVES);
+  constexpr size_t smem = (size_t)kRbStages * kRbABuf + (size_t)WAVES * kRbStages * NT * (1024 + NG * 256);
+  static_assert(smem <= 160 * 1024, "int4_mm_rb_kernel: LDS");
   float* ws = nullptr;
   unsigned* tickets = nullptr;
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split <= kTiledMaxWgs, "int4_mm_tiled: %u x %u tiles x %d parts exceed the split-K workspace",
+    AO_REQUIRE((int64_t)grid.x * grid.y * split * (BN / 128.0) <= kTiledMaxWgs, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     if (int rc = tiled_workspace(&ws, &tickets)) return rc;
   }
-  auto kern = int4_mm_tiled_kernel<G, TNW>;
+  auto kern = int4_mm_rb_kernel<G, WAVES, NT, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(int4_mm_tiled_kernel)");
+    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(int4_mm_rb_kernel)");
     attr_set = true;
   }
-  ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const uint32_t*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
-             (int)M, (int)N, (int)K, ws, tickets);
-  AO_LAUNCH_CHECK("int4_mm_tiled_kernel launch");
+  ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)M,
+             (int)N, (int)K, ws, tickets, g_mm_trace);
+  AO_LAUNCH_CHECK("int4_mm_rb_kernel launch");
   return AO_OK;
 }
 
@@ -1006,26 +1100,32 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 16 || g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
-  // 16 < M: dequantise each weight block once per workgroup (int4_mm_tiled_kernel).  Widest tile (least
-  // re-staging of x) whose grid, cut along K into at most 8 parts of >= 8 k-blocks, still has ~200
-  // workgroups; modes 500 + S force the number of parts, wpb the tile width.
-  const int64_t slabs = (M + 127) / 128, ntiles = N >> 4, kblocks = K >> 7;
-  int tnw = 2, split = 1;
-  for (int t : {8, 4, 2}) {
-    const int64_t base = ((ntiles + t - 1) / t) * slabs;
-    int64_t s = std::max<int64_t>(1, std::min<int64_t>({(int64_t)kTiledMaxWgs / std::max<int64_t>(base, 1), 8, kblocks / 8}));
-    if (base >= 200) s = 1;
-    tnw = t;
-    split = (int)s;
-    if (g_tune_wpb == t || (g_tune_wpb == 0 && base * s >= 190)) break;
+  // 16 < M: int4_mm_rb_kernel.  128-column tiles (8 waves) when that still gives ~a workgroup per CU; otherwise
+  // 64-column tiles (4 waves) cut along K into at most 8 parts of >= 8 k-blocks so that the grid fills the chip
+  // (measured on the Llama-3-8B projections at M = 128: o_proj 39.8 -> 14.6 us, down_proj 129 -> 29.6 us).
+  // Modes 600 + 10 a + S: tuning / profiling (wpb 8 or 4 = waves per workgroup, S parts, a = ablation build).
+  const int64_t slabs = (M + 127) / 128, kblocks = K >> 7;
+  int bn = 128, split = 1;
+  if (((N + 127) / 128) * slabs < 190) {
+    bn = 64;
+    const int64_t base = ((N + 63) / 64) * slabs;
+    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)kTiledMaxWgs / base, 8, kblocks / 8}));
   }
-  if (g_tune_mode >= 500 && g_tune_mode < 600) {  // forced number of parts (clamped to what fits)
-    const int64_t base = ((ntiles + tnw - 1) / tnw) * slabs;
-    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)g_tune_mode - 500, kblocks, kTiledMaxWgs / std::max<int64_t>(base, 1)}));
+  if (g_tune_mode >= 600 && g_tune_mode < 700) {
+    const int abl = (g_tune_mode - 600) / 10;
+    bn = (g_tune_wpb == 4) ? 64 : 128;
+    const int64_t base = ((N + bn - 1) / bn) * slabs;
+    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode % 10), kblocks, kTiledMaxWgs / std::max<int64_t>(base, 1)}));
+    if constexpr (G == 128) {
+      if (abl == 1) return launch_mm_rb<G, 8, 1, 1>(x, qdata, sz, y, M, N, K, split, stream);
+      if (abl == 2) return launch_mm_rb<G, 8, 1, 2>(x, qdata, sz, y, M, N, K, split, stream);
+      if (abl == 3) return launch_mm_rb<G, 8, 1, 3>(x, qdata, sz, y, M, N, K, split, stream);
+      if (abl == 4) return launch_mm_rb<G, 8, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
+      if (abl == 5) return launch_mm_rb<G, 8, 1, 5>(x, qdata, sz, y, M, N, K, split, stream);
+      if (abl == 6) return launch_mm_rb<G, 4, 2>(x, qdata, sz, y, M, N, K, split, stream);
+    }
   }
-  if (tnw == 8) return launch_mm_tiled<G, 8>(x, qdata, sz, y, M, N, K, split, stream);
-  if (tnw == 4) return launch_mm_tiled<G, 4>(x, qdata, sz, y, M, N, K, split, stream);
-  return launch_mm_tiled<G, 2>(x, qdata, sz, y, M, N, K, split, stream);
+  return bn == 128 ? launch_mm_rb<G, 8, 1>(x, qdata, sz, y, M, N, K, split, stream) : launch_mm_rb<G, 4, 1>(x, qdata, sz, y, M, N, K, split, stream);
 }
 
 int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
@@ -1050,12 +1150,13 @@ extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, i
   (void)group_size;
   if (M == 1 && int4_gemv_stream_supported(K) && (N >> 4) < kManyTiles) return "int4_gemv_stream_kernel";
   if (M == 1 && K <= kGemvMaxK) return "int4_gemv_kernel";
-  if (M > 16) return "int4_mm_tiled_kernel";
+  if (M > 16) return "int4_mm_rb_kernel";
   return "int4_mm_kernel";
 }
 
 extern "C" int ao_int4_set_trace(unsigned long long* trace_dev) {
   int4_gemv_stream_set_trace(trace_dev);
+  g_mm_trace = trace_dev;
   return AO_OK;
 }
 

@@ -26,6 +26,7 @@
 //
 // Weight format: see int4_kernels.hip (bit-exact aten::_convert_weight_to_int4pack layout).
 #include "common.h"
+#include "lds_dma.h"
 
 #include <mutex>
 
@@ -79,37 +80,6 @@ __device__ __forceinline__ f32x4 widen_add4(s16x4 ident, uint32_t lo_pair, uint3
 // destination, so (b) cannot happen, and the wave's own ds_read after its vmcnt wait sees the data.
 // VMEM loads return in order, so "at most N outstanding" == "everything older than the N youngest
 // has landed"; an extra store or older load in the pipe only makes such a wait more conservative.
-__device__ __forceinline__ uint32_t lds_offset(const void* p) {
-  return (uint32_t)reinterpret_cast<uintptr_t>(p);  // flat address of LDS = aperture base (high dword) + offset
-}
-// each lane: 16 B from gsrc -> LDS[lds_dst + lane * 16]; lds_dst wave-uniform
-__device__ __forceinline__ void dma_b128_nt(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// each lane: 4 B from gsrc -> LDS[lds_dst + lane * 4]
-__device__ __forceinline__ void dma_b32(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// 16 B per lane, agent scope (sc1): reads past this XCD's L2.  One request per granule, so value
-// and tag are read together (two 4-byte DMAs could pair a stale value with a fresh tag).
-__device__ __forceinline__ void dma_b128_sc1(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// agent-scope write-through 16-byte store (no register destination: register-safe, fire and forget;
-// the trailing s_nop keeps the next instruction off the data registers until the store has read them)
-__device__ __forceinline__ void store_b128_sc1(void* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 // wait until at most `stages` ring stages (LPS DMAs each) are still in flight
 template <int LPS>
 __device__ __forceinline__ void wait_ring(int stages) {

@@ -156,17 +156,37 @@ def test_mm_bs1_repeatable_and_workspace_reuse():
     assert _rel(a, b) <= 1e-3 and np.mean(a == b) > 0.99
 
 
-# 16 < M takes the M-tiled kernel (dequantise once per workgroup, 8 m-tiles share it through LDS)
+# 16 < M takes the batched kernel (each packed block dequantised once per 128-row slab, straight into MFMA operands)
 @pytest.mark.parametrize(
     "m,n,k,g",
     [(17, 64, 1024, 128), (128, 6144, 4096, 128), (100, 256, 2048, 32), (200, 128, 3584, 64), (64, 48, 1152 * 2, 256),
-     (129, 4096, 14336, 128), (40, 28672, 256, 128), (33, 12800, 384, 64)],  # the last two: 8 and 4 n-tiles per workgroup
+     (129, 4096, 14336, 128), (40, 28672, 256, 128), (33, 12800, 384, 64)],  # wide and narrow N: 128- and 64-column tiles
 )
 def test_mm_tiled_batched(m, n, k, g):
     y, y_ref = _mm_case(m, n, k, g, 7 * m + n + k)
     assert y.shape == y_ref.shape
     assert _rel(y, y_ref) <= 1e-3  # BASELINE.json tolerance
     # exact dequant: one bf16 ulp, plus fp32 accumulation-order noise on cancelling outputs
+    assert np.all(np.abs(y - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + 1e-3 * np.abs(y_ref).max())
+    assert np.mean(y == y_ref) > 0.97
+
+
+# the batched kernel's tuning variants: 8 / 4 waves per workgroup, with and without split-K, the two-tiles-per-wave
+# build, every group size, ragged M / N
+@pytest.mark.parametrize("wpb,mode", [(8, 601), (8, 604), (4, 601), (4, 603), (8, 662)])
+@pytest.mark.parametrize(
+    "m,n,k,g", [(128, 256, 1024, 128), (17, 64, 1024, 32), (200, 208, 2048, 64), (129, 4096, 2048, 128), (64, 48, 2560, 256), (100, 6144, 512, 128)]
+)
+def test_mm_register_b_kernel(m, n, k, g, wpb, mode):
+    from ao_amd._lib import lib as _load
+
+    lib = _load()
+    lib.ao_int4_set_tuning(wpb, mode)
+    try:
+        y, y_ref = _mm_case(m, n, k, g, 3 * m + n + k + g)
+    finally:
+        lib.ao_int4_set_tuning(0, 0)
+    assert _rel(y, y_ref) <= 1e-3
     assert np.all(np.abs(y - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + 1e-3 * np.abs(y_ref).max())
     assert np.mean(y == y_ref) > 0.97
 
