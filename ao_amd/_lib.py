@@ -46,6 +46,9 @@ _SIGNATURES = {
     "ao_fp8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_mxfp8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _INT, _P],
     "ao_mxfp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "ao_moe_padded_rows": [_I64, _I64, _INT],
+    "ao_moe_pad_token_groups": [_P, _P, _P, _P, _P, _I64, _I64, _INT, _I64, _INT, _P],
+    "ao_moe_unpad_token_groups": [_P, _P, _P, _P, _I64, _I64, _INT, _I64, _P],
 }
 
 
@@ -82,6 +85,7 @@ def lib():
         l.ao_last_error.argtypes = []
         l.ao_last_error.restype = ctypes.c_char_p
         l.ao_int4_mm_kernel_name.restype = ctypes.c_char_p
+        l.ao_moe_padded_rows.restype = _I64
         _lib = l
     return _lib
 

@@ -22,6 +22,8 @@ __all__ = [
     "fp8_scaled_mm",
     "mxfp8_quantize",
     "mxfp8_grouped_mm",
+    "fused_pad_token_groups",
+    "fused_unpad_token_groups",
 ]
 
 
@@ -365,6 +367,66 @@ def mxfp8_grouped_mm(a, a_scale, b, b_scale, offs):
         _lib.check(
             _lib.lib().ao_mxfp8_grouped_mm(
                 _ptr(a), _ptr(a_scale), _ptr(b), _ptr(b_scale), _ptr(offs.contiguous()), _ptr(out), m, n, k, e, _stream()
+            )
+        )
+    return out
+
+
+def _check_token_groups(name, inputs, offsets):
+    if inputs.dim() != 2:
+        raise AssertionError("input activations must be 2d")
+    if inputs.dtype not in (torch.float32, torch.bfloat16):
+        raise AssertionError("inputs must be float32 or bfloat16")
+    if offsets.dtype != torch.int32:
+        raise AssertionError("offsets must be int32")
+    if offsets.dim() != 1 or offsets.numel() == 0:
+        raise RuntimeError(f"{name}: offsets must be a non-empty 1-d tensor of group end offsets")
+
+
+def fused_pad_token_groups(inputs, offsets, alignment_size=32):
+    """torchao::fused_pad_token_groups (kernels/mxfp8/quant.py:1244-1283; semantics torch_pad_token_groups,
+    quant.py:368-430): every token group is moved to a start that is a multiple of `alignment_size` inside a
+    zero-filled buffer of the reference's upper-bound size (no host sync).  Returns (padded_tokens,
+    padded_group_start_offsets, padded_group_end_offsets)."""
+    dev = _require_gpu("fused_pad_token_groups", inputs, offsets)
+    _check_token_groups("fused_pad_token_groups", inputs, offsets)
+    inputs = inputs.contiguous()
+    offsets = offsets.contiguous()
+    tokens, dim = inputs.shape
+    groups = offsets.numel()
+    if alignment_size <= 0:
+        raise ValueError(f"fused_pad_token_groups: alignment_size must be positive, got {alignment_size}")
+    rows = _lib.lib().ao_moe_padded_rows(tokens, groups, alignment_size)
+    padded = torch.empty((rows, dim), dtype=inputs.dtype, device=dev)  # the kernel writes every row
+    starts = torch.empty(groups, dtype=torch.int32, device=dev)
+    ends = torch.empty(groups, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            _lib.lib().ao_moe_pad_token_groups(
+                _ptr(inputs), _ptr(offsets), _ptr(padded), _ptr(starts), _ptr(ends), tokens, dim, inputs.element_size(), groups,
+                alignment_size, _stream()
+            )
+        )
+    return padded, starts, ends
+
+
+def fused_unpad_token_groups(inputs, offsets, padded_group_start_offsets, num_tokens, alignment_size=32):
+    """torchao::fused_unpad_token_groups (kernels/mxfp8/quant.py:1319-1363; semantics torch_unpad_token_groups,
+    quant.py:433-480): gathers the `num_tokens` real rows back out of a padded buffer."""
+    dev = _require_gpu("fused_unpad_token_groups", inputs, offsets, padded_group_start_offsets)
+    _check_token_groups("fused_unpad_token_groups", inputs, offsets)
+    if padded_group_start_offsets.dtype != torch.int32:
+        raise AssertionError("padded_group_start_offsets must be int32")
+    if padded_group_start_offsets.numel() != offsets.numel():
+        raise RuntimeError("fused_unpad_token_groups: offsets and padded_group_start_offsets must have one entry per group")
+    inputs = inputs.contiguous()
+    dim = inputs.shape[1]
+    out = torch.empty((num_tokens, dim), dtype=inputs.dtype, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(
+            _lib.lib().ao_moe_unpad_token_groups(
+                _ptr(inputs), _ptr(offsets.contiguous()), _ptr(padded_group_start_offsets.contiguous()), _ptr(out), num_tokens, dim,
+                inputs.element_size(), offsets.numel(), _stream()
             )
         )
     return out

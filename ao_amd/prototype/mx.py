@@ -16,7 +16,7 @@ import torch
 
 from .. import ops
 
-__all__ = ["ScaleCalculationMode", "to_mx", "mx_dequantize", "_to_mxfp8_then_scaled_grouped_mm"]
+__all__ = ["ScaleCalculationMode", "to_mx", "mx_dequantize", "_to_mxfp8_then_scaled_grouped_mm", "pad_token_groups", "unpad_token_groups"]
 
 BLOCK = 32
 
@@ -79,3 +79,16 @@ def _to_mxfp8_then_scaled_grouped_mm(
     b = B_t.transpose(-2, -1).contiguous()
     b_q, b_s = ops.mxfp8_quantize(b, scale_calculation_mode)
     return ops.mxfp8_grouped_mm(a_q, a_s, b_q, b_s, offs.to(torch.int32))
+
+
+def pad_token_groups(input_act: torch.Tensor, group_end_offsets: torch.Tensor, alignment_size: int = 32):
+    """Mirror of torchao.prototype.moe_training.utils.pad_token_groups (utils.py:412-445): pad every token group to
+    the next multiple of `alignment_size` (32 for MXFP8, 16 for FP8) so that grouped-GEMM tiles never straddle two
+    experts.  Returns (padded_input_act, padded_group_start_offsets, padded_group_end_offsets)."""
+    return ops.fused_pad_token_groups(input_act, group_end_offsets, alignment_size)
+
+
+def unpad_token_groups(padded_output: torch.Tensor, original_group_end_offsets: torch.Tensor,
+                       padded_group_start_offsets: torch.Tensor, num_tokens: int, alignment_size: int = 32) -> torch.Tensor:
+    """Mirror of torchao.prototype.moe_training.utils.unpad_token_groups (utils.py:448-490)."""
+    return ops.fused_unpad_token_groups(padded_output, original_group_end_offsets, padded_group_start_offsets, num_tokens, alignment_size)

@@ -24,6 +24,11 @@ _lib_def.define("int8_scaled_mm(Tensor xq, Tensor x_scale, Tensor wq, Tensor w_s
 _lib_def.define("fp8_scaled_mm(Tensor a, Tensor b, Tensor scale_a, Tensor scale_b, Tensor? bias) -> Tensor")
 _lib_def.define("mxfp8_quantize(Tensor x, str scaling_mode) -> (Tensor, Tensor)")
 _lib_def.define("mxfp8_grouped_mm(Tensor a, Tensor a_scale, Tensor b, Tensor b_scale, Tensor offs) -> Tensor")
+# same schemas as torchao::fused_pad_token_groups / fused_unpad_token_groups (kernels/mxfp8/quant.py:1244-1246, 1319-1321)
+_lib_def.define("fused_pad_token_groups(Tensor inputs, Tensor offsets, int alignment_size) -> (Tensor, Tensor, Tensor)")
+_lib_def.define(
+    "fused_unpad_token_groups(Tensor inputs, Tensor offsets, Tensor padded_group_start_offsets, int num_tokens, int alignment_size) -> Tensor"
+)
 
 _lib_impl = torch.library.Library("ao_mi355", "IMPL", "CUDA")
 _lib_impl.impl("weight_int4pack_mm", ops.weight_int4pack_mm)
@@ -32,6 +37,8 @@ _lib_impl.impl("int8_scaled_mm", ops.int8_scaled_mm)
 _lib_impl.impl("fp8_scaled_mm", ops.fp8_scaled_mm)
 _lib_impl.impl("mxfp8_quantize", lambda x, mode: ops.mxfp8_quantize(x, mode))
 _lib_impl.impl("mxfp8_grouped_mm", ops.mxfp8_grouped_mm)
+_lib_impl.impl("fused_pad_token_groups", ops.fused_pad_token_groups)
+_lib_impl.impl("fused_unpad_token_groups", ops.fused_unpad_token_groups)
 
 
 @torch.library.register_fake("ao_mi355::weight_int4pack_mm")
@@ -64,6 +71,18 @@ def _(x, scaling_mode):
 @torch.library.register_fake("ao_mi355::mxfp8_grouped_mm")
 def _(a, a_scale, b, b_scale, offs):
     return a.new_empty((a.shape[0], b.shape[1]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::fused_pad_token_groups")
+def _(inputs, offsets, alignment_size):
+    rows = inputs.shape[0] + offsets.shape[0] * alignment_size
+    rows = (rows + alignment_size - 1) // alignment_size * alignment_size
+    return (inputs.new_empty((rows, inputs.shape[1])), offsets.new_empty(offsets.shape), offsets.new_empty(offsets.shape))
+
+
+@torch.library.register_fake("ao_mi355::fused_unpad_token_groups")
+def _(inputs, offsets, padded_group_start_offsets, num_tokens, alignment_size):
+    return inputs.new_empty((num_tokens, inputs.shape[1]))
 
 
 _aten_impl = None

@@ -191,6 +191,31 @@ int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale,
                         const int32_t* offs, uint16_t* out, int64_t M_total,
                         int64_t N, int64_t K, int64_t E, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * MoE token-group padding (glue either side of the MXFP8 grouped GEMM)
+ * ------------------------------------------------------------------------- */
+
+/* Rows of the padded buffer: align_up(num_tokens + num_groups * alignment, alignment) -- the upper bound the
+ * reference allocates so that no host sync is needed (quant.py:414-420).  Host-only helper. */
+int64_t ao_moe_padded_rows(int64_t num_tokens, int64_t num_groups, int alignment);
+
+/* Replaces torchao::fused_pad_token_groups (schema torchao/prototype/moe_training/kernels/mxfp8/quant.py:1244-1246;
+ * semantics torch_pad_token_groups, quant.py:368-430).
+ *   inputs  [num_tokens][dim] bf16 or fp32 (elem_bytes 2 or 4); offsets int32 [num_groups] cumulative group ends;
+ *   padded  [ao_moe_padded_rows(...)][dim], every row written (groups copied to aligned starts, the rest zero);
+ *   padded_starts / padded_ends int32 [num_groups]. */
+int ao_moe_pad_token_groups(const void* inputs, const int32_t* offsets, void* padded,
+                            int32_t* padded_starts, int32_t* padded_ends, int64_t num_tokens,
+                            int64_t dim, int elem_bytes, int64_t num_groups, int alignment,
+                            void* stream);
+
+/* Replaces torchao::fused_unpad_token_groups (schema quant.py:1319-1321; semantics torch_unpad_token_groups,
+ * quant.py:433-480): out[t] = padded[padded_starts[g] + t - offsets[g-1]] for the group g holding token t.
+ * Tokens past offsets[num_groups-1] (the reference raises after a host sync) are written as zeros. */
+int ao_moe_unpad_token_groups(const void* padded, const int32_t* offsets,
+                              const int32_t* padded_starts, void* out, int64_t num_tokens,
+                              int64_t dim, int elem_bytes, int64_t num_groups, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,9 +148,35 @@ def make_mx():
     print("mx.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def make_moe():
+    """Outputs of the reference's torch_pad_token_groups / torch_unpad_token_groups (the checker of its CUDA kernels)."""
+    from torchao.prototype.moe_training.kernels.mxfp8.quant import torch_pad_token_groups, torch_unpad_token_groups
+
+    out = {}
+    gen = torch.Generator().manual_seed(11)
+    cases = {
+        "ragged": ([5, 5, 37, 64, 64, 70], 32, 24, torch.bfloat16),   # empty groups, one already aligned
+        "aligned16": ([16, 48, 64], 16, 40, torch.float32),
+        "single": ([3], 32, 8, torch.bfloat16),
+        "odd_dim": ([2, 9, 9, 20], 4, 7, torch.bfloat16),
+    }
+    for name, (ends, align, dim, dtype) in cases.items():
+        x = torch.randn(ends[-1], dim, generator=gen).to(dtype)
+        offs = torch.tensor(ends, dtype=torch.int32)
+        p, s, e = torch_pad_token_groups(x, offs, align)
+        u = torch_unpad_token_groups(p, offs, s, ends[-1], align)
+        assert torch.equal(u, x)
+        as_np = (lambda t: bits(t)) if dtype == torch.bfloat16 else (lambda t: t.numpy())
+        out.update({f"{name}_x": as_np(x), f"{name}_offs": offs.numpy(), f"{name}_align": np.int32(align),
+                    f"{name}_padded": as_np(p), f"{name}_starts": s.numpy().astype(np.int32), f"{name}_ends": e.numpy().astype(np.int32)})
+    np.savez_compressed(os.path.join(HERE, "moe_pad.npz"), **out)
+    print("moe_pad.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
 def make_rest():
     make_int8_fp8()
     make_mx()
+    make_moe()
 
 
 if __name__ == "__main__":

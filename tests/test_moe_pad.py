@@ -1,0 +1,128 @@
+"""MoE token-group padding: oracle vs the reference's outputs (CPU), HIP kernels vs oracle (GPU, bit exact)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, np_from_torch_bf16, torch_bf16_from_f32  # noqa: F401
+from oracle import moe_ref as R
+
+CASES = ["ragged", "aligned16", "single", "odd_dim"]
+
+
+@pytest.fixture(scope="module")
+def golden_moe():
+    return np.load(os.path.join(GOLDEN, "moe_pad.npz"))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_outputs(golden_moe, case):
+    d = golden_moe
+    p, s, e = R.pad_token_groups(d[f"{case}_x"], d[f"{case}_offs"], int(d[f"{case}_align"]))
+    assert np.array_equal(p, d[f"{case}_padded"]) and np.array_equal(s, d[f"{case}_starts"]) and np.array_equal(e, d[f"{case}_ends"])
+    u = R.unpad_token_groups(p, d[f"{case}_offs"], s, d[f"{case}_x"].shape[0])
+    assert np.array_equal(u, d[f"{case}_x"])
+
+
+def test_oracle_unpad_size_mismatch_raises():
+    x = np.zeros((4, 2), np.float32)
+    p, s, _ = R.pad_token_groups(x, [1, 4], 4)
+    with pytest.raises(RuntimeError, match="Unpad output size mismatch"):
+        R.unpad_token_groups(p, [1, 4], s, 5)
+
+
+# ---- GPU ---------------------------------------------------------------------------------
+def _to_dev(a):
+    """golden array -> device tensor (uint16 = bf16 bit patterns)"""
+    if a.dtype == np.uint16:
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16).cuda()
+    return torch.from_numpy(a.copy()).cuda()
+
+
+def _bits(t):
+    t = t.cpu().contiguous()
+    return t.view(torch.int16).numpy().view(np.uint16) if t.dtype == torch.bfloat16 else t.numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_kernels_match_reference_outputs(golden_moe, case):
+    from ao_amd import ops
+
+    d = golden_moe
+    x, offs, align = _to_dev(d[f"{case}_x"]), torch.from_numpy(d[f"{case}_offs"]).cuda(), int(d[f"{case}_align"])
+    p, s, e = ops.fused_pad_token_groups(x, offs, align)
+    assert np.array_equal(_bits(p), d[f"{case}_padded"])
+    assert np.array_equal(s.cpu().numpy(), d[f"{case}_starts"]) and np.array_equal(e.cpu().numpy(), d[f"{case}_ends"])
+    u = ops.fused_unpad_token_groups(p, offs, s, x.shape[0], align)
+    assert torch.equal(u, x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("groups,dim,align", [(8, 7168, 32), (128, 2048, 32), (200, 96, 16), (3, 5, 32)])
+def test_kernels_vs_oracle_random_groups(groups, dim, align, dtype):
+    """DeepSeek-V3-sized rows, more than 64 groups (two ballot passes), empty groups, rows that are not a multiple
+    of 16 bytes; output rows past the last group must be zero even though the buffer starts uninitialised."""
+    from ao_amd import ops
+    from ao_amd.prototype.mx import pad_token_groups, unpad_token_groups
+
+    rng = np.random.default_rng(groups * 1000 + dim)
+    sizes = rng.integers(0, 70, size=groups)
+    sizes[rng.integers(0, groups)] = 0
+    ends = np.cumsum(sizes).astype(np.int32)
+    tokens = int(ends[-1])
+    x = torch.randn(tokens, dim, generator=torch.Generator().manual_seed(1)).to(dtype).cuda()
+    offs = torch.from_numpy(ends).cuda()
+    torch.full((tokens + groups * align + align, dim), float("nan"), device="cuda", dtype=dtype)  # dirty the allocator's block
+    p, s, e = pad_token_groups(x, offs, align)
+    xr = _bits(x)
+    pr, sr, er = R.pad_token_groups(xr, ends, align)
+    assert p.shape == pr.shape and np.array_equal(_bits(p), pr)
+    assert np.array_equal(s.cpu().numpy(), sr) and np.array_equal(e.cpu().numpy(), er)
+    u = unpad_token_groups(p, offs, s, tokens, align)
+    assert torch.equal(u, x)
+    # the dispatcher route (what a torch.ops.torchao.* call site would be retargeted to)
+    import ao_amd.torch_ops  # noqa: F401
+
+    p2, s2, e2 = torch.ops.ao_mi355.fused_pad_token_groups(x, offs, align)
+    assert torch.equal(p2, p) and torch.equal(s2, s) and torch.equal(e2, e)
+    assert torch.equal(torch.ops.ao_mi355.fused_unpad_token_groups(p2, offs, s2, tokens, align), x)
+
+
+@pytest.mark.gpu
+def test_padded_mxfp8_grouped_mm_round_trip():
+    """pad -> quantise -> grouped GEMM on aligned groups -> unpad equals the grouped GEMM on the ragged groups
+    (zero rows quantise to zero and never reach a real token's output)."""
+    from ao_amd import ops
+    from ao_amd.prototype.mx import _to_mxfp8_then_scaled_grouped_mm, pad_token_groups, unpad_token_groups
+
+    E, N, K = 4, 64, 256
+    ends = np.array([5, 5, 40, 77], dtype=np.int32)
+    gen = torch.Generator().manual_seed(3)
+    a = torch.randn(int(ends[-1]), K, generator=gen).to(torch.bfloat16).cuda()
+    w = (torch.randn(E, N, K, generator=gen) * 0.1).to(torch.bfloat16).cuda()
+    offs = torch.from_numpy(ends).cuda()
+    direct = _to_mxfp8_then_scaled_grouped_mm(a, w.transpose(-2, -1), offs)
+    pa, ps, pe = pad_token_groups(a, offs, 32)
+    padded_out = _to_mxfp8_then_scaled_grouped_mm(pa, w.transpose(-2, -1), pe)
+    assert torch.equal(unpad_token_groups(padded_out, offs, ps, a.shape[0], 32), direct)
+
+
+@pytest.mark.gpu
+def test_argument_errors():
+    from ao_amd import ops
+
+    x = torch.zeros(4, 8, device="cuda", dtype=torch.bfloat16)
+    offs = torch.tensor([4], dtype=torch.int32, device="cuda")
+    with pytest.raises(AssertionError, match="offsets must be int32"):
+        ops.fused_pad_token_groups(x, offs.long(), 32)
+    with pytest.raises(AssertionError, match="float32 or bfloat16"):
+        ops.fused_pad_token_groups(x.half(), offs, 32)
+    with pytest.raises(AssertionError, match="2d"):
+        ops.fused_pad_token_groups(x[0], offs, 32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.fused_pad_token_groups(x.cpu(), offs.cpu(), 32)
+    p, s, e = ops.fused_pad_token_groups(x[:0], torch.tensor([0], dtype=torch.int32, device="cuda"), 32)  # no tokens
+    assert p.shape == (32, 8) and not p.any() and s.item() == 0 and e.item() == 0
