@@ -25,13 +25,6 @@
 #include "lds_dma.h"
 
 namespace ao {
-// int4_stream_kernels.hip: the balanced streaming M = 1 kernel (the product decode path)
-bool int4_gemv_stream_supported(int64_t K);
-void int4_gemv_stream_set_waves(int waves);
-void int4_gemv_stream_set_trace(unsigned long long* p);
-int launch_int4_gemv_stream(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N,
-                            int64_t K, int group_size, int ablation, hipStream_t stream);
-
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -329,159 +322,6 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
       for (int w = 0; w < nwaves; ++w) sum += red[w * 256 + tid];
       y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(sum);
     }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// M == 1 (decode) GEMV:  y[1,N] = x[1,K] @ dequant(qdata)^T
-//
-// grid = N/16 workgroups, WPB waves each; a workgroup owns one 16-wide n-tile,
-// its waves split K into contiguous runs of 1 KiB weight blocks.
-//   1. every wave issues its x-staging loads and then its first DEPTH weight
-//      blocks (non-temporal dwordx4 straight to VGPRs) + their scale/zero words;
-//   2. the workgroup writes x ONCE into LDS in A-fragment order
-//      xs[kb][kq][j][8] (k = 128 kb + 32 j + 16 h + 4 kq + i at slot 4 h + i), so
-//      the main loop's A operands are four ds_read_b128 at a per-lane running
-//      address -- no per-block x traffic, no per-block LDS store; lanes that do
-//      not hold row 0 of the 16x16 MFMA tile read a shared 64-byte zero row;
-//   3. main loop: dequantise in registers (exact oracle rounding), 4 MFMAs per
-//      block, refill the ring;
-//   4. one barrier for the cross-wave (split-K) reduction of 16 floats per wave.
-// ---------------------------------------------------------------------------
-template <int G, int DEPTH, int DQ, int ABL = 0, int WPE = 8>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void int4_gemv_kernel(const uint16_t* __restrict__ x,
-                                                        const u32x4* __restrict__ qdata,
-                                                        const uint32_t* __restrict__ sz,
-                                                        uint16_t* __restrict__ y, int N, int K) {
-  constexpr int NG = (G >= 128) ? 1 : (128 / G);
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K*2 xs][64 zero][nwaves*16 f32]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nwaves = blockDim.x >> 6;
-  const int ntile = blockIdx.x;
-  const int kblocks = K >> 7;
-  const int kb0 = (kblocks * wave) / nwaves;
-  const int kb1 = (kblocks * (wave + 1)) / nwaves;
-  const int n = ntile * 16 + (lane & 15);
-  const int kq = lane >> 4;
-
-  char* xs = smem;
-  char* zero_row = smem + (size_t)K * 2;
-  float* red = reinterpret_cast<float*>(zero_row + 64);
-
-  // ---- 1a. x staging loads: 8-byte units, dest unit d <- source unit of the same 128-k block
-  constexpr int MAXU = 8;  // units per thread kept in registers per pass
-  const int units = K >> 2;
-  u32x2 xu[MAXU];
-  auto src_unit = [](int d) {
-    const int du = d & 31;  // dest unit within the block: kq*8 + j*2 + h
-    return (d & ~31) + 8 * ((du >> 1) & 3) + 4 * (du & 1) + (du >> 3);
-  };
-#pragma unroll
-  for (int r = 0; r < MAXU; ++r) {
-    const int d = tid + r * (int)blockDim.x;
-    if (d < units) xu[r] = *reinterpret_cast<const u32x2*>(x + (size_t)src_unit(d) * 4);
-  }
-  // The CU's vector-memory pipe serves requests in issue order across waves: put every wave's x
-  // loads in the pipe before any wave's 4 KiB of weights (int4_stream_kernels.hip, trace build).
-  __builtin_amdgcn_s_barrier();
-
-  // ---- 1b. weight ring
-  struct Stage {
-    u32x4 w;
-    uint32_t sz[NG];
-  };
-  Stage st[DEPTH];
-  const u32x4* wp = qdata + ((size_t)ntile * kblocks) * 64 + lane;
-  auto issue = [&](Stage& s, int kb) {
-    if (ABL == 2) {
-      s.w = u32x4{(uint32_t)lane * 0x01010101u, (uint32_t)kb, 0x12345678u, (uint32_t)lane};
-    } else {
-      s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
-    }
-    const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
-#pragma unroll
-    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
-  };
-  const int kb_last = max(kb1 - 1, kb0);
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
-
-  // ---- 2. x -> LDS (fragment order), zero row
-#pragma unroll
-  for (int r = 0; r < MAXU; ++r) {
-    const int d = tid + r * (int)blockDim.x;
-    if (d < units) *reinterpret_cast<u32x2*>(xs + (size_t)d * 8) = xu[r];
-  }
-  for (int d = tid + MAXU * (int)blockDim.x; d < units; d += blockDim.x)  // K > 32 * threads: rare
-    *reinterpret_cast<u32x2*>(xs + (size_t)d * 8) = *reinterpret_cast<const u32x2*>(x + (size_t)src_unit(d) * 4);
-  if (tid < 16) reinterpret_cast<uint32_t*>(zero_row)[tid] = 0u;
-  // LDS-only barrier: __syncthreads() carries a fence that waits vmcnt(0), i.e. for the whole
-  // weight ring issued above -- the loads would no longer overlap the x staging
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-  // ---- 3. main loop
-  const bool row0 = (lane & 15) == 0;
-  const char* a_ptr = row0 ? (xs + ((size_t)kb0 * 4 + kq) * 64) : zero_row;
-  const int a_step = row0 ? 256 : 0;
-
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const s16x4 ident = identity_fragment<DQ>(lane);
-
-  auto consume = [&](const Stage& s) {
-    if (ABL == 1) {
-      acc.x += bits_to_f32((s.w.x ^ s.w.y ^ s.w.z ^ s.w.w ^ s.sz[0]) & 0x3f800000u);
-      return;
-    }
-    u32x4 a[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_ptr + j * 16);
-    a_ptr += a_step;
-    const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
-      const float sc = bf16_lo_to_f32(s.sz[gi]);
-      const float zp = bf16_hi_to_f32(s.sz[gi]);
-      uint32_t b[4];
-      if constexpr (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
-      else dequant_word_mfma<DQ>(wds[j], sc, -8.0f * sc, zp, ident, b);
-      const u32x4 bv = {b[0], b[1], b[2], b[3]};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
-                                                    __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
-    }
-  };
-
-  int kb = kb0;
-  for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      consume(st[d]);
-      issue(st[d], kb + d + DEPTH);
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (kb + d < kb1) {
-      consume(st[d]);
-      if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
-    }
-  }
-  kb += DEPTH;
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (kb + d < kb1) consume(st[d]);
-  }
-
-  // ---- 4. split-K reduction: row 0 of the tile lives in acc.x of lanes 0..15
-  if (lane < 16) red[wave * 16 + lane] = acc.x;
-  __syncthreads();
-  if (tid < 16) {
-    float sum = 0.f;
-    for (int w = 0; w < nwaves; ++w) sum += red[w * 16 + tid];
-    y[ntile * 16 + tid] = f32_to_bf16_bits(sum);
   }
 }
 
@@ -1013,22 +853,20 @@ __global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __res
 }
 
 int g_tune_wpb = 0;
-int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 100/101/110 per-tile M = 1 kernel (product / loads only / all-VALU dequant), 400-403 streaming kernel
+int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 95-99 small-M A/B builds, 600-699 batched kernel (parts, ablation / trace builds)
 
-template <int G, int MAXM>
+template <int G, int MAXM, int DEPTH = 4>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
               int64_t N, int64_t K, hipStream_t stream) {
-  constexpr int DEPTH = 4;
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;
   constexpr int SLAB = (MAXM + 1) * ROWSTRIDE;
   const int kblocks = (int)(K >> 7);
   const int64_t ntiles = N >> 4;
   const int64_t mslabs = (M + 15) / 16;
-  // waves per workgroup: keep >= ~4 weight blocks per wave, and at least ~8
-  // waves per CU across the grid; 4 <= WPB <= 16 (>= 256 threads for the epilogue)
-  int wpb = 4;
-  while (wpb < 16 && kblocks / (wpb * 2) >= 4) wpb *= 2;
-  if (ntiles * mslabs >= 2048 && wpb > 4) wpb /= 2;
+  // waves per workgroup: 8 once a wave still gets >= 2 weight blocks (measured at M = 1 on the Llama-3-8B shapes:
+  // 4 waves 800, 8 waves 868, 16 waves 705 tok/s), else 4 (>= 256 threads for the epilogue)
+  int wpb = (kblocks >= 16) ? 8 : 4;
+  if (ntiles * mslabs >= 2048 && wpb > 4 && MAXM > 1) wpb /= 2;
   if (g_tune_wpb >= 4 && g_tune_wpb <= 16) wpb = g_tune_wpb;
   if (MAXM > 4 && wpb > 8) wpb = 8;  // 16-row variant is built for <= 512 threads
   if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
@@ -1041,62 +879,16 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   return AO_OK;
 }
 
-template <int G, int DEPTH, int DQ, int ABL, int WPE = 8>
-int launch_gemv_variant(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N,
-                        int64_t K, int wpb, hipStream_t stream) {
-  const size_t smem = (size_t)K * 2 + 64 + (size_t)wpb * 16 * sizeof(float);
-  auto kern = int4_gemv_kernel<G, DEPTH, DQ, ABL, WPE>;
-  if (smem > 48 * 1024) {
-    static size_t granted = 0;  // monotonic; a racing duplicate call is harmless
-    if (smem > granted) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(int4_gemv_kernel)");
-      granted = smem;
-    }
-  }
-  ao::launch(kern, dim3((unsigned)(N >> 4)), dim3(wpb * 64), smem, stream, x, reinterpret_cast<const u32x4*>(qdata),
-             reinterpret_cast<const uint32_t*>(sz), y, (int)N, (int)K);
-  AO_LAUNCH_CHECK("int4_gemv_kernel launch");
-  return AO_OK;
-}
-
-constexpr int64_t kManyTiles = 1024;  // n-tiles from which the per-tile grid beats the persistent one
-constexpr int64_t kGemvMaxK = 65536;  // x (2 B/k) must fit LDS next to the reduction scratch
-
-template <int G>
-int launch_gemv(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t N, int64_t K,
-                hipStream_t stream) {
-  const int kblocks = (int)(K >> 7);
-  const int64_t ntiles = N >> 4;
-  // waves per workgroup: >= ~4 weight blocks per wave; all workgroups co-resident (8 waves/SIMD)
-  int wpb = 4;
-  while (wpb < 16 && kblocks / (wpb * 2) >= 4) wpb *= 2;
-  if (ntiles * wpb > 256 * 32 && wpb > 4) wpb /= 2;
-  if (g_tune_wpb >= 1 && g_tune_wpb <= 16) wpb = g_tune_wpb;
-  if (wpb > kblocks) wpb = kblocks;
-  switch (g_tune_mode) {
-    case 0: case 100: return launch_gemv_variant<G, 4, 4, 0>(x, qdata, sz, y, N, K, wpb, stream);
-    case 101: return launch_gemv_variant<G, 4, 4, 1>(x, qdata, sz, y, N, K, wpb, stream);  // loads only
-    case 110: return launch_gemv_variant<G, 4, 0, 0>(x, qdata, sz, y, N, K, wpb, stream);  // all-VALU dequant
-    default: ao::set_error("bad gemv tuning mode %d", g_tune_mode); return AO_ERR_INVALID_ARGUMENT;
-  }
-}
-
 template <int G>
 int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
                 int64_t N, int64_t K, hipStream_t stream) {
-  // M == 1 product dispatch (mode 0), measured in-graph on cold weights (profiles/int4_lab_trace_r01.txt):
-  //   * fewer than kManyTiles n-tiles: the balanced streaming kernel (one workgroup per CU) -- start-up
-  //     and tile imbalance dominate there;
-  //   * more (merged gate_up_proj: 1792 tiles): one small workgroup per tile, scheduled by the
-  //     hardware, whose register ring has the cheaper per-block issue cost (19.8 vs 22.5 us).
-  // Modes 400-403 force the streaming kernel (+ablation/trace builds), 100-399 the per-tile variants.
-  const bool force_stream = g_tune_mode >= 400 && g_tune_mode <= 403;
-  if (M == 1 && int4_gemv_stream_supported(K) && ((g_tune_mode == 0 && (N >> 4) < kManyTiles) || force_stream)) {
-    int4_gemv_stream_set_waves(g_tune_wpb);  // 8 or (default) 16 waves per workgroup
-    return launch_int4_gemv_stream(x, qdata, sz, y, N, K, G, force_stream ? g_tune_mode - 400 : 0, stream);
-  }
-  if (M == 1 && K <= kGemvMaxK && (g_tune_mode == 0 || g_tune_mode >= 100)) return launch_gemv<G>(x, qdata, sz, y, N, K, stream);
+  // M <= 16: one workgroup per 16-wide n-tile, waves split K (int4_mm_kernel).  M == 1 uses the single-row build: in
+  // the hipGraph bench it beat both purpose-built decode kernels this round tried (a persistent balanced streaming
+  // kernel with hand-counted LDS-DMA rings and a per-tile kernel with workgroup-shared x): 868 vs 732 tok/s.
+  // Modes 95-98: A/B builds for profiling (ring depth 6 / 8, the 4-row build at M = 1).
+  if (M == 1 && g_tune_mode == 98) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
+  if (M == 1 && g_tune_mode == 96) return launch_mm<G, 1, 8>(x, qdata, sz, y, M, N, K, stream);
+  if (M == 1 && g_tune_mode == 95) return launch_mm<G, 1, 6>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 16 || g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
@@ -1148,14 +940,11 @@ using namespace ao;
 
 extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size) {
   (void)group_size;
-  if (M == 1 && int4_gemv_stream_supported(K) && (N >> 4) < kManyTiles) return "int4_gemv_stream_kernel";
-  if (M == 1 && K <= kGemvMaxK) return "int4_gemv_kernel";
   if (M > 16) return "int4_mm_rb_kernel";
   return "int4_mm_kernel";
 }
 
 extern "C" int ao_int4_set_trace(unsigned long long* trace_dev) {
-  int4_gemv_stream_set_trace(trace_dev);
   g_mm_trace = trace_dev;
   return AO_OK;
 }

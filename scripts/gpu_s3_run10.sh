@@ -1,5 +1,5 @@
 #!/bin/bash
-# Session-3 final validation: full parity suite, smoke, headline bench (+ torchrun world=1 path), rocprofv3 stats + PMC
+# Final validation: full parity suite, smoke, headline bench (+ torchrun world=1 path), rocprofv3 stats + PMC
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
@@ -19,5 +19,5 @@ echo "== rocprof pmc =="
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_pmc_fetch -o int4 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-layout > $O/rocprof_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_pmc_write -o int4 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-layout > $O/rocprof_pmc_write.log 2>&1
 cd $R
-python scripts/pmc_summary.py $O/prof_pmc_fetch $O/prof_pmc_write -o $O/int4_pmc_r01.json | grep -A8 "int4_gemv" | head -40
+python scripts/pmc_summary.py $O/prof_pmc_fetch $O/prof_pmc_write -o $O/int4_pmc_r01.json | grep -A8 "int4_mm" | head -40
 find $O/prof_pmc_fetch $O/prof_pmc_write -name "*counter_collection.csv" -size +20M -delete 2>/dev/null

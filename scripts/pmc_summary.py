@@ -16,7 +16,7 @@ import json
 import os
 from collections import defaultdict
 
-KERNELS = ["int4_gemv_stream_kernel", "int4_gemv_kernel", "int4_mm_kernel", "int4_quantize_kernel"]
+KERNELS = ["int4_mm_kernel", "int4_mm_rb_kernel", "int4_quantize_kernel"]
 
 
 def main():
