@@ -15,6 +15,12 @@
 
 namespace ao {
 
+// fp8_rb_kernels.hip: weight-streaming kernel for 64 < M with few output tiles
+bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
+void fp8_rowwise_rb_set_mode(int mode);
+bool fp8_rowwise_rb_forced();
+int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
+                   int64_t M, int64_t N, int64_t K, hipStream_t stream);
 int fp8_rowwise_stream(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b,
                        const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K, hipStream_t stream);
 
@@ -415,6 +421,8 @@ using namespace ao;
 extern "C" int ao_gemm8_set_variant(int variant) {
   g_gemm8_force_regstage = (variant == 1);
   g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16) ? variant : 0;
+  // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
+  fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : variant != 0 ? 1 : 0);
   return AO_OK;
 }
 
@@ -454,9 +462,18 @@ extern "C" int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float*
   AO_REQUIRE_PTR(scale_a);
   AO_REQUIRE_PTR(scale_b);
   AO_REQUIRE_PTR(y);
-  // decode-size batches are weight-bandwidth bound: stream the weights (stream8_kernels.hip)
-  if (M <= 64 && K % 128 == 0)
+  // Weight-bandwidth-bound sizes stream the weights once instead of tiling a GEMM (Llama-70B TP8 shards, us per call,
+  // profiles/bench_8bit_r01_fp8.jsonl):
+  //   * M <= 32: stream8_kernels.hip -- activations straight from L2 per wave, no LDS staging, no split-K
+  //     (gate_up 7168x8192: 15 us at M = 1, 20 at 16; the LDS-staged kernel below needs 23);
+  //   * 32 < M and too few 128 x 128 tiles to fill the chip: fp8_rb_kernels.hip (24 us at M = 64 where the kernel above
+  //     needs 40; 27 us at M = 128 where the tiled GEMM needs 55);
+  //   * otherwise the tiled LDS-DMA GEMM.
+  // (at 32 < M <= 64 it only wins once K is long enough to amortise its start-up and split-K meeting: o_proj shard 8192x1024 8.5 vs 10.9 us)
+  const bool rb = fp8_rowwise_rb_preferred(M, N, K) && (M > 64 || K >= 4096 || fp8_rowwise_rb_forced());
+  if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb)) && !(fp8_rowwise_rb_forced() && rb))
     return fp8_rowwise_stream(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
+  if (rb) return fp8_rowwise_rb(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
   Gemm8Args p{a, b, scale_a, scale_b, bias, y, (int)M, (int)N, (int)K};
   return launch_gemm8<EPI_FP8_ROWWISE>(p, (hipStream_t)stream);
 }

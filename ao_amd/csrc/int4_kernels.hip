@@ -23,8 +23,10 @@
 
 #include "common.h"
 #include "lds_dma.h"
+#include "splitk.h"
 
 namespace ao {
+void fp8_rowwise_rb_set_trace(unsigned long long* p);  // fp8_rb_kernels.hip
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -326,62 +328,6 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Split-K meeting of the batched kernels: every part parks its fp32 tile in the workspace
-// ([tile][part][reg][thread], 16 B per thread and register: coalesced), takes a ticket, and the last one
-// to arrive adds the parts in part order (so the sum does not depend on arrival order) and returns true:
-// it stores the tile.  The parts sit on different XCDs (non-coherent L2s): the tiles are written through
-// and read with agent-scope (sc1) accesses instead of device fences -- a fence writes back / invalidates
-// the whole L2 and cost ~60 us per launch.  `flag` is any LDS word no wave is still using.
-// ---------------------------------------------------------------------------
-template <int NREG, int NTHR>
-__device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
-  constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
-  constexpr int kRegBytes = NTHR * 16;
-  constexpr int kPartBytes = NREG * kRegBytes;
-  const __amdgpu_buffer_rsrc_t rws =
-      __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * S * (kPartBytes / 4), 0, S * kPartBytes, 0x00020000);
-#pragma unroll
-  for (int r = 0; r < NREG; ++r)
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kSc1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag = (t == (unsigned)S - 1);
-    // everyone has arrived: leave the ticket ready for the next launch
-    if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!*flag) return false;
-  // parts are read in batches (<= 32 loads in flight per thread; indices past S re-read the last part and are
-  // not added), summed in part order
-  constexpr int U = (NREG >= 16) ? 2 : 4;
-  f32x4 sum[NREG];
-#pragma unroll
-  for (int r = 0; r < NREG; ++r) sum[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int q0 = 0; q0 < S; q0 += U) {
-    f32x4 v[U][NREG];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int r = 0; r < NREG; ++r)
-        v[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, min(q0 + u, S - 1) * kPartBytes, kSc1));
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool keep = q0 + u < S;
-#pragma unroll
-      for (int r = 0; r < NREG; ++r) {
-        sum[r].x += keep ? v[u][r].x : 0.f; sum[r].y += keep ? v[u][r].y : 0.f;
-        sum[r].z += keep ? v[u][r].z : 0.f; sum[r].w += keep ? v[u][r].w : 0.f;
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < NREG; ++r) acc[r] = sum[r];
-  return true;
-}
-
-// ---------------------------------------------------------------------------
 // 16 < M (batched decode / small prefill, the "bs = 128" half of the BASELINE metric), "register-B" form: each packed
 // block is dequantised once per 128-row slab and the dequantised weights never touch LDS -- a wave that owns NT n-tiles
 // dequantises their packed words straight into B operands of v_mfma_f32_16x16x32_bf16 and multiplies all 128 rows
@@ -622,46 +568,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   dump();
 }
 
-// Split-K workspace of the batched kernel: kTiledSlots rotating slots (launches in flight per device) of
-// kTiledMaxWgs fp32 tiles (128 x 128) + one ticket per output tile.  Allocated on first use.
-constexpr int kTiledSlots = 4;
-constexpr int kTiledMaxWgs = 256;
-constexpr size_t kTiledSlotFloats = (size_t)kTiledMaxWgs * 128 * 128;
-struct TiledWs {
-  float* part = nullptr;
-  unsigned* tickets = nullptr;
-  unsigned next_slot = 0;
-};
-std::mutex g_tiled_mu;
-TiledWs g_tiled_ws[64];
-
-int tiled_workspace(float** part, unsigned** tickets) {
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return hip_failed(e, "hipGetDevice");
-  AO_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
-  std::lock_guard<std::mutex> lock(g_tiled_mu);
-  TiledWs& w = g_tiled_ws[dev];
-  if (w.part == nullptr) {
-    const size_t bytes = kTiledSlots * (kTiledSlotFloats * sizeof(float) + kTiledMaxWgs * sizeof(unsigned));
-    char* p = nullptr;
-    e = hipMalloc(&p, bytes);
-    if (e != hipSuccess)
-      return hip_failed(e, "hipMalloc(int4 tiled split-K workspace); call ao_int4_weight_int4pack_mm with this M once "
-                           "outside stream capture before capturing it into a graph");
-    unsigned* t = reinterpret_cast<unsigned*>(p + kTiledSlots * kTiledSlotFloats * sizeof(float));
-    e = hipMemset(t, 0, kTiledSlots * kTiledMaxWgs * sizeof(unsigned));
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(int4 tiled split-K tickets)"); }
-    w.part = reinterpret_cast<float*>(p);
-    w.tickets = t;
-  }
-  const unsigned slot = w.next_slot++ % kTiledSlots;
-  *part = w.part + slot * kTiledSlotFloats;
-  *tickets = w.tickets + slot * kTiledMaxWgs;
-  return AO_OK;
-}
-
 unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
 
 template <int G, int WAVES, int NT, int ABL = 0>
@@ -675,9 +581,9 @@ int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, ui
   float* ws = nullptr;
   unsigned* tickets = nullptr;
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split * (BN / 128.0) <= kTiledMaxWgs, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
+    AO_REQUIRE((int64_t)grid.x * grid.y * split * (BN / 128.0) <= kSplitMaxTiles, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
-    if (int rc = tiled_workspace(&ws, &tickets)) return rc;
+    if (int rc = splitk_workspace(&ws, &tickets)) return rc;
   }
   auto kern = int4_mm_rb_kernel<G, WAVES, NT, ABL>;
   static bool attr_set = false;
@@ -901,13 +807,13 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   if (((N + 127) / 128) * slabs < 190) {
     bn = 64;
     const int64_t base = ((N + 63) / 64) * slabs;
-    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)kTiledMaxWgs / base, 8, kblocks / 8}));
+    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)kSplitMaxTiles / base, 8, kblocks / 8}));
   }
   if (g_tune_mode >= 600 && g_tune_mode < 700) {
     const int abl = (g_tune_mode - 600) / 10;
     bn = (g_tune_wpb == 4) ? 64 : 128;
     const int64_t base = ((N + bn - 1) / bn) * slabs;
-    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode % 10), kblocks, kTiledMaxWgs / std::max<int64_t>(base, 1)}));
+    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode % 10), kblocks, kSplitMaxTiles / std::max<int64_t>(base, 1)}));
     if constexpr (G == 128) {
       if (abl == 1) return launch_mm_rb<G, 8, 1, 1>(x, qdata, sz, y, M, N, K, split, stream);
       if (abl == 2) return launch_mm_rb<G, 8, 1, 2>(x, qdata, sz, y, M, N, K, split, stream);
@@ -946,6 +852,7 @@ extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, i
 
 extern "C" int ao_int4_set_trace(unsigned long long* trace_dev) {
   g_mm_trace = trace_dev;
+  fp8_rowwise_rb_set_trace(trace_dev);
   return AO_OK;
 }
 

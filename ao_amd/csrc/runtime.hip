@@ -3,7 +3,9 @@
 #include <stdio.h>
 
 #include "common.h"
+#include "splitk.h"
 
+#include <mutex>
 #include <vector>
 
 namespace ao {
@@ -34,6 +36,44 @@ void set_error(const char* fmt, ...) {
 int hip_failed(hipError_t e, const char* what) {
   set_error("%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
   return AO_ERR_HIP;
+}
+
+// ---- split-K workspace (splitk.h): the library's only device-side state ----------------------------
+namespace {
+struct SplitWs {
+  float* part = nullptr;
+  unsigned* tickets = nullptr;
+  unsigned next_slot = 0;
+};
+std::mutex g_split_mu;
+SplitWs g_split_ws[64];
+}  // namespace
+
+int splitk_workspace(float** part, unsigned** tickets) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_failed(e, "hipGetDevice");
+  AO_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  SplitWs& w = g_split_ws[dev];
+  if (w.part == nullptr) {
+    const size_t bytes = kSplitSlots * (kSplitSlotFloats * sizeof(float) + kSplitMaxTiles * sizeof(unsigned));
+    char* p = nullptr;
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+      return hip_failed(e, "hipMalloc(split-K workspace); call the op with this shape once outside stream capture before "
+                           "capturing it into a graph");
+    unsigned* t = reinterpret_cast<unsigned*>(p + kSplitSlots * kSplitSlotFloats * sizeof(float));
+    e = hipMemset(t, 0, kSplitSlots * kSplitMaxTiles * sizeof(unsigned));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(split-K tickets)"); }
+    w.part = reinterpret_cast<float*>(p);
+    w.tickets = t;
+  }
+  const unsigned slot = w.next_slot++ % kSplitSlots;
+  *part = w.part + slot * kSplitSlotFloats;
+  *tickets = w.tickets + slot * kSplitMaxTiles;
+  return AO_OK;
 }
 }  // namespace ao
 

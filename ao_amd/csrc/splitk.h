@@ -1,0 +1,71 @@
+// Split-K meeting shared by the batched kernels (int4 register-B, fp8 rowwise register-B).
+#pragma once
+#include "common.h"
+
+namespace ao {
+
+// Workspace: kSplitSlots rotating slots (launches in flight per device) of kSplitMaxTiles fp32 tiles of 128 x 128
+// + one ticket per output tile.  Allocated on first use (outside stream capture); runtime.hip.
+constexpr int kSplitSlots = 4;
+constexpr int kSplitMaxTiles = 256;
+constexpr size_t kSplitSlotFloats = (size_t)kSplitMaxTiles * 128 * 128;
+int splitk_workspace(float** part, unsigned** tickets);
+
+// ---------------------------------------------------------------------------
+// Split-K meeting: every part parks its fp32 tile in the workspace
+// ([tile][part][reg][thread], 16 B per thread and register: coalesced), takes a ticket, and the last one
+// to arrive adds the parts in part order (so the sum does not depend on arrival order) and returns true:
+// it stores the tile.  The parts sit on different XCDs (non-coherent L2s): the tiles are written through
+// and read with agent-scope (sc1) accesses instead of device fences -- a fence writes back / invalidates
+// the whole L2 and cost ~60 us per launch.  `flag` is any LDS word no wave is still using.
+// ---------------------------------------------------------------------------
+template <int NREG, int NTHR>
+__device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
+  constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
+  constexpr int kRegBytes = NTHR * 16;
+  constexpr int kPartBytes = NREG * kRegBytes;
+  const __amdgpu_buffer_rsrc_t rws =
+      __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * S * (kPartBytes / 4), 0, S * kPartBytes, 0x00020000);
+#pragma unroll
+  for (int r = 0; r < NREG; ++r)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kSc1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == (unsigned)S - 1);
+    // everyone has arrived: leave the ticket ready for the next launch
+    if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!*flag) return false;
+  // parts are read in batches (<= 32 loads in flight per thread; indices past S re-read the last part and are
+  // not added), summed in part order
+  constexpr int U = (NREG >= 16) ? 2 : 4;
+  f32x4 sum[NREG];
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) sum[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < S; q0 += U) {
+    f32x4 v[U][NREG];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < NREG; ++r)
+        v[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, min(q0 + u, S - 1) * kPartBytes, kSc1));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool keep = q0 + u < S;
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        sum[r].x += keep ? v[u][r].x : 0.f; sum[r].y += keep ? v[u][r].y : 0.f;
+        sum[r].z += keep ? v[u][r].z : 0.f; sum[r].w += keep ? v[u][r].w : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) acc[r] = sum[r];
+  return true;
+}
+
+
+}  // namespace ao

@@ -111,8 +111,8 @@ int ao_gemm8_set_variant(int variant);
 /* Name of the kernel ao_int4_weight_int4pack_mm launches for this problem (product dispatch, no
  * tuning override): what a profiler's kernel table should be matched against.  Static string. */
 const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size);
-/* Profiling only: device buffer [grid][6] of 100 MHz s_memrealtime stamps written by the
- * trace build of the M = 1 kernel (tuning mode 403); NULL disables. */
+/* Profiling only: device buffer [workgroups][16] of s_memtime stamps written by the trace builds of the batched
+ * kernels (int4: tuning mode 65S; fp8 rowwise mid-M kernel: whenever the pointer is set); NULL disables. */
 int ao_int4_set_trace(unsigned long long* trace_dev);
 
 /* ------------------------------------------------------------------------- *

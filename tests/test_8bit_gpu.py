@@ -256,6 +256,40 @@ def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
     assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
 
 
+@pytest.mark.parametrize("m,n,k,bias", [(128, 1024, 8192, False), (128, 7168, 8192, True), (200, 8192, 1024, True), (2048, 1024, 1024, False),
+                                        (96, 48, 256, True), (65, 4096, 3584, False), (1000, 208, 384, True)])
+def test_fp8_weight_streaming_mid_m(m, n, k, bias):
+    """64 < M on narrow (TP-sharded) weights takes fp8_rb_kernel: both tile widths, split-K from 1 to 16 parts, ragged M,
+    N not a multiple of the tile, bias; forced on for every shape (variant 101) and bit-reproducible."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    x = _randn_bf16((m, k), 11 * m + k)
+    w = _randn_bf16((n, k), 13 * n + k, 0.05)
+    b = _randn_bf16((n,), 9) if bias else None
+    xq, xs = ops.fp8_quantize_rowwise(x.to(DEV))
+    wq, ws = ops.fp8_quantize_rowwise(w.to(DEV))
+    bd = None if b is None else b.to(DEV)
+    try:
+        lib.ao_gemm8_set_variant(101)
+        y = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), bd)
+        for _ in range(5):
+            assert torch.equal(ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), bd), y)
+        lib.ao_gemm8_set_variant(100)
+        y_gemm = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), bd)
+    finally:
+        lib.ao_gemm8_set_variant(0)
+    y_ref = F.scaled_mm(
+        xq.view(torch.uint8).cpu().numpy(), wq.view(torch.uint8).cpu().numpy(),
+        xs.flatten().cpu().numpy(), ws.flatten().cpu().numpy(), None if b is None else b.float().numpy(),
+    )
+    yn = np_from_torch_bf16(y)
+    assert _rel(yn, y_ref) <= 1e-3
+    atol = 1e-5 * np.sqrt(k) * float(np.abs(y_ref).max())
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + atol)
+    assert _rel(np_from_torch_bf16(y_gemm), yn) <= 1e-3  # the GEMM kernels agree up to accumulation order
+
+
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("m,n,k", [(130, 208, 1152), (300, 528, 256), (513, 384, 4096)])  # N % 16 == 0 (fp8 requirement)
 def test_gemm8_every_kernel_variant(variant, m, n, k):

@@ -25,16 +25,29 @@ LLAMA70B = [("qkv_proj", 10240, 8192), ("o_proj", 8192, 8192), ("gate_up_proj", 
 
 
 def timeit(fn, iters, warmup=3):
+    """Seconds per call.  The calls are captured into one hipGraph and replayed (like bench.py), so that kernels of a
+    few microseconds are not hidden behind ~18 us of eager Python + launch overhead per call."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(iters):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(reps):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    return e0.elapsed_time(e1) * 1e-3 / (iters * reps)
 
 
 def main():
@@ -76,7 +89,7 @@ def main():
             rec(kernel="int8_scaled_mm", shape=name, M=M, N=n, K=k, us=t * 1e6, TOPs=f / t / 1e12, frac_mfma=f / t / PEAK_INT8,
                 us_with_act_quant=t2 * 1e6)
     if "fp8" in which:
-        for m in sorted({1, 128, M}):
+        for m in sorted({1, 16, 64, 128, M}):
             for name, n, k in LLAMA70B_TP8:
                 x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
                 w = torch.randn(n, k, device=dev, dtype=torch.bfloat16) * 0.02
