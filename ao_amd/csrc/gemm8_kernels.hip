@@ -15,12 +15,16 @@
 
 namespace ao {
 
-// fp8_rb_kernels.hip: weight-streaming kernel for 64 < M with few output tiles
+// rb8_kernels.hip: weight-streaming kernels for problems with few output tiles
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
 int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                    int64_t M, int64_t N, int64_t K, hipStream_t stream);
+int int8_scaled_rb(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
+                   int64_t M, int64_t N, int64_t K, hipStream_t stream);
+int int8_scaled_stream(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
+                       int64_t M, int64_t N, int64_t K, hipStream_t stream);
 int fp8_rowwise_stream(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b,
                        const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K, hipStream_t stream);
 
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
 }
 
 bool g_gemm8_force_regstage = false;  // profiling: ao_gemm8_set_variant(1)
+bool g_gemm8_tiled_only = false;      // profiling / A-B tests: ao_gemm8_set_variant(100) -- never a weight-streaming kernel
 
 int g_gemm8_tm = 0;  // profiling: 0 = by shape, 2 / 4 = force
 
@@ -420,6 +425,7 @@ using namespace ao;
 
 extern "C" int ao_gemm8_set_variant(int variant) {
   g_gemm8_force_regstage = (variant == 1);
+  g_gemm8_tiled_only = (variant == 100);
   g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16) ? variant : 0;
   // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
   fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : variant != 0 ? 1 : 0);
@@ -435,6 +441,12 @@ extern "C" int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const i
   AO_REQUIRE_PTR(wq);
   AO_REQUIRE_PTR(w_scale);
   AO_REQUIRE_PTR(y);
+  // weight-bandwidth-bound sizes stream the weights once, as for fp8 below: M <= 32 per-tile streaming kernel
+  // (stream8_kernels.hip), few output tiles the LDS-staged one (rb8_kernels.hip); Llama-3-8B down_proj at M = 1 took 77 us
+  // through the tiled GEMM
+  if (N % 16 == 0 && K % 128 == 0 && M <= 32 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only)
+    return int8_scaled_stream(xq, wq, x_scale, w_scale, bias, y, M, N, K, (hipStream_t)stream);
+  if (N % 16 == 0 && fp8_rowwise_rb_preferred(M, N, K)) return int8_scaled_rb(xq, wq, x_scale, w_scale, bias, y, M, N, K, (hipStream_t)stream);
   Gemm8Args p{reinterpret_cast<const uint8_t*>(xq), reinterpret_cast<const uint8_t*>(wq), x_scale, w_scale, bias, y,
               (int)M, (int)N, (int)K};
   return launch_gemm8<EPI_INT8_SCALED>(p, (hipStream_t)stream);
@@ -466,12 +478,12 @@ extern "C" int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float*
   // profiles/bench_8bit_r01_fp8.jsonl):
   //   * M <= 32: stream8_kernels.hip -- activations straight from L2 per wave, no LDS staging, no split-K
   //     (gate_up 7168x8192: 15 us at M = 1, 20 at 16; the LDS-staged kernel below needs 23);
-  //   * 32 < M and too few 128 x 128 tiles to fill the chip: fp8_rb_kernels.hip (24 us at M = 64 where the kernel above
+  //   * 32 < M and too few 128 x 128 tiles to fill the chip: rb8_kernels.hip (24 us at M = 64 where the kernel above
   //     needs 40; 27 us at M = 128 where the tiled GEMM needs 55);
   //   * otherwise the tiled LDS-DMA GEMM.
   // (at 32 < M <= 64 it only wins once K is long enough to amortise its start-up and split-K meeting: o_proj shard 8192x1024 8.5 vs 10.9 us)
   const bool rb = fp8_rowwise_rb_preferred(M, N, K) && (M > 64 || K >= 4096 || fp8_rowwise_rb_forced());
-  if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb)) && !(fp8_rowwise_rb_forced() && rb))
+  if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb)) && !(fp8_rowwise_rb_forced() && rb) && !g_gemm8_tiled_only)
     return fp8_rowwise_stream(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
   if (rb) return fp8_rowwise_rb(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
   Gemm8Args p{a, b, scale_a, scale_b, bias, y, (int)M, (int)N, (int)K};

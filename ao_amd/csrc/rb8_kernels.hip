@@ -1,14 +1,15 @@
-// float8 rowwise linear for mid-size batches (64 < M, few output tiles) on gfx950 -- the TP-sharded Llama-70B shapes
-// of BASELINE config 4 at batched-decode sizes, where a 128 x 128 / 256 x 256 GEMM grid covers a fraction of the
-// chip and the op is bound by streaming the weights once.
+// 1-byte-weight linears whose GEMM grid would not fill the chip, on gfx950: float8 rowwise at 32 < M (the TP-sharded
+// Llama-70B shapes of BASELINE config 4 at batched-decode sizes) and int8 dynamic at any M with few output tiles
+// (decode and small batches of config 3's model).  The op is then bound by streaming the weights once.
 //
-//   y[M,N] = bf16((a[M,K] . b[N,K]^T) * scale_a[m] * scale_b[n] + bias[n])       (aten::_scaled_mm, rowwise scales;
-//   call site torchao/float8/inference.py:104-123)
+//   fp8 :  y[M,N] = bf16((a . b^T) * scale_a[m] * scale_b[n] + bias[n])     aten::_scaled_mm rowwise, float8/inference.py:104-123
+//   int8:  y[M,N] = bf16(bf16(i32(a . b^T) * sx[m]) * sw[n] + bias[n])      _int_mm + scales, int8_tensor.py:305-359
 //
 // Same structure as the batched int4 kernel (int4_kernels.hip, int4_mm_rb_kernel) without the dequant: a wave owns
 // one 16-wide n-tile and all 128 rows of the slab.  Its weight rows go HBM -> wave-private LDS ring (full 128-byte lines
-// per request) -> registers as the B operand of v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; lane (n, kq)
-// holds k = 16 kq .. +15 and 64 + 16 kq .. +15 of the 128-k step); the activation tile [128 rows][128 B] is staged once per workgroup by
+// per request) -> registers as the B operand of v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales) or of two
+// v_mfma_i32_16x16x64_i8 (lane (n, kq) holds k = 16 kq .. +15 and 64 + 16 kq .. +15 of the 128-k step);
+// the activation tile [128 rows][128 B] is staged once per workgroup by
 // LDS-DMA with a source-side swizzle (chunk position c' of row r holds global 16-byte chunk c' ^ ((r >> 1) & 7)) so
 // that the two ds_read_b128 of an A operand are bank-conflict free.  Activations are fetched 2 steps ahead (L2 hits),
 // weights 5 steps ahead (with 2 the loop ran at 0.9 us per step: too few HBM bytes in flight); one hand-counted
@@ -29,9 +30,9 @@ constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
 constexpr int kWStages = 6;  // weight ring (per wave), filled 5 steps ahead: the HBM stream needs the bytes in flight
 constexpr int kABuf = 128 * 128;  // one activation stage: 128 rows x 128 k bytes
 
-struct Fp8RbArgs {
-  const uint8_t* a;       // [M][K] e4m3
-  const uint8_t* b;       // [N][K] e4m3
+struct Rb8Args {
+  const uint8_t* a;       // [M][K] e4m3 / int8
+  const uint8_t* b;       // [N][K] e4m3 / int8
   const float* scale_a;   // [M]
   const float* scale_b;   // [N]
   const uint16_t* bias;   // [N] bf16 or null
@@ -44,8 +45,8 @@ struct Fp8RbArgs {
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
 // loop done, meeting done, exit
-template <int WAVES, bool TRACE = false>
-__global__ __launch_bounds__(64 * WAVES) void fp8_rb_kernel(Fp8RbArgs p) {
+template <int WAVES, bool INT8, bool TRACE = false>
+__global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
   constexpr int ADMA = 16 / WAVES;  // activation DMAs per wave and stage (8 rows each)
@@ -123,8 +124,15 @@ __global__ __launch_bounds__(64 * WAVES) void fp8_rb_kernel(Fp8RbArgs p) {
     for (int mt = 0; mt < 8; ++mt) {
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
       const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + (pa ^ 64));
-      const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-      acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, 127, 0, 127);
+      if constexpr (INT8) {  // acc holds int32 bit patterns
+        i32x4 c = __builtin_bit_cast(i32x4, acc[mt]);
+        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, b0), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, b1), c, 0, 0, 0);
+        acc[mt] = __builtin_bit_cast(f32x4, c);
+      } else {
+        const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+        acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, 127, 0, 127);
+      }
     }
     stage = (stage == 2) ? 0 : stage + 1;
     wstage = (wstage == kWStages - 1) ? 0 : wstage + 1;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(64 * WAVES) void fp8_rb_kernel(Fp8RbArgs p) {
       for (int i = 0; i < 13; ++i) t[i] = ts[i];
     }
   };
-  if (S > 1 && !split_k_meet<8, 64 * WAVES>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
+  if (S > 1 && !split_k_meet<8, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
     dump();
     return;
   }
@@ -162,7 +170,13 @@ __global__ __launch_bounds__(64 * WAVES) void fp8_rb_kernel(Fp8RbArgs p) {
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + mt * 16 + kq * 4 + r;
       if (m < p.M) {
-        float v = acc[mt][r] * sa[mt * 4 + r] * sb;
+        float v;
+        if constexpr (INT8) {
+          // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+          v = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt])[r] * sa[mt * 4 + r]) * sb;
+        } else {
+          v = acc[mt][r] * sa[mt * 4 + r] * sb;
+        }
         if (p.bias != nullptr) v += bias;
         y[(size_t)m * p.N + n] = f32_to_bf16_bits(v);
       }
@@ -172,26 +186,26 @@ __global__ __launch_bounds__(64 * WAVES) void fp8_rb_kernel(Fp8RbArgs p) {
 
 unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 
-template <int WAVES>
-int launch_fp8_rb(Fp8RbArgs p, int split, hipStream_t stream) {
+template <int WAVES, bool INT8>
+int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   constexpr int BN = WAVES * 16;
   dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + 127) / 128), (unsigned)split), block(64 * WAVES);
   constexpr size_t smem = (size_t)kStages * kABuf + (size_t)WAVES * kWStages * 2048;
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN <= (int64_t)kSplitMaxTiles * 128, "fp8_rb: %u x %u tiles x %d parts exceed the split-K workspace",
+    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN <= (int64_t)kSplitMaxTiles * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     if (int rc = splitk_workspace(&p.ws, &p.tickets)) return rc;
   }
   p.trace = g_fp8_rb_trace;
-  auto kern = (p.trace != nullptr) ? fp8_rb_kernel<WAVES, true> : fp8_rb_kernel<WAVES, false>;
+  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, INT8, true> : rb8_kernel<WAVES, INT8, false>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[p.trace != nullptr]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(fp8_rb_kernel)");
+    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(rb8_kernel)");
     attr_set[p.trace != nullptr] = true;
   }
   ao::launch(kern, grid, block, smem, stream, p);
-  AO_LAUNCH_CHECK("fp8_rb_kernel launch");
+  AO_LAUNCH_CHECK("rb8_kernel launch");
   return AO_OK;
 }
 
@@ -203,7 +217,7 @@ void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
 bool fp8_rowwise_rb_forced() { return g_fp8_rb_force >= 2; }
 
-// True when this kernel is the better choice: the 128 x 128 GEMM grid would leave most of the chip idle.
+// True when this kernel is the better choice: the 128 x 128 GEMM grid would leave most of the chip idle (same rule for int8).
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
   if (K % 128 != 0 || N % 16 != 0 || M * K >= (1ll << 32) || N * K >= (1ll << 32)) return false;
   if (g_fp8_rb_force == 1) return false;
@@ -211,9 +225,12 @@ bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
   return ((N + 127) / 128) * ((M + 127) / 128) < 190;
 }
 
-int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
-                   int64_t M, int64_t N, int64_t K, hipStream_t stream) {
-  Fp8RbArgs p{a, b, scale_a, scale_b, bias, y, (int)M, (int)N, (int)K, nullptr, nullptr};
+namespace {
+
+template <bool INT8>
+int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M,
+            int64_t N, int64_t K, hipStream_t stream) {
+  Rb8Args p{a, b, scale_a, scale_b, bias, y, (int)M, (int)N, (int)K, nullptr, nullptr, nullptr};
   const int64_t slabs = (M + 127) / 128, ksteps = K >> 7;
   // 128-column tiles while they give ~half a chip of workgroups before splitting, else 64-column tiles; K cut into at most
   // 16 parts of >= 4 steps so that the grid approaches one workgroup per CU
@@ -224,7 +241,19 @@ int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, con
   const int64_t fit = (int64_t)kSplitMaxTiles * 128 / (base * bn);
   const int64_t target = (g_fp8_rb_force == 3) ? 512 : 256;
   const int split = (int)std::max<int64_t>(1, std::min<int64_t>({target / base, fit, 16, ksteps / 4}));
-  return narrow ? launch_fp8_rb<4>(p, split, stream) : launch_fp8_rb<8>(p, split, stream);
+  return narrow ? launch_rb8<4, INT8>(p, split, stream) : launch_rb8<8, INT8>(p, split, stream);
+}
+
+}  // namespace
+
+int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
+                   int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+  return rb8_run<false>(a, b, scale_a, scale_b, bias, y, M, N, K, stream);
+}
+
+int int8_scaled_rb(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
+                   int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+  return rb8_run<true>(reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b), scale_a, scale_b, bias, y, M, N, K, stream);
 }
 
 }  // namespace ao

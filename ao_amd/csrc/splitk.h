@@ -19,7 +19,8 @@ int splitk_workspace(float** part, unsigned** tickets);
 // and read with agent-scope (sc1) accesses instead of device fences -- a fence writes back / invalidates
 // the whole L2 and cost ~60 us per launch.  `flag` is any LDS word no wave is still using.
 // ---------------------------------------------------------------------------
-template <int NREG, int NTHR>
+// INT: the registers hold int32 partial sums (exact integer adds) instead of fp32.
+template <int NREG, int NTHR, bool INT = false>
 __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
   constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
   constexpr int kRegBytes = NTHR * 16;
@@ -57,8 +58,13 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
       const bool keep = q0 + u < S;
 #pragma unroll
       for (int r = 0; r < NREG; ++r) {
-        sum[r].x += keep ? v[u][r].x : 0.f; sum[r].y += keep ? v[u][r].y : 0.f;
-        sum[r].z += keep ? v[u][r].z : 0.f; sum[r].w += keep ? v[u][r].w : 0.f;
+        if constexpr (INT) {
+          const i32x4 a = __builtin_bit_cast(i32x4, sum[r]), b = __builtin_bit_cast(i32x4, v[u][r]);
+          sum[r] = __builtin_bit_cast(f32x4, i32x4{a.x + (keep ? b.x : 0), a.y + (keep ? b.y : 0), a.z + (keep ? b.z : 0), a.w + (keep ? b.w : 0)});
+        } else {
+          sum[r].x += keep ? v[u][r].x : 0.f; sum[r].y += keep ? v[u][r].y : 0.f;
+          sum[r].z += keep ? v[u][r].z : 0.f; sum[r].w += keep ? v[u][r].w : 0.f;
+        }
       }
     }
   }

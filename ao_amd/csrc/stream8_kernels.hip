@@ -33,10 +33,13 @@ struct Stream8Args {
   int M_total, N, K, E;
 };
 
-// MX = block-scaled operands (scales from memory); otherwise unit scales + fp32 row/col epilogue.
+// KIND: block-scaled e4m3 operands (scales from memory) / e4m3 with unit block scales + fp32 row/col epilogue / int8 with
+// int32 accumulation (two v_mfma_i32_16x16x64_i8 per step) + the int8 linear's two-rounding epilogue.
 // MT = m-tiles (16 rows each) handled per pass.
-template <bool MX, int MT>
+enum Stream8Kind { S8_FP8_ROWWISE = 0, S8_MX = 1, S8_INT8 = 2 };
+template <int KIND, int MT>
 __global__ __launch_bounds__(512) void stream8_kernel(Stream8Args p) {
+  constexpr bool MX = (KIND == S8_MX), INT8 = (KIND == S8_INT8);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [nwaves][MT][256]
 
@@ -97,8 +100,15 @@ __global__ __launch_bounds__(512) void stream8_kernel(Stream8Args p) {
           int sa = 127;
           if (MX) sa = (int)((*reinterpret_cast<const uint32_t*>(asrow[t] + ks * 4)) >> (8 * kq)) & 0xff;
           if (!valid[t]) { a0 = u32x4{0, 0, 0, 0}; a1 = u32x4{0, 0, 0, 0}; sa = 127; }
-          const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[t], 0, 0, 0, sa, 0, sb);
+          if constexpr (INT8) {  // acc holds int32 bit patterns
+            i32x4 c = __builtin_bit_cast(i32x4, acc[t]);
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, b0), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, b1), c, 0, 0, 0);
+            acc[t] = __builtin_bit_cast(f32x4, c);
+          } else {
+            const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[t], 0, 0, 0, sa, 0, sb);
+          }
         }
       }
     }
@@ -115,9 +125,17 @@ __global__ __launch_bounds__(512) void stream8_kernel(Stream8Args p) {
       const int row = t * 16 + (rc >> 4), col = rc & 15;
       if (row < rows) {
         float sum = 0.f;
-        for (int w = 0; w < nwaves; ++w) sum += red[((size_t)w * MT + t) * 256 + rc];
+        int isum = 0;
+        for (int w = 0; w < nwaves; ++w) {
+          if constexpr (INT8) isum += __float_as_int(red[((size_t)w * MT + t) * 256 + rc]);
+          else sum += red[((size_t)w * MT + t) * 256 + rc];
+        }
         const int gm = row_begin + m_base + row, gn = ntile * 16 + col;
-        if (!MX) {
+        if constexpr (INT8) {
+          // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+          sum = round_bf16((float)isum * p.row_scale[gm]) * p.col_scale[gn];
+          if (p.bias != nullptr) sum += bf16_lo_to_f32(p.bias[gn]);
+        } else if (!MX) {
           sum = sum * p.row_scale[gm] * p.col_scale[gn];
           if (p.bias != nullptr) sum += bf16_lo_to_f32(p.bias[gn]);
         }
@@ -341,7 +359,7 @@ int launch_mx_grouped(const Stream8Args& p, hipStream_t stream) {
   return launch_mx_grouped_tn<MT, 2>(p, stream);
 }
 
-template <bool MX>
+template <int KIND>
 int launch_stream8(const Stream8Args& p, int max_rows_per_group, hipStream_t stream) {
   const int ksteps = p.K >> 7;
   int wpb = 1;
@@ -350,9 +368,9 @@ int launch_stream8(const Stream8Args& p, int max_rows_per_group, hipStream_t str
   const int mt = max_rows_per_group <= 16 ? 1 : (max_rows_per_group <= 32 ? 2 : 4);
   const size_t smem = (size_t)wpb * mt * 256 * sizeof(float);
   switch (mt) {
-    case 1: ao::launch(stream8_kernel<MX, 1>, grid, block, smem, stream, p); break;
-    case 2: ao::launch(stream8_kernel<MX, 2>, grid, block, smem, stream, p); break;
-    default: ao::launch(stream8_kernel<MX, 4>, grid, block, smem, stream, p); break;
+    case 1: ao::launch(stream8_kernel<KIND, 1>, grid, block, smem, stream, p); break;
+    case 2: ao::launch(stream8_kernel<KIND, 2>, grid, block, smem, stream, p); break;
+    default: ao::launch(stream8_kernel<KIND, 4>, grid, block, smem, stream, p); break;
   }
   AO_LAUNCH_CHECK("stream8_kernel launch");
   return AO_OK;
@@ -366,7 +384,17 @@ int fp8_rowwise_stream(const uint8_t* a, const uint8_t* b, const float* scale_a,
   Stream8Args p{};
   p.a = a; p.b = b; p.row_scale = scale_a; p.col_scale = scale_b; p.bias = bias; p.out = y;
   p.M_total = (int)M; p.N = (int)N; p.K = (int)K; p.E = 1;
-  return launch_stream8<false>(p, (int)M, stream);
+  return launch_stream8<S8_FP8_ROWWISE>(p, (int)M, stream);
+}
+
+// the same for the int8 dynamic-activation linear at decode batch sizes (int8_tensor.py:305-359)
+int int8_scaled_stream(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
+                       int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+  Stream8Args p{};
+  p.a = reinterpret_cast<const uint8_t*>(a); p.b = reinterpret_cast<const uint8_t*>(b);
+  p.row_scale = scale_a; p.col_scale = scale_b; p.bias = bias; p.out = y;
+  p.M_total = (int)M; p.N = (int)N; p.K = (int)K; p.E = 1;
+  return launch_stream8<S8_INT8>(p, (int)M, stream);
 }
 
 }  // namespace ao
@@ -402,5 +430,5 @@ extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, con
     return launch_mx_grouped<4>(p, (hipStream_t)stream);
   }
   // other K: the per-tile kernel, m-tiling for the worst case (a group cannot exceed M_total rows)
-  return launch_stream8<true>(p, (int)M_total, (hipStream_t)stream);
+  return launch_stream8<S8_MX>(p, (int)M_total, (hipStream_t)stream);
 }

@@ -84,6 +84,33 @@ def test_int8_linear_vs_oracle(m, n, k, bias):
     assert np.array_equal(c.cpu().numpy(), I.int_mm(xq.cpu().numpy(), wq.cpu().numpy()))
 
 
+@pytest.mark.parametrize("m,n,k,bias", [(1, 4096, 14336, False), (16, 6144, 4096, True), (128, 4096, 4096, True), (200, 48, 512, True),
+                                        (64, 28672, 4096, False), (1, 16, 128, False)])
+def test_int8_weight_streaming_small_m(m, n, k, bias):
+    """M <= 32 takes the per-tile streaming kernel, few output tiles the LDS-staged one (rb8_kernel<INT8>), both forced here in
+    turn: integer (split-K) sums + the reference's two roundings stay bit-exact, and equal to the tiled GEMM's bits."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    x = _randn_bf16((m, k), 17 * m + k)
+    w = _randn_bf16((n, k), 19 * n + k, 0.05)
+    b = _randn_bf16((n,), 5) if bias else None
+    xq, xs = ops.int8_quantize_rowwise(x.to(DEV))
+    wq, ws = ops.int8_quantize_rowwise(w.to(DEV))
+    bd = None if b is None else b.to(DEV)
+    y = ops.int8_scaled_mm(xq, xs, wq, ws, bd)
+    try:
+        lib.ao_gemm8_set_variant(100)  # never a weight-streaming kernel
+        y_gemm = ops.int8_scaled_mm(xq, xs, wq, ws, bd)
+        lib.ao_gemm8_set_variant(101)  # always the LDS-staged one
+        y_rb = ops.int8_scaled_mm(xq, xs, wq, ws, bd)
+    finally:
+        lib.ao_gemm8_set_variant(0)
+    assert torch.equal(y, y_gemm) and torch.equal(y_rb, y_gemm)
+    y_ref = I.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+    assert np.array_equal(np_from_torch_bf16(y), y_ref)
+
+
 def test_int8_extremes_exact():
     """int32 accumulation at full range: K * 127 * 128 stays exact."""
     m, n, k = 33, 64, 8192
