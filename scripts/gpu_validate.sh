@@ -21,3 +21,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_pmc_write 
 cd $R
 python scripts/pmc_summary.py $O/prof_pmc_fetch $O/prof_pmc_write -o $O/int4_pmc_r01.json | grep -A8 "int4_mm" | head -40
 find $O/prof_pmc_fetch $O/prof_pmc_write -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
+echo "== secondary workloads =="
+timeout 600 python tools/bench_8bit.py --m 2048 --iters 10 2>/dev/null | grep "^{" > $O/bench_8bit_r01.jsonl; wc -l $O/bench_8bit_r01.jsonl
+timeout 300 python bench.py --batch 128 --steps 20 --warmup 3 --no-cpu-baseline --no-second-layout 2>/dev/null > $O/bench_bs128.json; cut -c1-200 $O/bench_bs128.json
+timeout 120 python tools/bench_moe_pad.py 2>/dev/null | grep "^{" > $O/bench_moe_pad.json; cut -c1-200 $O/bench_moe_pad.json
