@@ -19,6 +19,7 @@ namespace ao {
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
+extern int g_mx_variant;  // stream8_kernels.hip
 int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                    int64_t M, int64_t N, int64_t K, hipStream_t stream);
 int int8_scaled_rb(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
@@ -426,9 +427,10 @@ using namespace ao;
 extern "C" int ao_gemm8_set_variant(int variant) {
   g_gemm8_force_regstage = (variant == 1);
   g_gemm8_tiled_only = (variant == 100);
+  g_mx_variant = (variant == 110) ? 1 : (variant == 111) ? 2 : 0;
   g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16) ? variant : 0;
   // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
-  fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : variant != 0 ? 1 : 0);
+  fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : (variant != 0 && variant < 110) ? 1 : 0);
   return AO_OK;
 }
 

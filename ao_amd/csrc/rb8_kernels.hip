@@ -27,17 +27,25 @@ namespace {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
-constexpr int kWStages = 6;  // weight ring (per wave), filled 5 steps ahead: the HBM stream needs the bytes in flight
+// weight ring (per wave), filled kWStages - 1 steps ahead: the HBM stream needs the bytes in flight.  6 stages; 5 for the
+// 8-wave MX form, whose scale rings would otherwise push the workgroup past 160 KiB of LDS
+constexpr int w_stages(int waves, int kind) { return (waves == 8 && kind == 2) ? 5 : 6; }
 constexpr int kABuf = 128 * 128;  // one activation stage: 128 rows x 128 k bytes
+
+enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2 };
 
 struct Rb8Args {
   const uint8_t* a;       // [M][K] e4m3 / int8
-  const uint8_t* b;       // [N][K] e4m3 / int8
-  const float* scale_a;   // [M]
+  const uint8_t* b;       // [N][K] e4m3 / int8; MX: [E][N][K]
+  const float* scale_a;   // [M]           (rowwise kinds)
   const float* scale_b;   // [N]
   const uint16_t* bias;   // [N] bf16 or null
   uint16_t* y;            // [M][N] bf16
   int M, N, K;
+  const uint8_t* a_mx;    // MX: [M][K/32] e8m0
+  const uint8_t* b_mx;    // MX: [E][N][K/32] e8m0
+  const int32_t* offs;    // MX: [E] cumulative group ends (null: one group)
+  int slabs, E;           // MX: 128-row slabs per group the grid provides (grid.y = E * slabs)
   float* ws;
   unsigned* tickets;
   unsigned long long* trace;  // profiling build only
@@ -45,19 +53,22 @@ struct Rb8Args {
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
 // loop done, meeting done, exit
-template <int WAVES, bool INT8, bool TRACE = false>
+template <int WAVES, int KIND, bool TRACE = false>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
+  constexpr bool INT8 = (KIND == RB8_INT8), MX = (KIND == RB8_MX);
   constexpr int ADMA = 16 / WAVES;  // activation DMAs per wave and stage (8 rows each)
-  constexpr int LPS = ADMA + 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][128][128 B] a | [WAVES][6][2 KiB] b
+  constexpr int LPS = ADMA + 2 + (MX ? 2 : 0);
+  constexpr int RPW = 128 / WAVES;  // MX: activation-scale rows fetched per wave
+  constexpr int kWStages = w_stages(WAVES, KIND);
+  // [3][128][128 B] a | [WAVES][6][2 KiB] b | MX: [3][WAVES][256 B] a scales | [WAVES][6][256 B] b scales
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
-  const int m0 = blockIdx.y * 128;
   const int ntiles = p.N >> 4;
   const int tile = blockIdx.x * WAVES + wave;
   const int tile_c = min(tile, ntiles - 1);  // tiles past N alias the last one; never stored
@@ -65,12 +76,21 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int S = gridDim.z, ks = blockIdx.z;
   const int k0 = (int)(((long long)ksteps * ks) / S);
   const int nk = (int)(((long long)ksteps * (ks + 1)) / S) - k0;
+  // rows of this workgroup: [m0, m_end) -- a 128-row slab of the matrix, or of one expert's token group
+  int m0 = blockIdx.y * 128, m_end = p.M, expert = 0;
+  if constexpr (MX) {
+    expert = blockIdx.y / p.slabs;
+    const int begin = (p.offs != nullptr && expert > 0) ? p.offs[expert - 1] : 0;
+    m_end = (p.offs != nullptr) ? p.offs[expert] : p.M;
+    m0 = begin + (blockIdx.y % p.slabs) * 128;
+    if (m0 >= m_end) return;  // uniform: empty group / slab past the group (before any DMA or barrier)
+  }
 
   uint32_t aoff[ADMA];
 #pragma unroll
   for (int i = 0; i < ADMA; ++i) {
     const int row = 8 * (ADMA * wave + i) + (lane >> 3);
-    aoff[i] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
+    aoff[i] = (uint32_t)min(m0 + row, m_end - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
   }
   // weight DMA i (0, 1) of a step fetches rows 8 i + (lane >> 3) of the n-tile as FULL 128-byte lines (chunk position lane & 7,
   // same swizzle as the activations); half-line requests -- one lane group per 64 bytes -- ran the stream at 3.7 TB/s
@@ -80,19 +100,29 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     const int row = 8 * i + (lane >> 3);
     boff[i] = (uint32_t)row * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
   }
-  const uint8_t* brows = p.b + (size_t)tile_c * 16 * p.K;
+  const uint8_t* brows = p.b + ((size_t)expert * p.N + (size_t)tile_c * 16) * p.K;
   const uint32_t a_lds = lds_offset(smem);
   const uint32_t w_lds = a_lds + kStages * kABuf + wave * (kWStages * 2048);
+  // MX block scales: one dword (4 e8m0 bytes = the 4 blocks of a 128-k step) per row and step.  Wave w fetches the dwords of
+  // activation rows RPW w .. + RPW - 1 (lanes past RPW repeat them into slots nobody reads) and of its own 16 weight rows.
+  const uint32_t kb32 = (uint32_t)(p.K >> 5);
+  const uint32_t asoff = MX ? (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32 : 0u;
+  const uint32_t bsoff = (uint32_t)nl * kb32;
+  const uint8_t* bsrows = MX ? p.b_mx + ((size_t)expert * p.N + (size_t)tile_c * 16) * kb32 : nullptr;
+  const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (kWStages * 2048);
+  const uint32_t bs_lds = as_lds + kStages * WAVES * 256 + wave * (kWStages * 256);
   // k clamped: the fills past the end re-read the last step (unused)
   auto issue_a = [&](int stage, int k) {
     const int kk = k0 + min(k, nk - 1);
 #pragma unroll
     for (int i = 0; i < ADMA; ++i) dma_b128_s(p.a + (size_t)kk * 128, aoff[i], a_lds + stage * kABuf + (ADMA * wave + i) * 1024);
+    if constexpr (MX) dma_b32_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (stage * WAVES + wave) * 256);
   };
   auto issue_w = [&](int stage, int k) {
     const int kk = k0 + min(k, nk - 1);
     dma_b128_nt_s(brows + (size_t)kk * 128, boff[0], w_lds + stage * 2048);
     dma_b128_nt_s(brows + (size_t)kk * 128, boff[1], w_lds + stage * 2048 + 1024);
+    if constexpr (MX) dma_b32_s(bsrows + (size_t)kk * 4, bsoff, bs_lds + stage * 256);
   };
 
   f32x4 acc[8];
@@ -101,25 +131,32 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // A operand of lane (row r = nl, kq): chunks kq and 4 + kq of the row, at positions chunk ^ ((r >> 1) & 7)
   const int pa = nl * 128 + (((kq ^ (nl >> 1)) & 7) << 4);  // second half: ^ 64; + 2048 per m-tile
 
-  // Issue order is w(0..2) | a(0) w(3) | a(1) w(4), then per step a(k+2) w(k+5): when step k starts, the LPS + 2 youngest
-  // requests are a(k+1), w(k+4) and w(k+3); everything older -- a(k) and w(k) .. w(k+2) -- has landed.
-  issue_w(0, 0); issue_w(1, 1); issue_w(2, 2);
-  issue_a(0, 0); issue_w(3, 3);
-  issue_a(1, 1); issue_w(4, 4);
+  // Issue order (6 stages) is w(0..2) | a(0) w(3) | a(1) w(4), then per step a(k+2) w(k+5): when step k starts, the youngest requests
+  // are a(k+1), w(k+4) (one stage: LPS) and w(k+3) (2 DMAs, 3 with MX scales); everything older -- a(k), w(k) .. w(k+2) -- has landed.
+#pragma unroll
+  for (int i = 0; i < kWStages - 3; ++i) issue_w(i, i);
+  issue_a(0, 0); issue_w(kWStages - 3, kWStages - 3);
+  issue_a(1, 1); issue_w(kWStages - 2, kWStages - 2);
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
   int stage = 0, wstage = 0;
   for (int k = 0; k < nk; ++k) {
-    wait_vmcnt<LPS + 2>();
+    wait_vmcnt<LPS + 2 + (MX ? 1 : 0)>();
     // everyone's share of the activation tile has landed, and everyone has finished reading step k - 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (TRACE && k < 8) ts[2 + k] = __builtin_amdgcn_s_memtime();
     issue_a((stage == 0) ? 2 : stage - 1, k + 2);
-    issue_w((wstage == 0) ? kWStages - 1 : wstage - 1, k + 5);
+    issue_w((wstage == 0) ? kWStages - 1 : wstage - 1, k + kWStages - 1);
     const char* A = smem + stage * kABuf;
     const char* W = smem + kStages * kABuf + (wave * kWStages + wstage) * 2048;
     const u32x4 b0 = *reinterpret_cast<const u32x4*>(W + pa);  // the n-tile's 16 rows are laid out like an m-tile
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(W + (pa ^ 64));
     const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    // MX: the scale byte of lane group kq is that of 32-k block kq of the step (operand layout probed on gfx950, stream8_kernels.hip)
+    [[maybe_unused]] const char* AS = smem + kStages * kABuf + WAVES * (kWStages * 2048) + stage * WAVES * 256;
+    int sb = 127;
+    if constexpr (MX)
+      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + kStages * WAVES * 256 +
+                                                    (wave * kWStages + wstage) * 256 + nl * 4) >> (8 * kq)) & 0xff;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
@@ -131,7 +168,12 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
         acc[mt] = __builtin_bit_cast(f32x4, c);
       } else {
         const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-        acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, 127, 0, 127);
+        int sa = 127;
+        if constexpr (MX) {  // row mt * 16 + nl sits in the region of wave row / RPW, slot row % RPW
+          const int row = mt * 16 + nl;
+          sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * 256 + (row % RPW) * 4) >> (8 * kq)) & 0xff;
+        }
+        acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, sa, 0, sb);
       }
     }
     stage = (stage == 2) ? 0 : stage + 1;
@@ -157,47 +199,61 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
   if (tile >= ntiles) { dump(); return; }
   const int n = tile * 16 + nl;
-  const float* __restrict__ scale_a = p.scale_a;
   uint16_t* __restrict__ y = p.y;
-  const float sb = p.scale_b[n];
-  const float bias = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
-  float sa[32];  // all row scales first: the stores below must not sit between dependent loads
+  if constexpr (MX) {  // scales were applied by the MFMA: out = bf16(acc)
 #pragma unroll
-  for (int i = 0; i < 32; ++i) sa[i] = scale_a[min(m0 + (i >> 2) * 16 + kq * 4 + (i & 3), p.M - 1)];
+    for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + mt * 16 + kq * 4 + r;
-      if (m < p.M) {
-        float v;
-        if constexpr (INT8) {
-          // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
-          v = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt])[r] * sa[mt * 4 + r]) * sb;
-        } else {
-          v = acc[mt][r] * sa[mt * 4 + r] * sb;
-        }
-        if (p.bias != nullptr) v += bias;
-        y[(size_t)m * p.N + n] = f32_to_bf16_bits(v);
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mt * 16 + kq * 4 + r;
+        if (m < m_end) y[(size_t)m * p.N + n] = f32_to_bf16_bits(acc[mt][r]);
       }
-    }
+  } else {
+    const float* __restrict__ scale_a = p.scale_a;
+    const float sb = p.scale_b[n];
+    const float bias = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
+    float sa[32];  // all row scales first: the stores below must not sit between dependent loads
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sa[i] = scale_a[min(m0 + (i >> 2) * 16 + kq * 4 + (i & 3), p.M - 1)];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mt * 16 + kq * 4 + r;
+        if (m < p.M) {
+          float v;
+          if constexpr (INT8) {
+            // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+            v = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt])[r] * sa[mt * 4 + r]) * sb;
+          } else {
+            v = acc[mt][r] * sa[mt * 4 + r] * sb;
+          }
+          if (p.bias != nullptr) v += bias;
+          y[(size_t)m * p.N + n] = f32_to_bf16_bits(v);
+        }
+      }
+  }
   dump();
 }
 
 unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 
-template <int WAVES, bool INT8>
+template <int WAVES, int KIND>
 int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   constexpr int BN = WAVES * 16;
-  dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + 127) / 128), (unsigned)split), block(64 * WAVES);
-  constexpr size_t smem = (size_t)kStages * kABuf + (size_t)WAVES * kWStages * 2048;
+  const unsigned gy = (KIND == RB8_MX) ? (unsigned)(p.slabs * (p.offs != nullptr ? p.E : 1)) : (unsigned)((p.M + 127) / 128);
+  dim3 grid((unsigned)((p.N + BN - 1) / BN), gy, (unsigned)split), block(64 * WAVES);
+  constexpr int kWStages = w_stages(WAVES, KIND);
+  constexpr size_t smem = (size_t)kStages * kABuf + (size_t)WAVES * kWStages * 2048 +
+                          ((KIND == RB8_MX) ? (size_t)(kStages + kWStages) * WAVES * 256 : 0);
+  static_assert(smem <= 160 * 1024, "rb8_kernel: LDS");
   if (split > 1) {
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN <= (int64_t)kSplitMaxTiles * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     if (int rc = splitk_workspace(&p.ws, &p.tickets)) return rc;
   }
   p.trace = g_fp8_rb_trace;
-  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, INT8, true> : rb8_kernel<WAVES, INT8, false>;
+  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, true> : rb8_kernel<WAVES, KIND, false>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[p.trace != nullptr]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -227,10 +283,12 @@ bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
 
 namespace {
 
-template <bool INT8>
+template <int KIND>
 int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M,
             int64_t N, int64_t K, hipStream_t stream) {
-  Rb8Args p{a, b, scale_a, scale_b, bias, y, (int)M, (int)N, (int)K, nullptr, nullptr, nullptr};
+  Rb8Args p{};
+  p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.y = y;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
   const int64_t slabs = (M + 127) / 128, ksteps = K >> 7;
   // 128-column tiles while they give ~half a chip of workgroups before splitting, else 64-column tiles; K cut into at most
   // 16 parts of >= 4 steps so that the grid approaches one workgroup per CU
@@ -241,19 +299,34 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   const int64_t fit = (int64_t)kSplitMaxTiles * 128 / (base * bn);
   const int64_t target = (g_fp8_rb_force == 3) ? 512 : 256;
   const int split = (int)std::max<int64_t>(1, std::min<int64_t>({target / base, fit, 16, ksteps / 4}));
-  return narrow ? launch_rb8<4, INT8>(p, split, stream) : launch_rb8<8, INT8>(p, split, stream);
+  return narrow ? launch_rb8<4, KIND>(p, split, stream) : launch_rb8<8, KIND>(p, split, stream);
 }
 
 }  // namespace
 
 int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                    int64_t M, int64_t N, int64_t K, hipStream_t stream) {
-  return rb8_run<false>(a, b, scale_a, scale_b, bias, y, M, N, K, stream);
+  return rb8_run<RB8_FP8>(a, b, scale_a, scale_b, bias, y, M, N, K, stream);
 }
 
 int int8_scaled_rb(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                    int64_t M, int64_t N, int64_t K, hipStream_t stream) {
-  return rb8_run<true>(reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b), scale_a, scale_b, bias, y, M, N, K, stream);
+  return rb8_run<RB8_INT8>(reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b), scale_a, scale_b, bias, y, M, N, K, stream);
+}
+
+// MXFP8 grouped GEMM (aten::_scaled_grouped_mm as called from mxfp8_grouped_mm.py:541, numerics of :959-1023): out rows of
+// group e = dq(a rows) . dq(b[e])^T with the E8M0 block scales as MFMA operands.  Group sizes live on the device:
+// `rows_hint` = rows the largest group is expected to have; the grid provides ceil(rows_hint / 128) slabs per group
+// (callers pass M_total when they cannot bound it: empty slabs exit at once).
+int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b, const uint8_t* b_scale, const int32_t* offs, uint16_t* out,
+                     int64_t M_total, int64_t N, int64_t K, int64_t E, int64_t rows_hint, hipStream_t stream) {
+  Rb8Args p{};
+  p.a = a; p.b = b; p.y = out; p.a_mx = a_scale; p.b_mx = b_scale; p.offs = offs;
+  p.M = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
+  p.slabs = (int)std::max<int64_t>(1, (std::min(rows_hint, M_total) + 127) / 128);
+  // 64-column tiles when 128-column ones would not give every CU a workgroup even if every group had tokens
+  const int64_t groups = (offs != nullptr ? E : 1) * p.slabs;
+  return (((N + 127) / 128) * groups < 400) ? launch_rb8<4, RB8_MX>(p, 1, stream) : launch_rb8<8, RB8_MX>(p, 1, stream);
 }
 
 }  // namespace ao

@@ -16,6 +16,10 @@
 #include <type_traits>
 
 namespace ao {
+// rb8_kernels.hip: LDS-staged weight-streaming form (full-line weight requests)
+int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b, const uint8_t* b_scale, const int32_t* offs, uint16_t* out,
+                     int64_t M_total, int64_t N, int64_t K, int64_t E, int64_t rows_hint, hipStream_t stream);
+int g_mx_variant = 0;  // profiling / A-B tests (ao_gemm8_set_variant 110 / 111): 0 by shape, 1 always the LDS-staged kernel, 2 never
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -420,6 +424,10 @@ extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, con
   Stream8Args p{};
   p.a = a; p.a_scale = a_scale; p.b = b; p.b_scale = b_scale; p.offs = offs; p.out = out;
   p.M_total = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
+  // Kernel choice by the average group size (the sizes themselves live on the device).  Mixtral-8x7B expert shapes, 8 experts,
+  // profiles/bench_8bit_r01_session4.jsonl: 16 rows per expert -- A-stationary 98 / 119 us (w1, w2), LDS-staged 104 / 136;
+  // 128 rows per expert -- A-stationary 381 / 474 us (it re-streams the weights per 64-row pass), LDS-staged 211 / 172.
+  if (g_mx_variant == 1 || (g_mx_variant == 0 && M_total >= 48 * E)) return mxfp8_grouped_rb(a, a_scale, b, b_scale, offs, out, M_total, N, K, E, M_total, (hipStream_t)stream);
   if (offs != nullptr && K % 2048 == 0) {
     // Group sizes live on the device.  Size the m-tiling for twice the AVERAGE group: a larger group
     // takes another pass over its expert's weights (correct, slower), while sizing for the worst

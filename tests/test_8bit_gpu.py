@@ -283,6 +283,43 @@ def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
     assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
 
 
+@pytest.mark.parametrize(
+    "sizes,n,k",
+    [([8, 8, 8, 8], 80, 2048), ([16, 16, 16, 16], 256, 4096), ([40, 0, 5, 27], 80, 512), ([200, 1, 3, 0], 144, 1024), ([0, 0, 130], 4096, 384),
+     ([16, 32, 16, 0, 32, 0, 16, 16], 2048, 2048)],
+)
+def test_mxfp8_grouped_mm_lds_staged_kernel(sizes, n, k):
+    """The LDS-staged weight-streaming form (rb8_kernel<RB8_MX>, forced with variant 110): groups larger than one 128-row
+    slab, empty experts, both tile widths, N not a multiple of the tile; same bits on repeated launches and agreement
+    with the A-stationary / per-tile kernels up to accumulation order."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    E = len(sizes)
+    M = sum(sizes)
+    a = _randn_bf16((M, k), 41 + n)
+    w = _randn_bf16((E, n, k), 42 + k, 0.1)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32)
+    a_d, a_s = ops.mxfp8_quantize(a.to(DEV), "rceil")
+    w_d, w_s = ops.mxfp8_quantize(w.to(DEV), "rceil")
+    try:
+        lib.ao_gemm8_set_variant(110)
+        y = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+        assert torch.equal(ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV)), y)
+        lib.ao_gemm8_set_variant(111)
+        y_other = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+    finally:
+        lib.ao_gemm8_set_variant(0)
+    y_ref, mag = MX.grouped_mm(
+        a_d.view(torch.uint8).cpu().numpy(), a_s.view(torch.uint8).cpu().numpy(),
+        w_d.view(torch.uint8).cpu().numpy(), w_s.view(torch.uint8).cpu().numpy(), offs.numpy(), return_abs=True,
+    )
+    yn = np_from_torch_bf16(y)
+    assert _rel(yn, y_ref) <= 1e-3
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
+    assert _rel(np_from_torch_bf16(y_other), yn) <= 1e-3
+
+
 @pytest.mark.parametrize("m,n,k,bias", [(128, 1024, 8192, False), (128, 7168, 8192, True), (200, 8192, 1024, True), (2048, 1024, 1024, False),
                                         (96, 48, 256, True), (65, 4096, 3584, False), (1000, 208, 384, True)])
 def test_fp8_weight_streaming_mid_m(m, n, k, bias):

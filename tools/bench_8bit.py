@@ -103,6 +103,9 @@ def main():
     if "mx" in which:
         E, rows = 8, 128
         sizes = [32, 0, 32, 16, 16, 0, 32, 0]
+        if args.m != 2048:  # --m R: R rows spread evenly over the 8 experts instead of the default ragged decode batch
+            rows = args.m
+            sizes = [rows // E] * E
         offs = torch.tensor([sum(sizes[: i + 1]) for i in range(E)], dtype=torch.int32, device=dev)
         for name, n, k in (("w1/w3", 14336, 4096), ("w2", 4096, 14336)):
             a = torch.randn(rows, k, device=dev, dtype=torch.bfloat16)
