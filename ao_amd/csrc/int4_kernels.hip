@@ -353,12 +353,12 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 //     queue in the texture path and hold the wave ~120 cycles each; spreading them further or staggering them
 //     between waves measured 7 % slower).
 // ---------------------------------------------------------------------------
-constexpr int kRbABuf = 128 * 256;  // one x stage: 32 KiB
 constexpr int kRbStages = 3;
 
 // ABL (profiling builds only): 1 no 16x16x32 MFMAs, 2 no dequant, 3 no A reads, 4 no DMAs, 5 product + s_memtime stamps of wave 0
 // (16 u64 per workgroup: entry, ring primed, barrier of k-blocks 0..7 passed, loop done, meeting done, exit)
-template <int G, int WAVES, int NT, int ABL = 0>
+// MT = 16-row m-tiles per slab (8, 4, 2, 1): batches below 128 rows stage, read and multiply only the rows they have.
+template <int G, int WAVES, int NT, int MT = 8, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M,
     int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets, unsigned long long* __restrict__ trace) {
@@ -367,16 +367,18 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
   constexpr int WBLK = 1024 + NG * 256;   // one n-tile's share of a ring stage: packed block + NG x 64 scale/zero words
   constexpr int WST = NT * WBLK;
-  constexpr int ADMA = 32 / WAVES;        // x DMAs per wave and stage (4 rows each)
+  constexpr int ADMA = 4 * MT / WAVES;    // x DMAs per wave and stage (4 rows each)
+  static_assert(ADMA >= 1, "every wave issues the same number of DMAs per stage");
+  constexpr int ABUF = MT * 4096;         // one x stage: 16 MT rows x 256 B
   constexpr int LPS = ADMA + NT * (1 + NG);  // DMAs per wave and stage
-  constexpr int SLOTS = 16 * NT;          // MFMA pairs per k-block
+  constexpr int SLOTS = 16 * NT;          // schedule slots per k-block (MT / 4 MFMAs each)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][128 rows][256 B] x | [WAVES][3][WST]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, grp = lane >> 4;
-  const int m0 = blockIdx.y * 128;
+  const int m0 = blockIdx.y * (16 * MT);
   const int ntiles = N >> 4;
   const int kblocks = K >> 7;
   const int tile0 = blockIdx.x * (WAVES * NT) + wave * NT;  // this wave's first n-tile
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     aoff[i] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)K * 2u + (((lane & 15) ^ (row & 15)) << 4);
   }
   const uint32_t a_lds = lds_offset(smem);
-  const uint32_t w_lds = a_lds + kRbStages * kRbABuf + wave * (kRbStages * WST);
+  const uint32_t w_lds = a_lds + kRbStages * ABUF + wave * (kRbStages * WST);
   // One DMA of the stage's LPS (compile-time index): the x rows first, then per n-tile the packed block and its
   // scale/zero words.  kb clamped: the fill past the end re-reads the last block (unused)
   auto issue_one = [&](auto idx_c, int stage, int kb) {
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     if (ABL == 4) return;
     const int k = kb0 + min(kb, nkb - 1);
     if constexpr (idx < ADMA) {
-      dma_b128_s(x + (size_t)k * 128, aoff[idx], a_lds + stage * kRbABuf + (ADMA * wave + idx) * 1024);
+      dma_b128_s(x + (size_t)k * 128, aoff[idx], a_lds + stage * ABUF + (ADMA * wave + idx) * 1024);
     } else {
       constexpr int t = (idx - ADMA) / (1 + NG), part = (idx - ADMA) % (1 + NG);
       const int tile = min(tile0 + t, ntiles - 1);  // tiles past N alias the last one; their columns are never stored
@@ -419,9 +421,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     (std::make_integer_sequence<int, LPS>{});
   };
 
-  f32x4 acc[8 * NT];  // [n-tile][m-tile]
+  f32x4 acc[MT * NT];  // [n-tile][m-tile]
 #pragma unroll
-  for (int i = 0; i < 8 * NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT * NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // lane (row r = nl, group g = 2a + t): A operand of phase p = chunk 2p ^ (8a | t) of row r, at position chunk ^ r
   const int ga = grp >> 1, gt = grp & 1;
@@ -432,8 +434,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   const int zg0 = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga, zg1 = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga + 1;
 
   auto kblock = [&](int stage, int refill, int kb) {
-    const char* A = smem + stage * kRbABuf;
-    const char* Wst = smem + kRbStages * kRbABuf + (wave * kRbStages + stage) * WST;
+    const char* A = smem + stage * ABUF;
+    const char* Wst = smem + kRbStages * ABUF + (wave * kRbStages + stage) * WST;
     uint32_t word[NT][2][2];  // [tile][e][which packed lane]
     float sc[NT][2], zp[NT][2];
 #pragma unroll
@@ -446,10 +448,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
       sc[t][0] = bf16_lo_to_f32(z0); zp[t][0] = bf16_hi_to_f32(z0);
       sc[t][1] = bf16_lo_to_f32(z1); zp[t][1] = bf16_hi_to_f32(z1);
     }
-    auto read_a = [&](u32x4 (&a)[8], int p) {
+    auto read_a = [&](u32x4 (&a)[MT], int p) {
       const char* ap = A + (pbase ^ (p << 5));
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         if (ABL == 3) { a[mt] = u32x4{(uint32_t)pbase, (uint32_t)mt, (uint32_t)p, word[0][0][0]}; continue; }
         a[mt] = *reinterpret_cast<const u32x4*>(ap + mt * 4096);
       }
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
       dequant_stage<decltype(st_c)::value>(d, word[t][e][which], sc[t][e], -8.0f * sc[t][e], zp[t][e], ident);
     };
     DequantPipe dq[NT][2];
-    u32x4 a[8], an[8];
+    u32x4 a[MT], an[MT];
     u32x4 bv[NT][2];  // [tile][h] B operands of the current e
     auto take_b = [&] {
 #pragma unroll
@@ -497,11 +499,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
                 stage_of(std::integral_constant<int, q % 4>{}, dq[w / 2][w % 2], w / 2, 1, w % 2);
               }
 #pragma unroll
-              for (int u = 0; u < 2; ++u) {
-                const int mt = (c % 4) * 2 + u;
-                if (ABL == 1) { acc[t * 8 + mt].x += bits_to_f32(a[mt].x ^ bv[t][h].x ^ a[mt].y ^ a[mt].z ^ a[mt].w ^ bv[t][h].y ^ bv[t][h].z ^ bv[t][h].w); continue; }
-                acc[t * 8 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
-                                                                         __builtin_bit_cast(bf16x8, bv[t][h]), acc[t * 8 + mt], 0, 0, 0);
+              for (int mt = (c % 4) * MT / 4; mt < (c % 4 + 1) * MT / 4; ++mt) {  // this slot's share of the tile's MT MFMAs
+                if (ABL == 1) { acc[t * MT + mt].x += bits_to_f32(a[mt].x ^ bv[t][h].x ^ a[mt].y ^ a[mt].z ^ a[mt].w ^ bv[t][h].y ^ bv[t][h].z ^ bv[t][h].w); continue; }
+                acc[t * MT + mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
+                                                                          __builtin_bit_cast(bf16x8, bv[t][h]), acc[t * MT + mt], 0, 0, 0);
               }
             }()),
             ...);
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
          if constexpr (p == 1) take_b();
          if constexpr (p < 3) {
 #pragma unroll
-           for (int mt = 0; mt < 8; ++mt) a[mt] = an[mt];
+           for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
          }
        }()),
        ...);
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     }
   };
 
-  if (S > 1 && !split_k_meet<8 * NT, 64 * WAVES>(acc, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
+  if (S > 1 && !split_k_meet<MT * NT, 64 * WAVES>(acc, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
     dump();
     return;
   }
@@ -558,11 +559,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     if (tile0 + t >= ntiles) continue;
     const int nn = (tile0 + t) * 16 + nl;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + mt * 16 + grp * 4 + r;
-        if (m < M) y[(size_t)m * N + nn] = f32_to_bf16_bits(acc[t * 8 + mt][r]);
+        if (m < M) y[(size_t)m * N + nn] = f32_to_bf16_bits(acc[t * MT + mt][r]);
       }
   }
   dump();
@@ -570,22 +571,23 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
 
 unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
 
-template <int G, int WAVES, int NT, int ABL = 0>
+template <int G, int WAVES, int NT, int MT = 8, int ABL = 0>
 int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
                  hipStream_t stream) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
   constexpr int BN = WAVES * NT * 16;
-  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + 127) / 128), (unsigned)split), block(64 * WAVES);
-  constexpr size_t smem = (size_t)kRbStages * kRbABuf + (size_t)WAVES * kRbStages * NT * (1024 + NG * 256);
+  constexpr int BM = 16 * MT;
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)split), block(64 * WAVES);
+  constexpr size_t smem = (size_t)kRbStages * MT * 4096 + (size_t)WAVES * kRbStages * NT * (1024 + NG * 256);
   static_assert(smem <= 160 * 1024, "int4_mm_rb_kernel: LDS");
   float* ws = nullptr;
   unsigned* tickets = nullptr;
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split * (BN / 128.0) <= kSplitMaxTiles, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
+    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     if (int rc = splitk_workspace(&ws, &tickets)) return rc;
   }
-  auto kern = int4_mm_rb_kernel<G, WAVES, NT, ABL>;
+  auto kern = int4_mm_rb_kernel<G, WAVES, NT, MT, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -797,33 +799,56 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   if (M == 1 && g_tune_mode == 95) return launch_mm<G, 1, 6>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
-  if (M <= 16 || g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
-  // 16 < M: int4_mm_rb_kernel.  128-column tiles (8 waves) when that still gives ~a workgroup per CU; otherwise
-  // 64-column tiles (4 waves) cut along K into at most 8 parts of >= 8 k-blocks so that the grid fills the chip
-  // (measured on the Llama-3-8B projections at M = 128: o_proj 39.8 -> 14.6 us, down_proj 129 -> 29.6 us).
-  // Modes 600 + 10 a + S: tuning / profiling (wpb 8 or 4 = waves per workgroup, S parts, a = ablation build).
-  const int64_t slabs = (M + 127) / 128, kblocks = K >> 7;
-  int bn = 128, split = 1;
-  if (((N + 127) / 128) * slabs < 190) {
-    bn = 64;
-    const int64_t base = ((N + 63) / 64) * slabs;
-    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)kSplitMaxTiles / base, 8, kblocks / 8}));
-  }
+  // 4 < M <= 16: the per-tile kernel re-reads x for every 16 output columns (4 KiB of x per 1 KiB of weights at 16 rows): fine
+  // for the narrow projections, 1.5x the M = 1 time on the wide ones -- those (>= 1024 n-tiles) take the batched kernel with
+  // 16-row slabs, where 4 n-tiles share one staged x tile (gate_up_proj at M = 16: 32 -> 21 us)
+  if ((M <= 16 && g_tune_mode < 600 && (N >> 4) < 1024) || g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+  // 4 < M: int4_mm_rb_kernel on slabs of 16 / 32 / 64 / 128 rows (MT m-tiles: only the rows that exist are staged, read and
+  // multiplied).  128-column tiles (8 waves) when that still gives ~a workgroup per CU; otherwise 64-column tiles (4 waves) cut
+  // along K into at most 8 parts of >= 8 k-blocks so that the grid fills the chip (Llama-3-8B projections at M = 128: o_proj
+  // 39.8 -> 14.6 us, down_proj 129 -> 29.6 us).  Modes 600 + 10 a + S (128-row slabs; wpb 8 / 4 waves, S parts, a = ablation /
+  // trace build) and 700 + 10 log2(MT) + S: tuning / profiling.
+  const int64_t kblocks = K >> 7;
+  int mt = (M <= 16) ? 1 : (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
+  int forced_split = 0, waves = 0;
   if (g_tune_mode >= 600 && g_tune_mode < 700) {
     const int abl = (g_tune_mode - 600) / 10;
-    bn = (g_tune_wpb == 4) ? 64 : 128;
-    const int64_t base = ((N + bn - 1) / bn) * slabs;
-    split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode % 10), kblocks, kSplitMaxTiles / std::max<int64_t>(base, 1)}));
+    mt = 8;
+    waves = (g_tune_wpb == 4) ? 4 : 8;
+    forced_split = std::max(1, g_tune_mode % 10);
     if constexpr (G == 128) {
-      if (abl == 1) return launch_mm_rb<G, 8, 1, 1>(x, qdata, sz, y, M, N, K, split, stream);
-      if (abl == 2) return launch_mm_rb<G, 8, 1, 2>(x, qdata, sz, y, M, N, K, split, stream);
-      if (abl == 3) return launch_mm_rb<G, 8, 1, 3>(x, qdata, sz, y, M, N, K, split, stream);
-      if (abl == 4) return launch_mm_rb<G, 8, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
-      if (abl == 5) return launch_mm_rb<G, 8, 1, 5>(x, qdata, sz, y, M, N, K, split, stream);
-      if (abl == 6) return launch_mm_rb<G, 4, 2>(x, qdata, sz, y, M, N, K, split, stream);
+      const int64_t base = ((N + 127) / 128) * ((M + 127) / 128);
+      const int sp = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)forced_split, kblocks, kSplitMaxTiles / std::max<int64_t>(base, 1)}));
+      if (abl == 1) return launch_mm_rb<G, 8, 1, 8, 1>(x, qdata, sz, y, M, N, K, sp, stream);
+      if (abl == 2) return launch_mm_rb<G, 8, 1, 8, 2>(x, qdata, sz, y, M, N, K, sp, stream);
+      if (abl == 3) return launch_mm_rb<G, 8, 1, 8, 3>(x, qdata, sz, y, M, N, K, sp, stream);
+      if (abl == 4) return launch_mm_rb<G, 8, 1, 8, 4>(x, qdata, sz, y, M, N, K, sp, stream);
+      if (abl == 5) return launch_mm_rb<G, 8, 1, 8, 5>(x, qdata, sz, y, M, N, K, sp, stream);
+      if (abl == 6) return launch_mm_rb<G, 4, 2>(x, qdata, sz, y, M, N, K, sp, stream);
     }
+  } else if (g_tune_mode >= 700 && g_tune_mode < 800) {
+    mt = 1 << std::min(3, (g_tune_mode - 700) / 10);
+    waves = (g_tune_wpb == 8 && mt >= 2) ? 8 : 4;
+    forced_split = std::max(1, g_tune_mode % 10);
   }
-  return bn == 128 ? launch_mm_rb<G, 8, 1>(x, qdata, sz, y, M, N, K, split, stream) : launch_mm_rb<G, 4, 1>(x, qdata, sz, y, M, N, K, split, stream);
+  const int64_t slabs = (M + 16 * mt - 1) / (16 * mt);
+  if (waves == 0) waves = (mt >= 2 && ((N + 127) / 128) * slabs >= 190) ? 8 : 4;
+  const int bn = waves * 16;
+  const int64_t base = ((N + bn - 1) / bn) * slabs;
+  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * 16 * mt);
+  int split = 1;
+  if (forced_split > 0) split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)forced_split, kblocks, fit}));
+  // (16-row slabs are light -- 27 KiB of LDS, 4 waves -- so several workgroups share a CU: aim for ~1500 of them)
+  else if (waves == 4) split = (int)std::max<int64_t>(1, std::min<int64_t>({(mt == 1 ? 1536 : 256) / base, fit, 8, kblocks / 8}));
+  if (waves == 8) {
+    if (mt == 8) return launch_mm_rb<G, 8, 1, 8>(x, qdata, sz, y, M, N, K, split, stream);
+    if (mt == 4) return launch_mm_rb<G, 8, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
+    return launch_mm_rb<G, 8, 1, 2>(x, qdata, sz, y, M, N, K, split, stream);
+  }
+  if (mt == 8) return launch_mm_rb<G, 4, 1, 8>(x, qdata, sz, y, M, N, K, split, stream);
+  if (mt == 4) return launch_mm_rb<G, 4, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
+  if (mt == 2) return launch_mm_rb<G, 4, 1, 2>(x, qdata, sz, y, M, N, K, split, stream);
+  return launch_mm_rb<G, 4, 1, 1>(x, qdata, sz, y, M, N, K, split, stream);
 }
 
 int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
@@ -846,7 +871,7 @@ using namespace ao;
 
 extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size) {
   (void)group_size;
-  if (M > 16) return "int4_mm_rb_kernel";
+  if (M > 16 || (M > 4 && (N >> 4) >= 1024)) return "int4_mm_rb_kernel";
   return "int4_mm_kernel";
 }
 

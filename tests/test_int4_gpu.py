@@ -189,6 +189,23 @@ def test_mm_register_b_kernel(m, n, k, g, wpb, mode):
     assert np.mean(y == y_ref) > 0.97
 
 
+# slab heights below 128 rows (MT = 1, 2, 4 m-tiles): forced through tuning modes 700 + 10 log2(MT) + parts, and by default for 16 < M <= 64
+@pytest.mark.parametrize("wpb,mode", [(4, 701), (4, 704), (4, 711), (8, 712), (4, 722), (8, 721)])
+@pytest.mark.parametrize("m,n,k,g", [(5, 64, 1024, 128), (16, 4096, 2048, 128), (17, 208, 2048, 64), (40, 6144, 512, 32), (64, 48, 2560, 256), (100, 256, 1024, 128)])
+def test_mm_register_b_short_slabs(m, n, k, g, wpb, mode):
+    from ao_amd._lib import lib as _load
+
+    lib = _load()
+    lib.ao_int4_set_tuning(wpb, mode)
+    try:
+        y, y_ref = _mm_case(m, n, k, g, 5 * m + n + k + g)
+    finally:
+        lib.ao_int4_set_tuning(0, 0)
+    assert _rel(y, y_ref) <= 1e-3
+    assert np.all(np.abs(y - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + 1e-3 * np.abs(y_ref).max())
+    assert np.mean(y == y_ref) > 0.97
+
+
 def test_mm_tiled_split_k_is_deterministic_and_reusable():
     """Narrow N at bs = 128 cuts K into parts that meet through a workspace + ticket: the sum is taken in
     part order, so repeated launches (which also rotate workspace slots and reuse tickets) agree bit for bit."""
