@@ -790,19 +790,25 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
 template <int G>
 int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
                 int64_t N, int64_t K, hipStream_t stream) {
-  // M <= 16: one workgroup per 16-wide n-tile, waves split K (int4_mm_kernel).  M == 1 uses the single-row build: in
-  // the hipGraph bench it beat both purpose-built decode kernels this round tried (a persistent balanced streaming
-  // kernel with hand-counted LDS-DMA rings and a per-tile kernel with workgroup-shared x): 868 vs 732 tok/s.
-  // Modes 95-98: A/B builds for profiling (ring depth 6 / 8, the 4-row build at M = 1).
+  // M <= 16: one workgroup per 16-wide n-tile, waves split K (int4_mm_kernel, built for 1, 4 or 16 rows).  In the hipGraph
+  // bench the single-row build beat both purpose-built decode kernels this round tried (a persistent balanced streaming kernel
+  // with hand-counted LDS-DMA rings and a per-tile kernel with workgroup-shared x): 868 vs 732 tok/s.
+  // At 4 < M <= 16 the per-tile kernel re-reads x for every 16 output columns (4 KiB of x per 1 KiB of weights at 16 rows): fine
+  // for the narrow projections, 1.5x the M = 1 time on wide ones -- weights of >= 1024 n-tiles (merged gate_up_proj, lm_head) take
+  // the batched kernel below with 16-row slabs, where 4 n-tiles share one staged x tile (gate_up_proj at M = 16: 32 -> 21.8 us).
+  // (At M <= 4 the same switch measured 16.2 vs 17.4 us on one box and 19.7 vs 14.2 us on another: not taken.)
+  // Modes 94-99: A/B builds for profiling (94 never / 93 always the batched kernel on wide weights at M <= 16, 95 / 96 ring depth
+  // 6 / 8, 98 the 4-row build at M = 1, 99 the 16-row build at any M).
+  const bool wide = (N >> 4) >= 1024 && g_tune_mode != 94;
   if (M == 1 && g_tune_mode == 98) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 96) return launch_mm<G, 1, 8>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 95) return launch_mm<G, 1, 6>(x, qdata, sz, y, M, N, K, stream);
-  if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
-  if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
-  // 4 < M <= 16: the per-tile kernel re-reads x for every 16 output columns (4 KiB of x per 1 KiB of weights at 16 rows): fine
-  // for the narrow projections, 1.5x the M = 1 time on the wide ones -- those (>= 1024 n-tiles) take the batched kernel with
-  // 16-row slabs, where 4 n-tiles share one staged x tile (gate_up_proj at M = 16: 32 -> 21 us)
-  if ((M <= 16 && g_tune_mode < 600 && (N >> 4) < 1024) || g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+  if (g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+  if (M <= 16 && g_tune_mode < 600 && !(wide && (M > 4 || g_tune_mode == 93))) {
+    if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
+    if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
+    return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+  }
   // 4 < M: int4_mm_rb_kernel on slabs of 16 / 32 / 64 / 128 rows (MT m-tiles: only the rows that exist are staged, read and
   // multiplied).  128-column tiles (8 waves) when that still gives ~a workgroup per CU; otherwise 64-column tiles (4 waves) cut
   // along K into at most 8 parts of >= 8 k-blocks so that the grid fills the chip (Llama-3-8B projections at M = 128: o_proj
@@ -838,8 +844,8 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * 16 * mt);
   int split = 1;
   if (forced_split > 0) split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)forced_split, kblocks, fit}));
-  // (16-row slabs are light -- 27 KiB of LDS, 4 waves -- so several workgroups share a CU: aim for ~1500 of them)
-  else if (waves == 4) split = (int)std::max<int64_t>(1, std::min<int64_t>({(mt == 1 ? 1536 : 256) / base, fit, 8, kblocks / 8}));
+  // (16-row slabs are light -- 27 KiB of LDS, 4 waves -- so several workgroups share a CU: aim for ~1000 of them)
+  else if (waves == 4) split = (int)std::max<int64_t>(1, std::min<int64_t>({(mt == 1 ? 1024 : 256) / base, fit, 8, kblocks / 8}));
   if (waves == 8) {
     if (mt == 8) return launch_mm_rb<G, 8, 1, 8>(x, qdata, sz, y, M, N, K, split, stream);
     if (mt == 4) return launch_mm_rb<G, 8, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
