@@ -931,14 +931,25 @@ extern "C" int ao_int4_weight_int4pack_mm(const uint16_t* x, const int32_t* qdat
   if (M == 0) return AO_OK;
   AO_REQUIRE_PTR(x);
   AO_REQUIRE_PTR(y);
-  AO_REQUIRE((M + 15) / 16 <= 65535, "ao_int4_weight_int4pack_mm: M=%lld too large for one launch", (long long)M);
   hipStream_t s = (hipStream_t)stream;
-  switch (group_size) {
-    case 32: return dispatch_mm<32>(x, qdata, scale_and_zero, y, M, N, K, s);
-    case 64: return dispatch_mm<64>(x, qdata, scale_and_zero, y, M, N, K, s);
-    case 128: return dispatch_mm<128>(x, qdata, scale_and_zero, y, M, N, K, s);
-    default: return dispatch_mm<256>(x, qdata, scale_and_zero, y, M, N, K, s);
+  // The batched kernel addresses x rows with 32-bit byte offsets and grid.y is 16-bit: very tall activations go in row
+  // chunks (a multiple of 128 rows, < 4 GiB of x and <= 65535 slabs each), one launch per chunk.
+  const int64_t by_bytes = ((1ll << 32) - 1) / (2 * K) / 128 * 128;
+  const int64_t chunk = std::max<int64_t>(128, std::min<int64_t>(by_bytes, 65535ll * 16));
+  for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+    const int64_t rows = std::min(chunk, M - m0);
+    const uint16_t* xc = x + m0 * K;
+    uint16_t* yc = y + m0 * N;
+    int rc;
+    switch (group_size) {
+      case 32: rc = dispatch_mm<32>(xc, qdata, scale_and_zero, yc, rows, N, K, s); break;
+      case 64: rc = dispatch_mm<64>(xc, qdata, scale_and_zero, yc, rows, N, K, s); break;
+      case 128: rc = dispatch_mm<128>(xc, qdata, scale_and_zero, yc, rows, N, K, s); break;
+      default: rc = dispatch_mm<256>(xc, qdata, scale_and_zero, yc, rows, N, K, s); break;
+    }
+    if (rc != AO_OK) return rc;
   }
+  return AO_OK;
 }
 
 extern "C" int ao_int4_dequantize(const int32_t* qdata, const uint16_t* scale_and_zero,

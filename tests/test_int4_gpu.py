@@ -206,6 +206,21 @@ def test_mm_register_b_short_slabs(m, n, k, g, wpb, mode):
     assert np.mean(y == y_ref) > 0.97
 
 
+def test_mm_very_tall_activation_goes_in_row_chunks():
+    """More than 4 GiB of x (32-bit row offsets inside the batched kernel): the entry point launches row chunks;
+    the result equals separate calls on the two halves."""
+    n, k, g = 16, 128, 128
+    m = (1 << 32) // (2 * k) + 1000  # 16.8 M rows, 4.3 GB of bf16 activations
+    w = _rand_weight(n, k, 9).to(DEV)
+    qdata, sz = ops.int4_quantize_tinygemm(w, g)
+    x = torch.empty(m, k, device=DEV, dtype=torch.bfloat16).normal_()
+    y = ops.weight_int4pack_mm(x, qdata, g, sz)
+    half = m // 2 // 128 * 128
+    assert torch.equal(y[:half], ops.weight_int4pack_mm(x[:half], qdata, g, sz))
+    assert torch.equal(y[half:], ops.weight_int4pack_mm(x[half:], qdata, g, sz))
+    assert torch.equal(y[-3:], ops.weight_int4pack_mm(x[-3:], qdata, g, sz))  # last rows of the last chunk vs the small-M kernel
+
+
 def test_mm_tiled_split_k_is_deterministic_and_reusable():
     """Narrow N at bs = 128 cuts K into parts that meet through a workspace + ticket: the sum is taken in
     part order, so repeated launches (which also rotate workspace slots and reuse tickets) agree bit for bit."""
