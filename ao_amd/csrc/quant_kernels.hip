@@ -11,6 +11,7 @@
 //          quant_primitives.py:2192-2212, 2271-2287
 //   mx   : prototype/mx_formats/mx_tensor.py:111-225 (RCEIL), :228-409 (to_mx)
 #include "common.h"
+#include "quant_math.h"
 
 namespace ao {
 namespace {
@@ -29,19 +30,6 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return v;
 }
 
-// NaN-propagating max like torch.amax: fmaxf drops NaN, so track it separately
-__device__ __forceinline__ float amax8(const u32x4& v, bool& has_nan) {
-  float m = 0.f;
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = fabsf(bf16_lo_to_f32(w[i])), b = fabsf(bf16_hi_to_f32(w[i]));
-    has_nan |= (a != a) | (b != b);
-    m = fmaxf(m, fmaxf(a, b));
-  }
-  return m;
-}
-
 // ---- int8 per-row symmetric ----------------------------------------------------
 // scale = f32(max(bf16(amax / 127.5), bf16(f32_eps)));  q = clamp(rint(x * (1/scale)), -128, 127)
 __global__ __launch_bounds__(kThreads) void int8_quant_rowwise_kernel(const uint16_t* __restrict__ x,
@@ -55,40 +43,15 @@ __global__ __launch_bounds__(kThreads) void int8_quant_rowwise_kernel(const uint
   bool has_nan = false;
   for (int64_t i = threadIdx.x; i < nvec; i += kThreads) m = fmaxf(m, amax8(xr[i], has_nan));
   m = block_max(has_nan ? INFINITY : m, red);  // (NaN rows are outside the contract)
-  float s = round_bf16(m / 127.5f);
-  s = fmaxf(s, 1.1920928955078125e-07f);  // fp32 eps, exactly representable in bf16
+  const float s = int8_row_scale(m);
   const float inv = 1.0f / s;
   if (threadIdx.x == 0) scale[row] = s;
   u32x2* qr = reinterpret_cast<u32x2*>(q + row * K);
-  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) {
-    const u32x4 v = xr[i];
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t out[2] = {0u, 0u};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a = fminf(fmaxf(rintf(bf16_lo_to_f32(w[j]) * inv), -128.f), 127.f);
-      const float b = fminf(fmaxf(rintf(bf16_hi_to_f32(w[j]) * inv), -128.f), 127.f);
-      const uint32_t pa = (uint32_t)(int)a & 0xffu, pb = (uint32_t)(int)b & 0xffu;
-      out[j >> 1] |= (pa | (pb << 8)) << ((j & 1) * 16);
-    }
-    qr[i] = u32x2{out[0], out[1]};
-  }
+  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) qr[i] = int8_quant8(xr[i], inv);
 }
 
 // ---- fp8 e4m3fn per-row ----------------------------------------------------------
 // scale = f32(bf16(amax / 448));  q = e4m3_rne(clamp(f32(x) / scale, -448, 448))
-__device__ __forceinline__ uint32_t cvt4_e4m3(float a, float b, float c, float d) {
-  uint32_t r = 0;
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-  return r;
-}
-
-__device__ __forceinline__ float clamp448(float v) {
-  // torch.clamp propagates NaN; fminf/fmaxf would not
-  return (v != v) ? v : fminf(fmaxf(v, -448.f), 448.f);
-}
-
 __global__ __launch_bounds__(kThreads) void fp8_quant_rowwise_kernel(const uint16_t* __restrict__ x,
                                                                      uint8_t* __restrict__ q,
                                                                      float* __restrict__ scale, int64_t K) {
@@ -100,17 +63,10 @@ __global__ __launch_bounds__(kThreads) void fp8_quant_rowwise_kernel(const uint1
   bool has_nan = false;
   for (int64_t i = threadIdx.x; i < nvec; i += kThreads) m = fmaxf(m, amax8(xr[i], has_nan));
   m = block_max(has_nan ? INFINITY : m, red);
-  const float s = round_bf16(m / 448.0f);
+  const float s = fp8_row_scale(m);
   if (threadIdx.x == 0) scale[row] = s;
   u32x2* qr = reinterpret_cast<u32x2*>(q + row * K);
-  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) {
-    const u32x4 v = xr[i];
-    float f[8] = {bf16_lo_to_f32(v.x), bf16_hi_to_f32(v.x), bf16_lo_to_f32(v.y), bf16_hi_to_f32(v.y),
-                  bf16_lo_to_f32(v.z), bf16_hi_to_f32(v.z), bf16_lo_to_f32(v.w), bf16_hi_to_f32(v.w)};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = clamp448(f[j] / s);  // IEEE division, like torch
-    qr[i] = u32x2{cvt4_e4m3(f[0], f[1], f[2], f[3]), cvt4_e4m3(f[4], f[5], f[6], f[7])};
-  }
+  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) qr[i] = fp8_quant8(xr[i], s);
 }
 
 // ---- MXFP8: one E8M0 scale per 32 elements along the row -------------------------

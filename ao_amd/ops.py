@@ -22,6 +22,10 @@ __all__ = [
     "fp8_scaled_mm",
     "mxfp8_quantize",
     "mxfp8_grouped_mm",
+    "dynamic_linear_fits",
+    "dynamic_linear_preferred",
+    "int8_dynamic_linear",
+    "fp8_dynamic_linear",
     "fused_pad_token_groups",
     "fused_unpad_token_groups",
 ]
@@ -430,3 +434,53 @@ def fused_unpad_token_groups(inputs, offsets, padded_group_start_offsets, num_to
             )
         )
     return out
+
+
+def dynamic_linear_fits(m: int, n: int, k: int) -> bool:
+    """Whether the fused cast + matmul kernels take this shape (decode sizes: the cast activation must fit LDS)."""
+    return bool(_lib.lib().ao_dyn_linear_fits(m, n, k))
+
+
+def dynamic_linear_preferred(m: int, n: int, k: int) -> bool:
+    """Whether the fused kernel beats cast + matmul: every workgroup (one per 16 output columns) casts the whole activation
+    itself, so the redundant work must stay small.  Measured on Llama-3-8B int8 (us, cast + matmul vs fused): M = 1 qkv 10.3 vs
+    8.2, o 8.9 vs 6.9, down 21.5 vs 17.4, gate_up 26.5 vs 26.5; M = 2 qkv 10.6 vs 8.9 but gate_up 27.0 vs 28.5; M = 4 gate_up
+    28.5 vs 35.1."""
+    return dynamic_linear_fits(m, n, k) and m * (n // 16) <= 1024
+
+
+def _dynamic_linear(name, entry, x, wq, w_scale, bias, wdtype):
+    dev = _require_gpu(name, x, wq, w_scale, bias)
+    if x.dim() != 2 or x.dtype != torch.bfloat16:
+        raise RuntimeError(f"{name}: x must be a 2-D bfloat16 tensor, got {tuple(x.shape)} {x.dtype}")
+    if wq.dim() != 2 or wq.dtype != wdtype:
+        raise RuntimeError(f"{name}: weight must be a 2-D {wdtype} tensor [N, K]")
+    x = x.contiguous()
+    wq = wq.contiguous()
+    m, k = x.shape
+    n, k2 = wq.shape
+    if k != k2:
+        raise RuntimeError(f"{name}: K mismatch {k} vs {k2}")
+    w_scale = w_scale.reshape(-1).to(torch.float32).contiguous()
+    if w_scale.numel() != n:
+        raise RuntimeError(f"{name}: weight scale must be per-row ([N])")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+        if bias.numel() != n:
+            raise RuntimeError(f"{name}: bias must have N elements")
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(entry(_ptr(x), _ptr(wq.view(torch.uint8) if wdtype != torch.int8 else wq), _ptr(w_scale), _ptr(bias), _ptr(y), m, n, k, _stream()))
+    return y
+
+
+def int8_dynamic_linear(x, wq, w_scale, bias=None):
+    """Int8Tensor F.linear with dynamic per-row activation quantisation in ONE launch (int8_tensor.py:176-248, 305-359): same
+    bits as int8_quantize_rowwise + int8_scaled_mm.  Shapes accepted: dynamic_linear_fits(M, N, K)."""
+    return _dynamic_linear("int8_dynamic_linear", _lib.lib().ao_int8_dynamic_linear, x, wq, w_scale, bias, torch.int8)
+
+
+def fp8_dynamic_linear(x, wq, w_scale, bias=None):
+    """Float8Tensor F.linear with dynamic per-row e4m3 activation quantisation in ONE launch (float8_tensor.py:167-253,
+    float8/inference.py:104-123): same bits as fp8_quantize_rowwise + fp8_scaled_mm at these sizes."""
+    return _dynamic_linear("fp8_dynamic_linear", _lib.lib().ao_fp8_dynamic_linear, x, wq, w_scale, bias, torch.float8_e4m3fn)

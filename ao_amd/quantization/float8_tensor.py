@@ -109,8 +109,11 @@ def _(func, types, args, kwargs):
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
     else:
-        xq, xs = ops.fp8_quantize_rowwise(x2)
-        y = ops.fp8_scaled_mm(xq, w.qdata.t(), xs, w.scale.t(), bias)
+        if ops.dynamic_linear_preferred(x2.shape[0], n, x2.shape[1]):  # decode sizes: activation cast fused into the matmul
+            y = ops.fp8_dynamic_linear(x2, w.qdata, w.scale, bias)
+        else:
+            xq, xs = ops.fp8_quantize_rowwise(x2)
+            y = ops.fp8_scaled_mm(xq, w.qdata.t(), xs, w.scale.t(), bias)
         bias = None
     y = y.reshape(*x.shape[:-1], n)
     if bias is not None:

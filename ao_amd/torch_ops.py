@@ -22,6 +22,8 @@ _lib_def.define("weight_int4pack_mm(Tensor x, Tensor qdata, int group_size, Tens
 _lib_def.define("convert_weight_to_int4pack(Tensor w_u8, int inner_k_tiles) -> Tensor")
 _lib_def.define("int8_scaled_mm(Tensor xq, Tensor x_scale, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("fp8_scaled_mm(Tensor a, Tensor b, Tensor scale_a, Tensor scale_b, Tensor? bias) -> Tensor")
+_lib_def.define("int8_dynamic_linear(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
+_lib_def.define("fp8_dynamic_linear(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("mxfp8_quantize(Tensor x, str scaling_mode) -> (Tensor, Tensor)")
 _lib_def.define("mxfp8_grouped_mm(Tensor a, Tensor a_scale, Tensor b, Tensor b_scale, Tensor offs) -> Tensor")
 # same schemas as torchao::fused_pad_token_groups / fused_unpad_token_groups (kernels/mxfp8/quant.py:1244-1246, 1319-1321)
@@ -35,6 +37,8 @@ _lib_impl.impl("weight_int4pack_mm", ops.weight_int4pack_mm)
 _lib_impl.impl("convert_weight_to_int4pack", ops.convert_weight_to_int4pack)
 _lib_impl.impl("int8_scaled_mm", ops.int8_scaled_mm)
 _lib_impl.impl("fp8_scaled_mm", ops.fp8_scaled_mm)
+_lib_impl.impl("int8_dynamic_linear", ops.int8_dynamic_linear)
+_lib_impl.impl("fp8_dynamic_linear", ops.fp8_dynamic_linear)
 _lib_impl.impl("mxfp8_quantize", lambda x, mode: ops.mxfp8_quantize(x, mode))
 _lib_impl.impl("mxfp8_grouped_mm", ops.mxfp8_grouped_mm)
 _lib_impl.impl("fused_pad_token_groups", ops.fused_pad_token_groups)
@@ -60,6 +64,16 @@ def _(xq, x_scale, wq, w_scale, bias):
 @torch.library.register_fake("ao_mi355::fp8_scaled_mm")
 def _(a, b, scale_a, scale_b, bias):
     return a.new_empty((a.shape[0], b.shape[1]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::int8_dynamic_linear")
+def _(x, wq, w_scale, bias):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::fp8_dynamic_linear")
+def _(x, wq, w_scale, bias):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
 
 
 @torch.library.register_fake("ao_mi355::mxfp8_quantize")

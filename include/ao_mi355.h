@@ -216,6 +216,29 @@ int ao_moe_unpad_token_groups(const void* padded, const int32_t* offsets,
                               const int32_t* padded_starts, void* out, int64_t num_tokens,
                               int64_t dim, int elem_bytes, int64_t num_groups, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Dynamic-activation linears with the activation cast fused in (decode sizes)
+ * ------------------------------------------------------------------------- */
+
+/* 1 when the fused entry points below accept the shape: 0 < M <= 16, M * (K + 16) <= 65536 (the cast activation lives in
+ * LDS), N % 16 == 0, K % 128 == 0.  Host-only helper. */
+int ao_dyn_linear_fits(int64_t M, int64_t N, int64_t K);
+
+/* Replaces the Int8Tensor F.linear with dynamic activation quantisation as ONE launch: Int8Tensor.from_hp(x, PerRow)
+ * (int8_tensor.py:176-248) followed by _int_scaled_matmul + weight scale (int8/kernels.py:114-144, int8_tensor.py:305-359).
+ * Same bits as ao_int8_quantize_rowwise + ao_int8_scaled_mm.
+ *   x bf16 [M][K]; wq int8 [N][K]; w_scale fp32 [N]; bias bf16 [N] or NULL; y bf16 [M][N]. */
+int ao_int8_dynamic_linear(const uint16_t* x, const int8_t* wq, const float* w_scale,
+                           const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
+                           void* stream);
+
+/* Same for float8 rowwise: Float8Tensor.from_hp(x, PerRow) (float8_tensor.py:167-253) + aten::_scaled_mm with rowwise scales
+ * (float8/inference.py:104-123).  Same bits as ao_fp8_quantize_rowwise + ao_fp8_scaled_mm at these sizes.
+ *   x bf16 [M][K]; wq e4m3fn [N][K]; w_scale fp32 [N]; bias bf16 [N] or NULL; y bf16 [M][N]. */
+int ao_fp8_dynamic_linear(const uint16_t* x, const uint8_t* wq, const float* w_scale,
+                          const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,42 @@ def test_int8_weight_streaming_small_m(m, n, k, bias):
     assert np.array_equal(np_from_torch_bf16(y), y_ref)
 
 
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+@pytest.mark.parametrize("m,n,k,bias", [(1, 4096, 4096, False), (4, 6144, 4096, True), (15, 256, 4096, True), (3, 48, 14336, False),
+                                        (1, 16, 128, True), (16, 64, 2048, False)])
+def test_fused_dynamic_linear_equals_cast_plus_matmul(kind, m, n, k, bias):
+    """the decode-size linears with the activation cast fused in give the bits of the two-launch path
+    (and therefore the oracle's for int8)."""
+    x = _randn_bf16((m, k), 23 * m + k)
+    x[0, :7] = torch.tensor([0.0, -0.0, 1e-30, 3.0e38, -3.0e38, 448.0, -57344.0]).to(torch.bfloat16)[: min(7, k)]
+    w = _randn_bf16((n, k), 29 * n + k, 0.05)
+    b = _randn_bf16((n,), 5) if bias else None
+    bd = None if b is None else b.to(DEV)
+    assert ops.dynamic_linear_fits(m, n, k)
+    if kind == "int8":
+        wq, ws = ops.int8_quantize_rowwise(w.to(DEV))
+        xq, xs = ops.int8_quantize_rowwise(x.to(DEV))
+        two = ops.int8_scaled_mm(xq, xs, wq, ws, bd)
+        one = ops.int8_dynamic_linear(x.to(DEV), wq, ws, bd)
+        y_ref = I.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+        assert np.array_equal(np_from_torch_bf16(one), y_ref)
+    else:
+        wq, ws = ops.fp8_quantize_rowwise(w.to(DEV))
+        xq, xs = ops.fp8_quantize_rowwise(x.to(DEV))
+        two = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), bd)
+        one = ops.fp8_dynamic_linear(x.to(DEV), wq, ws, bd)
+    assert torch.equal(one, two)
+
+
+def test_fused_dynamic_linear_shape_limits():
+    assert ops.dynamic_linear_fits(16, 64, 2048) and not ops.dynamic_linear_fits(17, 64, 2048)
+    assert not ops.dynamic_linear_fits(8, 64, 14336) and not ops.dynamic_linear_fits(1, 40, 4096) and not ops.dynamic_linear_fits(1, 64, 4000)
+    x = torch.zeros(8, 14336, dtype=torch.bfloat16, device=DEV)
+    wq = torch.zeros(64, 14336, dtype=torch.int8, device=DEV)
+    with pytest.raises(ValueError, match="fused form holds the cast activation in LDS"):
+        ops.int8_dynamic_linear(x, wq, torch.ones(64, device=DEV))
+
+
 def test_int8_extremes_exact():
     """int32 accumulation at full range: K * 127 * 128 stays exact."""
     m, n, k = 33, 64, 8192

@@ -86,8 +86,11 @@ def main():
             t = timeit(lambda: ops.int8_scaled_mm(xq, xs, wq, ws), args.iters)
             t2 = timeit(lambda: ops.int8_scaled_mm(*ops.int8_quantize_rowwise(x), wq, ws), args.iters)
             f = 2.0 * M * n * k
+            extra = {}
+            if ops.dynamic_linear_fits(M, n, k):  # decode sizes: cast fused into the matmul (one launch)
+                extra["us_fused_act_quant"] = timeit(lambda: ops.int8_dynamic_linear(x, wq, ws), args.iters) * 1e6
             rec(kernel="int8_scaled_mm", shape=name, M=M, N=n, K=k, us=t * 1e6, TOPs=f / t / 1e12, frac_mfma=f / t / PEAK_INT8,
-                us_with_act_quant=t2 * 1e6)
+                us_with_act_quant=t2 * 1e6, **extra)
     if "fp8" in which:
         for m in sorted({1, 16, 64, 128, M}):
             for name, n, k in LLAMA70B_TP8:
