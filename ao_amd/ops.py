@@ -39,6 +39,23 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(dev):
+    """Device guard for a launch: a no-op when `dev` is already current (torch.cuda.device() costs ~3 us per call, as much as a
+    small decode kernel)."""
+    return _NO_GUARD if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 def _require_gpu(name, *tensors):
     dev = None
     for t in tensors:
@@ -77,7 +94,7 @@ def convert_weight_to_int4pack(w_u8: torch.Tensor, inner_k_tiles: int) -> torch.
     out = torch.empty(
         (n // 8, k // (inner_k_tiles * 16), 32, inner_k_tiles // 2), dtype=torch.int32, device=dev
     )
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_int4_convert_weight_to_int4pack(
                 _ptr(w_u8), _ptr(out), n, k, inner_k_tiles, _stream()
@@ -94,7 +111,7 @@ def unpack_int4pack(qdata: torch.Tensor, inner_k_tiles: int = 8) -> torch.Tensor
     n = qdata.shape[0] * 8
     k = qdata.shape[1] * inner_k_tiles * 16
     out = torch.empty((n, k // 2), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_int4_unpack_int4pack(_ptr(qdata), _ptr(out), n, k, inner_k_tiles, _stream())
         )
@@ -145,7 +162,7 @@ def weight_int4pack_mm(
     y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
     if m == 0:
         return y
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_int4_weight_int4pack_mm(
                 _ptr(x), _ptr(qdata), _ptr(scale_and_zero), _ptr(y), m, n, k, group_size, _stream()
@@ -160,7 +177,7 @@ def int4_dequantize(qdata: torch.Tensor, scale_and_zero: torch.Tensor, group_siz
     dev = _require_gpu("int4_dequantize", qdata, scale_and_zero)
     n, k = _int4_dims("int4_dequantize", qdata, scale_and_zero, group_size)
     w = torch.empty((n, k), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_int4_dequantize(_ptr(qdata), _ptr(scale_and_zero), _ptr(w), n, k, group_size, _stream())
         )
@@ -179,7 +196,7 @@ def int4_quantize_tinygemm(w: torch.Tensor, group_size: int):
     n, k = w.shape
     qdata = torch.empty((n // 8, k // 128, 32, 4), dtype=torch.int32, device=dev)
     sz = torch.empty((k // max(group_size, 1), n, 2), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_int4_quantize_tinygemm(_ptr(w), _ptr(qdata), _ptr(sz), n, k, group_size, _stream())
         )
@@ -206,7 +223,7 @@ def int8_quantize_rowwise(x: torch.Tensor):
     m, k = x.shape
     q = torch.empty((m, k), dtype=torch.int8, device=dev)
     s = torch.empty((m, 1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().ao_int8_quantize_rowwise(_ptr(x), _ptr(q), _ptr(s), m, k, _stream()))
     return q, s
 
@@ -232,7 +249,7 @@ def int8_scaled_mm(xq, x_scale, wq, w_scale, bias=None):
         if bias.numel() != n:
             raise RuntimeError("int8_scaled_mm: bias must have N elements")
     y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_int8_scaled_mm(
                 _ptr(xq), _ptr(x_scale), _ptr(wq), _ptr(w_scale), _ptr(bias), _ptr(y), m, n, k, _stream()
@@ -258,7 +275,7 @@ def int_mm(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     m, k = a.shape
     n = b_t.shape[0]
     c = torch.empty((m, n), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().ao_int8_int_mm(_ptr(a), _ptr(b_t), _ptr(c), m, n, k, _stream()))
     return c
 
@@ -275,7 +292,7 @@ def fp8_quantize_rowwise(x: torch.Tensor):
     m, k = x.shape
     q = torch.empty((m, k), dtype=torch.uint8, device=dev)
     s = torch.empty((m, 1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().ao_fp8_quantize_rowwise(_ptr(x), _ptr(q), _ptr(s), m, k, _stream()))
     return q.view(torch.float8_e4m3fn), s
 
@@ -311,7 +328,7 @@ def fp8_scaled_mm(a, b, scale_a, scale_b, bias=None):
     if bias is not None:
         bias = bias.to(torch.bfloat16).contiguous()
     y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_fp8_scaled_mm(
                 _ptr(a), _ptr(b_t), _ptr(scale_a), _ptr(scale_b), _ptr(bias), _ptr(y), m, n, k, _stream()
@@ -344,7 +361,7 @@ def mxfp8_quantize(x: torch.Tensor, scaling_mode: str = "rceil"):
     r = x.numel() // c
     q = torch.empty(x.shape, dtype=torch.uint8, device=dev)
     s = torch.empty((*x.shape[:-1], c // 32), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(_lib.lib().ao_mxfp8_quantize_rowwise(_ptr(x), _ptr(q), _ptr(s), r, c, mode, _stream()))
     return q.view(torch.float8_e4m3fn), s.view(torch.float8_e8m0fnu)
 
@@ -367,7 +384,7 @@ def mxfp8_grouped_mm(a, a_scale, b, b_scale, offs):
     if offs.dtype != torch.int32 or offs.numel() != e:
         raise RuntimeError("mxfp8_grouped_mm: offs must be int32 [E]")
     out = torch.zeros((m, n), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_mxfp8_grouped_mm(
                 _ptr(a), _ptr(a_scale), _ptr(b), _ptr(b_scale), _ptr(offs.contiguous()), _ptr(out), m, n, k, e, _stream()
@@ -404,7 +421,7 @@ def fused_pad_token_groups(inputs, offsets, alignment_size=32):
     padded = torch.empty((rows, dim), dtype=inputs.dtype, device=dev)  # the kernel writes every row
     starts = torch.empty(groups, dtype=torch.int32, device=dev)
     ends = torch.empty(groups, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_moe_pad_token_groups(
                 _ptr(inputs), _ptr(offsets), _ptr(padded), _ptr(starts), _ptr(ends), tokens, dim, inputs.element_size(), groups,
@@ -426,7 +443,7 @@ def fused_unpad_token_groups(inputs, offsets, padded_group_start_offsets, num_to
     inputs = inputs.contiguous()
     dim = inputs.shape[1]
     out = torch.empty((num_tokens, dim), dtype=inputs.dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(
             _lib.lib().ao_moe_unpad_token_groups(
                 _ptr(inputs), _ptr(offsets.contiguous()), _ptr(padded_group_start_offsets.contiguous()), _ptr(out), num_tokens, dim,
@@ -469,7 +486,7 @@ def _dynamic_linear(name, entry, x, wq, w_scale, bias, wdtype):
         if bias.numel() != n:
             raise RuntimeError(f"{name}: bias must have N elements")
     y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(entry(_ptr(x), _ptr(wq.view(torch.uint8) if wdtype != torch.int8 else wq), _ptr(w_scale), _ptr(bias), _ptr(y), m, n, k, _stream()))
     return y
 
