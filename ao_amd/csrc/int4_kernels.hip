@@ -60,8 +60,7 @@ __device__ __forceinline__ void dequant_word(uint32_t p, float s, float neg8s, f
 }
 
 // ---------------------------------------------------------------------------
-// The product form of the same exact sequence (DQ = 4; DQ = 0 is the all-VALU form above, kept
-// for A/B profiling).  All VALU instructions cost ~4.4 issue cycles per wave64 on gfx950
+// The product form of the same exact sequence (the all-VALU form above serves ao_int4_dequantize).  All VALU instructions cost ~4.4 issue cycles per wave64 on gfx950
 // (profiles/ubench_valu_r01.txt) and the matrix pipe is idle in a GEMV, so:
 //   * q -> fp32: a byte holding q (0..15) read as OCP e4m3 is q * 2^-9, so
 //     v_cvt_scalef32_pk_f32_fp8 with scale 2^9 converts two nibbles per instruction, exactly;
@@ -71,7 +70,6 @@ __device__ __forceinline__ void dequant_word(uint32_t p, float s, float neg8s, f
 // ---------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int DQ>
 __device__ __forceinline__ s16x4 identity_fragment(int lane) {
   // row (lane & 3) of the 4x4 identity as a 4x4x4 A operand (4 bf16, k = 0..3)
   const int hot = lane & 3;
@@ -83,16 +81,13 @@ __device__ __forceinline__ s16x4 identity_fragment(int lane) {
   return f;
 }
 
-template <int DQ>
 __device__ __forceinline__ f32x4 widen_add(s16x4 ident, uint32_t lo_pair, uint32_t hi_pair, f32x4 c) {
   const u32x2 bb = {lo_pair, hi_pair};
   return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ident, __builtin_bit_cast(s16x4, bb), c, 0, 0, 0);
 }
 
-template <int DQ>
 __device__ __forceinline__ void dequant_word_mfma(uint32_t p, float s, float neg8s, float z, s16x4 ident,
                                                   uint32_t (&out)[4]) {
-  static_assert(DQ == 4, "DQ: 0 (all VALU, dequant_word) or 4 (this)");
   const uint32_t lo = p & 0x0F0F0F0Fu;         // bytes: v0, v4, v1, v5
   const uint32_t hi = (p >> 4) & 0x0F0F0F0Fu;  // bytes: v2, v6, v3, v7
   const f32x2 r0 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, 512.0f, false);  // q0, q4
@@ -103,8 +98,8 @@ __device__ __forceinline__ void dequant_word_mfma(uint32_t p, float s, float neg
   const uint32_t tp0 = pack_bf16x2(t0.x, t1.x), tp1 = pack_bf16x2(t2.x, t3.x);  // t = bf16((q-8)*s): rounding #1
   const uint32_t tp2 = pack_bf16x2(t0.y, t1.y), tp3 = pack_bf16x2(t2.y, t3.y);
   const f32x4 zz = {z, z, z, z};
-  const f32x4 w0 = widen_add<DQ>(ident, tp0, tp1, zz);  // fl32(t + z), lanes' own values
-  const f32x4 w1 = widen_add<DQ>(ident, tp2, tp3, zz);
+  const f32x4 w0 = widen_add(ident, tp0, tp1, zz);  // fl32(t + z), lanes' own values
+  const f32x4 w1 = widen_add(ident, tp2, tp3, zz);
   out[0] = pack_bf16x2(w0.x, w0.y); out[1] = pack_bf16x2(w0.z, w0.w);  // rounding #2
   out[2] = pack_bf16x2(w1.x, w1.y); out[3] = pack_bf16x2(w1.z, w1.w);
 }
@@ -131,8 +126,8 @@ __device__ __forceinline__ void dequant_stage(DequantPipe& d, uint32_t p, float 
     d.tp2 = pack_bf16x2(t0.y, t1.y); d.tp3 = pack_bf16x2(t2.y, t3.y);
   } else if constexpr (STAGE == 2) {
     const f32x4 zz = {z, z, z, z};
-    d.w0 = widen_add<4>(ident, d.tp0, d.tp1, zz);
-    d.w1 = widen_add<4>(ident, d.tp2, d.tp3, zz);
+    d.w0 = widen_add(ident, d.tp0, d.tp1, zz);
+    d.w1 = widen_add(ident, d.tp2, d.tp3, zz);
   } else {
     d.out[0] = pack_bf16x2(d.w0.x, d.w0.y); d.out[1] = pack_bf16x2(d.w0.z, d.w0.w);  // rounding #2
     d.out[2] = pack_bf16x2(d.w1.x, d.w1.y); d.out[3] = pack_bf16x2(d.w1.z, d.w1.w);
@@ -158,9 +153,7 @@ struct XRegs {
   uint32_t v[kDwords];
 };
 
-// ABL: ablation builds for profiling only (0 = product kernel; 1 = loads but no
-// dequant/MFMA)
-template <int G, int MAXM, int DEPTH, int ABL = 0, int DQ = 4>
+template <int G, int MAXM, int DEPTH>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
     const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K) {
@@ -215,11 +208,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   // straight-line code and the compiler can use counted s_waitcnt vmcnt(N).
   const int last_row = rows - 1;
   auto issue = [&](Stage& s, int kb) {
-    if (ABL == 2) {
-      s.w = u32x4{(uint32_t)lane * 0x01010101u, (uint32_t)kb, 0x12345678u, (uint32_t)lane};
-    } else {
-      s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
-    }
+    s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
     const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
 #pragma unroll
     for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
@@ -241,13 +230,9 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   };
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const s16x4 ident = identity_fragment<DQ>(lane);
+  const s16x4 ident = identity_fragment(lane);
 
   auto consume = [&](const Stage& s) {
-    if (ABL == 1) {
-      acc.x += bits_to_f32((s.w.x ^ s.w.y ^ s.w.z ^ s.w.w ^ s.sz[0] ^ s.xr.v[0]) & 0x3f800000u);
-      return;
-    }
     // stage x (wave-private: DS ops of one wave execute in order, no barrier)
     if (MAXM <= 4) {
 #pragma unroll
@@ -273,8 +258,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
       const float sc = bf16_lo_to_f32(s.sz[gi]);
       const float zp = bf16_hi_to_f32(s.sz[gi]);
       uint32_t b[4];
-      if constexpr (DQ == 0) dequant_word(wds[j], sc, -8.0f * sc, zp, b);
-      else dequant_word_mfma<DQ>(wds[j], sc, -8.0f * sc, zp, ident, b);
+      dequant_word_mfma(wds[j], sc, -8.0f * sc, zp, ident, b);
       const u32x4 bv = {b[0], b[1], b[2], b[3]};
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
                                                     __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
@@ -385,7 +369,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   const int S = gridDim.z, ks = blockIdx.z;
   const int kb0 = (int)(((long long)kblocks * ks) / S);
   const int nkb = (int)(((long long)kblocks * (ks + 1)) / S) - kb0;
-  const s16x4 ident = identity_fragment<4>(lane);
+  const s16x4 ident = identity_fragment(lane);
 
   // x DMA i of this wave fills rows 4 (ADMA wave + i) + (lane >> 4), chunk position lane & 15
   uint32_t aoff[ADMA];  // byte offsets from x + k * 128 (rows past M alias row M - 1; never stored)
