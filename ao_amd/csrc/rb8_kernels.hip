@@ -30,7 +30,6 @@ constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
 // weight ring (per wave), filled kWStages - 1 steps ahead: the HBM stream needs the bytes in flight.  6 stages; 5 for the
 // 8-wave MX form, whose scale rings would otherwise push the workgroup past 160 KiB of LDS
 constexpr int w_stages(int waves, int kind) { return (waves == 8 && kind == 2) ? 5 : 6; }
-constexpr int kABuf = 128 * 128;  // one activation stage: 128 rows x 128 k bytes
 
 enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2 };
 
@@ -53,14 +52,18 @@ struct Rb8Args {
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
 // loop done, meeting done, exit
-template <int WAVES, int KIND, bool TRACE = false>
+// MT = 16-row m-tiles per slab (8, 4, 2): small batches / token groups stage, read and multiply only the rows they can have.
+template <int WAVES, int KIND, int MT = 8, bool TRACE = false>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
   constexpr bool INT8 = (KIND == RB8_INT8), MX = (KIND == RB8_MX);
-  constexpr int ADMA = 16 / WAVES;  // activation DMAs per wave and stage (8 rows each)
+  constexpr int ADMA = 2 * MT / WAVES;  // activation DMAs per wave and stage (8 rows each)
+  static_assert(ADMA >= 1, "every wave issues the same number of DMAs per stage");
+  constexpr int kABuf = MT * 2048;      // one activation stage: 16 MT rows x 128 k bytes
+  constexpr int BM = 16 * MT;
   constexpr int LPS = ADMA + 2 + (MX ? 2 : 0);
-  constexpr int RPW = 128 / WAVES;  // MX: activation-scale rows fetched per wave
+  constexpr int RPW = BM / WAVES;   // MX: activation-scale rows fetched per wave
   constexpr int kWStages = w_stages(WAVES, KIND);
   // [3][128][128 B] a | [WAVES][6][2 KiB] b | MX: [3][WAVES][256 B] a scales | [WAVES][6][256 B] b scales
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,12 +80,12 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int k0 = (int)(((long long)ksteps * ks) / S);
   const int nk = (int)(((long long)ksteps * (ks + 1)) / S) - k0;
   // rows of this workgroup: [m0, m_end) -- a 128-row slab of the matrix, or of one expert's token group
-  int m0 = blockIdx.y * 128, m_end = p.M, expert = 0;
+  int m0 = blockIdx.y * BM, m_end = p.M, expert = 0;
   if constexpr (MX) {
     expert = blockIdx.y / p.slabs;
     const int begin = (p.offs != nullptr && expert > 0) ? p.offs[expert - 1] : 0;
     m_end = (p.offs != nullptr) ? p.offs[expert] : p.M;
-    m0 = begin + (blockIdx.y % p.slabs) * 128;
+    m0 = begin + (blockIdx.y % p.slabs) * BM;
     if (m0 >= m_end) return;  // uniform: empty group / slab past the group (before any DMA or barrier)
   }
 
@@ -125,9 +128,9 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     if constexpr (MX) dma_b32_s(bsrows + (size_t)kk * 4, bsoff, bs_lds + stage * 256);
   };
 
-  f32x4 acc[8];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   // A operand of lane (row r = nl, kq): chunks kq and 4 + kq of the row, at positions chunk ^ ((r >> 1) & 7)
   const int pa = nl * 128 + (((kq ^ (nl >> 1)) & 7) << 4);  // second half: ^ 64; + 2048 per m-tile
 
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + kStages * WAVES * 256 +
                                                     (wave * kWStages + wstage) * 256 + nl * 4) >> (8 * kq)) & 0xff;
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
       const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + (pa ^ 64));
       if constexpr (INT8) {  // acc holds int32 bit patterns
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       for (int i = 0; i < 13; ++i) t[i] = ts[i];
     }
   };
-  if (S > 1 && !split_k_meet<8, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
+  if (S > 1 && !split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
     dump();
     return;
   }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   uint16_t* __restrict__ y = p.y;
   if constexpr (MX) {  // scales were applied by the MFMA: out = bf16(acc)
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + mt * 16 + kq * 4 + r;
@@ -212,11 +215,11 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     const float* __restrict__ scale_a = p.scale_a;
     const float sb = p.scale_b[n];
     const float bias = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
-    float sa[32];  // all row scales first: the stores below must not sit between dependent loads
+    float sa[4 * MT];  // all row scales first: the stores below must not sit between dependent loads
 #pragma unroll
-    for (int i = 0; i < 32; ++i) sa[i] = scale_a[min(m0 + (i >> 2) * 16 + kq * 4 + (i & 3), p.M - 1)];
+    for (int i = 0; i < 4 * MT; ++i) sa[i] = scale_a[min(m0 + (i >> 2) * 16 + kq * 4 + (i & 3), p.M - 1)];
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + mt * 16 + kq * 4 + r;
@@ -238,22 +241,23 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
 
 unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 
-template <int WAVES, int KIND>
+template <int WAVES, int KIND, int MT = 8>
 int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   constexpr int BN = WAVES * 16;
-  const unsigned gy = (KIND == RB8_MX) ? (unsigned)(p.slabs * (p.offs != nullptr ? p.E : 1)) : (unsigned)((p.M + 127) / 128);
+  constexpr int BM = 16 * MT;
+  const unsigned gy = (KIND == RB8_MX) ? (unsigned)(p.slabs * (p.offs != nullptr ? p.E : 1)) : (unsigned)((p.M + BM - 1) / BM);
   dim3 grid((unsigned)((p.N + BN - 1) / BN), gy, (unsigned)split), block(64 * WAVES);
   constexpr int kWStages = w_stages(WAVES, KIND);
-  constexpr size_t smem = (size_t)kStages * kABuf + (size_t)WAVES * kWStages * 2048 +
+  constexpr size_t smem = (size_t)kStages * MT * 2048 + (size_t)WAVES * kWStages * 2048 +
                           ((KIND == RB8_MX) ? (size_t)(kStages + kWStages) * WAVES * 256 : 0);
   static_assert(smem <= 160 * 1024, "rb8_kernel: LDS");
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN <= (int64_t)kSplitMaxTiles * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
+    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     if (int rc = splitk_workspace(&p.ws, &p.tickets)) return rc;
   }
   p.trace = g_fp8_rb_trace;
-  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, true> : rb8_kernel<WAVES, KIND, false>;
+  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true> : rb8_kernel<WAVES, KIND, MT, false>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[p.trace != nullptr]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -289,17 +293,19 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   Rb8Args p{};
   p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.y = y;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  const int64_t slabs = (M + 127) / 128, ksteps = K >> 7;
-  // 128-column tiles while they give ~half a chip of workgroups before splitting, else 64-column tiles; K cut into at most
-  // 16 parts of >= 4 steps so that the grid approaches one workgroup per CU
+  // slabs of 64 rows for M <= 64, else 128.  128-column tiles while they give ~half a chip of workgroups before splitting,
+  // else 64-column tiles; K cut into at most 16 parts of >= 4 steps so that the grid approaches one workgroup per CU
+  const int bm = (M <= 64) ? 64 : 128;
+  const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
   const bool wide = ((N + 127) / 128) * slabs * std::min<int64_t>(16, std::max<int64_t>(1, ksteps / 4)) >= 190;
   const bool narrow = !wide || g_fp8_rb_force == 3;
   const int bn = narrow ? 64 : 128;
   const int64_t base = ((N + bn - 1) / bn) * slabs;
-  const int64_t fit = (int64_t)kSplitMaxTiles * 128 / (base * bn);
+  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * bm);
   const int64_t target = (g_fp8_rb_force == 3) ? 512 : 256;
   const int split = (int)std::max<int64_t>(1, std::min<int64_t>({target / base, fit, 16, ksteps / 4}));
-  return narrow ? launch_rb8<4, KIND>(p, split, stream) : launch_rb8<8, KIND>(p, split, stream);
+  if (bm == 64) return narrow ? launch_rb8<4, KIND, 4>(p, split, stream) : launch_rb8<8, KIND, 4>(p, split, stream);
+  return narrow ? launch_rb8<4, KIND, 8>(p, split, stream) : launch_rb8<8, KIND, 8>(p, split, stream);
 }
 
 }  // namespace
@@ -323,10 +329,14 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
   Rb8Args p{};
   p.a = a; p.b = b; p.y = out; p.a_mx = a_scale; p.b_mx = b_scale; p.offs = offs;
   p.M = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
-  p.slabs = (int)std::max<int64_t>(1, (std::min(rows_hint, M_total) + 127) / 128);
+  // Slab height from the average group size (the sizes themselves live on the device): 32 rows for decode-size groups, else
+  // 128; the grid provides enough slabs per group for the largest group `rows_hint` allows, empty ones exit at once.
+  const int64_t groups = (offs != nullptr ? E : 1);
+  const int bm = (M_total <= 24 * groups) ? 32 : 128;
+  p.slabs = (int)std::max<int64_t>(1, (std::min(rows_hint, M_total) + bm - 1) / bm);
   // 64-column tiles when 128-column ones would not give every CU a workgroup even if every group had tokens
-  const int64_t groups = (offs != nullptr ? E : 1) * p.slabs;
-  return (((N + 127) / 128) * groups < 400) ? launch_rb8<4, RB8_MX>(p, 1, stream) : launch_rb8<8, RB8_MX>(p, 1, stream);
+  if (bm == 32) return launch_rb8<4, RB8_MX, 2>(p, 1, stream);
+  return (((N + 127) / 128) * groups * p.slabs < 400) ? launch_rb8<4, RB8_MX, 8>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);
 }
 
 }  // namespace ao

@@ -424,10 +424,11 @@ extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, con
   Stream8Args p{};
   p.a = a; p.a_scale = a_scale; p.b = b; p.b_scale = b_scale; p.offs = offs; p.out = out;
   p.M_total = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
-  // Kernel choice by the average group size (the sizes themselves live on the device).  Mixtral-8x7B expert shapes, 8 experts,
-  // profiles/bench_8bit_r01_session4.jsonl: 16 rows per expert -- A-stationary 98 / 119 us (w1, w2), LDS-staged 104 / 136;
-  // 128 rows per expert -- A-stationary 381 / 474 us (it re-streams the weights per 64-row pass), LDS-staged 211 / 172.
-  if (g_mx_variant == 1 || (g_mx_variant == 0 && M_total >= 48 * E)) return mxfp8_grouped_rb(a, a_scale, b, b_scale, offs, out, M_total, N, K, E, M_total, (hipStream_t)stream);
+  // The LDS-staged weight-streaming kernel (rb8_kernels.hip) is the product path; its slab height follows the average group
+  // size.  Mixtral-8x7B expert shapes, 8 experts (w1, w2; us): 16 rows per expert -- A-stationary kernel below 97 / 120,
+  // LDS-staged 89 / 110; 128 rows per expert -- 381 / 474 (the A-stationary kernel re-streams the weights per 64-row pass) vs
+  // 211 / 172.  Variant 111 keeps the older kernels reachable for A/B runs.
+  if (g_mx_variant != 2) return mxfp8_grouped_rb(a, a_scale, b, b_scale, offs, out, M_total, N, K, E, M_total, (hipStream_t)stream);
   if (offs != nullptr && K % 2048 == 0) {
     // Group sizes live on the device.  Size the m-tiling for twice the AVERAGE group: a larger group
     // takes another pass over its expert's weights (correct, slower), while sizing for the worst

@@ -300,7 +300,7 @@ def test_mxfp8_grouped_mm_vs_oracle(sizes):
      ([3, 0, 0, 1], 2048, 2048), ([32, 32, 32, 32, 0, 0, 0, 0], 192, 6144)],
 )
 def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
-    """K % 2048 == 0 takes the A-stationary kernel (mx_grouped_kernel): every m-tiling (avg group <= 8,
+    """With variant 111, K % 2048 == 0 takes the A-stationary kernel (mx_grouped_kernel): every m-tiling (avg group <= 8,
     <= 16, larger), groups larger than one pass, empty experts, N not a multiple of the tile group."""
     E = len(sizes)
     M = sum(sizes)
@@ -309,7 +309,13 @@ def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
     offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32)
     a_d, a_s = ops.mxfp8_quantize(a.to(DEV), "rceil")
     w_d, w_s = ops.mxfp8_quantize(w.to(DEV), "rceil")
-    y = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+    from ao_amd import _lib
+
+    try:
+        _lib.lib().ao_gemm8_set_variant(111)  # the older kernels (the LDS-staged one is the default path)
+        y = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+    finally:
+        _lib.lib().ao_gemm8_set_variant(0)
     y_ref, mag = MX.grouped_mm(
         a_d.view(torch.uint8).cpu().numpy(), a_s.view(torch.uint8).cpu().numpy(),
         w_d.view(torch.uint8).cpu().numpy(), w_s.view(torch.uint8).cpu().numpy(), offs.numpy(), return_abs=True,
