@@ -1,0 +1,106 @@
+"""Seeded shape sweep over the dispatch edges of every matmul entry point (GPU).  The references here are the library's
+own exact building blocks, each pinned to the oracle elsewhere: int4 -> ao_int4_dequantize (bit-exact vs the oracle) + an fp32
+matmul; int8 / fp8 -> cast + matmul vs the fused and forced-kernel paths; MX -> the older kernels (variant 111)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _cases(seed, n):
+    rng = np.random.default_rng(seed)
+    ms = [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 257, 300]
+    out = []
+    for _ in range(n):
+        m = int(rng.choice(ms))
+        n_ = int(rng.choice([16, 32, 48, 64, 80, 128, 208, 256, 512, 1040, 2048, 4096, 16384, 16400]))
+        k = int(rng.choice([128, 256, 384, 512, 1024, 1152, 2048, 2560, 4096]))
+        g = int(rng.choice([g for g in (32, 64, 128, 256) if k % g == 0]))
+        out.append((m, n_, k, g))
+    return out
+
+
+@pytest.mark.parametrize("chunk", range(6))
+def test_int4_mm_shape_sweep(chunk):
+    from ao_amd import ops
+
+    for m, n, k, g in _cases(100 + chunk, 14):
+        gen = torch.Generator(device=DEV).manual_seed(m * 7 + n + k)
+        w = (torch.randn(n, k, device=DEV, generator=gen) * 0.05).to(torch.bfloat16)
+        x = torch.randn(m, k, device=DEV, generator=gen).to(torch.bfloat16)
+        qdata, sz = ops.int4_quantize_tinygemm(w, g)
+        y = ops.weight_int4pack_mm(x, qdata, g, sz)
+        ref = (x.float() @ ops.int4_dequantize(qdata, sz, g).float().t()).to(torch.bfloat16)
+        assert y.shape == (m, n)
+        r = _rel(y, ref)
+        assert r <= 1e-3, (m, n, k, g, r)
+        assert torch.equal(ops.weight_int4pack_mm(x, qdata, g, sz), y), (m, n, k, g)  # reproducible
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_int8_fp8_linear_shape_sweep(chunk):
+    from ao_amd import _lib, ops
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(200 + chunk)
+    for _ in range(10):
+        m = int(rng.choice([1, 2, 4, 7, 16, 17, 32, 33, 64, 65, 128, 200, 513]))
+        n = int(rng.choice([16, 48, 64, 208, 256, 1024, 4096]))
+        k = int(rng.choice([128, 256, 512, 1024, 2048, 3584, 4096]))
+        gen = torch.Generator(device=DEV).manual_seed(m + 3 * n + k)
+        x = torch.randn(m, k, device=DEV, generator=gen).to(torch.bfloat16)
+        w = (torch.randn(n, k, device=DEV, generator=gen) * 0.05).to(torch.bfloat16)
+        b = torch.randn(n, device=DEV, generator=gen).to(torch.bfloat16)
+        wq8, ws8 = ops.int8_quantize_rowwise(w)
+        xq8, xs8 = ops.int8_quantize_rowwise(x)
+        wqf, wsf = ops.fp8_quantize_rowwise(w)
+        xqf, xsf = ops.fp8_quantize_rowwise(x)
+        y8 = ops.int8_scaled_mm(xq8, xs8, wq8, ws8, b)
+        yf = ops.fp8_scaled_mm(xqf, wqf.t(), xsf, wsf.t(), b)
+        try:
+            lib.ao_gemm8_set_variant(100)  # tiled GEMM only
+            g8 = ops.int8_scaled_mm(xq8, xs8, wq8, ws8, b)
+            gf = ops.fp8_scaled_mm(xqf, wqf.t(), xsf, wsf.t(), b)
+        finally:
+            lib.ao_gemm8_set_variant(0)
+        assert torch.equal(y8, g8), (m, n, k)          # integer accumulation: every int8 kernel gives the same bits
+        assert _rel(yf, gf) <= 1e-3, (m, n, k)         # fp32 accumulation order differs between fp8 kernels
+        if ops.dynamic_linear_fits(m, n, k):
+            assert torch.equal(ops.int8_dynamic_linear(x, wq8, ws8, b), y8), (m, n, k)
+            assert torch.equal(ops.fp8_dynamic_linear(x, wqf, wsf, b), yf), (m, n, k)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_mxfp8_grouped_shape_sweep(chunk):
+    from ao_amd import _lib, ops
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(300 + chunk)
+    for _ in range(6):
+        e = int(rng.choice([1, 3, 8]))
+        sizes = [int(s) for s in rng.choice([0, 1, 5, 16, 31, 33, 70, 140], size=e)]
+        if sum(sizes) == 0:
+            sizes[0] = 3
+        n = int(rng.choice([16, 80, 256, 1040]))
+        k = int(rng.choice([128, 384, 1024, 2048]))
+        mtot = sum(sizes)
+        gen = torch.Generator(device=DEV).manual_seed(mtot + n + k)
+        a = torch.randn(mtot, k, device=DEV, generator=gen).to(torch.bfloat16)
+        w = (torch.randn(e, n, k, device=DEV, generator=gen) * 0.1).to(torch.bfloat16)
+        offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device=DEV)
+        aq, a_s = ops.mxfp8_quantize(a, "rceil")
+        wq, w_s = ops.mxfp8_quantize(w, "rceil")
+        y = ops.mxfp8_grouped_mm(aq, a_s, wq, w_s, offs)
+        try:
+            lib.ao_gemm8_set_variant(111)
+            y_old = ops.mxfp8_grouped_mm(aq, a_s, wq, w_s, offs)
+        finally:
+            lib.ao_gemm8_set_variant(0)
+        assert _rel(y, y_old) <= 1e-3, (sizes, n, k)
