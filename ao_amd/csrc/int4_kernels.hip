@@ -153,13 +153,20 @@ struct XRegs {
   uint32_t v[kDwords];
 };
 
-template <int G, int MAXM, int DEPTH>
+// SCHED: instruction order of a block's dequant + products.
+//   0  word by word (dequantise one packed word, multiply, next word) -- MFMA and VALU work of a wave never overlap
+//   1  stage by stage over the block's four words, the 4x4x4 "add" MFMAs issued between the cvt_pk of earlier results
+//   3  profiling only: no dequant at all
+//   2  as 1, and software-pipelined across blocks: the four products of block b-1 are issued between the mask / convert /
+//      multiply VALU work of block b (x slab double-buffered so that block b-1's A fragments are still in LDS)
+template <int G, int MAXM, int DEPTH, int SCHED = 0>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
     const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);              // groups per 128-k block
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;          // bytes, padded vs bank conflicts
-  constexpr int SLAB = (MAXM + 1) * ROWSTRIDE;                // per-wave x slab (+ zero row)
+  constexpr int NSLAB = (SCHED == 2) ? 2 : 1;                 // x slabs per wave (rows 0..MAXM-1 each) + one shared zero row
+  constexpr int SLAB = (NSLAB * MAXM + 1) * ROWSTRIDE;        // per-wave x staging
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -175,8 +182,15 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   char* slab = smem + wave * SLAB;
   float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
 
-  // zero row (index MAXM) of this wave's slab: 256 B
-  *reinterpret_cast<uint32_t*>(slab + MAXM * ROWSTRIDE + lane * 4) = 0u;
+  // zero row (last row) of this wave's slab: 256 B
+  *reinterpret_cast<uint32_t*>(slab + NSLAB * MAXM * ROWSTRIDE + lane * 4) = 0u;
+  if constexpr (SCHED == 2) {
+    // the first iteration multiplies "block -1" (zero weights) by whatever slab 1 holds: make that finite
+#pragma unroll
+    for (int r = 0; r < MAXM; ++r)
+#pragma unroll
+      for (int i = 0; i < ROWSTRIDE / 256; ++i) *reinterpret_cast<uint32_t*>(slab + (MAXM + r) * ROWSTRIDE + i * 256 + lane * 4) = 0u;
+  }
 
   const int n = ntile * 16 + (lane & 15);
   const int kq = lane >> 4;
@@ -185,7 +199,9 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 
   // LDS addresses
   const int mrow = lane & 15;
-  const char* a_base = slab + ((mrow < rows) ? mrow : MAXM) * ROWSTRIDE + kq * 64;
+  const bool a_zero = !(mrow < rows);
+  const char* a_base = slab + (a_zero ? NSLAB * MAXM : mrow) * ROWSTRIDE + kq * 64;
+  const int a_step = a_zero ? 0 : MAXM * ROWSTRIDE;  // slab 0 -> slab 1 (SCHED 2)
   int st_off;  // byte offset (within a row) this lane stores its x piece at
   if (MAXM <= 4) {
     // dword = k = 2*lane, 2*lane+1
@@ -232,36 +248,108 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const s16x4 ident = identity_fragment(lane);
 
-  auto consume = [&](const Stage& s) {
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  uint32_t prev[4][4];  // SCHED 2: the previous block's dequantised words
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) prev[j][i] = 0u;
+
+  auto stage_x = [&](const Stage& s, char* dst) {
     // stage x (wave-private: DS ops of one wave execute in order, no barrier)
     if (MAXM <= 4) {
 #pragma unroll
       for (int r = 0; r < MAXM; ++r)
-        *reinterpret_cast<uint32_t*>(slab + r * ROWSTRIDE + st_off) = s.xr.v[r];
+        *reinterpret_cast<uint32_t*>(dst + r * ROWSTRIDE + st_off) = s.xr.v[r];
     } else {
 #pragma unroll
       for (int i = 0; i < MAXM / 4; ++i) {
         const int r = (lane >> 4) + 4 * i;
-        char* d = slab + r * ROWSTRIDE + st_off;
+        char* d = dst + r * ROWSTRIDE + st_off;
         *reinterpret_cast<u32x2*>(d) = u32x2{s.xr.v[4 * i + 0], s.xr.v[4 * i + 1]};
         *reinterpret_cast<u32x2*>(d + 64) = u32x2{s.xr.v[4 * i + 2], s.xr.v[4 * i + 3]};
       }
     }
-    u32x4 a[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
+  };
+  auto mma = [&](const u32x4& a, const uint32_t (&b)[4], f32x4& c) {
+    const u32x4 bv = {b[0], b[1], b[2], b[3]};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+  };
 
+  // PAR: which x slab this block uses (SCHED 2; compile-time: consecutive blocks alternate)
+  auto consume = [&](const Stage& s, auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
     const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
+    if constexpr (SCHED == 3) {
+      // profiling only: no dequant (the packed words go to the MFMA as they are) -- what the launch structure, the
+      // weight stream and the x staging cost without the VALU work
+      stage_x(s, slab);
+      u32x4 a[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
-      const float sc = bf16_lo_to_f32(s.sz[gi]);
-      const float zp = bf16_hi_to_f32(s.sz[gi]);
-      uint32_t b[4];
-      dequant_word_mfma(wds[j], sc, -8.0f * sc, zp, ident, b);
-      const u32x4 bv = {b[0], b[1], b[2], b[3]};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[j]),
-                                                    __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
+      const uint32_t b[4] = {wds[0] ^ s.sz[0], wds[1], wds[2], wds[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma(a[j], b, acc);
+    } else if constexpr (SCHED == 0) {
+      stage_x(s, slab);
+      u32x4 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gi = (G >= 128) ? 0 : ((j * 32) / G);
+        const float sc = bf16_lo_to_f32(s.sz[gi]);
+        const float zp = bf16_hi_to_f32(s.sz[gi]);
+        uint32_t b[4];
+        dequant_word_mfma(wds[j], sc, -8.0f * sc, zp, ident, b);
+        mma(a[j], b, acc);
+      }
+    } else {
+      float sc[4], n8s[4], zp[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gi = (G >= 128) ? 0 : ((j * 32) / G);
+        sc[j] = bf16_lo_to_f32(s.sz[gi]); zp[j] = bf16_hi_to_f32(s.sz[gi]); n8s[j] = -8.0f * sc[j];
+      }
+      DequantPipe d[4];
+      u32x4 a[4];
+      if constexpr (SCHED == 1) {
+        stage_x(s, slab);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
+      } else {
+        // this block's x into slab PAR; the previous block's A fragments out of slab PAR ^ 1
+        stage_x(s, slab + PAR * MAXM * ROWSTRIDE);
+        const char* ab = a_base + (PAR ^ 1) * a_step;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(ab + j * 16);
+        mma(a[0], prev[0], acc); mma(a[1], prev[1], acc2); mma(a[2], prev[2], acc); mma(a[3], prev[3], acc2);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dequant_stage<0>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dequant_stage<1>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dequant_stage<2>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dequant_stage<3>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
+      if constexpr (SCHED == 1) {
+        mma(a[0], d[0].out, acc); mma(a[1], d[1].out, acc2); mma(a[2], d[2].out, acc); mma(a[3], d[3].out, acc2);
+        __builtin_amdgcn_sched_group_barrier(0x2, 64, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) prev[j][i] = d[j].out[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 16, 0); }
+      }
+      // 4x4x4 "add" MFMAs with the cvt_pk of the results two MFMAs back in their shadow
+      __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x2, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+      if constexpr (SCHED == 1) __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
     }
   };
 
@@ -272,27 +360,43 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
 
   int kb = kb0;
+  // ring slots as compile-time indices (the slot's parity picks the x slab under SCHED 2)
+  auto for_slots = [&](auto&& f) {
+    [&]<int... D>(std::integer_sequence<int, D...>) { (f(std::integral_constant<int, D>{}), ...); }(std::make_integer_sequence<int, DEPTH>{});
+  };
   // steady state: every consumed stage is refilled, no branches in the body
   for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      consume(st[d]);
+    for_slots([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      consume(st[d], std::integral_constant<int, (d & 1)>{});
       issue(st[d], kb + d + DEPTH);
-    }
+    });
   }
   // drain: fewer than 2*DEPTH blocks left
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
+  for_slots([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
     if (kb + d < kb1) {
-      consume(st[d]);
+      consume(st[d], std::integral_constant<int, (d & 1)>{});
       if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
     }
-  }
+  });
   kb += DEPTH;
+  for_slots([&](auto dc) {
+    constexpr int d = decltype(dc)::value;
+    if (kb + d < kb1) consume(st[d], std::integral_constant<int, (d & 1)>{});
+  });
+  if constexpr (SCHED == 2) {
+    // the last block's products (its x sits in slab (count - 1) & 1; DEPTH is even, so ring slot parity = block parity)
+    static_assert(DEPTH % 2 == 0, "SCHED 2 alternates x slabs by ring slot");
+    if (kb1 > kb0) {
+      const char* ab = a_base + ((kb1 - kb0 - 1) & 1) * a_step;
+      u32x4 a[4];
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (kb + d < kb1) consume(st[d]);
+      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(ab + j * 16);
+      mma(a[0], prev[0], acc); mma(a[1], prev[1], acc2); mma(a[2], prev[2], acc); mma(a[3], prev[3], acc2);
+    }
   }
+  acc += acc2;
 
   // cross-wave reduction: red[wave][row][col]
   {
@@ -744,14 +848,14 @@ __global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __res
   }
 }
 
-int g_tune_wpb = 0;
-int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 95-99 small-M A/B builds, 600-699 batched kernel (parts, ablation / trace builds)
+thread_local int g_tune_wpb = 0;
+thread_local int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 95-99 small-M A/B builds, 600-699 batched kernel (parts, ablation / trace builds)
 
-template <int G, int MAXM, int DEPTH = 4>
+template <int G, int MAXM, int DEPTH = 4, int SCHED = 0>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
               int64_t N, int64_t K, hipStream_t stream) {
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;
-  constexpr int SLAB = (MAXM + 1) * ROWSTRIDE;
+  constexpr int SLAB = (((SCHED == 2) ? 2 : 1) * MAXM + 1) * ROWSTRIDE;
   const int kblocks = (int)(K >> 7);
   const int64_t ntiles = N >> 4;
   const int64_t mslabs = (M + 15) / 16;
@@ -764,7 +868,7 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
   const size_t smem = (size_t)wpb * (SLAB + 1024);
   dim3 grid((unsigned)ntiles, (unsigned)mslabs), block(wpb * 64);
-  ao::launch((int4_mm_kernel<G, MAXM, DEPTH>), grid, block, smem, stream, x,
+  ao::launch((int4_mm_kernel<G, MAXM, DEPTH, SCHED>), grid, block, smem, stream, x,
                      reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
                      (int)M, (int)N, (int)K);
   AO_LAUNCH_CHECK("int4_mm_kernel launch");
@@ -784,6 +888,10 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   // Modes 94-99: A/B builds for profiling (94 never / 93 always the batched kernel on wide weights at M <= 16, 95 / 96 ring depth
   // 6 / 8, 98 the 4-row build at M = 1, 99 the 16-row build at any M).
   const bool wide = (N >> 4) >= 1024 && g_tune_mode != 94;
+  if (M == 1 && g_tune_mode == 90) return launch_mm<G, 1, 4, 3>(x, qdata, sz, y, M, N, K, stream);
+  if (M == 1 && g_tune_mode == 91) return launch_mm<G, 1, 4, 1>(x, qdata, sz, y, M, N, K, stream);
+  if (M == 1 && g_tune_mode == 92) return launch_mm<G, 1, 4, 2>(x, qdata, sz, y, M, N, K, stream);
+  if (M == 1 && g_tune_mode == 89) return launch_mm<G, 1, 6, 2>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 98) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 96) return launch_mm<G, 1, 8>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 95) return launch_mm<G, 1, 6>(x, qdata, sz, y, M, N, K, stream);

@@ -16,13 +16,15 @@ import json
 import os
 from collections import defaultdict
 
-KERNELS = ["int4_mm_kernel", "int4_mm_rb_kernel", "int4_quantize_kernel"]
+KERNELS = ["int4_mm_kernel", "int4_mm_rb_kernel", "int4_quantize_kernel", "gemm8_dma_kernel", "rb8_kernel", "stream8_kernel",
+           "dyn8_kernel"]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("--source", default="rocprofv3 --pmc (separate passes per counter), bench.py --steps 2")
     args = ap.parse_args()
     acc = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values
     files = []
@@ -36,7 +38,7 @@ def main():
                 if k is None:
                     continue
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    out = {"source": "rocprofv3 --pmc (separate passes per counter), bench.py --steps 2", "files": [os.path.basename(f) for f in files],
+    out = {"source": args.source, "files": [os.path.basename(f) for f in files],
            "corrections": {"FETCH_SIZE": "x1024 (KB) x2 (gfx950 wide-read undercount)", "WRITE_SIZE": "x1024 (KB), uncalibrated"},
            "kernels": {}}
     for k, ctrs in acc.items():
@@ -49,7 +51,13 @@ def main():
         if write:
             e["WRITE_SIZE_raw_mean"] = sum(write) / len(write)
             e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE_raw_mean"] * 1024
-        e["hbm_bytes_per_launch"] = e.get("hbm_read_bytes_per_launch", 0.0) + e.get("hbm_write_bytes_per_launch", 0.0)
+        if fetch or write:
+            e["hbm_bytes_per_launch"] = e.get("hbm_read_bytes_per_launch", 0.0) + e.get("hbm_write_bytes_per_launch", 0.0)
+        # every other counter: mean per dispatch, as reported (SQ_* are summed over the chip's SQs; SQ_WAVE_CYCLES, SQ_WAIT_*,
+        # SQ_ACTIVE_INST_* count quad-cycles, SQ_BUSY_CYCLES and SQ_VALU_MFMA_BUSY_CYCLES count cycles -- MI355X_MICROARCH.md)
+        for cname, vals in sorted(ctrs.items()):
+            if cname not in ("FETCH_SIZE", "WRITE_SIZE"):
+                e[cname + "_mean"] = sum(vals) / len(vals)
         out["kernels"][k] = e
     with open(args.out, "w") as fh:
         json.dump(out, fh, indent=1)
