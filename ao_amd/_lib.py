@@ -45,10 +45,17 @@ _SIGNATURES = {
     "ao_fp8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _P],
     "ao_fp8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_mxfp8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _INT, _P],
+    "ao_mxfp8_quantize_colwise": [_P, _P, _P, _I64, _I64, _INT, _P],
     "ao_mxfp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "ao_dyn_linear_fits": [_I64, _I64, _I64],
     "ao_int8_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_fp8_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
+    "ao_rowwise_amax": [_P, _I64, _P, _I64, _I64, _P],
+    "ao_int8_quantize_rowwise_amax": [_P, _I64, _P, _P, _P, _I64, _I64, _P],
+    "ao_fp8_quantize_rowwise_amax": [_P, _I64, _P, _P, _P, _I64, _I64, _P],
+    "ao_fp8_mm_f32": [_P, _P, _P, _I64, _I64, _I64, _P],
+    "ao_int8_scale_epilogue": [_P, _P, _P, _P, _P, _I64, _I64, _P],
+    "ao_fp8_scale_epilogue": [_P, _P, _P, _P, _P, _I64, _I64, _P],
     "ao_moe_padded_rows": [_I64, _I64, _INT],
     "ao_moe_pad_token_groups": [_P, _P, _P, _P, _P, _I64, _I64, _INT, _I64, _INT, _P],
     "ao_moe_unpad_token_groups": [_P, _P, _P, _P, _I64, _I64, _INT, _I64, _P],

@@ -38,7 +38,8 @@ constexpr int LDS_STRIDE = BK + 16;          // 144 B
 constexpr int TILE_BYTES = BM * LDS_STRIDE;  // one operand tile
 constexpr int THREADS = 256;
 
-enum Epilogue { EPI_INT8_SCALED = 0, EPI_INT32 = 1, EPI_FP8_ROWWISE = 2 };
+// EPI_FP8_RAW: the unscaled fp32 accumulators (K-sharded row-parallel linears all-reduce them before the scale epilogue)
+enum Epilogue { EPI_INT8_SCALED = 0, EPI_INT32 = 1, EPI_FP8_ROWWISE = 2, EPI_FP8_RAW = 3 };
 
 struct Gemm8Args {
   const uint8_t* a;  // [M][K]
@@ -65,7 +66,7 @@ struct Acc<EPI_INT32> {
 
 template <int EPI>
 __global__ __launch_bounds__(THREADS) void gemm8_kernel(Gemm8Args p) {
-  constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE);
+  constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE && EPI != EPI_FP8_RAW);
   using acc_t = typename Acc<EPI>::type;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][A tile | B tile]
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void gemm8_kernel(Gemm8Args p) {
       const int gn = n0 + wn * 64 + j * 32 + (lane & 31);
       if (gn >= p.N) continue;
       float cs = 1.f, bias = 0.f;
-      if (EPI != EPI_INT32) {
+      if (EPI != EPI_INT32 && EPI != EPI_FP8_RAW) {
         cs = p.col_scale[gn];
         if (p.bias != nullptr) bias = bf16_lo_to_f32(p.bias[gn]);
       }
@@ -180,6 +181,8 @@ __global__ __launch_bounds__(THREADS) void gemm8_kernel(Gemm8Args p) {
         if (gm >= p.M) continue;
         if (EPI == EPI_INT32) {
           reinterpret_cast<int32_t*>(p.out)[(size_t)gm * p.N + gn] = (int32_t)acc[i][j][r];
+        } else if (EPI == EPI_FP8_RAW) {
+          reinterpret_cast<float*>(p.out)[(size_t)gm * p.N + gn] = (float)acc[i][j][r];
         } else if (EPI == EPI_INT8_SCALED) {
           // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
           const float t = round_bf16((float)acc[i][j][r] * p.row_scale[gm]);
@@ -220,7 +223,7 @@ __device__ __forceinline__ int swz(int row) { return (row & 7) ^ ((row >> 3) & 7
 // TNJ = 32-column MFMA tiles per wave along N (2 or 4).
 template <int EPI, int TM, int WN, int TNJ = 2>
 __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
-  constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE);
+  constexpr bool IS_INT = (EPI != EPI_FP8_ROWWISE && EPI != EPI_FP8_RAW);
   constexpr int NWAVES = 2 * WN;
   constexpr int WGM = TM * 64;            // workgroup rows
   constexpr int WGN = WN * TNJ * 32;      // workgroup columns
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
       const int gn = n0 + wn * (TNJ * 32) + j * 32 + (lane & 31);
       if (gn >= p.N) continue;
       float cs = 1.f, bias = 0.f;
-      if (EPI != EPI_INT32) {
+      if (EPI != EPI_INT32 && EPI != EPI_FP8_RAW) {
         cs = p.col_scale[gn];
         if (p.bias != nullptr) bias = bf16_lo_to_f32(p.bias[gn]);
       }
@@ -345,6 +348,8 @@ __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
         if (gm >= p.M) continue;
         if (EPI == EPI_INT32) {
           reinterpret_cast<int32_t*>(p.out)[(size_t)gm * p.N + gn] = (int32_t)acc[i][j][r];
+        } else if (EPI == EPI_FP8_RAW) {
+          reinterpret_cast<float*>(p.out)[(size_t)gm * p.N + gn] = (float)acc[i][j][r];
         } else if (EPI == EPI_INT8_SCALED) {
           const float t = round_bf16((float)acc[i][j][r] * p.row_scale[gm]);
           float y = t * cs;
@@ -464,6 +469,18 @@ extern "C" int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, in
   Gemm8Args p{reinterpret_cast<const uint8_t*>(a), reinterpret_cast<const uint8_t*>(b_t), nullptr, nullptr, nullptr, c,
               (int)M, (int)N, (int)K};
   return launch_gemm8<EPI_INT32>(p, (hipStream_t)stream);
+}
+
+// Unscaled e4m3 x e4m3 products, fp32 out: the partial sums a K-sharded (row-parallel) fp8 linear all-reduces before
+// ao_fp8_scale_epilogue applies scale_a[m] * scale_b[n] (+ bias) once, like the unsharded aten::_scaled_mm.
+extern "C" int ao_fp8_mm_f32(const uint8_t* a, const uint8_t* b, float* c, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (int rc = check_gemm_shape(__func__, M, N, K)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(a);
+  AO_REQUIRE_PTR(b);
+  AO_REQUIRE_PTR(c);
+  Gemm8Args p{a, b, nullptr, nullptr, nullptr, c, (int)M, (int)N, (int)K};
+  return launch_gemm8<EPI_FP8_RAW>(p, (hipStream_t)stream);
 }
 
 extern "C" int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b,

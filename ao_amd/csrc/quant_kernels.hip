@@ -10,6 +10,8 @@
 //   fp8  : quantize_/workflows/float8/float8_tensor.py:167-253,
 //          quant_primitives.py:2192-2212, 2271-2287
 //   mx   : prototype/mx_formats/mx_tensor.py:111-225 (RCEIL), :228-409 (to_mx)
+#include <algorithm>
+
 #include "common.h"
 #include "quant_math.h"
 
@@ -32,17 +34,24 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // ---- int8 per-row symmetric ----------------------------------------------------
 // scale = f32(max(bf16(amax / 127.5), bf16(f32_eps)));  q = clamp(rint(x * (1/scale)), -128, 127)
-__global__ __launch_bounds__(kThreads) void int8_quant_rowwise_kernel(const uint16_t* __restrict__ x,
+// `amax_in` (optional): the row's amax over the FULL K when x is only a K shard of the activation (row-parallel TP linears:
+// the scale must be the unsharded one); `ldx`: row stride of x in elements.
+__global__ __launch_bounds__(kThreads) void int8_quant_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                      const float* __restrict__ amax_in,
                                                                       int8_t* __restrict__ q,
                                                                       float* __restrict__ scale, int64_t K) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
-  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * K);
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
   const int64_t nvec = K >> 3;  // 8 bf16 per 16 B
   float m = 0.f;
-  bool has_nan = false;
-  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) m = fmaxf(m, amax8(xr[i], has_nan));
-  m = block_max(has_nan ? INFINITY : m, red);  // (NaN rows are outside the contract)
+  if (amax_in != nullptr) {
+    m = amax_in[row];
+  } else {
+    bool has_nan = false;
+    for (int64_t i = threadIdx.x; i < nvec; i += kThreads) m = fmaxf(m, amax8(xr[i], has_nan));
+    m = block_max(has_nan ? INFINITY : m, red);  // (NaN rows are outside the contract)
+  }
   const float s = int8_row_scale(m);
   const float inv = 1.0f / s;
   if (threadIdx.x == 0) scale[row] = s;
@@ -52,21 +61,61 @@ __global__ __launch_bounds__(kThreads) void int8_quant_rowwise_kernel(const uint
 
 // ---- fp8 e4m3fn per-row ----------------------------------------------------------
 // scale = f32(bf16(amax / 448));  q = e4m3_rne(clamp(f32(x) / scale, -448, 448))
-__global__ __launch_bounds__(kThreads) void fp8_quant_rowwise_kernel(const uint16_t* __restrict__ x,
+__global__ __launch_bounds__(kThreads) void fp8_quant_rowwise_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ amax_in,
                                                                      uint8_t* __restrict__ q,
                                                                      float* __restrict__ scale, int64_t K) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
-  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * K);
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
   const int64_t nvec = K >> 3;
   float m = 0.f;
-  bool has_nan = false;
-  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) m = fmaxf(m, amax8(xr[i], has_nan));
-  m = block_max(has_nan ? INFINITY : m, red);
+  if (amax_in != nullptr) {
+    m = amax_in[row];
+  } else {
+    bool has_nan = false;
+    for (int64_t i = threadIdx.x; i < nvec; i += kThreads) m = fmaxf(m, amax8(xr[i], has_nan));
+    m = block_max(has_nan ? INFINITY : m, red);
+  }
   const float s = fp8_row_scale(m);
   if (threadIdx.x == 0) scale[row] = s;
   u32x2* qr = reinterpret_cast<u32x2*>(q + row * K);
   for (int64_t i = threadIdx.x; i < nvec; i += kThreads) qr[i] = fp8_quant8(xr[i], s);
+}
+
+// ---- per-row amax of a (possibly strided) bf16 matrix: the local half of a full-K activation scale under K sharding -----
+__global__ __launch_bounds__(kThreads) void rowwise_amax_kernel(const uint16_t* __restrict__ x, int64_t ldx, float* __restrict__ amax,
+                                                                int64_t K) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
+  float m = 0.f;
+  bool has_nan = false;
+  for (int64_t i = threadIdx.x; i < (K >> 3); i += kThreads) m = fmaxf(m, amax8(xr[i], has_nan));
+  m = block_max(has_nan ? INFINITY : m, red);
+  if (threadIdx.x == 0) amax[row] = m;
+}
+
+// ---- scale epilogues over all-reduced accumulators (row-parallel TP linears): the arithmetic of the fused GEMM epilogues ----
+// int8: t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))        (int8_tensor.py:315-359)
+// fp8 : y = bf16(c * sa[m] * sb[n] (+ bias))                                (float8/inference.py:104-123)
+template <bool INT8>
+__global__ __launch_bounds__(kThreads) void scale_epilogue_kernel(const void* __restrict__ acc, const float* __restrict__ row_scale,
+                                                                  const float* __restrict__ col_scale, const uint16_t* __restrict__ bias,
+                                                                  uint16_t* __restrict__ y, int64_t N) {
+  const int64_t row = blockIdx.y;
+  const float rs = row_scale[row];
+  for (int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kThreads) {
+    float v;
+    if (INT8) {
+      const float t = round_bf16((float)reinterpret_cast<const int32_t*>(acc)[row * N + n] * rs);
+      v = t * col_scale[n];
+    } else {
+      v = reinterpret_cast<const float*>(acc)[row * N + n] * rs * col_scale[n];
+    }
+    if (bias != nullptr) v += bf16_lo_to_f32(bias[n]);
+    y[row * N + n] = f32_to_bf16_bits(v);
+  }
 }
 
 // ---- MXFP8: one E8M0 scale per 32 elements along the row -------------------------
@@ -119,6 +168,86 @@ __global__ __launch_bounds__(kThreads) void mxfp8_quant_kernel(const uint16_t* _
   if (part == 0) scale[blk] = (uint8_t)e;
 }
 
+// E8M0 scale exponent of one 32-block from its amax (to_mx, mx_tensor.py:255-330) and the reciprocal 2^(127 - e) built from the
+// E8M0 byte 254 - e (mx_tensor.py:132-158)
+template <int MODE>
+__device__ __forceinline__ uint32_t mx_block_exponent(float m, bool finite) {
+  uint32_t e;
+  if (MODE == AO_MX_SCALE_RCEIL) {
+    const uint32_t bits = f32_to_bits(m * (1.0f / 448.0f));
+    const uint32_t be = (bits >> 23) & 0xffu, mant = bits & 0x7fffffu;
+    const bool up = (be == 0) ? (mant > 0x400000u) : (mant != 0);
+    e = be + (up ? 1u : 0u);
+  } else {
+    const int ex = (int)((f32_to_bits(m) >> 23) & 0xffu) - 127 - 8;
+    e = (uint32_t)(min(max(ex, -127), 128) + 127);
+  }
+  return finite ? e : 255u;
+}
+__device__ __forceinline__ float mx_reciprocal(uint32_t e) {
+  const uint32_t re = (254u - e) & 0xffu;
+  uint32_t rbits = re << 23;
+  if (re == 0u) rbits = 0x00400000u;
+  if (re == 255u) rbits = 0x7F800001u;
+  return bits_to_f32(rbits);
+}
+
+// ---- MXFP8 colwise: one E8M0 scale per 32 elements along the ROWS (32 x 1 blocks), data written column-major -------------
+// (mxfp8_quantize.cuh:460-820 colwise branch; torch reference to_mx(x.t()).t()).  A 4-wave workgroup owns a 128 x 128 tile:
+// wave w owns the row block 32 w .. 32 w + 31 and a lane two adjacent columns -- the 32 rows of a column are 32 registers of
+// ONE lane, so amax and scale need no cross-lane step; rows are read as coalesced 256-byte pieces.  The codes go through LDS
+// (column stride 132 B: 2-way conflicts) so that every column leaves as one 128-byte run of the transposed output.
+constexpr int kColTile = 128;
+constexpr int kColLdsStride = 132;
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void mxfp8_quant_colwise_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ qt,
+                                                                       uint8_t* __restrict__ scale, int64_t R, int64_t C) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kColTile * kColLdsStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * kColTile, c0 = (int64_t)blockIdx.x * kColTile;
+  const int64_t rb = r0 + wave * 32, c = c0 + 2 * lane;
+  if (rb < R && c < C) {
+    uint32_t v[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r] = *reinterpret_cast<const uint32_t*>(x + (rb + r) * C + c);
+    float m0 = 0.f, m1 = 0.f;
+    bool nan0 = false, nan1 = false;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float a = fabsf(bf16_lo_to_f32(v[r])), b = fabsf(bf16_hi_to_f32(v[r]));
+      nan0 |= (a != a); nan1 |= (b != b);
+      m0 = fmaxf(m0, a); m1 = fmaxf(m1, b);
+    }
+    const uint32_t e0 = mx_block_exponent<MODE>(m0, !nan0 && m0 < INFINITY), e1 = mx_block_exponent<MODE>(m1, !nan1 && m1 < INFINITY);
+    const float q0 = mx_reciprocal(e0), q1 = mx_reciprocal(e1);
+    uint32_t* t0 = reinterpret_cast<uint32_t*>(tile + (2 * lane) * kColLdsStride + wave * 32);
+    uint32_t* t1 = reinterpret_cast<uint32_t*>(tile + (2 * lane + 1) * kColLdsStride + wave * 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = bf16_lo_to_f32(v[4 * i + j]) * q0;
+        b[j] = bf16_hi_to_f32(v[4 * i + j]) * q1;
+        if (MODE == AO_MX_SCALE_FLOOR) { a[j] = clamp448(a[j]); b[j] = clamp448(b[j]); }
+      }
+      t0[i] = cvt4_e4m3(a[0], a[1], a[2], a[3]);
+      t1[i] = cvt4_e4m3(b[0], b[1], b[2], b[3]);
+    }
+    *reinterpret_cast<uint16_t*>(scale + (rb >> 5) * C + c) = (uint16_t)(e0 | (e1 << 8));
+  }
+  __syncthreads();
+  // 128 columns x 8 pieces of 16 bytes (= 16 rows each)
+  for (int p = threadIdx.x; p < kColTile * 8; p += kThreads) {
+    const int col = p >> 3, part = p & 7;
+    const int64_t gc = c0 + col, gr = r0 + part * 16;
+    if (gc < C && gr < R) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(tile + col * kColLdsStride + part * 16);
+      *reinterpret_cast<u32x4*>(qt + gc * R + gr) = u32x4{src[0], src[1], src[2], src[3]};
+    }
+  }
+}
+
 int check_rows(const char* fn, int64_t M, int64_t K, int64_t mult) {
   AO_REQUIRE(M >= 0 && K > 0, "%s: bad shape M=%lld K=%lld", fn, (long long)M, (long long)K);
   AO_REQUIRE(K % mult == 0, "%s: K=%lld must be a multiple of %lld", fn, (long long)K, (long long)mult);
@@ -138,7 +267,7 @@ extern "C" int ao_int8_quantize_rowwise(const uint16_t* x, int8_t* q, float* sca
   AO_REQUIRE_PTR(x);
   AO_REQUIRE_PTR(q);
   AO_REQUIRE_PTR(scale);
-  ao::launch(int8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, q, scale, K);
+  ao::launch(int8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, K, (const float*)nullptr, q, scale, K);
   AO_LAUNCH_CHECK("int8_quant_rowwise_kernel launch");
   return AO_OK;
 }
@@ -150,9 +279,106 @@ extern "C" int ao_fp8_quantize_rowwise(const uint16_t* x, uint8_t* q, float* sca
   AO_REQUIRE_PTR(x);
   AO_REQUIRE_PTR(q);
   AO_REQUIRE_PTR(scale);
-  ao::launch(fp8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, q, scale, K);
+  ao::launch(fp8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, K, (const float*)nullptr, q, scale, K);
   AO_LAUNCH_CHECK("fp8_quant_rowwise_kernel launch");
   return AO_OK;
+}
+
+extern "C" int ao_mxfp8_quantize_colwise(const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0, int64_t R, int64_t C, int scaling_mode,
+                                         void* stream) {
+  if (int rc = check_rows(__func__, R, C, 32)) return rc;
+  AO_REQUIRE(R % 32 == 0, "ao_mxfp8_quantize_colwise: R=%lld must be a multiple of 32", (long long)R);
+  AO_REQUIRE(scaling_mode == AO_MX_SCALE_FLOOR || scaling_mode == AO_MX_SCALE_RCEIL,
+             "ao_mxfp8_quantize_colwise: scaling_mode must be AO_MX_SCALE_FLOOR or AO_MX_SCALE_RCEIL, got %d", scaling_mode);
+  if (R == 0) return AO_OK;
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(q_t);
+  AO_REQUIRE_PTR(scale_e8m0);
+  const int64_t gx = (C + kColTile - 1) / kColTile, gy = (R + kColTile - 1) / kColTile;
+  AO_REQUIRE(gy <= 65535, "ao_mxfp8_quantize_colwise: R=%lld too large for one launch", (long long)R);
+  hipStream_t s = (hipStream_t)stream;
+  if (scaling_mode == AO_MX_SCALE_RCEIL)
+    ao::launch(mxfp8_quant_colwise_kernel<AO_MX_SCALE_RCEIL>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, x, q_t, scale_e8m0, R, C);
+  else
+    ao::launch(mxfp8_quant_colwise_kernel<AO_MX_SCALE_FLOOR>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, x, q_t, scale_e8m0, R, C);
+  AO_LAUNCH_CHECK("mxfp8_quant_colwise_kernel launch");
+  return AO_OK;
+}
+
+namespace {
+int check_strided(const char* fn, int64_t M, int64_t K, int64_t ldx) {
+  if (int rc = check_rows(fn, M, K, 8)) return rc;
+  AO_REQUIRE(ldx >= K && ldx % 8 == 0, "%s: row stride %lld must be >= K=%lld and a multiple of 8 elements", fn, (long long)ldx, (long long)K);
+  return AO_OK;
+}
+}  // namespace
+
+extern "C" int ao_rowwise_amax(const uint16_t* x, int64_t ldx, float* amax, int64_t M, int64_t K, void* stream) {
+  if (int rc = check_strided(__func__, M, K, ldx)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(amax);
+  ao::launch(rowwise_amax_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, amax, K);
+  AO_LAUNCH_CHECK("rowwise_amax_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_int8_quantize_rowwise_amax(const uint16_t* x, int64_t ldx, const float* amax, int8_t* q, float* scale, int64_t M,
+                                             int64_t K, void* stream) {
+  if (int rc = check_strided(__func__, M, K, ldx)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(amax);
+  AO_REQUIRE_PTR(q);
+  AO_REQUIRE_PTR(scale);
+  ao::launch(int8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, amax, q, scale, K);
+  AO_LAUNCH_CHECK("int8_quant_rowwise_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_fp8_quantize_rowwise_amax(const uint16_t* x, int64_t ldx, const float* amax, uint8_t* q, float* scale, int64_t M,
+                                            int64_t K, void* stream) {
+  if (int rc = check_strided(__func__, M, K, ldx)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(amax);
+  AO_REQUIRE_PTR(q);
+  AO_REQUIRE_PTR(scale);
+  ao::launch(fp8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, amax, q, scale, K);
+  AO_LAUNCH_CHECK("fp8_quant_rowwise_kernel launch");
+  return AO_OK;
+}
+
+namespace {
+template <bool INT8>
+int scale_epilogue(const char* fn, const void* acc, const float* row_scale, const float* col_scale, const uint16_t* bias, uint16_t* y,
+                   int64_t M, int64_t N, void* stream) {
+  AO_REQUIRE(M >= 0 && N > 0 && M <= 65535ll * 65535ll, "%s: bad shape M=%lld N=%lld", fn, (long long)M, (long long)N);
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(acc);
+  AO_REQUIRE_PTR(row_scale);
+  AO_REQUIRE_PTR(col_scale);
+  AO_REQUIRE_PTR(y);
+  for (int64_t m0 = 0; m0 < M; m0 += 65535) {
+    const int64_t rows = std::min<int64_t>(65535, M - m0);
+    const char* a = reinterpret_cast<const char*>(acc) + m0 * N * 4;
+    dim3 grid((unsigned)std::min<int64_t>((N + kThreads - 1) / kThreads, 64), (unsigned)rows);
+    ao::launch(scale_epilogue_kernel<INT8>, grid, dim3(kThreads), 0, (hipStream_t)stream, (const void*)a, row_scale + m0, col_scale, bias,
+               y + m0 * N, N);
+  }
+  AO_LAUNCH_CHECK("scale_epilogue_kernel launch");
+  return AO_OK;
+}
+}  // namespace
+
+extern "C" int ao_int8_scale_epilogue(const int32_t* acc, const float* x_scale, const float* w_scale, const uint16_t* bias, uint16_t* y,
+                                      int64_t M, int64_t N, void* stream) {
+  return scale_epilogue<true>(__func__, acc, x_scale, w_scale, bias, y, M, N, stream);
+}
+
+extern "C" int ao_fp8_scale_epilogue(const float* acc, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
+                                     int64_t M, int64_t N, void* stream) {
+  return scale_epilogue<false>(__func__, acc, scale_a, scale_b, bias, y, M, N, stream);
 }
 
 extern "C" int ao_mxfp8_quantize_rowwise(const uint16_t* x, uint8_t* q, uint8_t* scale_e8m0, int64_t R,

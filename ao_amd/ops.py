@@ -28,6 +28,12 @@ __all__ = [
     "fp8_dynamic_linear",
     "fused_pad_token_groups",
     "fused_unpad_token_groups",
+    "rowwise_amax",
+    "int8_quantize_rowwise_amax",
+    "fp8_quantize_rowwise_amax",
+    "fp8_mm_f32",
+    "int8_scale_epilogue",
+    "fp8_scale_epilogue",
 ]
 
 
@@ -327,6 +333,8 @@ def fp8_scaled_mm(a, b, scale_a, scale_b, bias=None):
         raise RuntimeError("fp8_scaled_mm: only rowwise scaling is implemented (scale_a [M,1], scale_b [1,N])")
     if bias is not None:
         bias = bias.to(torch.bfloat16).contiguous()
+        if bias.numel() != n:
+            raise RuntimeError("fp8_scaled_mm: bias must have N elements")
     y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
     with _on(dev):
         _lib.check(
@@ -335,6 +343,109 @@ def fp8_scaled_mm(a, b, scale_a, scale_b, bias=None):
             )
         )
     return y
+
+
+# ---------------------------------------------------------------------------
+# K-sharded (row-parallel) 8-bit linears: building blocks (include/ao_mi355.h, last section)
+# ---------------------------------------------------------------------------
+def _strided_rows(name, x):
+    """bf16 [M, K] whose rows are K-contiguous; a column slice of a wider row-major tensor is taken as is (row stride)."""
+    if x.dtype != torch.bfloat16 or x.dim() != 2:
+        raise RuntimeError(f"{name}: expected a 2-D bfloat16 tensor, got {x.dim()}-D {x.dtype}")
+    if x.shape[1] % 8 != 0:
+        raise ValueError(f"{name}: K={x.shape[1]} must be a multiple of 8")
+    ok = x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+    if not ok and x.shape[0] > 0:
+        x = x.contiguous()
+    return x, (x.stride(0) if x.shape[0] > 1 else max(x.shape[1], x.stride(0)))
+
+
+def rowwise_amax(x: torch.Tensor) -> torch.Tensor:
+    """max |x| per row of a bf16 [M, K] matrix (fp32 [M]): the local half of a full-K activation scale."""
+    dev = _require_gpu("rowwise_amax", x)
+    x, ldx = _strided_rows("rowwise_amax", x)
+    m, k = x.shape
+    out = torch.empty((m,), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_rowwise_amax(_ptr(x), ldx, _ptr(out), m, k, _stream()))
+    return out
+
+
+def _quantize_rowwise_amax(name, fn, x, amax, qdtype):
+    dev = _require_gpu(name, x, amax)
+    x, ldx = _strided_rows(name, x)
+    m, k = x.shape
+    amax = amax.reshape(-1).to(torch.float32).contiguous()
+    if amax.numel() != m:
+        raise RuntimeError(f"{name}: amax must have one entry per row ({m}), got {amax.numel()}")
+    q = torch.empty((m, k), dtype=qdtype, device=dev)
+    s = torch.empty((m, 1), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.check(fn(_ptr(x), ldx, _ptr(amax), _ptr(q), _ptr(s), m, k, _stream()))
+    return q, s
+
+
+def int8_quantize_rowwise_amax(x: torch.Tensor, amax: torch.Tensor):
+    """Int8Tensor.from_hp arithmetic (int8_tensor.py:191-230) on a K shard of the activation, with the rows' amax over the
+    full K given: the shard of the unsharded qdata, and the unsharded scale."""
+    return _quantize_rowwise_amax("int8_quantize_rowwise_amax", _lib.lib().ao_int8_quantize_rowwise_amax, x, amax, torch.int8)
+
+
+def fp8_quantize_rowwise_amax(x: torch.Tensor, amax: torch.Tensor):
+    """Float8Tensor.from_hp arithmetic (float8_tensor.py:167-253) on a K shard, amax over the full K given."""
+    q, s = _quantize_rowwise_amax("fp8_quantize_rowwise_amax", _lib.lib().ao_fp8_quantize_rowwise_amax, x, amax, torch.uint8)
+    return q.view(torch.float8_e4m3fn), s
+
+
+def fp8_mm_f32(a, b):
+    """Unscaled e4m3 [M, K] @ e4m3 [K, N] (column-major, the `.t()` of a row-major [N, K] weight) -> fp32 [M, N]: the
+    accumulator of aten::_scaled_mm before its scale epilogue."""
+    dev = _require_gpu("fp8_mm_f32", a, b)
+    a = _fp8_bytes("fp8_mm_f32", a)
+    b = _fp8_bytes("fp8_mm_f32", b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0]:
+        raise RuntimeError(f"fp8_mm_f32: shapes {tuple(a.shape)} and {tuple(b.shape)} cannot be multiplied")
+    if not a.is_contiguous():
+        a = a.contiguous()
+    b_t = b.t()
+    if not b_t.is_contiguous():
+        b_t = b_t.contiguous()
+    m, k = a.shape
+    n = b_t.shape[0]
+    c = torch.empty((m, n), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_fp8_mm_f32(_ptr(a), _ptr(b_t), _ptr(c), m, n, k, _stream()))
+    return c
+
+
+def _scale_epilogue(name, fn, acc, acc_dtype, row_scale, col_scale, bias):
+    dev = _require_gpu(name, acc, row_scale, col_scale, bias)
+    if acc.dtype != acc_dtype or acc.dim() != 2:
+        raise RuntimeError(f"{name}: expected a 2-D {acc_dtype} accumulator, got {acc.dim()}-D {acc.dtype}")
+    acc = acc.contiguous()
+    m, n = acc.shape
+    row_scale = row_scale.reshape(-1).to(torch.float32).contiguous()
+    col_scale = col_scale.reshape(-1).to(torch.float32).contiguous()
+    if row_scale.numel() != m or col_scale.numel() != n:
+        raise RuntimeError(f"{name}: scales must be per-row ([M] and [N])")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+        if bias.numel() != n:
+            raise RuntimeError(f"{name}: bias must have N elements")
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(fn(_ptr(acc), _ptr(row_scale), _ptr(col_scale), _ptr(bias), _ptr(y), m, n, _stream()))
+    return y
+
+
+def int8_scale_epilogue(acc, x_scale, w_scale, bias=None):
+    """bf16(bf16(acc * x_scale[m]) * w_scale[n] (+ bias)) over int32 accumulators (int8_tensor.py:315-359)."""
+    return _scale_epilogue("int8_scale_epilogue", _lib.lib().ao_int8_scale_epilogue, acc, torch.int32, x_scale, w_scale, bias)
+
+
+def fp8_scale_epilogue(acc, scale_a, scale_b, bias=None):
+    """bf16(acc * scale_a[m] * scale_b[n] (+ bias)) over fp32 accumulators (float8/inference.py:104-123)."""
+    return _scale_epilogue("fp8_scale_epilogue", _lib.lib().ao_fp8_scale_epilogue, acc, torch.float32, scale_a, scale_b, bias)
 
 
 # ---------------------------------------------------------------------------

@@ -10,9 +10,15 @@ per linear, issued on the compute stream right behind the GEMM).
 
 Sharding units: N in multiples of 16 (one int4 n-tile; also the fp8/int8 kernels' store width),
 K in multiples of lcm(128, group_size) for int4 (one packed k-block) and of 128 for the 8-bit
-GEMMs.  Row-parallel 8-bit shards keep the per-row WEIGHT scale of the full K (a slice of a tensor
-quantized before sharding) and quantize the ACTIVATION shard locally -- what a serving stack that
-calls F.linear(x_shard, w_shard) per rank gets from the reference subclasses too.
+GEMMs.
+
+Row-parallel 8-bit linears reproduce the UNSHARDED oracle: the per-row weight scale
+is the full-K one (a slice of a tensor quantized before sharding keeps it), the per-row ACTIVATION
+scale is made the full-K one by an all_reduce(MAX) of the rows' amax ([M] fp32) before the cast, the
+raw accumulators (int32 / fp32 [M, N]) are all-reduced, and the scale epilogue runs once on the sum --
+int8 bit-exact, fp8 within fp32 summation order of the unsharded linear.  `reduce="bf16"` is the
+cheaper protocol a caller of F.linear(x_shard, w_shard) + all_reduce gets from the reference
+subclasses (locally scaled activation shards, bf16 partials; half the exchange bytes, ~1e-2 rel).
 """
 from typing import Optional, Tuple
 
@@ -64,12 +70,43 @@ class ColumnParallelLinear(nn.Module):
         return F.linear(x, self.weight, self.bias)
 
 
+class _GpuBlocks:
+    """The exact row-parallel protocol's compute steps on the MI355X kernels (ao_amd.ops)."""
+
+    @staticmethod
+    def amax(x):
+        from . import ops
+        return ops.rowwise_amax(x)
+
+    @staticmethod
+    def quantize(kind, x, amax):
+        from . import ops
+        return (ops.int8_quantize_rowwise_amax if kind == "int8" else ops.fp8_quantize_rowwise_amax)(x, amax)
+
+    @staticmethod
+    def partial_mm(kind, xq, w):
+        from . import ops
+        return ops.int_mm(xq, w.qdata.t()) if kind == "int8" else ops.fp8_mm_f32(xq, w.qdata.t())
+
+    @staticmethod
+    def epilogue(kind, acc, xs, w, bias):
+        from . import ops
+        return (ops.int8_scale_epilogue if kind == "int8" else ops.fp8_scale_epilogue)(acc, xs, w.scale, bias)
+
+
 class RowParallelLinear(nn.Module):
     """y = all_reduce_sum_r( x[..., k0:k1] @ W[:, k0:k1].T ) + b.  `input_is_parallel`: x already
-    holds only this rank's K shard (the output of a ColumnParallelLinear)."""
+    holds only this rank's K shard (the output of a ColumnParallelLinear).
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], group=None, input_is_parallel: bool = True):
+    8-bit dynamic-activation weights (Int8Tensor / Float8Tensor with act_quant_kwargs) take the exact
+    protocol of the module docstring unless reduce="bf16"; everything else (int4 weight-only, plain
+    tensors) all-reduces the bf16 partial of F.linear."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], group=None, input_is_parallel: bool = True,
+                 reduce: str = "exact", blocks=None):
         super().__init__()
+        if reduce not in ("exact", "bf16"):
+            raise ValueError(f"reduce must be 'exact' or 'bf16', got {reduce!r}")
         self.group = group
         self.input_is_parallel = input_is_parallel
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -77,8 +114,42 @@ class RowParallelLinear(nn.Module):
         self.weight = nn.Parameter(weight[:, k0:k1], requires_grad=False)
         self.bias = None if bias is None else nn.Parameter(bias.clone(), requires_grad=False)
         self.cols = (k0, k1)
+        name = type(weight).__name__
+        self.kind = {"Int8Tensor": "int8", "Float8Tensor": "fp8"}.get(name)
+        if self.kind is not None and getattr(weight, "act_quant_kwargs", None) is None:
+            self.kind = None
+        self.exact = reduce == "exact" and self.kind is not None
+        self.blocks = blocks or _GpuBlocks
+        # act_pre_scale (AWQ / SmoothQuant, per input feature): the full vector for a replicated input, the K shard's part else
+        self.pre_full = getattr(weight, "act_pre_scale", None)
+        self.pre_shard = self.pre_full
+        if self.pre_full is not None and self.pre_full.numel() == weight.shape[1]:
+            self.pre_shard = self.pre_full.reshape(-1)[k0:k1]
+
+    def _forward_exact(self, x):
+        w = self.weight
+        k0, k1 = self.cols
+        out_dtype = x.dtype
+        x2 = x.reshape(-1, x.shape[-1]).to(torch.bfloat16)
+        pre = self.pre_shard if self.input_is_parallel else self.pre_full
+        if pre is not None:
+            x2 = (x2 * pre).to(torch.bfloat16)
+        if self.input_is_parallel:
+            amax = self.blocks.amax(x2)                       # over this rank's K shard
+            dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)  # [M] fp32: the full-K amax
+            x_sh = x2
+        else:
+            amax = self.blocks.amax(x2)                       # x is replicated: the full-K amax is local
+            x_sh = x2[:, k0:k1]
+        xq, xs = self.blocks.quantize(self.kind, x_sh, amax)  # the shard of the unsharded qdata, the unsharded scale
+        acc = self.blocks.partial_mm(self.kind, xq, w)        # int32 / fp32 [M, N], unscaled
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+        y = self.blocks.epilogue(self.kind, acc, xs, w, self.bias)
+        return y.reshape(*x.shape[:-1], y.shape[-1]).to(out_dtype)
 
     def forward(self, x):
+        if self.exact:
+            return self._forward_exact(x)
         if not self.input_is_parallel:
             x = x[..., self.cols[0] : self.cols[1]]
         y = F.linear(x, self.weight, None)
@@ -91,7 +162,7 @@ class RowParallelLinear(nn.Module):
         return y
 
 
-def shard_linear_(module: nn.Linear, style: str, group=None, input_is_parallel: bool = True) -> nn.Module:
+def shard_linear_(module: nn.Linear, style: str, group=None, input_is_parallel: bool = True, reduce: str = "exact") -> nn.Module:
     """Replace an (already quantized or plain) nn.Linear by its TP shard; style "colwise" | "rowwise"
     (the names of torchao/testing/utils.py:370-467's DTensor harness)."""
     bias = module.bias.detach() if module.bias is not None else None
@@ -99,7 +170,7 @@ def shard_linear_(module: nn.Linear, style: str, group=None, input_is_parallel: 
     if style == "colwise":
         return ColumnParallelLinear(w, bias, group)
     if style == "rowwise":
-        return RowParallelLinear(w, bias, group, input_is_parallel)
+        return RowParallelLinear(w, bias, group, input_is_parallel, reduce)
     raise ValueError(f"unknown TP style {style!r} (colwise | rowwise)")
 
 

@@ -131,11 +131,14 @@ def _(func, types, args, kwargs):
     step = args[4] if len(args) > 4 else 1
     assert step == 1 and dim in (0, 1)
     end = min(end, self.shape[dim])
+    pre = self.act_pre_scale
     if dim == 0:
         q, s = self.qdata[start:end].contiguous(), self.scale[start:end].contiguous()
     else:
         q, s = self.qdata[:, start:end].contiguous(), self.scale
-    return Float8Tensor(q, s, [1, q.shape[1]], self.dtype_, self.act_quant_kwargs, self.act_pre_scale)
+        if pre is not None and pre.numel() == self.shape[1]:  # per-input-feature pre-scale follows the K slice
+            pre = pre.reshape(-1)[start:end]
+    return Float8Tensor(q, s, [1, q.shape[1]], self.dtype_, self.act_quant_kwargs, pre)
 
 
 torch.serialization.add_safe_globals([Float8Tensor, QuantizeTensorToFloat8Kwargs])

@@ -1,32 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- linear-layer tokens/s of the int4 weight-only Llama-3-8B decode path.
+"""bench.py -- linear-layer tokens/s of the low-bit Llama / Mixtral linears on MI355X (BASELINE.json).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one token (bs=1, seq=1) through every linear of Llama-3-8B,
-Int4WeightOnlyConfig(group_size=128), tile-packed weights (BASELINE.json
-configs[1]).  The 218.1 M weights of a layer are laid out the way the serving
-stack the reference targets (vLLM) instantiates the model:
-    qkv_proj 6144x4096, o_proj 4096x4096, gate_up_proj 28672x4096, down_proj 4096x14336
-(merged column-parallel projections are ONE nn.Linear there, so quantize_() sees
-one weight and F.linear issues one op).  --unmerged runs gate_proj and up_proj
-as two 14336x4096 linears (the HF module layout); same bytes, one more launch
-per layer; its tokens/s is also reported in config.unmerged_tokens_per_s.
-Every layer owns distinct weights (3.7 GB resident in HBM, far beyond the
-256 MiB Infinity Cache), inputs are synthetic and already in HBM, one stream,
-launches replayed from a hipGraph.
+Headline (the ONE JSON line's metric / value / roofline / cpu_baseline) = BASELINE.json configs[1]:
+Int4WeightOnlyConfig(group_size=128), Llama-3-8B linear shapes, bs=1 seq=1.  One "step" = one token through every
+linear of the 32 layers in the five-shape layout of SURVEY.md 8(d) (qkv 6144x4096, o 4096x4096, gate 14336x4096,
+up 14336x4096, down 4096x14336: 160 launches), every layer with its own weights (3.7 GB resident, far beyond the
+256 MiB Infinity Cache), inputs synthetic and already in HBM, one stream, launches replayed from a hipGraph.  The
+serving-stack layout with gate and up merged into one 28672x4096 linear (vLLM; 128 launches, same bytes) is timed
+in the same run and reported in config.merged_tokens_per_s.
 
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel (int4_mm_kernel): algorithmic bytes per launch /
-                  average kernel duration measured with HIP extension events
-  cpu_baseline -- oracle/lowbit_ref.c ("port" of the reference CPU dequant path)
-                  timed on the host cores on a bounded sample
-N > 1: one process per GPU, each rank decodes its own token stream (the path
-partitions by sequence; no data-path collective) -> weak scaling.
+The same line carries `configs`, one object per other BASELINE.json config, each with its own value, roofline and
+cpu_baseline (rank 0, N = 1 runs):
+  int4_bs128          configs[1]'s second half (bs = 128): same weights, 128-row activations (MFMA-bound)
+  int8_dyn_bs128x2048 configs[2]: int8 dynamic-activation / int8-weight, M = 128 x 2048 = 262144 rows in 2048-row chunks
+  fp8_tp8_shards      configs[3], one GPU's share: Float8 rowwise, the Llama-3-70B TP=8 shard linears, M in {1, 128, 2048}
+  mxfp8_mixtral_bs64  configs[4]: MXFP8 grouped GEMM, Mixtral-8x7B expert shapes, 64 tokens x top-2
+With N > 1 ranks: the headline runs one replica per GPU (the decode path partitions by token stream, no data-path
+collective: "weak"), and `configs.fp8_tp` runs configs[3] for real -- Llama-3-70B linears sharded TP = N
+(ao_amd/parallel.py: column-parallel qkv / gate_up, row-parallel o / down + RCCL all-reduce), all-reduce time separate.
+
+roofline     -- dominant kernel: algorithmic bytes (or flops) per launch / average kernel duration from HIP extension
+                events on the launch stream; the committed rocprofv3 summary of the same command is quoted beside it
+cpu_baseline -- oracle/lowbit_ref.c ("port" of the reference CPU dequant -> matmul path) on a bounded sample
 """
 import argparse
 import ctypes
+import csv
 import json
 import os
 import sys
@@ -38,22 +40,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same guide); the dequantised int4 path multiplies in bf16
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
+MFMA_8BIT_PEAK_TOPS = 5000.0     # dense fp8 / int8 MFMA (same guide: fp8 ~5 PF dense, int8 ~2x the bf16 rate)
+ROUND = "r02"                    # names of the committed rocprofv3 summaries under profiles/
 
-LLAMA3_8B_MERGED = [  # (name, N, K): vLLM's Llama modules
-    ("qkv_proj", 6144, 4096),
-    ("o_proj", 4096, 4096),
-    ("gate_up_proj", 28672, 4096),
-    ("down_proj", 4096, 14336),
-]
-LLAMA3_8B_UNMERGED = [  # HF module layout (qkv still merged, as SURVEY.md 8d)
-    ("qkv", 6144, 4096),
-    ("o", 4096, 4096),
-    ("gate", 14336, 4096),
-    ("up", 14336, 4096),
-    ("down", 4096, 14336),
-]
+LLAMA3_8B_MERGED = [("qkv_proj", 6144, 4096), ("o_proj", 4096, 4096), ("gate_up_proj", 28672, 4096), ("down_proj", 4096, 14336)]
+LLAMA3_8B_UNMERGED = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate", 14336, 4096), ("up", 14336, 4096), ("down", 4096, 14336)]
+LLAMA3_70B = [("qkv_proj", 10240, 8192, "col"), ("o_proj", 8192, 8192, "row"), ("gate_up_proj", 57344, 8192, "col"), ("down_proj", 8192, 28672, "row")]
+MIXTRAL = [("w1", 14336, 4096), ("w3", 14336, 4096), ("w2", 4096, 14336)]
 N_LAYERS = 32
 GROUP = 128
 
@@ -68,131 +63,42 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="tokens per step (bs); BASELINE headline is 1")
+    ap.add_argument("--batch", type=int, default=1, help="tokens per step of the headline run (BASELINE headline is 1)")
     ap.add_argument("--layers", type=int, default=N_LAYERS)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--unmerged", action="store_true", help="gate_proj and up_proj as two linears (HF layout)")
+    ap.add_argument("--merged", action="store_true", help="headline on the vLLM layout (gate_up merged) instead of the five shapes")
+    ap.add_argument("--unmerged", action="store_true", help=argparse.SUPPRESS)  # round-1 flag: the five shapes are the default now
     ap.add_argument("--no-second-layout", action="store_true", help="skip the short run of the other module layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--configs", default="int4_bs128,int8,fp8,mx,tp", help="comma list of secondary configs to run")
     ap.add_argument("--wpb", type=int, default=0, help="tuning: waves per workgroup override")
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
     return ap.parse_args()
 
 
-class Int4Linears:
-    """All packed weights of the synthetic model + a raw C-ABI launch list."""
-
-    def __init__(self, device, batch, layers, shapes):
-        from ao_amd import _lib, ops
-
-        self.lib = _lib.lib()
-        self.check = _lib.check
-        self.batch = batch
-        self.launches = []  # (x_ptr, q_ptr, sz_ptr, y_ptr, M, N, K, name)
-        self.keep = []
-        gen = torch.Generator(device=device).manual_seed(0)
-        self.shapes = shapes
-        for layer in range(layers):
-            for name, n, k in shapes:
-                # random-init weights of the real shape, quantized by the product kernel
-                w = torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02
-                qdata, sz = ops.int4_quantize_tinygemm(w, GROUP)
-                del w
-                x = torch.randn(batch, k, device=device, dtype=torch.bfloat16, generator=gen)
-                y = torch.empty(batch, n, device=device, dtype=torch.bfloat16)
-                self.keep.append((qdata, sz, x, y))
-                self.launches.append((x.data_ptr(), qdata.data_ptr(), sz.data_ptr(), y.data_ptr(), batch, n, k, name))
-        torch.cuda.synchronize()
-
-    def step(self, stream_ptr):
-        f = self.lib.ao_int4_weight_int4pack_mm
-        for (xp, qp, sp, yp, m, n, k, _) in self.launches:
-            rc = f(xp, qp, sp, yp, m, n, k, GROUP, stream_ptr)
-            if rc != 0:
-                self.check(rc)
-
-    def bytes_per_step(self):
-        return sum(algorithmic_bytes(m, n, k, GROUP) for (_, _, _, _, m, n, k, _) in self.launches)
-
-
-def profile_kernels(model, stream_ptr):
-    """Per-launch kernel durations (ms) of one eager step via HIP extension events."""
-    lib = model.lib
-    n = len(model.launches)
-    model.check(lib.ao_prof_enable(n))
-    model.step(stream_ptr)
-    buf = (ctypes.c_float * n)()
-    cnt = ctypes.c_int(0)
-    model.check(lib.ao_prof_collect(buf, n, ctypes.byref(cnt)))
-    return np.array(buf[: cnt.value], dtype=np.float64)
-
-
-def cpu_baseline(batch):
-    """Time the C port of the reference CPU dequant->matmul path on ONE layer."""
-    from oracle import c_ref
-
-    rng = np.random.default_rng(0)
-    threads = c_ref.num_threads()
-    t_layer = 0.0
-    reps = 0
-    budget_s = 12.0
-    t_begin = time.perf_counter()
-    per_linear = {}
-    while True:
-        t_layer_once = 0.0
-        for name, n, k in LLAMA3_8B_MERGED:
-            qdata = rng.integers(-(2**31), 2**31 - 1, size=(n // 8, k // 128, 32, 4), dtype=np.int64).astype(np.int32)
-            sz = np.empty((k // GROUP, n, 2), dtype=np.uint16)
-            sz[..., 0] = 0x3B00 + rng.integers(0, 64, size=sz.shape[:2])  # scale ~ 2e-3 (bf16 bits)
-            sz[..., 1] = 0x3A00 + rng.integers(0, 64, size=sz.shape[:2])  # zero  ~ 5e-4
-            x = (rng.standard_normal((batch, k)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
-            t0 = time.perf_counter()
-            c_ref.int4_linear(x, qdata, sz, n, k, GROUP)
-            dt = time.perf_counter() - t0
-            per_linear[name] = dt
-            t_layer_once += dt
-        t_layer += t_layer_once
-        reps += 1
-        if time.perf_counter() - t_begin > budget_s or reps >= 20:
-            break
-    t_layer /= reps
-    tok_s = batch / (t_layer * N_LAYERS)
-    return {
-        "value": tok_s,
-        "unit": "tokens/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"1 of {N_LAYERS} layers (4 merged linears, 218.1M int4 weights, bs={batch}), mean of {reps} reps, x{N_LAYERS} extrapolated; "
-        f"oracle/lowbit_ref.c (gcc -O3 -fopenmp, {threads} threads, host has {os.cpu_count()} cpus)",
-        "ms_per_layer": t_layer * 1e3,
-    }
-
-
-def build_and_time(args, device, shapes, steps, warmup, dist, world):
-    """Build the synthetic model for `shapes`, capture one step into a hipGraph, time `steps` replays.
-    Returns (model, stream, elapsed_s, graph_used)."""
-    model = Int4Linears(device, args.batch, args.layers, shapes)
-    stream = torch.cuda.Stream(device=device)
-    sp = stream.cuda_stream
-    graph = None
+# ----------------------------------------------------------------------------------------------------------------------
+# timing helpers
+# ----------------------------------------------------------------------------------------------------------------------
+def capture(fn, stream, use_graph=True):
+    """Run fn once eagerly (first touch, lazy workspaces), then capture it into a hipGraph.  Returns a replay callable."""
     with torch.cuda.stream(stream):
-        model.step(sp)  # first touch (also allocates the library's split-K workspace outside capture)
+        fn()
         stream.synchronize()
-        if not args.no_graph:
-            try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
-                    model.step(torch.cuda.current_stream().cuda_stream)
-            except Exception as e:  # noqa: BLE001
-                print(f"warning: hipGraph capture failed ({e!r}); launching eagerly", file=sys.stderr)
-                graph = None
+        if not use_graph:
+            return fn, False
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                fn()
+            return g.replay, True
+        except Exception as e:  # noqa: BLE001
+            print(f"warning: hipGraph capture failed ({e!r}); launching eagerly", file=sys.stderr)
+            return fn, False
 
-    def run_step():
-        if graph is not None:
-            graph.replay()
-        else:
-            model.step(sp)
 
+def time_steps(run, stream, device, steps, warmup, dist=None):
+    """W untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; MAX over ranks.  Seconds."""
     def sync_all():
         torch.cuda.synchronize(device)
         if dist is not None:
@@ -201,11 +107,11 @@ def build_and_time(args, device, shapes, steps, warmup, dist, world):
 
     with torch.cuda.stream(stream):
         for _ in range(warmup):
-            run_step()
+            run()
         sync_all()
         t0 = time.perf_counter()
         for _ in range(steps):
-            run_step()
+            run()
         torch.cuda.synchronize(device)
         elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -213,21 +119,426 @@ def build_and_time(args, device, shapes, steps, warmup, dist, world):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         sync_all()
-    return model, stream, elapsed, graph is not None
+    return elapsed
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
-    (profiles/int4_pmc_r01.json, written by scripts/pmc_summary.py from a separate counter run of
-    this same command); None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "int4_pmc_r01.json")
+def event_profile(lib, check, fn, n_max):
+    """Per-launch kernel durations (ms) of one eager pass via HIP extension events (ao_prof_enable / collect)."""
+    check(lib.ao_prof_enable(n_max))
+    fn()
+    buf = (ctypes.c_float * n_max)()
+    cnt = ctypes.c_int(0)
+    check(lib.ao_prof_collect(buf, n_max, ctypes.byref(cnt)))
+    return np.array(buf[: cnt.value], dtype=np.float64)
+
+
+def rocprof_avg_us(kernel_substr):
+    """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", f"int4_kernel_stats_{ROUND}.csv")
+    if not os.path.exists(path):
+        return None, None
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if kernel_substr in row.get("Name", ""):
+                return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def pmc_traffic(kernel):
+    path = os.path.join(ROOT, "profiles", f"int4_pmc_{ROUND}.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "int4_pmc_r01.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
         d = json.load(f)
-    return d, path
+    v = d.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+    return v, (os.path.relpath(path, ROOT) if v is not None else None)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# int4 weight-only (headline, bs = 128)
+# ----------------------------------------------------------------------------------------------------------------------
+class Int4Linears:
+    """All packed weights of the synthetic model + raw C-ABI launch lists per batch size."""
+
+    def __init__(self, device, layers, shapes):
+        from ao_amd import _lib, ops
+
+        self.lib = _lib.lib()
+        self.check = _lib.check
+        self.device = device
+        self.shapes = shapes
+        self.weights = []  # (qdata, sz, n, k, name)
+        self.gen = torch.Generator(device=device).manual_seed(0)
+        for _ in range(layers):
+            for name, n, k in shapes:
+                # random-init weights of the real shape, quantized by the product kernel
+                w = torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=self.gen) * 0.02
+                qdata, sz = ops.int4_quantize_tinygemm(w, GROUP)
+                del w
+                self.weights.append((qdata, sz, n, k, name))
+        self.io = {}
+        torch.cuda.synchronize()
+
+    def launches(self, batch):
+        if batch not in self.io:
+            keep, lst = [], []
+            for qdata, sz, n, k, name in self.weights:
+                x = torch.randn(batch, k, device=self.device, dtype=torch.bfloat16, generator=self.gen)
+                y = torch.empty(batch, n, device=self.device, dtype=torch.bfloat16)
+                keep.append((x, y))
+                lst.append((x.data_ptr(), qdata.data_ptr(), sz.data_ptr(), y.data_ptr(), batch, n, k, name))
+            self.io[batch] = (keep, lst)
+        return self.io[batch][1]
+
+    def step(self, batch, stream_ptr):
+        f = self.lib.ao_int4_weight_int4pack_mm
+        for (xp, qp, sp, yp, m, n, k, _) in self.launches(batch):
+            rc = f(xp, qp, sp, yp, m, n, k, GROUP, stream_ptr)
+            if rc != 0:
+                self.check(rc)
+
+    def bytes_per_step(self, batch):
+        return sum(algorithmic_bytes(batch, n, k, GROUP) for (_, _, n, k, _) in self.weights)
+
+    def flops_per_step(self, batch):
+        return sum(2.0 * batch * n * k for (_, _, n, k, _) in self.weights)
+
+
+def run_int4(model, batch, steps, warmup, stream, device, use_graph, dist=None):
+    """(seconds, graphed) for `steps` steps of the int4 model at `batch` rows."""
+    cur = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+    run, graphed = capture(lambda: model.step(batch, cur()), stream, use_graph)
+    return time_steps(run, stream, device, steps, warmup, dist), graphed
+
+
+def int4_kernel_table(model, batch, stream):
+    """Event-timed per-launch durations of one eager step, grouped by shape and by kernel."""
+    lib = model.lib
+    sp = stream.cuda_stream
+    with torch.cuda.stream(stream):
+        durs = [event_profile(lib, model.check, lambda: model.step(batch, sp), len(model.weights)) for _ in range(3)]
+    prof = np.mean(np.stack(durs), axis=0)  # ms per launch, launch order
+    per_shape, kernels = {}, {}
+    for name, n, k in model.shapes:
+        idx = [i for i, w in enumerate(model.weights) if w[4] == name]
+        b = algorithmic_bytes(batch, n, k, GROUP)
+        ms = float(prof[idx].mean())
+        kern = lib.ao_int4_mm_kernel_name(batch, n, k, GROUP).decode()
+        per_shape[name] = {"N": n, "K": k, "bytes": b, "us": ms * 1e3, "GBps": b / (ms * 1e-3) / 1e9, "kernel": kern}
+        kk = kernels.setdefault(kern, {"launches_per_step": 0, "bytes_per_step": 0, "flops_per_step": 0.0, "ms_per_step": 0.0})
+        kk["launches_per_step"] += len(idx)
+        kk["bytes_per_step"] += b * len(idx)
+        kk["flops_per_step"] += 2.0 * batch * n * k * len(idx)
+        kk["ms_per_step"] += float(prof[idx].sum())
+    for kk in kernels.values():
+        kk["avg_kernel_us"] = kk["ms_per_step"] * 1e3 / kk["launches_per_step"]
+        kk["algorithmic_bytes_per_launch"] = kk["bytes_per_step"] / kk["launches_per_step"]
+        kk["GBps"] = kk["bytes_per_step"] / (kk["ms_per_step"] * 1e-3) / 1e9
+        kk["TFLOPs"] = kk["flops_per_step"] / (kk["ms_per_step"] * 1e-3) / 1e12
+    return prof, per_shape, kernels
+
+
+def int4_roofline(model, batch, stream):
+    prof, per_shape, kernels = int4_kernel_table(model, batch, stream)
+    dom = max(kernels, key=lambda k_: kernels[k_]["ms_per_step"])
+    kd = kernels[dom]
+    mfma_bound = batch >= 64  # past the HBM ridge: weights are dequantised to bf16 and multiplied on the bf16 MFMA path
+    out = {
+        "kernel": dom,
+        "bound": "mfma" if mfma_bound else "hbm",
+        "achieved": kd["TFLOPs"] if mfma_bound else kd["GBps"],
+        "peak": MFMA_BF16_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if mfma_bound else "GB/s",
+        "avg_kernel_us": kd["avg_kernel_us"],
+        "timing": "HIP extension events on the launch stream, one eager step, mean of 3",
+        "launches_per_step": len(model.weights),
+        "sum_kernel_ms_per_step": float(prof.sum()),
+        "kernels": kernels,
+        "per_shape": per_shape,
+    }
+    out["frac"] = out["achieved"] / out["peak"]
+    if mfma_bound:
+        out["peak_note"] = ("dense bf16 MFMA peak: the int4 weights are dequantised to bf16 (the oracle's arithmetic) and multiplied by "
+                            "v_mfma_f32_16x16x32_bf16; the fp8 peak named by north_star does not bound this kernel")
+        out["frac_of_fp8_mfma_peak"] = out["achieved"] / MFMA_8BIT_PEAK_TOPS
+        out["traffic"] = None
+    else:
+        out["algorithmic_bytes_per_launch"] = kd["algorithmic_bytes_per_launch"]
+        out["traffic"], out["traffic_source"] = pmc_traffic(dom)
+        avg, src = rocprof_avg_us(dom + "<")
+        if avg is not None:  # the committed rocprofv3 --kernel-trace --stats summary of this command
+            out["rocprof"] = {"avg_kernel_us": avg, "achieved": kd["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9,
+                              "frac": kd["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "source": src}
+    return out
+
+
+def cpu_baseline_int4(batch):
+    """Time the C port of the reference CPU dequant->matmul path on ONE layer."""
+    from oracle import c_ref
+
+    rng = np.random.default_rng(0)
+    threads = c_ref.num_threads()
+    t_layer, reps, budget_s = 0.0, 0, 10.0
+    t_begin = time.perf_counter()
+    while True:
+        t_once = 0.0
+        for _, n, k in LLAMA3_8B_UNMERGED:
+            qdata = rng.integers(-(2**31), 2**31 - 1, size=(n // 8, k // 128, 32, 4), dtype=np.int64).astype(np.int32)
+            sz = np.empty((k // GROUP, n, 2), dtype=np.uint16)
+            sz[..., 0] = 0x3B00 + rng.integers(0, 64, size=sz.shape[:2])  # scale ~ 2e-3 (bf16 bits)
+            sz[..., 1] = 0x3A00 + rng.integers(0, 64, size=sz.shape[:2])  # zero  ~ 5e-4
+            x = (rng.standard_normal((batch, k)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            t0 = time.perf_counter()
+            c_ref.int4_linear(x, qdata, sz, n, k, GROUP)
+            t_once += time.perf_counter() - t0
+        t_layer += t_once
+        reps += 1
+        if time.perf_counter() - t_begin > budget_s or reps >= 20:
+            break
+    t_layer /= reps
+    return {
+        "value": batch / (t_layer * N_LAYERS), "unit": "tokens/s", "cores": threads, "kind": "port",
+        "sample": f"1 of {N_LAYERS} layers (5 linears, 218.1M int4 weights, bs={batch}), mean of {reps} reps, x{N_LAYERS} extrapolated; "
+                  f"oracle/lowbit_ref.c (gcc -O3 -fopenmp, {threads} threads, host has {os.cpu_count()} cpus)",
+        "ms_per_layer": t_layer * 1e3,
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# secondary configs (rank 0, one GPU)
+# ----------------------------------------------------------------------------------------------------------------------
+def _graph_time(fn, stream, device, steps, warmup=2):
+    run, graphed = capture(fn, stream)
+    return time_steps(run, stream, device, steps, warmup) / steps, graphed
+
+
+def config_int4_bs128(model, stream, device, args):
+    batch, steps = 128, 20
+    t, graphed = run_int4(model, batch, steps, 3, stream, device, not args.no_graph)
+    tok_s = batch * steps / t
+    roof = int4_roofline(model, batch, stream)
+    out = {"workload": "Int4WeightOnlyConfig(group_size=128) Llama-3-8B linear shapes (five-shape layout), bs=128 seq=1, 32 layers",
+           "value": tok_s, "unit": "tokens/s", "ms_per_step": t * 1e3 / steps, "dtype": "bf16 x int4 (dequant bf16, fp32 accumulate)",
+           "launch": "hipGraph replay" if graphed else "eager", "roofline": roof}
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline_int4(16)
+        cb["sample"] = "bs=16 sample of the bs=128 workload: " + cb["sample"]
+        out["cpu_baseline"] = cb
+    return out
+
+
+def config_int8(stream, device, args):
+    """configs[2]: Int8DynamicActivationInt8WeightConfig, Llama-3-8B shapes, M = 128 x 2048 rows as 128 chunks of 2048."""
+    from ao_amd import _lib, ops
+    lib = _lib.lib()
+    chunk, nchunk, rot = 2048, 128, 8
+    gen = torch.Generator(device=device).manual_seed(1)
+    ws, xs = [], {}
+    for name, n, k in LLAMA3_8B_UNMERGED:
+        w = torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02
+        ws.append((name, n, k) + ops.int8_quantize_rowwise(w))
+        if k not in xs:  # `rot` distinct activation chunks per K (rot x 2048 x K x 2 B >> the 256 MiB Infinity Cache at K = 14336)
+            xs[k] = [torch.randn(chunk, k, device=device, dtype=torch.bfloat16, generator=gen) for _ in range(rot)]
+    def layer():
+        for name, n, k, wq, wsc in ws:
+            for c in range(nchunk):
+                xq, xsc = ops.int8_quantize_rowwise(xs[k][c % rot])
+                ops.int8_scaled_mm(xq, xsc, wq, wsc)
+    with torch.cuda.stream(stream):
+        t, graphed = _graph_time(layer, stream, device, steps=2, warmup=1)
+        prof = event_profile(lib, _lib.check, layer, 2 * nchunk * len(ws) + 8)
+    M = chunk * nchunk
+    flops = sum(2.0 * M * n * k for _, n, k, _, _ in ws)
+    cast_ms, gemm_ms = float(prof[0::2].sum()), float(prof[1::2].sum())
+    out = {"workload": "Int8DynamicActivationInt8WeightConfig Llama-3-8B linear shapes, M = 128 x 2048 = 262144 rows in 2048-row chunks, "
+                       "1 of 32 layers timed (x32 = one forward; every layer does the same work)",
+           "value": M / (t * N_LAYERS), "unit": "tokens/s", "ms_per_layer": t * 1e3, "dtype": "int8 x int8 -> int32, bf16 out",
+           "launch": "hipGraph replay" if graphed else "eager", "launches_per_layer": 2 * nchunk * len(ws),
+           "roofline": {"kernel": "gemm8_dma_kernel", "bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_8BIT_PEAK_TOPS,
+                        "unit": "TOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_8BIT_PEAK_TOPS, "traffic": None,
+                        "timing": "HIP extension events, one eager layer", "gemm_ms_per_layer": gemm_ms, "act_cast_ms_per_layer": cast_ms,
+                        "end_to_end_TOPs": flops / t / 1e12}}
+    if not args.no_cpu_baseline:
+        from oracle import c_ref
+        rng = np.random.default_rng(1)
+        rows, tt = 16, 0.0
+        for name, n, k, wq, wsc in ws:
+            x = (rng.standard_normal((rows, k)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            wqc, wsn = wq.cpu().numpy(), wsc.flatten().cpu().numpy()
+            t0 = time.perf_counter()
+            c_ref.int8_dynamic_linear(x, wqc, wsn)
+            tt += time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": rows / (tt * N_LAYERS), "unit": "tokens/s", "cores": c_ref.num_threads(), "kind": "port",
+                               "sample": f"{rows} rows through the 5 linears of 1 layer, x32 extrapolated; oracle/lowbit_ref.c ao_ref_int8_dynamic_linear"}
+    return out
+
+
+def _fp8_layer_fns(device, shard_of, layers, ms, gen):
+    """Quantized Llama-3-70B shard weights (shard_of = TP degree), per-M activation sets, and a step function per M."""
+    from ao_amd import ops
+    wts = []
+    for _ in range(layers):
+        for name, n, k, style in LLAMA3_70B:
+            ns, ks = (n // shard_of, k) if style == "col" else (n, k // shard_of)
+            w = torch.randn(ns, ks, device=device, dtype=torch.bfloat16, generator=gen) * 0.02
+            wts.append((name, ns, ks) + ops.fp8_quantize_rowwise(w))
+            del w
+    xs = {m: {ks: torch.randn(m, ks, device=device, dtype=torch.bfloat16, generator=gen) for ks in {w[2] for w in wts}} for m in ms}
+    def step(m):
+        for name, ns, ks, wq, wsc in wts:
+            x = xs[m][ks]
+            if ops.dynamic_linear_preferred(m, ns, ks):
+                ops.fp8_dynamic_linear(x, wq, wsc)
+            else:
+                xq, xsc = ops.fp8_quantize_rowwise(x)
+                ops.fp8_scaled_mm(xq, wq.t(), xsc, wsc.t())
+    return wts, step
+
+
+def config_fp8_shards(stream, device, args):
+    """configs[3], one GPU's share of the work: the Llama-3-70B TP=8 shard linears (no collective on one GPU)."""
+    gen = torch.Generator(device=device).manual_seed(2)
+    layers, ms = 80, (1, 128, 2048)
+    wts, step = _fp8_layer_fns(device, 8, layers, ms, gen)
+    wbytes = sum(ns * ks for _, ns, ks, _, _ in wts)
+    res = {}
+    with torch.cuda.stream(stream):
+        for m in ms:
+            t, graphed = _graph_time(lambda: step(m), stream, device, steps=3 if m == 2048 else 10)
+            flops = sum(2.0 * m * ns * ks for _, ns, ks, _, _ in wts)
+            bts = wbytes + sum(m * ks * 2 + m * ns * 2 for _, ns, ks, _, _ in wts)
+            hbm = m <= 128  # AI = 2 M flop per weight byte: HBM-bound below M ~ 600
+            res[f"M{m}"] = {"tokens_per_s": m / t, "ms_per_step": t * 1e3, "TFLOPs": flops / t / 1e12, "GBps": bts / t / 1e9,
+                            "bound": "hbm" if hbm else "mfma", "frac": (bts / t / 1e9 / HBM_PEAK_GBS) if hbm else (flops / t / 1e12 / MFMA_8BIT_PEAK_TOPS)}
+    m = 2048
+    out = {"workload": "Float8DynamicActivationFloat8WeightConfig(PerRow) Llama-3-70B linear shapes, one GPU's TP=8 shards "
+                       "(qkv 1280x8192, o 8192x1024, gate_up 7168x8192, down 8192x3584), 80 layers, activation cast + scaled mm per linear",
+           "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (per GPU, M = 2048, before the all-reduce)", "dtype": "e4m3 x e4m3 -> fp32, bf16 out",
+           "by_M": res,
+           "roofline": {"kernel": "gemm8_dma_kernel", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
+                        "frac": res["M2048"]["frac"], "traffic": None, "timing": "hipGraph replay wall time of the whole step (casts included)"}}
+    if not args.no_cpu_baseline:
+        from oracle import c_ref
+        rng = np.random.default_rng(2)
+        rows, tt = 8, 0.0
+        for name, ns, ks, wq, wsc in wts[:4]:
+            x = (rng.standard_normal((rows, ks)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            wqc, wsn = wq.view(torch.uint8).cpu().numpy(), wsc.flatten().cpu().numpy()
+            t0 = time.perf_counter()
+            c_ref.fp8_rowwise_linear(x, wqc, wsn)
+            tt += time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": rows / (tt * layers), "unit": "tokens/s", "cores": c_ref.num_threads(), "kind": "port",
+                               "sample": f"{rows} rows through the 4 shard linears of 1 layer, x80 extrapolated; oracle/lowbit_ref.c ao_ref_fp8_rowwise_linear"}
+    return out
+
+
+def mixtral_offs(rows=128, experts=8, seed=0):
+    """group sizes = 32 * multinomial (seeded), cumulative ends."""
+    rng = np.random.default_rng(seed)
+    sizes = 32 * rng.multinomial(rows // 32, np.full(experts, 1.0 / experts))
+    return np.cumsum(sizes).astype(np.int32), sizes
+
+
+def config_mx(stream, device, args):
+    """configs[4]: MXFP8 grouped GEMM, Mixtral-8x7B expert shapes, 64 tokens x top-2 = 128 rows."""
+    from ao_amd import ops
+    E, rows, layers = 8, 128, N_LAYERS
+    offs_np, sizes = mixtral_offs(rows, E)
+    offs = torch.from_numpy(offs_np).to(device)
+    gen = torch.Generator(device=device).manual_seed(3)
+    wts = []
+    for _ in range(layers):
+        for name, n, k in MIXTRAL:
+            w = torch.randn(E, n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02
+            wts.append((name, n, k) + ops.mxfp8_quantize(w, "rceil"))  # expert weights are cast ONCE (weight prep)
+            del w
+    xs = {k: torch.randn(rows, k, device=device, dtype=torch.bfloat16, generator=gen) for k in (4096, 14336)}
+    def step():
+        for name, n, k, wq, wsc in wts:
+            aq, asc = ops.mxfp8_quantize(xs[k], "rceil")  # activations: dynamic cast every forward
+            ops.mxfp8_grouped_mm(aq, asc, wq, wsc, offs)
+    with torch.cuda.stream(stream):
+        t, graphed = _graph_time(step, stream, device, steps=5)
+    used = int((sizes > 0).sum())
+    bts = sum(used * n * k * (1 + 1 / 32) + rows * k * 2 + rows * k * (1 + 1 / 32) + rows * n * 2 for _, n, k, _, _ in wts)
+    flops = sum(2.0 * rows * n * k for _, n, k, _, _ in wts)
+    out = {"workload": f"MXFP8 grouped GEMM (to_mx RCEIL + scaled grouped mm), Mixtral-8x7B expert shapes E=8 (w1, w3 14336x4096; w2 4096x14336), "
+                       f"64 tokens x top-2 = 128 rows, group sizes {sizes.tolist()} (32 x multinomial, seed 0), 32 layers",
+           "value": 64 / t, "unit": "tokens/s", "ms_per_step": t * 1e3, "dtype": "e4m3 x e4m3 with E8M0 1x32 block scales, bf16 out",
+           "launch": "hipGraph replay" if graphed else "eager",
+           "roofline": {"kernel": "rb8_kernel<RB8_MX>", "bound": "hbm", "achieved": bts / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bts / t / 1e9 / HBM_PEAK_GBS, "traffic": None, "timing": "hipGraph replay wall time of the whole step (activation casts included)",
+                        "bytes_note": "weights of the experts that received tokens only", "TFLOPs": flops / t / 1e12}}
+    if not args.no_cpu_baseline:
+        from oracle import c_ref
+        rng = np.random.default_rng(3)
+        ncols = 1024
+        name, n, k, wq, wsc = wts[0]
+        a = (rng.standard_normal((rows, k)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        wqc, wsn = wq.view(torch.uint8)[:, :ncols].cpu().numpy(), wsc.view(torch.uint8)[:, :ncols].cpu().numpy()
+        t0 = time.perf_counter()
+        c_ref.mxfp8_grouped_mm(a, wqc, wsn, offs_np)
+        tt = time.perf_counter() - t0
+        per_layer = tt * 3 * (14336 / ncols)  # w1, w3 and w2 have the same N x K product
+        out["cpu_baseline"] = {"value": 64 / (per_layer * layers), "unit": "tokens/s", "cores": c_ref.num_threads(), "kind": "port",
+                               "sample": f"128 rows x {ncols} of w1's 14336 output columns (all 8 experts), scaled to 3 projections x 32 layers; "
+                                         "oracle/lowbit_ref.c ao_ref_mxfp8_grouped_mm (emulated dequant -> bf16 grouped mm path)"}
+    return out
+
+
+def config_fp8_tp(stream, device, args, dist, world):
+    """configs[3] for real when N > 1: Llama-3-70B linears sharded TP = N over RCCL (ao_amd/parallel.py)."""
+    from ao_amd import parallel
+    from ao_amd.quantization import Float8DynamicActivationFloat8WeightConfig, quantize_
+    gen = torch.Generator(device=device).manual_seed(4)
+    layers = 8  # of 80: the same four linears per layer; tokens/s is extrapolated x10 (weights of 8 layers are 2.7 GB per GPU at TP=8)
+    mods = []
+    for _ in range(layers):
+        for name, n, k, style in LLAMA3_70B:
+            lin = torch.nn.Linear(k, n, bias=False, device=device, dtype=torch.bfloat16)
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02)
+            quantize_(lin, Float8DynamicActivationFloat8WeightConfig())
+            mods.append((name, style, parallel.shard_linear_(lin, "colwise" if style == "col" else "rowwise", reduce="exact")))
+            del lin
+    torch.cuda.empty_cache()
+    res = {}
+    for m in (1, 128, 2048):
+        xs = {}
+        for name, style, mod in mods:
+            kdim = mod.weight.shape[1]
+            xs.setdefault(kdim, torch.randn(m, kdim, device=device, dtype=torch.bfloat16, generator=gen))
+        def step():
+            for name, style, mod in mods:
+                mod(xs[mod.weight.shape[1]])
+        steps = 5 if m == 2048 else 20
+        with torch.cuda.stream(stream):
+            for _ in range(3):
+                step()
+            t = time_steps(step, stream, device, steps, 2, dist) / steps
+            # the collectives alone, same sizes and order: amax MAX [M] + fp32 SUM [M, 8192] per row-parallel linear
+            bufs = [(torch.zeros(m, device=device), torch.zeros(m, 8192, device=device)) for _ in range(2)]
+            def comm():
+                for name, style, mod in mods:
+                    if style == "row":
+                        a, b = bufs[0]
+                        dist.all_reduce(a, op=dist.ReduceOp.MAX)
+                        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            for _ in range(3):
+                comm()
+            tc = time_steps(comm, stream, device, steps, 2, dist) / steps
+        flops = sum(2.0 * m * n * k for _, n, k, _ in LLAMA3_70B) * layers / world
+        res[f"M{m}"] = {"tokens_per_s": m / (t * 80 / layers), "ms_per_8_layers": t * 1e3, "allreduce_ms_per_8_layers": tc * 1e3,
+                        "allreduce_bytes_per_row_linear": m * 8192 * 4 + m * 4, "per_gpu_TFLOPs": flops / t / 1e12,
+                        "per_gpu_frac_of_fp8_mfma_peak": flops / t / 1e12 / MFMA_8BIT_PEAK_TOPS}
+    return {"workload": f"Float8 rowwise Llama-3-70B linears, TP={world} over RCCL (column-parallel qkv / gate_up, row-parallel o / down with the "
+                        "exact protocol: amax all-reduce(MAX) + fp32 accumulator all-reduce(SUM) + one scale epilogue), 8 of 80 layers timed, eager launches",
+            "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (M = 2048, x10 extrapolated to 80 layers)", "by_M": res}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -252,58 +563,51 @@ def main():
     if args.wpb or args.mode:
         lib.ao_int4_set_tuning(args.wpb, args.mode)
 
-    shapes = LLAMA3_8B_UNMERGED if args.unmerged else LLAMA3_8B_MERGED
-    model, stream, elapsed, graphed = build_and_time(args, device, shapes, args.steps, args.warmup, dist, world)
-    sp = stream.cuda_stream
+    merged = args.merged and not args.unmerged
+    shapes = LLAMA3_8B_MERGED if merged else LLAMA3_8B_UNMERGED
+    stream = torch.cuda.Stream(device=device)
+    model = Int4Linears(device, args.layers, shapes)
+    elapsed, graphed = run_int4(model, args.batch, args.steps, args.warmup, stream, device, not args.no_graph, dist)
     ms_per_step = elapsed * 1e3 / args.steps
     tokens_per_s = args.batch * world * args.steps / elapsed
 
-    # live per-kernel timing (eager pass, HIP extension events on `stream`)
-    prof = None
-    if rank == 0:
-        with torch.cuda.stream(stream):
-            durs = [profile_kernels(model, sp) for _ in range(3)]
-        prof = np.mean(np.stack(durs), axis=0)  # ms per launch, launch order
+    roof = int4_roofline(model, args.batch, stream) if rank == 0 else None
 
     # the other module layout, for the record (rank 0 of a 1-GPU run only: it doubles resident weights)
     other_tok_s = None
     if rank == 0 and world == 1 and not args.no_second_layout:
-        del_model = model  # keep the first model alive until its numbers are computed below
-        other_shapes = LLAMA3_8B_MERGED if args.unmerged else LLAMA3_8B_UNMERGED
+        m2 = Int4Linears(device, args.layers, LLAMA3_8B_UNMERGED if merged else LLAMA3_8B_MERGED)
         steps2 = min(args.steps, 20)
-        m2, _, e2, _ = build_and_time(args, device, other_shapes, steps2, min(args.warmup, 3), None, 1)
+        e2, _ = run_int4(m2, args.batch, steps2, min(args.warmup, 3), stream, device, not args.no_graph)
         other_tok_s = args.batch * steps2 / e2
         del m2
         torch.cuda.empty_cache()
 
+    configs = {}
+    want = set() if args.no_configs else set(args.configs.split(","))
+    if rank == 0 and world == 1 and args.batch == 1:
+        for key, fn in (("int4_bs128", lambda: config_int4_bs128(model, stream, device, args)),
+                        ("int8", lambda: config_int8(stream, device, args)),
+                        ("fp8", lambda: config_fp8_shards(stream, device, args)),
+                        ("mx", lambda: config_mx(stream, device, args))):
+            if key in want:
+                name = {"int8": "int8_dyn_bs128x2048", "fp8": "fp8_tp8_shards", "mx": "mxfp8_mixtral_bs64"}.get(key, key)
+                try:
+                    configs[name] = fn()
+                except Exception as e:  # noqa: BLE001 -- a secondary config must not take the headline line down
+                    configs[name] = {"error": repr(e)}
+                torch.cuda.empty_cache()
+    if world > 1 and "tp" in want and args.batch == 1:
+        model.io = {}
+        try:
+            tp = config_fp8_tp(stream, device, args, dist, world)
+        except Exception as e:  # noqa: BLE001
+            tp = {"error": repr(e)}
+        if rank == 0:
+            configs["fp8_tp"] = tp
+
     if rank == 0:
-        bytes_step = model.bytes_per_step()
-        n_launch = len(model.launches)
-        per_shape, kernels = {}, {}
-        for name, n, k in shapes:
-            idx = [i for i, l in enumerate(model.launches) if l[7] == name]
-            b = algorithmic_bytes(args.batch, n, k, GROUP)
-            ms = float(prof[idx].mean())
-            kern = lib.ao_int4_mm_kernel_name(args.batch, n, k, GROUP).decode()
-            per_shape[name] = {"N": n, "K": k, "bytes": b, "us": ms * 1e3, "GBps": b / (ms * 1e-3) / 1e9, "kernel": kern}
-            kk = kernels.setdefault(kern, {"launches_per_step": 0, "bytes_per_step": 0, "ms_per_step": 0.0})
-            kk["launches_per_step"] += len(idx)
-            kk["bytes_per_step"] += b * len(idx)
-            kk["ms_per_step"] += float(prof[idx].sum())
-        for kk in kernels.values():
-            kk["avg_kernel_us"] = kk["ms_per_step"] * 1e3 / kk["launches_per_step"]
-            kk["algorithmic_bytes_per_launch"] = kk["bytes_per_step"] / kk["launches_per_step"]
-            kk["GBps"] = kk["bytes_per_step"] / (kk["ms_per_step"] * 1e-3) / 1e9
-        dom = max(kernels, key=lambda k_: kernels[k_]["ms_per_step"])
-        achieved = kernels[dom]["GBps"]
-        # batched (bs >= 64) int4-wo is past the HBM ridge: weights are dequantised to bf16 and multiplied on the
-        # bf16 MFMA path, so the bounding roofline is the dense bf16 MFMA peak (2.5 PFLOP/s)
-        mfma_bound = args.batch >= 64
-        flops_step = sum(2.0 * m * n * k for (_, _, _, _, m, n, k, _) in model.launches)
-        pmc, pmc_path = pmc_traffic()
-        traffic = None
-        if pmc is not None and dom in pmc.get("kernels", {}):
-            traffic = pmc["kernels"][dom].get("hbm_bytes_per_launch")
+        bytes_step = model.bytes_per_step(args.batch)
         roofline_tok_s = HBM_PEAK_GBS * 1e9 / bytes_step * args.batch
         out = {
             "metric": "linear-layer tokens/sec, Llama-3-8B int4-wo (tinygemm g128), bs=%d" % args.batch,
@@ -321,34 +625,20 @@ def main():
             "config": {
                 "workload": "Int4WeightOnlyConfig(group_size=128) Llama-3-8B linear shapes, bs=%d seq=1, %d layers x {%s}"
                 % (args.batch, args.layers, ", ".join("%s %dx%d" % s_ for s_ in shapes)),
-                "module_layout": "HF (gate_proj, up_proj separate)" if args.unmerged else "vLLM (merged qkv_proj, gate_up_proj)",
+                "module_layout": "vLLM (merged qkv_proj, gate_up_proj)" if merged else "SURVEY.md 8(d) five shapes (qkv merged; gate, up separate)",
                 "launch": "hipGraph replay" if graphed else "eager",
                 "parallelism": "dp%d (one token stream per GPU, no collective)" % world,
                 "bytes_per_token": bytes_step,
                 "hbm_roofline_tokens_per_s": roofline_tok_s,
                 "frac_of_hbm_roofline_end_to_end": (tokens_per_s / world) / roofline_tok_s,
-                ("merged_tokens_per_s" if args.unmerged else "unmerged_tokens_per_s"): other_tok_s,
+                ("unmerged_tokens_per_s" if merged else "merged_tokens_per_s"): other_tok_s,
             },
-            "roofline": {
-                "kernel": dom,
-                "bound": "mfma" if mfma_bound else "hbm",
-                "achieved": (flops_step / (float(prof.sum()) * 1e-3) / 1e12) if mfma_bound else achieved,
-                "peak": MFMA_BF16_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
-                "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": ((flops_step / (float(prof.sum()) * 1e-3) / 1e12) / MFMA_BF16_PEAK_TFLOPS) if mfma_bound else achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": (os.path.relpath(pmc_path, ROOT) if traffic is not None else None),
-                "avg_kernel_us": kernels[dom]["avg_kernel_us"],
-                "algorithmic_bytes_per_launch": kernels[dom]["algorithmic_bytes_per_launch"],
-                "launches_per_step": n_launch,
-                "sum_kernel_ms_per_step": float(prof.sum()),
-                "all_launches_GBps": (bytes_step / (float(prof.sum()) * 1e-3)) / 1e9,
-                "kernels": kernels,
-                "per_shape": per_shape,
-            },
+            "roofline": roof,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.batch)
+            out["cpu_baseline"] = cpu_baseline_int4(args.batch)
+        if configs:
+            out["configs"] = configs
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

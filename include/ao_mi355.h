@@ -177,6 +177,13 @@ int ao_mxfp8_quantize_rowwise(const uint16_t* x, uint8_t* q, uint8_t* scale_e8m0
                               int64_t R, int64_t C, int scaling_mode,
                               void* stream);
 
+/* The colwise half of torchao::mxfp8_quantize (32 x 1 blocks: one scale per 32 ROWS of a column;
+ * csrc/cuda/mx_kernels/mxfp8_quantize.cuh:460-820, mxfp8_extension.cpp:160-175; == to_mx(x.t()).t()).
+ *   x bf16 [R][C] (R % 32 == 0, C % 32 == 0) -> q_t e4m3fn [C][R] (the column-major data the reference
+ *   returns as a {R, C} tensor with strides {1, R}), scale e8m0 [R/32][C] (its {C, R/32} tensor with strides {1, C}). */
+int ao_mxfp8_quantize_colwise(const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0,
+                              int64_t R, int64_t C, int scaling_mode, void* stream);
+
 /* Replaces aten::_scaled_grouped_mm as called from _compute_fwd_sm100
  * (torchao/prototype/moe_training/mxfp8_grouped_mm.py:541), with the numerics of
  * _emulated_mxfp8_scaled_grouped_mm_2d_3d (:959-1023):
@@ -238,6 +245,31 @@ int ao_int8_dynamic_linear(const uint16_t* x, const int8_t* wq, const float* w_s
 int ao_fp8_dynamic_linear(const uint16_t* x, const uint8_t* wq, const float* w_scale,
                           const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
                           void* stream);
+
+/* ---- K-sharded (row-parallel) 8-bit linears: the unsharded result from sharded operands ---------------------------------
+ * torchao delegates TP to its caller (DTensor / vLLM slice the subclasses: int8_tensor.py:362-422, float8_tensor.py:732-839;
+ * harness torchao/testing/utils.py:370-519).  A caller that wants the UNSHARDED linear's bits from K shards needs the
+ * activation scale over the full K and the scale epilogue applied once, after the partial sums are added:
+ *   amax_local = ao_rowwise_amax(x_shard);  all_reduce(MAX, amax);  q_shard = ao_*_quantize_rowwise_amax(x_shard, amax);
+ *   acc = ao_int8_int_mm / ao_fp8_mm_f32 (q_shard, w_shard);  all_reduce(SUM, acc);  y = ao_*_scale_epilogue(acc).
+ * `ldx` is the row stride of x in elements (a column slice of the full activation needs no copy). */
+int ao_rowwise_amax(const uint16_t* x, int64_t ldx, float* amax, int64_t M, int64_t K, void* stream);
+/* Int8Tensor.from_hp arithmetic (int8_tensor.py:191-230) with the row's amax given instead of reduced over x's K columns. */
+int ao_int8_quantize_rowwise_amax(const uint16_t* x, int64_t ldx, const float* amax, int8_t* q,
+                                  float* scale, int64_t M, int64_t K, void* stream);
+/* Float8Tensor.from_hp arithmetic (float8_tensor.py:167-253) with the row's amax given. */
+int ao_fp8_quantize_rowwise_amax(const uint16_t* x, int64_t ldx, const float* amax, uint8_t* q,
+                                 float* scale, int64_t M, int64_t K, void* stream);
+/* c fp32 [M][N] = a e4m3fn [M][K] @ b e4m3fn [N][K]^T, no scales: the accumulator of aten::_scaled_mm
+ * (float8/inference.py:104-123) before its scale epilogue. */
+int ao_fp8_mm_f32(const uint8_t* a, const uint8_t* b, float* c, int64_t M, int64_t N, int64_t K,
+                  void* stream);
+/* y = bf16( bf16(f32(acc) * x_scale[m]) * w_scale[n] (+ bias[n]) ): the epilogue of int8_tensor.py:315-359 on its own. */
+int ao_int8_scale_epilogue(const int32_t* acc, const float* x_scale, const float* w_scale,
+                           const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, void* stream);
+/* y = bf16( acc * scale_a[m] * scale_b[n] (+ bias[n]) ): the epilogue of aten::_scaled_mm (rowwise) on its own. */
+int ao_fp8_scale_epilogue(const float* acc, const float* scale_a, const float* scale_b,
+                          const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,3 +51,35 @@ def int4_linear(x_bits, qdata, sz_bits, n, k, g):
         _p(x_bits), _p(qdata), _p(sz_bits), _p(y), ctypes.c_int64(m), ctypes.c_int64(n), ctypes.c_int64(k), ctypes.c_int(g)
     )
     return y
+
+
+def int8_dynamic_linear(x_bits, wq, ws):
+    x_bits = np.ascontiguousarray(x_bits, dtype=np.uint16)
+    wq = np.ascontiguousarray(wq, dtype=np.int8)
+    ws = np.ascontiguousarray(ws, dtype=np.float32)
+    (m, k), n = x_bits.shape, wq.shape[0]
+    y = np.empty((m, n), dtype=np.uint16)
+    lib().ao_ref_int8_dynamic_linear(_p(x_bits), _p(wq), _p(ws), _p(y), ctypes.c_int64(m), ctypes.c_int64(n), ctypes.c_int64(k))
+    return y
+
+
+def fp8_rowwise_linear(x_bits, wq, ws):
+    x_bits = np.ascontiguousarray(x_bits, dtype=np.uint16)
+    wq = np.ascontiguousarray(wq, dtype=np.uint8)
+    ws = np.ascontiguousarray(ws, dtype=np.float32)
+    (m, k), n = x_bits.shape, wq.shape[0]
+    y = np.empty((m, n), dtype=np.uint16)
+    lib().ao_ref_fp8_rowwise_linear(_p(x_bits), _p(wq), _p(ws), _p(y), ctypes.c_int64(m), ctypes.c_int64(n), ctypes.c_int64(k))
+    return y
+
+
+def mxfp8_grouped_mm(a_bits, wq, wscale, offs):
+    a_bits = np.ascontiguousarray(a_bits, dtype=np.uint16)
+    wq = np.ascontiguousarray(wq, dtype=np.uint8)
+    wscale = np.ascontiguousarray(wscale, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.int32)
+    (m, k), (e, n, _) = a_bits.shape, wq.shape
+    y = np.empty((m, n), dtype=np.uint16)
+    lib().ao_ref_mxfp8_grouped_mm(_p(a_bits), _p(wq), _p(wscale), _p(offs), _p(y), ctypes.c_int64(m), ctypes.c_int64(e),
+                                  ctypes.c_int64(n), ctypes.c_int64(k))
+    return y

@@ -47,8 +47,8 @@ def e4m3_to_f32(code):
     return E4M3[np.asarray(code, dtype=np.uint8)]
 
 
-def quantize_rowwise(x):
-    """Float8Tensor.from_hp(x, e4m3, PerRow):
+def quantize_rowwise(x, amax=None):
+    """Float8Tensor.from_hp(x, e4m3, PerRow) (`amax`: see int8_ref.quantize_rowwise):
     torchao/quantization/quantize_/workflows/float8/float8_tensor.py:167-253 ->
     _choose_scale_float8 (quant_primitives.py:2192-2212) and
     _quantize_affine_float8 (:2271-2287), input bf16:
@@ -57,8 +57,9 @@ def quantize_rowwise(x):
     Returns (codes uint8 [M,K], scale fp32 [M])."""
     x = np.asarray(x, dtype=np.float32)
     assert bf16.is_bf16(x)
-    amax = np.abs(x).max(axis=1)
-    scale = bf16.div(amax, E4M3_MAX).astype(np.float32)
+    if amax is None:
+        amax = np.abs(x).max(axis=1)
+    scale = bf16.div(np.asarray(amax, dtype=np.float32), E4M3_MAX).astype(np.float32)
     with np.errstate(divide="ignore", invalid="ignore"):
         t = (x / scale[:, None]).astype(np.float32)
     t = np.clip(t, -E4M3_MAX, E4M3_MAX)  # NaN stays NaN

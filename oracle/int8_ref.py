@@ -10,8 +10,10 @@ from . import bf16
 F32_EPS = np.float32(np.finfo(np.float32).eps)  # eps passed at int8_tensor.py:210
 
 
-def quantize_rowwise(x):
+def quantize_rowwise(x, amax=None):
     """Int8Tensor.from_hp(x, PerRow()) with the defaults (SYMMETRIC, int8).
+    `amax` (optional, [M]): the rows' amax when x is only a column shard of the tensor the reference would quantize
+    (K-sharded TP linears); default: reduced over x's own columns.
 
     torchao/quantization/quantize_/workflows/int8/int8_tensor.py:191-230 ->
     choose_qparams_affine (quant_primitives.py:1534-1583) and quantize_affine
@@ -23,9 +25,11 @@ def quantize_rowwise(x):
     """
     x = np.asarray(x, dtype=np.float32)
     assert bf16.is_bf16(x)
-    mn = np.minimum(x.min(axis=1), 0)
-    mx = np.maximum(x.max(axis=1), 0)
-    amax = np.maximum(-mn, mx)
+    if amax is None:
+        mn = np.minimum(x.min(axis=1), 0)
+        mx = np.maximum(x.max(axis=1), 0)
+        amax = np.maximum(-mn, mx)
+    amax = np.asarray(amax, dtype=np.float32)
     scale = bf16.div(amax, np.float32(127.5))
     scale = np.maximum(scale, bf16.bf16_round(F32_EPS)).astype(np.float32)
     inv = (np.float32(1.0) / scale).astype(np.float32)

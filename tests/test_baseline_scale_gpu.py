@@ -1,0 +1,205 @@
+"""GPU parity at the sizes BASELINE.json quotes ("parity holes at BASELINE scale"), HIP path vs the oracle:
+
+* int4 tinygemm linear at the merged gate_up_proj width (28672 x 4096, M = 1, g128) -- the headline's biggest launch;
+* MXFP8 grouped GEMM on the Mixtral-8x7B expert shapes (E = 8, 14336 x 4096 and 4096 x 14336) with the seeded multinomial
+  group sizes of SURVEY.md 8(d) (and the uniform 16-rows-per-expert case);
+* int8 dynamic / fp8 rowwise linears at M = 2048 on the four Llama-3-8B shapes and the Llama-3-70B TP=8 shards;
+* fp8_dynamic_linear (cast fused into the matmul) directly against oracle/fp8_ref;
+* the K-sharded (row-parallel) 8-bit protocol of ao_amd/parallel.py against the UNSHARDED oracle linear.
+
+The oracle side is bounded by sampling output rows / columns (the kernels still run the full shape): oracle/lowbit_ref.c
+(OpenMP; itself pinned to the numpy oracles in tests/test_oracle_c.py) or numpy on the sample.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import np_from_torch_bf16, torch_bf16_from_f32
+from oracle import bf16, c_ref, fp8_ref as F, int4_ref as R, int8_ref as I, mx_ref as MX
+
+pytestmark = pytest.mark.gpu
+
+from ao_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _randn_bf16(shape, seed, scale=1.0, device="cpu"):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=device) * scale).to(torch.bfloat16)
+
+
+def _bits(t):
+    """bf16 torch tensor -> uint16 numpy"""
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+# ---- int4: the merged gate_up_proj launch of the headline ---------------------------------------------------------
+@pytest.mark.parametrize("n,k,m", [(28672, 4096, 1), (14336, 4096, 1), (4096, 14336, 1), (28672, 4096, 3)])
+def test_int4_mm_baseline_shapes_vs_oracle(n, k, m):
+    g = 128
+    w = _randn_bf16((n, k), n + k, 0.02, DEV)
+    x = _randn_bf16((m, k), n + k + 1, 1.0, DEV)
+    qdata, sz = ops.int4_quantize_tinygemm(w, g)
+    y = np_from_torch_bf16(ops.weight_int4pack_mm(x, qdata, g, sz))
+    # the weight prep itself against the numpy oracle on a slab of rows (bit-exact), the matmul against the C port of
+    # the reference dequant -> matmul path on the GPU-produced (= oracle-identical) packed weight
+    wn = w[:64].float().cpu().numpy()
+    s, z = R.choose_qparams_tinygemm(wn, g)
+    q = R.quantize_tinygemm(wn, s, z, g)
+    assert np.array_equal(qdata[:8].cpu().numpy(), R.convert_weight_to_int4pack(R.nibble_pack(q)))
+    y_ref = bf16.from_bits(c_ref.int4_linear(_bits(x), qdata.cpu().numpy(), _bits(sz), n, k, g))
+    assert _rel(y, y_ref) <= 1e-3
+    assert np.all(np.abs(y - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + 1e-6)
+    assert np.mean(y == y_ref) > 0.97
+
+
+# ---- MXFP8 grouped GEMM: Mixtral-8x7B expert shapes ------------------------------------------------------------------
+def _mixtral_offs(kind, rows=128, experts=8, seed=0):
+    if kind == "uniform16":
+        sizes = np.full(experts, rows // experts)
+    else:  # offs = 32 * round(multinomial) cumulative (seeded), 64 tokens x top-2 = 128 rows
+        rng = np.random.default_rng(seed)
+        sizes = 32 * rng.multinomial(rows // 32, np.full(experts, 1.0 / experts))
+    return np.cumsum(sizes).astype(np.int32), sizes
+
+
+@pytest.mark.parametrize("kind", ["multinomial32", "uniform16"])
+@pytest.mark.parametrize("n,k", [(14336, 4096), (4096, 14336)])
+def test_mxfp8_grouped_mm_mixtral_vs_oracle(n, k, kind):
+    E = 8
+    offs, sizes = _mixtral_offs(kind)
+    M = int(offs[-1])
+    a = _randn_bf16((M, k), 31, 1.0, DEV)
+    w = _randn_bf16((E, n, k), 32, 0.02, DEV)
+    w_d, w_s = ops.mxfp8_quantize(w, "rceil")
+    del w
+    a_d, a_s = ops.mxfp8_quantize(a, "rceil")
+    y = np_from_torch_bf16(ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, torch.from_numpy(offs).to(DEV)))
+    # oracle on a sample of output columns (every 7th 16-wide tile and the last one), every row
+    tiles = np.unique(np.concatenate([np.arange(0, n // 16, 7), [n // 16 - 1]]))
+    cols = (tiles[:, None] * 16 + np.arange(16)[None, :]).reshape(-1)
+    ci = torch.from_numpy(cols).to(DEV)
+    wq_s = w_d.view(torch.uint8)[:, ci].cpu().numpy()
+    ws_s = w_s.view(torch.uint8)[:, ci].cpu().numpy()
+    y_ref = bf16.from_bits(c_ref.mxfp8_grouped_mm(_bits(a), wq_s, ws_s, offs))
+    # the cast of the activations on the GPU is bit-exact against the oracle's (so both sides multiply the same codes)
+    aq, asc = MX.to_mx(a.float().cpu().numpy(), MX.RCEIL)
+    assert np.array_equal(a_d.view(torch.uint8).cpu().numpy(), aq) and np.array_equal(a_s.view(torch.uint8).cpu().numpy(), asc)
+    ys = y[:, cols]
+    assert _rel(ys, y_ref) <= 1e-3
+    # one bf16 ulp + fp32 accumulation-order noise relative to the column's magnitude
+    scale = np.abs(y_ref).max() + 1e-30
+    assert np.all(np.abs(ys - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + scale * 2.0 ** -12)
+
+
+# ---- int8 dynamic / fp8 rowwise at M = 2048 ---------------------------------------------------------------------------
+LLAMA8B = [(6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)]
+LLAMA70B_TP8 = [(1024, 8192), (8192, 1024), (7168, 8192), (8192, 3584)]
+
+
+def _sample(n, m, seed):
+    rng = np.random.default_rng(seed)
+    rows = np.unique(np.concatenate([[0, m - 1], rng.integers(0, m, 14)]))
+    tiles = np.unique(np.concatenate([[0, n // 16 - 1], rng.integers(0, n // 16, 30)]))
+    cols = (tiles[:, None] * 16 + np.arange(16)[None, :]).reshape(-1)
+    return rows, cols
+
+
+@pytest.mark.parametrize("n,k", LLAMA8B + LLAMA70B_TP8)
+def test_int8_dynamic_linear_m2048_vs_oracle(n, k):
+    m = 2048
+    x = _randn_bf16((m, k), n + 3, 1.0, DEV)
+    w = _randn_bf16((n, k), k + 5, 0.02, DEV)
+    wq, ws = ops.int8_quantize_rowwise(w)
+    xq, xs = ops.int8_quantize_rowwise(x)
+    y = ops.int8_scaled_mm(xq, xs, wq, ws)
+    rows, cols = _sample(n, m, n + k)
+    ri, ci = torch.from_numpy(rows).to(DEV), torch.from_numpy(cols).to(DEV)
+    y_ref = c_ref.int8_dynamic_linear(_bits(x[ri]), wq[ci].cpu().numpy(), ws.flatten()[ci].cpu().numpy())
+    got = _bits(y[ri][:, ci])
+    assert np.array_equal(got, y_ref)  # int32 accumulation + the reference's two roundings: bit for bit
+
+
+@pytest.mark.parametrize("n,k", LLAMA8B + LLAMA70B_TP8)
+def test_fp8_rowwise_linear_m2048_vs_oracle(n, k):
+    m = 2048
+    x = _randn_bf16((m, k), n + 7, 1.0, DEV)
+    w = _randn_bf16((n, k), k + 9, 0.02, DEV)
+    wq, ws = ops.fp8_quantize_rowwise(w)
+    xq, xs = ops.fp8_quantize_rowwise(x)
+    y = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t())
+    rows, cols = _sample(n, m, n + k + 1)
+    ri, ci = torch.from_numpy(rows).to(DEV), torch.from_numpy(cols).to(DEV)
+    y_ref = bf16.from_bits(c_ref.fp8_rowwise_linear(_bits(x[ri]), wq.view(torch.uint8)[ci].cpu().numpy(), ws.flatten()[ci].cpu().numpy()))
+    got = np_from_torch_bf16(y[ri][:, ci])
+    assert _rel(got, y_ref) <= 1e-3
+    assert np.all(np.abs(got - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -14)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1024, 8192), (1, 8192, 3584), (4, 4096, 4096), (2, 256, 1024)])
+def test_fp8_dynamic_linear_vs_oracle_directly(m, n, k):
+    if not ops.dynamic_linear_fits(m, n, k):
+        pytest.skip("shape outside the fused kernel's range")
+    x = _randn_bf16((m, k), 3 * n + m, 1.0)
+    w = _randn_bf16((n, k), 5 * k + m, 0.02)
+    bias = _randn_bf16((n,), 17)
+    wq, ws = ops.fp8_quantize_rowwise(w.to(DEV))
+    y = np_from_torch_bf16(ops.fp8_dynamic_linear(x.to(DEV), wq, ws, bias.to(DEV)))
+    y_ref = F.linear(x.float().numpy(), w.float().numpy(), bias.float().numpy())
+    assert _rel(y, y_ref) <= 1e-3
+    assert np.all(np.abs(y - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -14)
+
+
+# ---- K-sharded (row-parallel) 8-bit linears: the unsharded oracle from sharded operands ---------------------------------
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_row_parallel_blocks_match_unsharded_oracle(kind, world):
+    """Every rank's steps of ao_amd.parallel.RowParallelLinear's exact protocol, run on one GPU and combined the way the
+    collectives would (max of the amax, integer / fp32 sum of the accumulators), against the UNSHARDED oracle linear."""
+    from ao_amd.parallel import shard_bounds
+
+    n, k, m = 512, 3584, 37  # 3584 / 128 = 28 k-units: uneven shards at world 8
+    x = _randn_bf16((m, k), 41, 1.0)
+    x[:, 777] *= 32.0  # the row amax sits in one shard
+    w = _randn_bf16((n, k), 42, 0.05)
+    bias = _randn_bf16((n,), 43)
+    ref = I if kind == "int8" else F
+    want = ref.linear(x.float().numpy(), w.float().numpy(), bias.float().numpy())
+    xd, wd = x.to(DEV), w.to(DEV)
+    wq, ws = (ops.int8_quantize_rowwise if kind == "int8" else ops.fp8_quantize_rowwise)(wd)
+    spans = [shard_bounds(k, world, r, 128) for r in range(world)]
+    amax = torch.stack([ops.rowwise_amax(xd[:, k0:k1]) for k0, k1 in spans]).amax(dim=0)  # all_reduce(MAX)
+    assert torch.equal(amax, xd.float().abs().amax(dim=1))
+    acc = None
+    for k0, k1 in spans:
+        if kind == "int8":
+            xq, xs = ops.int8_quantize_rowwise_amax(xd[:, k0:k1], amax)  # strided view: no copy
+            part = ops.int_mm(xq, wq[:, k0:k1].contiguous().t())
+        else:
+            xq, xs = ops.fp8_quantize_rowwise_amax(xd[:, k0:k1], amax)
+            part = ops.fp8_mm_f32(xq, wq[:, k0:k1].contiguous().t())
+        acc = part if acc is None else acc + part  # all_reduce(SUM)
+    # the shard casts are the shards of the unsharded cast, the scale is the unsharded scale
+    xq_full, xs_full = (ops.int8_quantize_rowwise if kind == "int8" else ops.fp8_quantize_rowwise)(xd)
+    assert torch.equal(xs, xs_full)
+    assert torch.equal(xq.view(torch.uint8), xq_full.view(torch.uint8)[:, spans[-1][0]:])
+    y = (ops.int8_scale_epilogue if kind == "int8" else ops.fp8_scale_epilogue)(acc, xs, ws, bias.to(DEV))
+    yn = np_from_torch_bf16(y)
+    if kind == "int8":
+        assert np.array_equal(yn, want)
+    else:
+        assert _rel(yn, want) <= 1e-3
+        assert np.all(np.abs(yn - want) <= np.abs(want) * 2.0 ** -7 + np.abs(want).max() * 2.0 ** -14)
+    # and it equals the unsharded product path on the same GPU
+    y_full = (ops.int8_scaled_mm(xq_full, xs_full, wq, ws, bias.to(DEV)) if kind == "int8"
+              else ops.fp8_scaled_mm(xq_full, wq.t(), xs_full, ws.t(), bias.to(DEV)))
+    if kind == "int8":
+        assert torch.equal(y, y_full)
+    else:
+        assert _rel(yn, np_from_torch_bf16(y_full)) <= 1e-3

@@ -61,6 +61,99 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+class _OracleBlocks:
+    """The exact row-parallel protocol's compute steps restated with the numpy oracle (CPU): what the HIP kernels compute
+    on the GPU (tests/test_subclass_gpu.py checks those against the same oracle)."""
+
+    @staticmethod
+    def amax(x):
+        return x.float().abs().amax(dim=1)
+
+    @staticmethod
+    def quantize(kind, x, amax):
+        import numpy as np
+        from oracle import fp8_ref, int8_ref
+        f = int8_ref.quantize_rowwise if kind == "int8" else fp8_ref.quantize_rowwise
+        q, s = f(x.float().numpy(), amax.numpy())
+        return torch.from_numpy(q), torch.from_numpy(np.ascontiguousarray(s)).reshape(-1, 1)
+
+    @staticmethod
+    def partial_mm(kind, xq, w):
+        from oracle import fp8_ref, int8_ref
+        if kind == "int8":
+            return torch.from_numpy(int8_ref.int_mm(xq.numpy(), w.qdata.numpy()))
+        a = fp8_ref.e4m3_to_f32(xq.numpy()).astype("float64")
+        b = fp8_ref.e4m3_to_f32(w.qdata.numpy()).astype("float64")
+        return torch.from_numpy((a @ b.T).astype("float32"))
+
+    @staticmethod
+    def epilogue(kind, acc, xs, w, bias):
+        import numpy as np
+        from oracle import bf16
+        c = acc.numpy().astype(np.float32)
+        xs, ws = xs.numpy().reshape(-1, 1).astype(np.float32), w.scale.numpy().reshape(1, -1).astype(np.float32)
+        y = bf16.bf16_round(c * xs) * ws if kind == "int8" else c * xs * ws
+        if bias is not None:
+            y = y + bias.float().numpy()[None, :]
+        return torch.from_numpy(bf16.bf16_round(y.astype(np.float32))).to(torch.bfloat16)
+
+
+def _worker_8bit(rank, world, port, q):
+    """Row-parallel int8 / fp8 dynamic linears over K shards == the UNSHARDED oracle linear (int8 bit for bit)."""
+    import numpy as np
+    from ao_amd.quantization.float8_tensor import Float8Tensor, QuantizeTensorToFloat8Kwargs
+    from ao_amd.quantization.int8_tensor import Int8Tensor, QuantizeTensorToInt8Kwargs
+    from oracle import bf16, fp8_ref, int8_ref
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)
+        n, k, m = 32, 512, 5
+        w = bf16.bf16_round((rng.standard_normal((n, k)) * 0.05).astype(np.float32))
+        x = bf16.bf16_round(rng.standard_normal((m, k)).astype(np.float32))
+        x[:, 300] *= 32.0  # the full-K amax sits in one rank's shard only (power of two: stays bf16)
+        bias = bf16.bf16_round(rng.standard_normal(n).astype(np.float32))
+        xt, bt = torch.from_numpy(x).to(torch.bfloat16), torch.from_numpy(bias).to(torch.bfloat16)
+        out = []
+        for kind, ref, cls, kw in (("int8", int8_ref, Int8Tensor, QuantizeTensorToInt8Kwargs()),
+                                   ("fp8", fp8_ref, Float8Tensor, QuantizeTensorToFloat8Kwargs())):
+            wq, ws = ref.quantize_rowwise(w)
+            wt = cls(torch.from_numpy(wq), torch.from_numpy(np.ascontiguousarray(ws)).reshape(-1, 1), [1, k], torch.bfloat16,
+                     act_quant_kwargs=kw)
+            want = ref.linear(x, w, bias)
+            for parallel_in in (False, True):
+                row = RowParallelLinear(wt, bt, input_is_parallel=parallel_in, blocks=_OracleBlocks)
+                k0, k1 = row.cols
+                y = row(xt[:, k0:k1] if parallel_in else xt).float().numpy()
+                exact = bool(np.array_equal(y, want))
+                rel = float(np.linalg.norm(y - want) / np.linalg.norm(want))
+                out.append((kind, parallel_in, exact, rel))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_parallel_8bit_matches_unsharded_oracle_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_8bit, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for _ in range(world):
+        rank, out = q.get(timeout=10)
+        for kind, parallel_in, exact, rel in out:
+            if kind == "int8":
+                assert exact, (rank, kind, parallel_in, rel)  # integer partial sums: bit for bit the unsharded linear
+            else:
+                assert rel <= 1e-6, (rank, kind, parallel_in, rel)  # fp32 partial sums instead of one float64 sum
+
+
 def test_tp_mlp_world2_gloo():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

@@ -32,8 +32,9 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     shapes = bench.LLAMA3_8B_MERGED if args.layout == "merged" else bench.LLAMA3_8B_UNMERGED
-    model = bench.Int4Linears(dev, args.batch, bench.N_LAYERS, shapes)
+    model = bench.Int4Linears(dev, bench.N_LAYERS, shapes)
     lib = model.lib
+    B = args.batch
     stream = torch.cuda.Stream(device=dev)
     sp = stream.cuda_stream
     cfgs = [(int(w), int(m)) for w in args.wpbs.split(",") for m in args.modes.split(",")]
@@ -41,15 +42,15 @@ def main():
     with torch.cuda.stream(stream):
         for cfg in cfgs:
             lib.ao_int4_set_tuning(*cfg)
-            model.step(sp)
+            model.step(B, sp)
             stream.synchronize()
-            ys = [k[3].float().clone() for k in model.keep[: len(shapes)]]
+            ys = [k[1].float().clone() for k in model.io[B][0][: len(shapes)]]
             if ref is None:
                 ref = ys
             maxrel[cfg] = max(float((a - b).norm() / b.norm()) for a, b in zip(ys, ref))
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
-                model.step(torch.cuda.current_stream().cuda_stream)
+                model.step(B, torch.cuda.current_stream().cuda_stream)
             graphs[cfg] = g
         times = {cfg: [] for cfg in cfgs}
         for _ in range(args.rounds):
@@ -66,10 +67,10 @@ def main():
                 times[cfg].append(e0.elapsed_time(e1) / args.steps)
         for cfg in cfgs:
             lib.ao_int4_set_tuning(*cfg)
-            durs = np.mean(np.stack([bench.profile_kernels(model, sp) for _ in range(2)]), axis=0)
+            durs = np.mean(np.stack([bench.event_profile(lib, model.check, lambda: model.step(B, sp), len(model.weights)) for _ in range(2)]), axis=0)
             per_shape = {}
             for name, n, k in shapes:
-                idx = [i for i, l in enumerate(model.launches) if l[7] == name]
+                idx = [i for i, w in enumerate(model.weights) if w[4] == name]
                 per_shape[name] = round(float(durs[idx].mean()) * 1e3, 2)
             t = sorted(times[cfg])
             print(json.dumps({
