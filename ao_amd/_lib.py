@@ -35,6 +35,9 @@ _SIGNATURES = {
     "ao_int4_weight_int4pack_mm": [_P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_int4_dequantize": [_P, _P, _P, _I64, _I64, _INT, _P],
     "ao_int4_quantize_tinygemm": [_P, _P, _P, _I64, _I64, _INT, _P],
+    "ao_int4_hqq_workspace_bytes": [_I64, _I64, _INT],
+    "ao_int4_quantize_hqq": [_P, _P, _P, _P, _I64, _I64, _INT, _P],
+    "ao_int4_plain_quantize": [_P, _P, _P, _P, _I64, _I64, _INT, _INT, _P],
     "ao_int4_set_tuning": [_INT, _INT],
     "ao_int4_set_trace": [_P],
     "ao_gemm8_set_variant": [_INT],
@@ -46,6 +49,7 @@ _SIGNATURES = {
     "ao_fp8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_mxfp8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _INT, _P],
     "ao_mxfp8_quantize_colwise": [_P, _P, _P, _I64, _I64, _INT, _P],
+    "ao_fp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "ao_mxfp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "ao_dyn_linear_fits": [_I64, _I64, _I64],
     "ao_int8_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
@@ -96,6 +100,7 @@ def lib():
         l.ao_last_error.restype = ctypes.c_char_p
         l.ao_int4_mm_kernel_name.restype = ctypes.c_char_p
         l.ao_moe_padded_rows.restype = _I64
+        l.ao_int4_hqq_workspace_bytes.restype = _I64
         _lib = l
     return _lib
 

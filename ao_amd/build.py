@@ -13,6 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "_C_mi355.so")
+OPS_LIB = os.path.join(HERE, "_C_mi355_ops.so")  # C++ dispatcher registrations (csrc_torch/binding.cpp), links against LIB
+OPS_SRC = os.path.join(HERE, "csrc_torch", "binding.cpp")
+CXX = os.environ.get("CXX", "g++")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
     "--offload-arch=gfx950",
@@ -44,9 +47,39 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_ops(force=False, verbose=False):
+    """Compile the host-only dispatcher binding against the installed torch (no device code: plain g++)."""
+    if not force and os.path.exists(OPS_LIB) and os.path.getmtime(OPS_LIB) >= max(os.path.getmtime(OPS_SRC), os.path.getmtime(LIB)):
+        return OPS_LIB
+    import torch
+
+    t = os.path.dirname(torch.__file__)
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           f"-I{t}/include", f"-I{t}/include/torch/csrc/api/include", "-I/opt/rocm/include", OPS_SRC, "-o", OPS_LIB,
+           f"-L{t}/lib", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", f"-L{HERE}", "-l:_C_mi355.so",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{t}/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if out.returncode != 0:
+        raise RuntimeError(f"building {OPS_LIB} failed:\n{out.stdout.decode()}")
+    return OPS_LIB
+
+
+def _prune_objects(bdir, keep):
+    """Objects of sources that no longer exist must not linger (they never ship -- ao_amd/build/ is gpurun-ignored -- but a
+    stale object is a stale object)."""
+    for f in os.listdir(bdir):
+        p = os.path.join(bdir, f)
+        if f.endswith(".o") and p not in keep:
+            os.remove(p)
+
+
 def build(force=False, verbose=False):
-    """Compile every .hip under ao_amd/csrc into one shared library."""
+    """Compile every .hip under ao_amd/csrc into one shared library, then the dispatcher binding."""
     if not force and not _stale():
+        build_ops(force=False, verbose=verbose)
         return LIB
     objs = []
     procs = []
@@ -63,10 +96,12 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    _prune_objects(bdir, set(objs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if out.returncode != 0:
         raise RuntimeError(f"link failed:\n{out.stdout.decode()}")
+    build_ops(force=True, verbose=verbose)
     return LIB
 
 

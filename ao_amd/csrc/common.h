@@ -12,6 +12,9 @@ namespace ao {
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 int hip_failed(hipError_t e, const char* what);  // sets message, returns AO_ERR_HIP
 
+// opt a kernel into > 48 KiB of dynamic LDS on the current device (once per kernel and device; runtime.hip)
+int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what);
+
 #define AO_REQUIRE(cond, ...)                \
   do {                                       \
     if (!(cond)) {                           \

@@ -135,12 +135,7 @@ int launch_dyn8(const Dyn8Args& p, hipStream_t stream) {
   while (wpb < 8 && ksteps / (wpb * 2) >= 2) wpb *= 2;
   const size_t smem = (size_t)p.M * (p.K + 16) + (size_t)(wpb * kMaxRows + kMaxRows + wpb * 256) * sizeof(float);
   auto kern = dyn8_kernel<INT8>;
-  static size_t granted = 48 * 1024;  // monotonic; a racing duplicate call is harmless
-  if (smem > granted) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(dyn8_kernel)");
-    granted = smem;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(dyn8_kernel)")) return rc;
   ao::launch(kern, dim3((unsigned)(p.N / 16)), dim3(wpb * 64), smem, stream, p);
   AO_LAUNCH_CHECK("dyn8_kernel launch");
   return AO_OK;

@@ -19,7 +19,7 @@ namespace ao {
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
-extern int g_mx_variant;  // stream8_kernels.hip
+extern thread_local int g_mx_variant;  // stream8_kernels.hip
 int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                    int64_t M, int64_t N, int64_t K, hipStream_t stream);
 int int8_scaled_rb(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
@@ -364,23 +364,17 @@ __global__ __launch_bounds__(128 * WN) void gemm8_dma_kernel(Gemm8Args p) {
     }
 }
 
-bool g_gemm8_force_regstage = false;  // profiling: ao_gemm8_set_variant(1)
-bool g_gemm8_tiled_only = false;      // profiling / A-B tests: ao_gemm8_set_variant(100) -- never a weight-streaming kernel
+thread_local bool g_gemm8_force_regstage = false;  // profiling: ao_gemm8_set_variant(1)
+thread_local bool g_gemm8_tiled_only = false;      // profiling / A-B tests: ao_gemm8_set_variant(100) -- never a weight-streaming kernel
 
-int g_gemm8_tm = 0;  // profiling: 0 = by shape, 2 / 4 = force
+thread_local int g_gemm8_tm = 0;  // profiling: 0 = by shape, 2 / 4 = force
 
 template <int EPI, int TM, int WN, int TNJ = 2>
 int launch_gemm8_dma_tm(const Gemm8Args& p, hipStream_t stream) {
   constexpr int WGM = TM * 64, WGN = WN * TNJ * 32;
   dim3 grid((unsigned)((p.N + WGN - 1) / WGN), (unsigned)((p.M + WGM - 1) / WGM)), block(128 * WN);
   const size_t smem = 2 * (size_t)(WGM + WGN) * BK;  // 64 KiB (128 x 128) ... 128 KiB (256 x 256)
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_dma_kernel<EPI, TM, WN, TNJ>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(gemm8_dma_kernel)");
-    attr_set = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_dma_kernel<EPI, TM, WN, TNJ>), smem, "hipFuncSetAttribute(gemm8_dma_kernel)")) return rc;
   ao::launch(gemm8_dma_kernel<EPI, TM, WN, TNJ>, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("gemm8_dma_kernel launch");
   return AO_OK;
@@ -404,13 +398,7 @@ int launch_gemm8(const Gemm8Args& p, hipStream_t stream) {
   if (p.K % BK == 0 && !g_gemm8_force_regstage) return launch_gemm8_dma<EPI>(p, stream);  // K % 128 == 0 (the pipelined kernels need K % 64)
   dim3 grid((unsigned)((p.N + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM)), block(THREADS);
   const size_t smem = 2 * 2 * TILE_BYTES;  // 73,728 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(gemm8_kernel)");
-    attr_set = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_kernel<EPI>), smem, "hipFuncSetAttribute(gemm8_kernel)")) return rc;
   ao::launch(gemm8_kernel<EPI>, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("gemm8_kernel launch");
   return AO_OK;

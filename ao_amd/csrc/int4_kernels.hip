@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   dump();
 }
 
-unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
+thread_local unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
 
 template <int G, int WAVES, int NT, int MT = 8, int ABL = 0>
 int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
@@ -673,15 +673,10 @@ int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, ui
   if (split > 1) {
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
-    if (int rc = splitk_workspace(&ws, &tickets)) return rc;
+    if (int rc = splitk_workspace(stream, &ws, &tickets)) return rc;
   }
   auto kern = int4_mm_rb_kernel<G, WAVES, NT, MT, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(int4_mm_rb_kernel)");
-    attr_set = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_rb_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)M,
              (int)N, (int)K, ws, tickets, g_mm_trace);
   AO_LAUNCH_CHECK("int4_mm_rb_kernel launch");

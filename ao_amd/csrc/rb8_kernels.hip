@@ -31,13 +31,14 @@ constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
 // 8-wave MX form, whose scale rings would otherwise push the workgroup past 160 KiB of LDS
 constexpr int w_stages(int waves, int kind) { return (waves == 8 && kind == 2) ? 5 : 6; }
 
-enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2 };
+// RB8_FP8_GROUPED: rowwise e4m3 like RB8_FP8, rows grouped by expert like RB8_MX (Float8Tensor's _grouped_mm, float8_tensor.py:1085-1122)
+enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2, RB8_FP8_GROUPED = 3 };
 
 struct Rb8Args {
   const uint8_t* a;       // [M][K] e4m3 / int8
-  const uint8_t* b;       // [N][K] e4m3 / int8; MX: [E][N][K]
+  const uint8_t* b;       // [N][K] e4m3 / int8; grouped kinds: [E][N][K]
   const float* scale_a;   // [M]           (rowwise kinds)
-  const float* scale_b;   // [N]
+  const float* scale_b;   // [N]; RB8_FP8_GROUPED: [E][N]
   const uint16_t* bias;   // [N] bf16 or null
   uint16_t* y;            // [M][N] bf16
   int M, N, K;
@@ -57,7 +58,7 @@ template <int WAVES, int KIND, int MT = 8, bool TRACE = false>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
-  constexpr bool INT8 = (KIND == RB8_INT8), MX = (KIND == RB8_MX);
+  constexpr bool INT8 = (KIND == RB8_INT8), MX = (KIND == RB8_MX), GROUPED = (KIND == RB8_MX || KIND == RB8_FP8_GROUPED);
   constexpr int ADMA = 2 * MT / WAVES;  // activation DMAs per wave and stage (8 rows each)
   static_assert(ADMA >= 1, "every wave issues the same number of DMAs per stage");
   constexpr int kABuf = MT * 2048;      // one activation stage: 16 MT rows x 128 k bytes
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int nk = (int)(((long long)ksteps * (ks + 1)) / S) - k0;
   // rows of this workgroup: [m0, m_end) -- a 128-row slab of the matrix, or of one expert's token group
   int m0 = blockIdx.y * BM, m_end = p.M, expert = 0;
-  if constexpr (MX) {
+  if constexpr (GROUPED) {
     expert = blockIdx.y / p.slabs;
     const int begin = (p.offs != nullptr && expert > 0) ? p.offs[expert - 1] : 0;
     m_end = (p.offs != nullptr) ? p.offs[expert] : p.M;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       }
   } else {
     const float* __restrict__ scale_a = p.scale_a;
-    const float sb = p.scale_b[n];
+    const float sb = p.scale_b[(size_t)expert * p.N + n];
     const float bias = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
     float sa[4 * MT];  // all row scales first: the stores below must not sit between dependent loads
 #pragma unroll
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + mt * 16 + kq * 4 + r;
-        if (m < p.M) {
+        if (m < m_end) {  // (= p.M for the ungrouped kinds)
           float v;
           if constexpr (INT8) {
             // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
@@ -239,13 +240,14 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   dump();
 }
 
-unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
+thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 
 template <int WAVES, int KIND, int MT = 8>
 int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   constexpr int BN = WAVES * 16;
   constexpr int BM = 16 * MT;
-  const unsigned gy = (KIND == RB8_MX) ? (unsigned)(p.slabs * (p.offs != nullptr ? p.E : 1)) : (unsigned)((p.M + BM - 1) / BM);
+  constexpr bool kGrouped = (KIND == RB8_MX || KIND == RB8_FP8_GROUPED);
+  const unsigned gy = kGrouped ? (unsigned)(p.slabs * (p.offs != nullptr ? p.E : 1)) : (unsigned)((p.M + BM - 1) / BM);
   dim3 grid((unsigned)((p.N + BN - 1) / BN), gy, (unsigned)split), block(64 * WAVES);
   constexpr int kWStages = w_stages(WAVES, KIND);
   constexpr size_t smem = (size_t)kStages * MT * 2048 + (size_t)WAVES * kWStages * 2048 +
@@ -254,22 +256,17 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   if (split > 1) {
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
-    if (int rc = splitk_workspace(&p.ws, &p.tickets)) return rc;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets)) return rc;
   }
   p.trace = g_fp8_rb_trace;
   auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true> : rb8_kernel<WAVES, KIND, MT, false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[p.trace != nullptr]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return hip_failed(e, "hipFuncSetAttribute(rb8_kernel)");
-    attr_set[p.trace != nullptr] = true;
-  }
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(rb8_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("rb8_kernel launch");
   return AO_OK;
 }
 
-int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 never, 2 always, 3 always + 64-column tiles, two workgroups per CU
+thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 never, 2 always, 3 always + 64-column tiles, two workgroups per CU
 
 }  // namespace
 
@@ -337,6 +334,19 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
   // 64-column tiles when 128-column ones would not give every CU a workgroup even if every group had tokens
   if (bm == 32) return launch_rb8<4, RB8_MX, 2>(p, 1, stream);
   return (((N + 127) / 128) * groups * p.slabs < 400) ? launch_rb8<4, RB8_MX, 8>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);
+}
+
+// Float8Tensor's _grouped_mm, rowwise (float8_tensor.py:1085-1122 -> scaled_grouped_mm with RowWise scales):
+//   out[rows of group e] = bf16((a . b[e]^T) * scale_a[m] * scale_b[e][n]); the grouping of the MXFP8 form, the epilogue of fp8 rowwise
+int fp8_rowwise_grouped_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const int32_t* offs, uint16_t* out,
+                           int64_t M_total, int64_t N, int64_t K, int64_t E, hipStream_t stream) {
+  Rb8Args p{};
+  p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.y = out; p.offs = offs;
+  p.M = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
+  const int bm = (M_total <= 24 * E) ? 32 : 128;
+  p.slabs = (int)std::max<int64_t>(1, (M_total + bm - 1) / bm);
+  if (bm == 32) return launch_rb8<4, RB8_FP8_GROUPED, 2>(p, 1, stream);
+  return (((N + 127) / 128) * E * p.slabs < 400) ? launch_rb8<4, RB8_FP8_GROUPED, 8>(p, 1, stream) : launch_rb8<8, RB8_FP8_GROUPED, 8>(p, 1, stream);
 }
 
 }  // namespace ao

@@ -38,41 +38,79 @@ int hip_failed(hipError_t e, const char* what) {
   return AO_ERR_HIP;
 }
 
-// ---- split-K workspace (splitk.h): the library's only device-side state ----------------------------
+// ---- dynamic-LDS opt-in per (kernel, device) -------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember which (kernel, device) pairs
+// have it, under a mutex (the launchers used to keep one unsynchronised process-wide flag per template).
 namespace {
-struct SplitWs {
-  float* part = nullptr;
-  unsigned* tickets = nullptr;
-  unsigned next_slot = 0;
-};
-std::mutex g_split_mu;
-SplitWs g_split_ws[64];
+std::mutex g_attr_mu;
+struct AttrDone { const void* kernel; int dev; size_t bytes; };
+std::vector<AttrDone> g_attr_done;
 }  // namespace
 
-int splitk_workspace(float** part, unsigned** tickets) {
+int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
+  if (bytes <= 48 * 1024) return AO_OK;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_failed(e, "hipGetDevice");
+  std::lock_guard<std::mutex> lock(g_attr_mu);
+  AttrDone* slot = nullptr;
+  for (auto& kd : g_attr_done)
+    if (kd.kernel == kernel && kd.dev == dev) slot = &kd;
+  if (slot != nullptr && slot->bytes >= bytes) return AO_OK;  // the attribute is a maximum: only ever raised
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return hip_failed(e, what);
+  if (slot != nullptr) slot->bytes = bytes; else g_attr_done.push_back(AttrDone{kernel, dev, bytes});
+  return AO_OK;
+}
+
+// ---- split-K workspace (splitk.h): the library's only device-side state ----------------------------------------------
+// One workspace (fp32 / int32 parts + tickets) per (device, stream), allocated on the first split-K launch on that stream.
+// Launches on ONE stream are ordered, and the last arriver of a launch leaves every ticket at zero, so consecutive launches
+// on a stream share their workspace safely; launches on different streams never share one.  (Round 1 rotated 4
+// process-wide slots with no tie to streams: more than 4 split-K kernels in flight across streams aliased a slot.)
+namespace {
+struct SplitWs {
+  hipStream_t stream = nullptr;
+  bool used = false;
+  float* part = nullptr;
+  unsigned* tickets = nullptr;
+};
+std::mutex g_split_mu;
+SplitWs g_split_ws[64][kSplitSlots];
+}  // namespace
+
+int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return hip_failed(e, "hipGetDevice");
   AO_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
   std::lock_guard<std::mutex> lock(g_split_mu);
-  SplitWs& w = g_split_ws[dev];
-  if (w.part == nullptr) {
-    const size_t bytes = kSplitSlots * (kSplitSlotFloats * sizeof(float) + kSplitMaxTiles * sizeof(unsigned));
+  SplitWs* w = nullptr;
+  for (int i = 0; i < kSplitSlots && w == nullptr; ++i)
+    if (g_split_ws[dev][i].used && g_split_ws[dev][i].stream == stream) w = &g_split_ws[dev][i];
+  for (int i = 0; i < kSplitSlots && w == nullptr; ++i)
+    if (!g_split_ws[dev][i].used) w = &g_split_ws[dev][i];
+  AO_REQUIRE(w != nullptr, "split-K kernels were launched on more than %d streams of device %d: each stream owns a %zu MB workspace; "
+             "reuse streams (a captured graph keeps using the workspace of the stream it was captured on)", kSplitSlots, dev,
+             (kSplitSlotFloats * sizeof(float)) >> 20);
+  if (w->part == nullptr) {
+    const size_t bytes = kSplitSlotFloats * sizeof(float) + kSplitMaxTiles * sizeof(unsigned);
     char* p = nullptr;
     e = hipMalloc(&p, bytes);
     if (e != hipSuccess)
-      return hip_failed(e, "hipMalloc(split-K workspace); call the op with this shape once outside stream capture before "
-                           "capturing it into a graph");
-    unsigned* t = reinterpret_cast<unsigned*>(p + kSplitSlots * kSplitSlotFloats * sizeof(float));
-    e = hipMemset(t, 0, kSplitSlots * kSplitMaxTiles * sizeof(unsigned));
+      return hip_failed(e, "hipMalloc(split-K workspace); call the op with this shape once on this stream outside stream capture "
+                           "before capturing it into a graph");
+    unsigned* t = reinterpret_cast<unsigned*>(p + kSplitSlotFloats * sizeof(float));
+    e = hipMemset(t, 0, kSplitMaxTiles * sizeof(unsigned));
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(split-K tickets)"); }
-    w.part = reinterpret_cast<float*>(p);
-    w.tickets = t;
+    w->part = reinterpret_cast<float*>(p);
+    w->tickets = t;
   }
-  const unsigned slot = w.next_slot++ % kSplitSlots;
-  *part = w.part + slot * kSplitSlotFloats;
-  *tickets = w.tickets + slot * kSplitMaxTiles;
+  w->used = true;
+  w->stream = stream;
+  *part = w->part;
+  *tickets = w->tickets;
   return AO_OK;
 }
 }  // namespace ao

@@ -4,12 +4,12 @@
 
 namespace ao {
 
-// Workspace: kSplitSlots rotating slots (launches in flight per device) of kSplitMaxTiles fp32 tiles of 128 x 128
-// + one ticket per output tile.  Allocated on first use (outside stream capture); runtime.hip.
-constexpr int kSplitSlots = 4;
+// Workspace: one per (device, stream), at most kSplitSlots streams per device, each kSplitMaxTiles fp32 tiles of 128 x 128
+// + one ticket per output tile.  Allocated on the first split-K launch on a stream (outside stream capture); runtime.hip.
+constexpr int kSplitSlots = 8;
 constexpr int kSplitMaxTiles = 256;
 constexpr size_t kSplitSlotFloats = (size_t)kSplitMaxTiles * 128 * 128;
-int splitk_workspace(float** part, unsigned** tickets);
+int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets);
 
 // ---------------------------------------------------------------------------
 // Split-K meeting: every part parks its fp32 tile in the workspace

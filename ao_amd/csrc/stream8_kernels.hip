@@ -17,9 +17,11 @@
 
 namespace ao {
 // rb8_kernels.hip: LDS-staged weight-streaming form (full-line weight requests)
+int fp8_rowwise_grouped_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const int32_t* offs, uint16_t* out,
+                           int64_t M_total, int64_t N, int64_t K, int64_t E, hipStream_t stream);  // rb8_kernels.hip
 int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b, const uint8_t* b_scale, const int32_t* offs, uint16_t* out,
                      int64_t M_total, int64_t N, int64_t K, int64_t E, int64_t rows_hint, hipStream_t stream);
-int g_mx_variant = 0;  // profiling / A-B tests (ao_gemm8_set_variant 110 / 111): 0 by shape, 1 always the LDS-staged kernel, 2 never
+thread_local int g_mx_variant = 0;  // profiling / A-B tests (ao_gemm8_set_variant 110 / 111): 0 by shape, 1 always the LDS-staged kernel, 2 never
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -405,6 +407,24 @@ int int8_scaled_stream(const int8_t* a, const int8_t* b, const float* scale_a, c
 
 using namespace ao;
 
+extern "C" int ao_fp8_grouped_mm(const uint8_t* a, const float* scale_a, const uint8_t* b, const float* scale_b, const int32_t* offs,
+                                 uint16_t* out, int64_t M_total, int64_t N, int64_t K, int64_t E, void* stream) {
+  AO_REQUIRE(M_total >= 0 && N > 0 && K > 0 && E > 0, "ao_fp8_grouped_mm: bad shape M_total=%lld N=%lld K=%lld E=%lld", (long long)M_total,
+             (long long)N, (long long)K, (long long)E);
+  AO_REQUIRE(K % 128 == 0 && N % 16 == 0, "ao_fp8_grouped_mm: K=%lld must be a multiple of 128 and N=%lld of 16", (long long)K, (long long)N);
+  const int64_t bm = (M_total <= 24 * E) ? 32 : 128;
+  AO_REQUIRE(M_total * K < (1ll << 32) && N * K < (1ll << 32) && E * ((M_total + bm - 1) / bm) <= 65535 && E < 65536,
+             "ao_fp8_grouped_mm: tensor too large for one launch (M_total * K and N * K must stay below 4 Gi elements)");
+  if (M_total == 0) return AO_OK;
+  AO_REQUIRE_PTR(a);
+  AO_REQUIRE_PTR(scale_a);
+  AO_REQUIRE_PTR(b);
+  AO_REQUIRE_PTR(scale_b);
+  AO_REQUIRE_PTR(offs);
+  AO_REQUIRE_PTR(out);
+  return fp8_rowwise_grouped_rb(a, b, scale_a, scale_b, offs, out, M_total, N, K, E, (hipStream_t)stream);
+}
+
 extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
                                    const uint8_t* b_scale, const int32_t* offs, uint16_t* out, int64_t M_total,
                                    int64_t N, int64_t K, int64_t E, void* stream) {
@@ -428,7 +448,11 @@ extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, con
   // size.  Mixtral-8x7B expert shapes, 8 experts (w1, w2; us): 16 rows per expert -- A-stationary kernel below 97 / 120,
   // LDS-staged 89 / 110; 128 rows per expert -- 381 / 474 (the A-stationary kernel re-streams the weights per 64-row pass) vs
   // 211 / 172.  Variant 111 keeps the older kernels reachable for A/B runs.
-  if (g_mx_variant != 2) return mxfp8_grouped_rb(a, a_scale, b, b_scale, offs, out, M_total, N, K, E, M_total, (hipStream_t)stream);
+  // (it addresses activation rows with 32-bit byte offsets and puts experts x slabs on grid.y: tensors beyond either bound --
+  // M_total * K >= 4 GiB, or more than 65535 (expert, slab) pairs -- take the per-tile kernels below, which have neither limit)
+  const int64_t rb_bm = (M_total <= 24 * (offs != nullptr ? E : 1)) ? 32 : 128;
+  const bool rb_ok = M_total * K < (1ll << 32) && N * K < (1ll << 32) && (offs != nullptr ? E : 1) * ((M_total + rb_bm - 1) / rb_bm) <= 65535;
+  if (g_mx_variant != 2 && rb_ok) return mxfp8_grouped_rb(a, a_scale, b, b_scale, offs, out, M_total, N, K, E, M_total, (hipStream_t)stream);
   if (offs != nullptr && K % 2048 == 0) {
     // Group sizes live on the device.  Size the m-tiling for twice the AVERAGE group: a larger group
     // takes another pass over its expert's weights (correct, slower), while sizing for the worst

@@ -23,8 +23,8 @@
 #include <tuple>
 
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
 #include "../../include/ao_mi355.h"
@@ -33,7 +33,9 @@ namespace {
 
 using at::Tensor;
 
-void* current_stream(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+// PyTorch-ROCm presents HIP devices as device type "cuda": the stream comes from the masquerading accessor, the device guard
+// is the generic one (it resolves to the masquerading guard implementation registered for that device type)
+void* current_stream(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream(); }
 
 void check_rc(int rc, const char* op) { TORCH_CHECK(rc == AO_OK, op, ": ", ao_last_error()); }
 
@@ -53,7 +55,7 @@ Tensor weight_int4pack_mm(const Tensor& self, const Tensor& mat2, int64_t qGroup
   const int64_t M = self.size(0), K = self.size(1), N = mat2.size(0) * 8;
   TORCH_CHECK(mat2.size(1) * 128 == K, op, ": K mismatch between self and mat2");
   TORCH_CHECK(qScaleAndZeros.size(1) == N && qScaleAndZeros.size(0) * qGroupSize == K, op, ": qScaleAndZeros shape does not match");
-  c10::hip::HIPGuard guard(self.device());
+  c10::DeviceGuard guard(self.device());
   const Tensor x = self.contiguous(), q = mat2.contiguous(), sz = qScaleAndZeros.contiguous();
   Tensor y = at::empty({M, N}, self.options());
   check_rc(ao_int4_weight_int4pack_mm(reinterpret_cast<const uint16_t*>(x.data_ptr()), q.data_ptr<int32_t>(),
@@ -68,7 +70,7 @@ Tensor convert_weight_to_int4pack(const Tensor& self, int64_t innerKTiles) {
   TORCH_CHECK(self.dim() == 2 && self.scalar_type() == at::kByte, op, ": self must be a 2-D uint8 tensor [N, K/2]");
   TORCH_CHECK(innerKTiles == 8, op, ": innerKTiles must be 8 on MI355X (torchao fixes it), got ", innerKTiles);
   const int64_t N = self.size(0), K = self.size(1) * 2;
-  c10::hip::HIPGuard guard(self.device());
+  c10::DeviceGuard guard(self.device());
   const Tensor w = self.contiguous();
   Tensor q = at::empty({N / 8, K / 128, 32, 4}, self.options().dtype(at::kInt));
   check_rc(ao_int4_convert_weight_to_int4pack(w.data_ptr<uint8_t>(), q.data_ptr<int32_t>(), N, K, 8, current_stream(self)), op);
@@ -82,7 +84,7 @@ Tensor int_mm(const Tensor& self, const Tensor& mat2) {
   TORCH_CHECK(self.dim() == 2 && mat2.dim() == 2 && self.scalar_type() == at::kChar && mat2.scalar_type() == at::kChar,
               op, ": expected 2-D int8 tensors");
   TORCH_CHECK(self.size(1) == mat2.size(0), op, ": shapes cannot be multiplied");
-  c10::hip::HIPGuard guard(self.device());
+  c10::DeviceGuard guard(self.device());
   const Tensor a = self.contiguous(), bt = mat2.t().contiguous();  // K-major weight: free for the reference's `.contiguous().t()`
   const int64_t M = a.size(0), K = a.size(1), N = bt.size(0);
   Tensor c = at::empty({M, N}, self.options().dtype(at::kInt));
@@ -105,7 +107,7 @@ Tensor scaled_mm(const Tensor& self, const Tensor& mat2, const Tensor& scale_a, 
   const int64_t M = self.size(0), K = self.size(1), N = mat2.size(1);
   TORCH_CHECK(scale_a.numel() == M && scale_b.numel() == N && scale_a.scalar_type() == at::kFloat && scale_b.scalar_type() == at::kFloat,
               op, ": only rowwise fp32 scales (scale_a [M,1], scale_b [1,N]) are implemented");
-  c10::hip::HIPGuard guard(self.device());
+  c10::DeviceGuard guard(self.device());
   const Tensor a = self.contiguous(), bt = mat2.t().contiguous();  // mat2 is column-major [K,N] = row-major [N,K]: no copy
   const Tensor sa = scale_a.reshape({-1}).contiguous(), sb = scale_b.reshape({-1}).contiguous();
   Tensor bb;
@@ -147,7 +149,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mxfp8_quantize(const Tensor& input, b
   const int64_t rows = input.size(0), cols = input.size(1);
   TORCH_CHECK(rows >= 32 && rows % 32 == 0, op, ": rows must be a multiple of 32");
   TORCH_CHECK(cols >= 32 && cols % 32 == 0, op, ": cols must be a multiple of 32");
-  c10::hip::HIPGuard guard(input.device());
+  c10::DeviceGuard guard(input.device());
   const auto o8 = input.options().dtype(at::kFloat8_e4m3fn), oe = input.options().dtype(at::kFloat8_e8m0fnu);
   Tensor out_r = at::empty({0}, o8), out_c = at::empty({0}, o8), sc_r = at::empty({0}, oe), sc_c = at::empty({0}, oe);
   const uint16_t* x = reinterpret_cast<const uint16_t*>(input.data_ptr());
@@ -189,7 +191,7 @@ Tensor scaled_grouped_mm(const Tensor& self, const Tensor& mat2, const Tensor& s
                   (scale_b.scalar_type() == at::kFloat8_e8m0fnu || scale_b.scalar_type() == at::kByte);
   TORCH_CHECK(e8 && scale_a.numel() == M * (K / 32) && scale_b.numel() == E * N * (K / 32), op,
               ": only the MXFP8 form is implemented: E8M0 scales [M, K/32] and [E, N, K/32], row-major, not blocked");
-  c10::hip::HIPGuard guard(self.device());
+  c10::DeviceGuard guard(self.device());
   const Tensor a = self.contiguous(), b = mat2.transpose(1, 2).contiguous();  // [E, N, K]: no copy for the reference's layout
   const Tensor sa = scale_a.contiguous(), sb = scale_b.contiguous(), of = offs->contiguous();
   Tensor y = at::empty({M, N}, self.options().dtype(at::kBFloat16));
@@ -215,7 +217,7 @@ std::tuple<Tensor, Tensor, Tensor> fused_pad_token_groups(const Tensor& inputs, 
   const int64_t T = inputs.size(0), D = inputs.size(1), G = offsets.size(0);
   const int64_t rows = ao_moe_padded_rows(T, G, (int)alignment_size);
   TORCH_CHECK(rows >= 0, op, ": ", ao_last_error());
-  c10::hip::HIPGuard guard(inputs.device());
+  c10::DeviceGuard guard(inputs.device());
   Tensor padded = at::empty({rows, D}, inputs.options());
   Tensor starts = at::empty({G}, offsets.options()), ends = at::empty({G}, offsets.options());
   check_rc(ao_moe_pad_token_groups(inputs.data_ptr(), offsets.data_ptr<int32_t>(), padded.data_ptr(), starts.data_ptr<int32_t>(),
@@ -235,7 +237,7 @@ Tensor fused_unpad_token_groups(const Tensor& padded, const Tensor& offsets, con
               op, ": offsets must be int32 tensors of the same shape");
   TORCH_CHECK(num_tokens >= 0, op, ": num_tokens must be non-negative");
   const int eb = elem_bytes_of(padded, op);
-  c10::hip::HIPGuard guard(padded.device());
+  c10::DeviceGuard guard(padded.device());
   Tensor out = at::empty({num_tokens, padded.size(1)}, padded.options());
   check_rc(ao_moe_unpad_token_groups(padded.data_ptr(), offsets.contiguous().data_ptr<int32_t>(), padded_starts.contiguous().data_ptr<int32_t>(),
                                      out.data_ptr(), num_tokens, padded.size(1), eb, offsets.size(0), current_stream(padded)), op);

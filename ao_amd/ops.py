@@ -15,6 +15,8 @@ __all__ = [
     "weight_int4pack_mm",
     "int4_dequantize",
     "int4_quantize_tinygemm",
+    "int4_plain_quantize",
+    "int4_quantize_hqq",
     "int8_quantize_rowwise",
     "int8_scaled_mm",
     "int_mm",
@@ -28,6 +30,10 @@ __all__ = [
     "fp8_dynamic_linear",
     "fused_pad_token_groups",
     "fused_unpad_token_groups",
+    "int8_linear",
+    "fp8_linear",
+    "mxfp8_quantize_colwise",
+    "fp8_grouped_mm",
     "rowwise_amax",
     "int8_quantize_rowwise_amax",
     "fp8_quantize_rowwise_amax",
@@ -207,6 +213,47 @@ def int4_quantize_tinygemm(w: torch.Tensor, group_size: int):
             _lib.lib().ao_int4_quantize_tinygemm(_ptr(w), _ptr(qdata), _ptr(sz), n, k, group_size, _stream())
         )
     return qdata, sz
+
+
+def int4_quantize_hqq(w: torch.Tensor, group_size: int):
+    """HQQ qparams + codes in the tinygemm format (Int4TilePackedTo4dTensor.from_hp with Int4ChooseQParamsAlgorithm.HQQ,
+    int4_tile_packed_to_4d_tensor.py:149-236).  w bf16 [N, K] (N % 16 == 0, K % 128 == 0) ->
+    (qdata int32 [N/8, K/128, 32, 4], scale_and_zero bf16 [K/g, N, 2]).  Synchronises the stream (the optimizer's early stop
+    reads a global error every iteration, as the reference's does)."""
+    dev = _require_gpu("int4_quantize_hqq", w)
+    if w.dtype != torch.bfloat16 or w.dim() != 2:
+        raise RuntimeError("int4_quantize_hqq: expected a 2-D bfloat16 tensor")
+    w = w.contiguous()
+    n, k = w.shape
+    if n % 16 != 0 or k % 128 != 0 or group_size not in (32, 64, 128, 256) or k % group_size != 0:
+        raise ValueError(f"int4_quantize_hqq: shape {tuple(w.shape)} / group_size {group_size} not supported (N % 16, K % 128, g 32|64|128|256)")
+    lib = _lib.lib()
+    ws = torch.empty((int(lib.ao_int4_hqq_workspace_bytes(n, k, group_size)),), dtype=torch.uint8, device=dev)
+    nib = torch.empty((n, k // 2), dtype=torch.uint8, device=dev)
+    sz = torch.empty((k // group_size, n, 2), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(lib.ao_int4_quantize_hqq(_ptr(w), _ptr(nib), _ptr(sz), _ptr(ws), n, k, group_size, _stream()))
+    return convert_weight_to_int4pack(nib, 8), sz
+
+
+def int4_plain_quantize(w: torch.Tensor, group_size: int, symmetric: bool = False):
+    """Int4Tensor.from_hp's arithmetic, PLAIN packing (quantize_/workflows/int4/int4_tensor.py:130-186; mslk's
+    int4_row_quantize_zp / int4_row_quantize + pack_int4 as restated by the reference, qat/fake_quantizer.py:148-190).
+    w bf16 [N, K] -> (qdata uint8 [N, K/2] even k in the low nibble, scale bf16 [K/g, N], zero_point bf16 [K/g, N])."""
+    dev = _require_gpu("int4_plain_quantize", w)
+    if w.dtype != torch.bfloat16 or w.dim() != 2:
+        raise RuntimeError("int4_plain_quantize: expected a 2-D bfloat16 tensor")
+    w = w.contiguous()
+    n, k = w.shape
+    if group_size not in (32, 64, 128, 256) or k % 128 != 0 or k % group_size != 0:
+        raise ValueError(f"int4_plain_quantize: group_size {group_size} / K={k} not supported (group 32|64|128|256, K % 128 == 0)")
+    qdata = torch.empty((n, k // 2), dtype=torch.uint8, device=dev)
+    scale = torch.empty((k // group_size, n), dtype=torch.bfloat16, device=dev)
+    zero = torch.empty((k // group_size, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_int4_plain_quantize(_ptr(w), _ptr(qdata), _ptr(scale), _ptr(zero), n, k, group_size, int(bool(symmetric)),
+                                                     _stream()))
+    return qdata, scale, zero
 
 
 # ---------------------------------------------------------------------------
@@ -477,6 +524,49 @@ def mxfp8_quantize(x: torch.Tensor, scaling_mode: str = "rceil"):
     return q.view(torch.float8_e4m3fn), s.view(torch.float8_e8m0fnu)
 
 
+def fp8_grouped_mm(a, scale_a, b, scale_b, offs):
+    """Float8Tensor's aten::_grouped_mm, rowwise scales (float8_tensor.py:1085-1122).  a e4m3 [M, K]; scale_a fp32 [M(,1)];
+    b e4m3 [E, N, K]; scale_b fp32 [E, N(,1)]; offs int32 [E] -> bf16 [M, N] (rows past offs[-1] are zero)."""
+    dev = _require_gpu("fp8_grouped_mm", a, scale_a, b, scale_b, offs)
+    a = _fp8_bytes("fp8_grouped_mm", a).contiguous()
+    b = _fp8_bytes("fp8_grouped_mm", b).contiguous()
+    if a.dim() != 2 or b.dim() != 3 or a.shape[1] != b.shape[2]:
+        raise RuntimeError(f"fp8_grouped_mm: shapes {tuple(a.shape)} and {tuple(b.shape)} are not compatible")
+    m, k = a.shape
+    e, n, _ = b.shape
+    scale_a = scale_a.reshape(-1).to(torch.float32).contiguous()
+    scale_b = scale_b.reshape(-1).to(torch.float32).contiguous()
+    if scale_a.numel() != m or scale_b.numel() != e * n:
+        raise RuntimeError("fp8_grouped_mm: scales must be rowwise ([M] and [E, N])")
+    if offs.dtype != torch.int32 or offs.numel() != e:
+        raise RuntimeError("fp8_grouped_mm: offs must be int32 [E]")
+    out = torch.zeros((m, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_fp8_grouped_mm(_ptr(a), _ptr(scale_a), _ptr(b), _ptr(scale_b), _ptr(offs.contiguous()), _ptr(out), m, n, k, e,
+                                                _stream()))
+    return out
+
+
+def mxfp8_quantize_colwise(x: torch.Tensor, scaling_mode: str = "rceil"):
+    """Colwise (32x1) MXFP8 cast: torchao::mxfp8_quantize(colwise=True) == to_mx(x.t()).t()
+    (csrc/cuda/mx_kernels/mxfp8_extension.cpp:160-175).  x bf16 [R, C] -> (data float8_e4m3fn {R, C} with strides {1, R},
+    scale float8_e8m0fnu {C, R/32} with strides {1, C})."""
+    dev = _require_gpu("mxfp8_quantize_colwise", x)
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or not x.is_contiguous():
+        raise RuntimeError("mxfp8_quantize_colwise: expected a contiguous 2-D bfloat16 tensor")
+    mode = MX_SCALE_MODES.get(str(getattr(scaling_mode, "value", scaling_mode)).lower())
+    if mode is None:
+        raise RuntimeError(f"mxfp8_quantize_colwise: unsupported scaling mode {scaling_mode!r} (floor | rceil)")
+    r, c = x.shape
+    if r % 32 != 0 or c % 32 != 0:
+        raise RuntimeError(f"mxfp8_quantize_colwise: shape {tuple(x.shape)} must be multiples of 32 in both dimensions")
+    qt = torch.empty((c, r), dtype=torch.uint8, device=dev)
+    st = torch.empty((r // 32, c), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_mxfp8_quantize_colwise(_ptr(x), _ptr(qt), _ptr(st), r, c, mode, _stream()))
+    return qt.view(torch.float8_e4m3fn).t(), st.view(torch.float8_e8m0fnu).t()
+
+
 def mxfp8_grouped_mm(a, a_scale, b, b_scale, offs):
     """aten::_scaled_grouped_mm for MXFP8 (mxfp8_grouped_mm.py:541), numerics of the
     emulated path (:959-1023).  a e4m3 [M, K]; a_scale e8m0 [M, K/32]; b e4m3
@@ -575,6 +665,23 @@ def dynamic_linear_preferred(m: int, n: int, k: int) -> bool:
     8.2, o 8.9 vs 6.9, down 21.5 vs 17.4, gate_up 26.5 vs 26.5; M = 2 qkv 10.6 vs 8.9 but gate_up 27.0 vs 28.5; M = 4 gate_up
     28.5 vs 35.1."""
     return dynamic_linear_fits(m, n, k) and m * (n // 16) <= 1024
+
+
+def int8_linear(x2: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias=None) -> torch.Tensor:
+    """The Int8Tensor dynamic-activation F.linear on a 2-D bf16 activation (int8_tensor.py:266-359): decode sizes take the
+    fused cast + matmul kernel, everything else ao_int8_quantize_rowwise + ao_int8_scaled_mm.  Same bits either way."""
+    if dynamic_linear_preferred(x2.shape[0], wq.shape[0], x2.shape[1]):
+        return int8_dynamic_linear(x2, wq, w_scale, bias)
+    xq, xs = int8_quantize_rowwise(x2)
+    return int8_scaled_mm(xq, xs, wq, w_scale, bias)
+
+
+def fp8_linear(x2: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias=None) -> torch.Tensor:
+    """The Float8Tensor rowwise dynamic-activation F.linear on a 2-D bf16 activation (float8_tensor.py:338-469)."""
+    if dynamic_linear_preferred(x2.shape[0], wq.shape[0], x2.shape[1]):
+        return fp8_dynamic_linear(x2, wq, w_scale, bias)
+    xq, xs = fp8_quantize_rowwise(x2)
+    return fp8_scaled_mm(xq, wq.t(), xs, w_scale.t(), bias)
 
 
 def _dynamic_linear(name, entry, x, wq, w_scale, bias, wdtype):

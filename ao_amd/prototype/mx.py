@@ -52,13 +52,48 @@ def mx_dequantize(scale_e8m0: torch.Tensor, data_lp: torch.Tensor, output_dtype=
     return x.reshape(data_lp.shape).to(output_dtype)
 
 
+class MXFP8ExpertWeights:
+    """Expert weights cast to MXFP8 once (1 x 32 blocks along K of the [E, N, K] tensor): what the grouped GEMM streams.
+    The reference casts B_t inside every forward (mxfp8_grouped_mm.py:330-371) because it also trains them; for inference
+    the cast of Mixtral's w1 alone re-reads 940 MB of bf16 per call, so it is hoisted here."""
+
+    def __init__(self, data: torch.Tensor, scale: torch.Tensor):
+        self.data, self.scale = data, scale  # e4m3 [E, N, K], e8m0 [E, N, K/32]
+
+    @classmethod
+    def from_hp(cls, B_t: torch.Tensor, scale_calculation_mode: "ScaleCalculationMode" = None):
+        assert B_t.ndim == 3 and B_t.dtype == torch.bfloat16, "B_t must be a 3-D bfloat16 tensor [E, K, N]"
+        mode = ScaleCalculationMode.RCEIL if scale_calculation_mode is None else scale_calculation_mode
+        return cls(*ops.mxfp8_quantize(B_t.transpose(-2, -1).contiguous(), mode))
+
+    @property
+    def shape(self):  # the [E, K, N] shape of the B_t it stands for
+        e, n, k = self.data.shape
+        return torch.Size((e, k, n))
+
+
+_WEIGHT_MEMO = {}  # (data_ptr, version, shape, mode) -> MXFP8ExpertWeights, bounded
+_WEIGHT_MEMO_MAX = 256
+
+
+def _cached_expert_weights(B_t, mode):
+    key = (B_t.data_ptr(), B_t._version, tuple(B_t.shape), tuple(B_t.stride()), str(mode))
+    hit = _WEIGHT_MEMO.get(key)
+    if hit is None:
+        if len(_WEIGHT_MEMO) >= _WEIGHT_MEMO_MAX:
+            _WEIGHT_MEMO.pop(next(iter(_WEIGHT_MEMO)))
+        hit = _WEIGHT_MEMO[key] = MXFP8ExpertWeights.from_hp(B_t, mode)
+    return hit
+
+
 def _to_mxfp8_then_scaled_grouped_mm(
     A: torch.Tensor,
-    B_t: torch.Tensor,
+    B_t,
     offs: Optional[torch.Tensor] = None,
     block_size: int = BLOCK,
     out_dtype: Optional[torch.dtype] = torch.bfloat16,
     scale_calculation_mode: ScaleCalculationMode = ScaleCalculationMode.RCEIL,
+    cache_weights: bool = False,
 ) -> torch.Tensor:
     """Forward of the reference's MXFP8 MoE grouped GEMM.
 
@@ -66,8 +101,16 @@ def _to_mxfp8_then_scaled_grouped_mm(
     B_t   bf16 [E, K, N]      expert weights, "transposed" view of [E, N, K] (strides (N*K, 1, N))
     offs  int32 [E]           cumulative group ends along M
     ->    bf16 [M_total, N]
+    B_t may also be an MXFP8ExpertWeights (cast once, MXFP8ExpertWeights.from_hp(B_t)); `cache_weights=True` memoises that
+    cast per weight tensor (keyed on its storage and version counter: an in-place update re-casts) -- inference only.
     Raises like the reference for unsupported arguments (:167-200)."""
     assert A.ndim == 2, "A must be 2D"
+    if isinstance(B_t, MXFP8ExpertWeights):
+        assert block_size == BLOCK, "Only block_size=32 is supported"
+        assert offs is not None, "offs must be provided for 2d-2d and 2d-3d grouped mm"
+        assert A.dtype == torch.bfloat16 and A.shape[-1] == B_t.shape[-2], f"shape {A.shape} and {B_t.shape} are not compatible"
+        a_q, a_s = ops.mxfp8_quantize(A.contiguous(), scale_calculation_mode)
+        return ops.mxfp8_grouped_mm(a_q, a_s, B_t.data, B_t.scale, offs.to(torch.int32))
     assert B_t.ndim == 3, "B must be 3D"
     assert block_size == BLOCK, "Only block_size=32 is supported"
     assert offs is not None, "offs must be provided for 2d-2d and 2d-3d grouped mm"
@@ -76,9 +119,8 @@ def _to_mxfp8_then_scaled_grouped_mm(
     assert A.shape[-1] == B_t.shape[-2], f"shape {A.shape} and {B_t.shape} are not compatible for _scaled_grouped_mm"
     a_q, a_s = ops.mxfp8_quantize(A.contiguous(), scale_calculation_mode)
     # weights: 1x32 blocks along K of the [E, N, K] tensor (the reference quantises B_t.transpose(-2, -1))
-    b = B_t.transpose(-2, -1).contiguous()
-    b_q, b_s = ops.mxfp8_quantize(b, scale_calculation_mode)
-    return ops.mxfp8_grouped_mm(a_q, a_s, b_q, b_s, offs.to(torch.int32))
+    w = _cached_expert_weights(B_t, scale_calculation_mode) if cache_weights else MXFP8ExpertWeights.from_hp(B_t, scale_calculation_mode)
+    return ops.mxfp8_grouped_mm(a_q, a_s, w.data, w.scale, offs.to(torch.int32))
 
 
 def pad_token_groups(input_act: torch.Tensor, group_end_offsets: torch.Tensor, alignment_size: int = 32):

@@ -1,6 +1,7 @@
 from .config import (  # noqa: F401
     AOBaseConfig,
     Float8DynamicActivationFloat8WeightConfig,
+    Float8DynamicActivationInt4WeightConfig,
     Int4ChooseQParamsAlgorithm,
     Int4PackingFormat,
     Int4WeightOnlyConfig,
@@ -8,6 +9,7 @@ from .config import (  # noqa: F401
 )
 from .granularity import PerGroup, PerRow, PerTensor  # noqa: F401
 from .float8_tensor import Float8Tensor, QuantizeTensorToFloat8Kwargs  # noqa: F401
+from .int4_plain_tensor import Int4Tensor  # noqa: F401
 from .int4_tensor import Int4TilePackedTo4dTensor  # noqa: F401
 from .int8_tensor import Int8Tensor, QuantizeTensorToInt8Kwargs  # noqa: F401
 from .quant_api import quantize_  # noqa: F401

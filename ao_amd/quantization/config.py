@@ -27,14 +27,13 @@ class Int4ChooseQParamsAlgorithm(str, enum.Enum):
 class Int4WeightOnlyConfig(AOBaseConfig):
     """int4 groupwise weight-only (reference quant_api.py:502-533).
 
-    On MI355X the implemented packing format is TILE_PACKED_TO_4D (the tinygemm
-    layout consumed by the HIP `_weight_int4pack_mm` kernel); it is the default
-    here because the reference's default (PLAIN) needs the un-vendored `mslk`
-    kernels.  ntile is 16 on ROCm."""
+    Defaults as the reference: PLAIN packing (Int4Tensor -- served on MI355X by the tinygemm kernels through a one-time
+    re-layout, int4_plain_tensor.py), tinygemm qparams.  TILE_PACKED_TO_4D (Int4TilePackedTo4dTensor) is the format whose
+    checkpoint bytes the HIP `_weight_int4pack_mm` kernel reads directly; ntile is 16 on ROCm."""
 
     group_size: int = 128
     set_inductor_config: bool = False
-    int4_packing_format: Int4PackingFormat = Int4PackingFormat.TILE_PACKED_TO_4D
+    int4_packing_format: Int4PackingFormat = Int4PackingFormat.PLAIN
     int4_choose_qparams_algorithm: Int4ChooseQParamsAlgorithm = Int4ChooseQParamsAlgorithm.TINYGEMM
     int4_tile_packed_ntile: int = 16
     version: int = 2
@@ -63,3 +62,15 @@ class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
     granularity: Granularity = field(default_factory=PerRow)
     set_inductor_config: bool = False
     version: int = 2
+
+
+@dataclass
+class Float8DynamicActivationInt4WeightConfig(AOBaseConfig):
+    """float8 e4m3 rowwise dynamic activation x int4 groupwise (symmetric) weight, PLAIN packing (reference
+    quant_api.py:630-699: group_size 128, Int4Tensor with activation_dtype float8_e4m3fn)."""
+
+    int4_packing_format: Int4PackingFormat = Int4PackingFormat.PLAIN
+    group_size: int = 128
+
+    def __post_init__(self):
+        self.int4_packing_format = Int4PackingFormat(self.int4_packing_format)

@@ -73,10 +73,12 @@ class Float8Tensor(LowBitTensorBase):
         if hp_tensor.dtype != torch.bfloat16:
             # reference quant_api.py:1211-1216: PerRow quantization only works for bfloat16 precision
             raise AssertionError("PerRow quantization only works for bfloat16 precision input weight")
-        if hp_tensor.dim() != 2:
-            raise NotImplementedError("Float8Tensor.from_hp on MI355X takes 2-D tensors")
-        qdata, scale = ops.fp8_quantize_rowwise(hp_tensor.contiguous())
-        return cls(qdata, scale, [1, hp_tensor.shape[-1]], hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs)
+        if hp_tensor.dim() not in (2, 3):
+            raise NotImplementedError("Float8Tensor.from_hp on MI355X takes 2-D weights or 3-D [E, N, K] expert weights")
+        k = hp_tensor.shape[-1]
+        qdata, scale = ops.fp8_quantize_rowwise(hp_tensor.contiguous().reshape(-1, k))  # PerRow: one scale per row of every expert
+        qdata, scale = qdata.reshape(hp_tensor.shape), scale.reshape(*hp_tensor.shape[:-1], 1)
+        return cls(qdata, scale, [1] * (hp_tensor.dim() - 1) + [k], hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs)
 
     def dequantize(self, output_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """reference :255-275: fp8 -> fp32 * scale, then cast"""
@@ -109,11 +111,8 @@ def _(func, types, args, kwargs):
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
     else:
-        if ops.dynamic_linear_preferred(x2.shape[0], n, x2.shape[1]):  # decode sizes: activation cast fused into the matmul
-            y = ops.fp8_dynamic_linear(x2, w.qdata, w.scale, bias)
-        else:
-            xq, xs = ops.fp8_quantize_rowwise(x2)
-            y = ops.fp8_scaled_mm(xq, w.qdata.t(), xs, w.scale.t(), bias)
+        from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
+        y = kernels(x2).fp8_linear(x2, w.qdata, w.scale, bias)
         bias = None
     y = y.reshape(*x.shape[:-1], n)
     if bias is not None:
@@ -139,6 +138,35 @@ def _(func, types, args, kwargs):
         if pre is not None and pre.numel() == self.shape[1]:  # per-input-feature pre-scale follows the K slice
             pre = pre.reshape(-1)[start:end]
     return Float8Tensor(q, s, [1, q.shape[1]], self.dtype_, self.act_quant_kwargs, pre)
+
+
+@implements(aten.transpose.int)
+def _(func, types, args, kwargs):
+    """reference :970-1000: a view with qdata / scale transposed and block_size swapped (MoE callers pass w.transpose(-2, -1))"""
+    self, d0, d1 = args[0], args[1], args[2]
+    bs = list(self.block_size)
+    bs[d0], bs[d1] = bs[d1], bs[d0]
+    return Float8Tensor(self.qdata.transpose(d0, d1), self.scale.transpose(d0, d1), bs, self.dtype_, self.act_quant_kwargs, self.act_pre_scale)
+
+
+@implements(aten._grouped_mm.default)
+def _(func, types, args, kwargs):
+    """reference float8_grouped_mm (:1085-1122): mat_b is the transposed view [E, K, N] of expert weights quantized PerRow along K;
+    the token rows are cast per row to e4m3 and every group multiplies its expert: scaled_grouped_mm with RowWise scales."""
+    mat_a, mat_b = args[0], args[1]
+    offs = args[2] if len(args) > 2 else kwargs.get("offs", None)
+    assert isinstance(mat_b, Float8Tensor)
+    assert offs is not None, "offs is required for _grouped_mm"
+    is_b_transposed = mat_b.qdata.stride(-2) < mat_b.qdata.stride(-1)
+    assert is_b_transposed and mat_b.qdata.dim() == 3 and mat_a.dim() == 2, "unsupported"
+    output_dtype = mat_a.dtype
+    wq = mat_b.qdata.transpose(-2, -1)  # [E, N, K], K-contiguous: no copy for the reference's layout
+    ws = mat_b.scale.transpose(-2, -1)  # [E, N, 1]
+    if mat_b.act_quant_kwargs is None:
+        raise NotImplementedError("weight-only Float8Tensor _grouped_mm is not on the MI355X hot path: use dynamic activation quantization")
+    _check(mat_b.act_quant_kwargs.granularity, mat_b.act_quant_kwargs.float8_dtype)  # PerRow only, like the reference
+    aq, a_s = ops.fp8_quantize_rowwise(mat_a.to(torch.bfloat16).contiguous())
+    return ops.fp8_grouped_mm(aq, a_s, wq, ws, offs.to(torch.int32)).to(output_dtype)
 
 
 torch.serialization.add_safe_globals([Float8Tensor, QuantizeTensorToFloat8Kwargs])

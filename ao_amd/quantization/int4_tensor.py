@@ -52,11 +52,11 @@ class Int4TilePackedTo4dTensor(LowBitTensorBase):
         return s
 
     @classmethod
-    def from_hp(cls, hp_tensor: torch.Tensor, block_size: List[int], ntile_size: Optional[int] = 16):
-        """Quantize a bf16 [N, K] weight (reference from_hp, :96-236, TINYGEMM
-        qparams).  Pads K to a multiple of 1024 and N to a multiple of
-        `ntile_size` (16 on ROCm, quant_api.py:514), then runs the fused
-        choose_qparams + quantize + tile-pack kernel."""
+    def from_hp(cls, hp_tensor: torch.Tensor, block_size: List[int], int4_choose_qparams_algorithm="tinygemm",
+                ntile_size: Optional[int] = 16):
+        """Quantize a bf16 [N, K] weight (reference from_hp, :96-236).  Pads K to a multiple of 1024 and N to a multiple
+        of `ntile_size` (16 on ROCm, quant_api.py:514), then runs the fused choose_qparams + quantize + tile-pack kernel
+        (TINYGEMM qparams) or the HQQ optimizer kernels + tile pack (int4_choose_qparams_algorithm = "hqq", :149-168)."""
         assert len(block_size) == hp_tensor.ndim, (
             f"Expecting the length of block_size to be equal to the dimension of the weight, got {block_size=} and {hp_tensor.ndim=}"
         )
@@ -77,7 +77,12 @@ class Int4TilePackedTo4dTensor(LowBitTensorBase):
         k = find_multiple(k0, 1024)
         n = find_multiple(n0, nt)
         w = F.pad(hp_tensor, (0, k - k0, 0, n - n0)) if (k != k0 or n != n0) else hp_tensor
-        qdata, scale_and_zero = ops.int4_quantize_tinygemm(w.contiguous(), group_size)
+        algo = str(getattr(int4_choose_qparams_algorithm, "value", int4_choose_qparams_algorithm)).lower()
+        assert algo in ("tinygemm", "hqq"), f"Unsupported Int4ChooseQParamsAlgorithm: {int4_choose_qparams_algorithm}"
+        if algo == "hqq":
+            qdata, scale_and_zero = ops.int4_quantize_hqq(w.contiguous(), group_size)
+        else:
+            qdata, scale_and_zero = ops.int4_quantize_tinygemm(w.contiguous(), group_size)
         return cls(qdata, scale_and_zero, list(block_size), original_shape, act_pre_scale=None)
 
     def dequantize(self) -> torch.Tensor:
@@ -122,7 +127,8 @@ def _(func, types, args, kwargs):
     if act_mat.numel() == 0:
         y = act_mat.new_zeros((act_mat.shape[0], n_out))
     else:
-        y = ops.weight_int4pack_mm(act_mat, weight_tensor.qdata, groupsize, weight_tensor.scale_and_zero)
+        from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
+        y = kernels(act_mat).weight_int4pack_mm(act_mat, weight_tensor.qdata, groupsize, weight_tensor.scale_and_zero)
         y = y[:, :n_out]
     y = y.reshape(*orig_act_size[:-1], n_out)
     if bias is not None:

@@ -109,11 +109,8 @@ def _(func, types, args, kwargs):
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
     else:
-        if ops.dynamic_linear_preferred(x2.shape[0], n, x2.shape[1]):  # decode sizes: activation cast fused into the matmul
-            y = ops.int8_dynamic_linear(x2, w.qdata, w.scale, bias)
-        else:
-            xq, xs = ops.int8_quantize_rowwise(x2)
-            y = ops.int8_scaled_mm(xq, xs, w.qdata, w.scale, bias)
+        from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
+        y = kernels(x2).int8_linear(x2, w.qdata, w.scale, bias)
         bias = None
     y = y.reshape(*x.shape[:-1], n)
     if bias is not None:

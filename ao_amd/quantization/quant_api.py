@@ -13,6 +13,7 @@ import torch.nn as nn
 from .config import (
     AOBaseConfig,
     Float8DynamicActivationFloat8WeightConfig,
+    Float8DynamicActivationInt4WeightConfig,
     Int4ChooseQParamsAlgorithm,
     Int4PackingFormat,
     Int4WeightOnlyConfig,
@@ -88,13 +89,23 @@ def _int4_weight_only_quantize_tensor(weight, config):
         return weight
     block_size = [1 for _ in range(weight.ndim - 1)] + [group_size]
     assert config.version == 2
-    if config.int4_choose_qparams_algorithm == Int4ChooseQParamsAlgorithm.HQQ:
-        raise NotImplementedError("Int4ChooseQParamsAlgorithm.HQQ is not implemented on the MI355X path yet")
+    hqq = config.int4_choose_qparams_algorithm == Int4ChooseQParamsAlgorithm.HQQ
+    if hqq and config.int4_packing_format != Int4PackingFormat.TILE_PACKED_TO_4D:
+        # reference quant_api.py:560-565
+        raise AssertionError(
+            f"Int4ChooseQParamsAlgorithm.HQQ is not supported by packing format {config.int4_packing_format}, "
+            f"it's only supported by Int4PackingFormat.TILE_PACKED_TO_4D currently"
+        )
     if config.int4_packing_format == Int4PackingFormat.TILE_PACKED_TO_4D:
-        return Int4TilePackedTo4dTensor.from_hp(weight, block_size, ntile_size=config.int4_tile_packed_ntile)
+        return Int4TilePackedTo4dTensor.from_hp(weight, block_size, int4_choose_qparams_algorithm=config.int4_choose_qparams_algorithm,
+                                                ntile_size=config.int4_tile_packed_ntile)
+    if config.int4_packing_format == Int4PackingFormat.PLAIN:
+        from .int4_plain_tensor import Int4Tensor
+
+        return Int4Tensor.from_hp(weight, block_size)
     raise ValueError(
         f"Unsupported int4 packing format on MI355X: {config.int4_packing_format} "
-        "(only tile_packed_to_4d is implemented; plain/preshuffled need the un-vendored mslk kernels)"
+        "(plain and tile_packed_to_4d are implemented; preshuffled is an H100 WGMMA layout, plain_int32 is XPU / NPU)"
     )
 
 
@@ -104,6 +115,28 @@ def _int4_weight_only_transform(module, config, *, parameter_name="weight"):
         f"applying int4 weight only quant requires module to have {parameter_name} attribute but {module} does not have one"
     )
     new_weight = _int4_weight_only_quantize_tensor(getattr(module, parameter_name), config)
+    setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
+    return module
+
+
+@register_quantize_module_handler(Float8DynamicActivationInt4WeightConfig)
+def _float8_dynamic_activation_int4_weight_transform(module, config, *, parameter_name="weight"):
+    """reference quant_api.py:660-699: Int4Tensor (PLAIN) with activation_dtype float8_e4m3fn; shapes whose K is not a multiple
+    of the group size are left unquantized."""
+    from .int4_plain_tensor import Int4Tensor
+
+    assert hasattr(module, parameter_name), (
+        f"applying float8 dynamic activation int4 weight quant requires module to have {parameter_name} attribute"
+    )
+    weight = getattr(module, parameter_name)
+    assert config.int4_packing_format == Int4PackingFormat.PLAIN, (
+        f"only the plain packing format is implemented on MI355X for this config, got {config.int4_packing_format}"
+    )
+    if weight.shape[-1] % config.group_size != 0:
+        logger.info(f"Skipping quantizing weight of shape {weight.shape}: not compatible with group_size {config.group_size}")
+        return module
+    block_size = [1 for _ in range(weight.ndim - 1)] + [config.group_size]
+    new_weight = Int4Tensor.from_hp(weight, block_size, activation_dtype=torch.float8_e4m3fn)
     setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
     return module
 

@@ -162,6 +162,25 @@ int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float* scale_a,
                      const float* scale_b, const uint16_t* bias, uint16_t* y,
                      int64_t M, int64_t N, int64_t K, void* stream);
 
+/* HQQ qparams + codes for the tinygemm format: Int4TilePackedTo4dTensor.from_hp(..., HQQ)
+ * (int4_tile_packed_to_4d_tensor.py:149-168 -> quant_primitives.py:1891-1997, optimizer :1797-1866 in float16 as on a GPU).
+ *   w bf16 [N][K] -> nibble_bytes uint8 [N][K/2] (even k in the HIGH nibble: the input of
+ *   ao_int4_convert_weight_to_int4pack), scale_and_zero bf16 [K/g][N][2].
+ *   workspace: ao_int4_hqq_workspace_bytes(N, K, g) device bytes.  Host-synchronous like the reference: the optimizer's
+ *   early stop reads a global error every iteration (<= 20 stream synchronisations); not capturable in a graph. */
+int64_t ao_int4_hqq_workspace_bytes(int64_t N, int64_t K, int group_size);
+int ao_int4_quantize_hqq(const uint16_t* w, uint8_t* nibble_bytes, uint16_t* scale_and_zero, void* workspace,
+                         int64_t N, int64_t K, int group_size, void* stream);
+
+/* Int4Tensor.from_hp, PLAIN packing (quantize_/workflows/int4/int4_tensor.py:130-186): the arithmetic of mslk's
+ * int4_row_quantize_zp / int4_row_quantize + pack_int4 (un-vendored; restated by the reference at
+ * quantization/qat/fake_quantizer.py:148-190 and prototype/gptq/api.py:167-221), fp32 math:
+ *   symmetric = 0: scale = max(max - min, 1e-6) / 15, zero = min + 8 scale, q = clamp(rint((w - min) / scale), 0, 15) - 8
+ *   symmetric = 1: scale = max(max|w| / 8, 1e-6), zero = 0, q = clamp(rint(w / scale), -8, 7)   (fp8-activation flavour)
+ *   w bf16 [N][K] -> qdata uint8 [N][K/2] (even k in the LOW nibble), scale / zero_point bf16 [K/g][N]. */
+int ao_int4_plain_quantize(const uint16_t* w, uint8_t* qdata, uint16_t* scale, uint16_t* zero_point,
+                           int64_t N, int64_t K, int group_size, int symmetric, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * MXFP8 (e4m3 elements, E8M0 scale per 32 along the contraction dim)
  * ------------------------------------------------------------------------- */
@@ -197,6 +216,14 @@ int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale,
                         const uint8_t* b, const uint8_t* b_scale,
                         const int32_t* offs, uint16_t* out, int64_t M_total,
                         int64_t N, int64_t K, int64_t E, void* stream);
+
+/* Float8Tensor's aten::_grouped_mm with rowwise scales (float8_tensor.py:1085-1122 -> scaled_grouped_mm, RowWise recipes):
+ *   out[offs[e-1]:offs[e]] = bf16( (a_rows @ b[e]^T)_f32 * scale_a[m] * scale_b[e][n] )
+ *   a e4m3 [M_total][K]; scale_a fp32 [M_total]; b e4m3 [E][N][K]; scale_b fp32 [E][N]; offs int32 [E]; out bf16 [M_total][N].
+ *   Rows past offs[E-1] are not written. */
+int ao_fp8_grouped_mm(const uint8_t* a, const float* scale_a, const uint8_t* b, const float* scale_b,
+                      const int32_t* offs, uint16_t* out, int64_t M_total, int64_t N, int64_t K,
+                      int64_t E, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * MoE token-group padding (glue either side of the MXFP8 grouped GEMM)

@@ -83,3 +83,17 @@ def linear(x, w, bias=None):
     xq, xs = quantize_rowwise(x)
     wq, ws = quantize_rowwise(w)
     return scaled_mm(xq, wq, xs, ws, bias)
+
+
+def grouped_mm(a, b, scale_a, scale_b, offs):
+    """Float8Tensor's aten::_grouped_mm, rowwise (float8_tensor.py:1085-1122 -> scaled_grouped_mm with RowWise recipes):
+    out[offs[e-1]:offs[e]] = bf16((a_rows @ b[e]^T) * scale_a[m] * scale_b[e][n]).  a codes [M, K]; b codes [E, N, K];
+    scale_a [M]; scale_b [E, N]; rows past offs[-1] stay zero."""
+    out = np.zeros((a.shape[0], b.shape[1]), dtype=np.float32)
+    start = 0
+    for e in range(b.shape[0]):
+        end = int(offs[e])
+        if end > start:
+            out[start:end] = scaled_mm(a[start:end], b[e], np.asarray(scale_a)[start:end], np.asarray(scale_b)[e])
+        start = end
+    return out

@@ -173,10 +173,68 @@ def make_moe():
     print("moe_pad.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def make_int4_plain():
+    """Int4Tensor (PLAIN) weight preparation: mslk is absent, so the fixtures come from the reference's OWN restatements of its
+    numerics -- Int4WeightFakeQuantizer (qat/fake_quantizer.py:148-190) and the GPTQ helpers (prototype/gptq/api.py:167-221)."""
+    from torchao.prototype.gptq.api import _int4_row_dequantize_zp, _int4_row_quantize_zp_precomputed_qparams
+    from torchao.quantization.qat.fake_quantize_config import Int4WeightFakeQuantizeConfig
+    from torchao.quantization.qat.fake_quantizer import Int4WeightFakeQuantizer
+
+    out = {}
+    for name, n, k, g in [("g32", 16, 256, 32), ("g128", 32, 1024, 128), ("g256", 8, 512, 256)]:
+        gen = torch.Generator().manual_seed(4321 + g)
+        w = (torch.randn(n, k, generator=gen) * 0.02).to(torch.bfloat16)
+        w[0, :g] = 0.25  # constant group: max - min clamps at 1e-6
+        w[1, :g] = 0.0
+        w[2, :g] = torch.linspace(-3.0, 5.0, g).to(torch.bfloat16)
+        fq_zp = Int4WeightFakeQuantizer(Int4WeightFakeQuantizeConfig(group_size=g, activation_dtype=torch.bfloat16))(w)
+        out[f"{name}_w"] = bits(w)
+        out[f"{name}_fq_zp"] = bits(fq_zp)  # bf16((q * scale + zero) in fp32)
+        # scale / zero as the fake quantizer computes them (fp32), then the GPTQ helpers' quantize / dequantize given them
+        wg = w.float().view(n, -1, g)
+        mx, mn = wg.amax(-1, keepdim=True), wg.amin(-1, keepdim=True)
+        scale = torch.clamp(mx - mn, min=1e-6) / 15
+        zero = mn + scale * 8
+        s_t, z_t = scale.view(n, -1).t().contiguous(), zero.view(n, -1).t().contiguous()  # [K/g, N] like mslk returns them
+        q = _int4_row_quantize_zp_precomputed_qparams(w, s_t, z_t, g)
+        out[f"{name}_scale_f32"] = s_t.numpy()
+        out[f"{name}_zero_f32"] = z_t.numpy()
+        out[f"{name}_q"] = q.numpy()
+        out[f"{name}_dq_f32"] = _int4_row_dequantize_zp(q, s_t, z_t, g).numpy()
+    np.savez_compressed(os.path.join(HERE, "int4_plain.npz"), **out)
+    print("int4_plain.npz:", len(out), "arrays")
+
+
+def make_hqq():
+    """HQQ qparams as Int4TilePackedTo4dTensor.from_hp computes them (int4_tile_packed_to_4d_tensor.py:149-168), with the
+    proximal optimizer's dtype forced to float16 -- what the reference uses on a GPU (quant_primitives.py:1832-1833) -- while
+    running here on the CPU."""
+    from functools import partial
+
+    from torchao.quantization.quant_primitives import _choose_qparams_and_quantize_affine_hqq, optimize_weights_proximal_legacy
+
+    out = {}
+    for name, n, k, g in [("g64", 16, 512, 64), ("g128", 32, 1024, 128)]:
+        gen = torch.Generator().manual_seed(777 + g)
+        w = (torch.randn(n, k, generator=gen) * 0.02).to(torch.bfloat16)
+        w[2, :g] = torch.linspace(-1.0, 2.0, g).to(torch.bfloat16)
+        q, scale, zero, _ = _choose_qparams_and_quantize_affine_hqq(
+            w, nbits=4, group_size=g, axis=1, compute_dtype=torch.bfloat16, device="cpu", verbose=False, raw_output=False,
+            optimize_weights=partial(optimize_weights_proximal_legacy, dtype=torch.float16))
+        out[f"{name}_w"] = bits(w)
+        out[f"{name}_q"] = q.numpy().astype(np.uint8)
+        out[f"{name}_scale"] = bits(scale.reshape(n, -1))
+        out[f"{name}_zero"] = bits(zero.reshape(n, -1))
+    np.savez_compressed(os.path.join(HERE, "hqq.npz"), **out)
+    print("hqq.npz:", len(out), "arrays")
+
+
 def make_rest():
     make_int8_fp8()
     make_mx()
     make_moe()
+    make_int4_plain()
+    make_hqq()
 
 
 if __name__ == "__main__":

@@ -203,3 +203,47 @@ def test_row_parallel_blocks_match_unsharded_oracle(kind, world):
         assert torch.equal(y, y_full)
     else:
         assert _rel(yn, np_from_torch_bf16(y_full)) <= 1e-3
+
+
+# ---- Float8Tensor _grouped_mm (rowwise) and the cached MXFP8 expert weights ------------------------------------------------
+@pytest.mark.parametrize("sizes,n,k", [([16, 16, 16, 16], 64, 512), ([32, 0, 5, 27], 256, 2048), ([1, 70, 3, 0], 144, 4096),
+                                       ([128, 0, 64, 200, 0, 0, 8, 0], 1024, 1024)])
+def test_fp8_grouped_mm_vs_oracle(sizes, n, k):
+    """torch._grouped_mm(x, Float8Tensor weight.transpose(-2, -1), offs) -- float8_tensor.py:1085-1122 -- against the numpy oracle
+    (rowwise e4m3 cast of the tokens, per-expert rowwise scaled matmul)."""
+    from ao_amd.quantization import Float8Tensor
+    from ao_amd.quantization.float8_tensor import QuantizeTensorToFloat8Kwargs
+
+    E, M = len(sizes), sum(sizes)
+    a = _randn_bf16((M, k), 51)
+    w = _randn_bf16((E, n, k), 52, 0.05)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32)
+    wt = Float8Tensor.from_hp(w.to(DEV), act_quant_kwargs=QuantizeTensorToFloat8Kwargs())
+    assert tuple(wt.shape) == (E, n, k) and tuple(wt.scale.shape) == (E, n, 1)
+    y = torch._grouped_mm(a.to(DEV), wt.transpose(-2, -1), offs=offs.to(DEV))
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (M, n)
+    wq, ws = F.quantize_rowwise(w.float().numpy().reshape(E * n, k))
+    assert np.array_equal(wt.qdata.view(torch.uint8).cpu().numpy().reshape(E * n, k), wq)
+    aq, a_s = F.quantize_rowwise(a.float().numpy())
+    y_ref = F.grouped_mm(aq, wq.reshape(E, n, k), a_s, ws.reshape(E, n), offs.numpy())
+    yn = np_from_torch_bf16(y)
+    assert _rel(yn, y_ref) <= 1e-3
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -14)
+
+
+def test_mxfp8_moe_forward_with_cached_expert_weights():
+    """_to_mxfp8_then_scaled_grouped_mm: casting the expert weights once (MXFP8ExpertWeights / cache_weights=True) gives the bits of
+    casting them in every call (the reference's forward), and an in-place weight update invalidates the memo."""
+    from ao_amd.prototype.mx import MXFP8ExpertWeights, _to_mxfp8_then_scaled_grouped_mm
+
+    E, n, k = 4, 256, 1024
+    a = _randn_bf16((96, k), 61).to(DEV)
+    b_t = _randn_bf16((E, n, k), 62, 0.05).to(DEV).transpose(-2, -1)  # [E, K, N] view of [E, N, K]
+    offs = torch.tensor([32, 32, 64, 96], dtype=torch.int32, device=DEV)
+    want = _to_mxfp8_then_scaled_grouped_mm(a, b_t, offs)
+    assert torch.equal(_to_mxfp8_then_scaled_grouped_mm(a, MXFP8ExpertWeights.from_hp(b_t), offs), want)
+    assert torch.equal(_to_mxfp8_then_scaled_grouped_mm(a, b_t, offs, cache_weights=True), want)
+    assert torch.equal(_to_mxfp8_then_scaled_grouped_mm(a, b_t, offs, cache_weights=True), want)  # memo hit
+    b_t.mul_(2.0)  # in-place update bumps the version counter: the memo must not serve the old cast
+    got = _to_mxfp8_then_scaled_grouped_mm(a, b_t, offs, cache_weights=True)
+    assert torch.equal(got, _to_mxfp8_then_scaled_grouped_mm(a, b_t, offs)) and not torch.equal(got, want)

@@ -20,8 +20,11 @@ def test_find_multiple():
 
 def test_config_defaults_and_validation():
     c = Int4WeightOnlyConfig()
-    assert c.group_size == 128 and c.int4_packing_format == Int4PackingFormat.TILE_PACKED_TO_4D
-    assert c.int4_tile_packed_ntile == 16 and c.version == 2
+    # the reference's defaults (quant_api.py:519-531): PLAIN packing, tinygemm qparams
+    assert c.group_size == 128 and c.int4_packing_format == Int4PackingFormat.PLAIN
+    assert c.int4_choose_qparams_algorithm == "tinygemm" and c.version == 2
+    assert c.int4_tile_packed_ntile == 16
+    assert Int4WeightOnlyConfig(int4_packing_format="tile_packed_to_4d").int4_packing_format == Int4PackingFormat.TILE_PACKED_TO_4D
     with pytest.raises(AssertionError):
         Int4WeightOnlyConfig(int4_tile_packed_ntile=12)
 
@@ -34,9 +37,26 @@ def test_quantize_rejects_non_config():
 
 def test_cant_initialize_in_cpu():
     # reference: test_int4_tile_packed_to_4d_tensor.py:194-202
+    for fmt in ("tile_packed_to_4d", "plain"):
+        m = torch.nn.Sequential(torch.nn.Linear(1024, 32, bias=False)).to(torch.bfloat16)
+        with pytest.raises(RuntimeError):
+            quantize_(m, Int4WeightOnlyConfig(group_size=128, int4_packing_format=fmt))
+
+
+def test_hqq_only_with_tile_packed_and_plain_checks():
+    # reference quant_api.py:560-565
     m = torch.nn.Sequential(torch.nn.Linear(1024, 32, bias=False)).to(torch.bfloat16)
-    with pytest.raises(RuntimeError):
-        quantize_(m, Int4WeightOnlyConfig(group_size=128))
+    with pytest.raises(AssertionError, match="HQQ is not supported by packing format"):
+        quantize_(m, Int4WeightOnlyConfig(group_size=128, int4_choose_qparams_algorithm="hqq"))
+    from ao_amd.quantization import Float8DynamicActivationInt4WeightConfig, Int4Tensor
+
+    w = torch.zeros(32, 1024, dtype=torch.bfloat16)
+    with pytest.raises(AssertionError):
+        Int4Tensor.from_hp(w, [1, 128], activation_dtype=torch.float16)
+    with pytest.raises(AssertionError):
+        Int4Tensor.from_hp(w, [1, 1])  # per-channel codes are not groupwise
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        quantize_(m, Float8DynamicActivationInt4WeightConfig())
 
 
 def test_incompatible_group_size_is_skipped_silently():

@@ -284,7 +284,7 @@ def test_quantize_linear_sqnr(shape, out_features, bias):
     lin = torch.nn.Linear(1024, out_features, bias=bias).to(torch.bfloat16).to(DEV)
     x = torch.randn(*shape, dtype=torch.bfloat16, device=DEV)
     ref = lin(x)
-    quantize_(lin, Int4WeightOnlyConfig(group_size=32))
+    quantize_(lin, Int4WeightOnlyConfig(group_size=32, int4_packing_format="tile_packed_to_4d"))
     assert isinstance(lin.weight, Int4TilePackedTo4dTensor)
     y = lin(x)
     assert y.shape == ref.shape and y.dtype == ref.dtype
