@@ -14,6 +14,9 @@
 #include "common.h"
 
 namespace ao {
+bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K);  // gemm8_p8_kernels.hip (epi numbering = enum Epilogue)
+int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
+             int64_t M, int64_t N, int64_t K, hipStream_t stream);
 
 // rb8_kernels.hip: weight-streaming kernels for problems with few output tiles
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
@@ -389,6 +392,12 @@ int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
   // (A 4-stage, 64-byte-K-step pipeline with hand-counted vmcnt was measured at 0.94-0.97x of these two-stage
   // kernels at both tile shapes, profiles/bench_8bit_r01_gemm.txt: the loop is LDS-read bound, not latency bound.)
   const int64_t big = (int64_t)((p.N + 255) / 256) * ((p.M + 255) / 256);
+  // The phase-interleaved 256 x 256 kernel (gemm8_p8_kernels.hip; variant 32 forces it) once the problem has >= 160 such tiles.
+  // Measured on the Llama-3-8B shapes (profiles/gemm8_variants_r02.txt, TOP/s int8, this kernel vs the two-stage kernels):
+  // M = 8192: 2046 / 2084 / 2492 / 2796 vs 1557 / 1508 / 1777 / 2153; M = 2048: qkv (192 tiles) 1832 vs 1210, gate_up 2148 vs 1566,
+  // but o / down (128 tiles: half the CUs idle) 1350 / 1710 vs 1330 / 1834; M = 512: gate_up (224 tiles) 2122 vs 1231.
+  if ((g_gemm8_tm == 32 || (g_gemm8_tm == 0 && big >= 160)) && gemm8_p8_fits(p.M, p.N, p.K))
+    return gemm8_p8((int)EPI, p.a, p.b, p.row_scale, p.col_scale, p.bias, p.out, p.M, p.N, p.K, stream);
   if (g_gemm8_tm == 8 || (g_gemm8_tm == 0 && big >= 512)) return launch_gemm8_dma_tm<EPI, 4, 4>(p, stream);
   return launch_gemm8_dma_tm<EPI, 2, 2>(p, stream);
 }
@@ -421,7 +430,7 @@ extern "C" int ao_gemm8_set_variant(int variant) {
   g_gemm8_force_regstage = (variant == 1);
   g_gemm8_tiled_only = (variant == 100);
   g_mx_variant = (variant == 110) ? 1 : (variant == 111) ? 2 : 0;
-  g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16) ? variant : 0;
+  g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16 || variant == 32) ? variant : 0;
   // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
   fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : (variant != 0 && variant < 110) ? 1 : 0);
   return AO_OK;

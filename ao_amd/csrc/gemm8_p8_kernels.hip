@@ -1,0 +1,282 @@
+// 1-byte-operand GEMM for large M on gfx950, phase-interleaved 256 x 256 tile: int8 x int8 -> int32 (aten::_int_mm + the
+// Int8Tensor scale epilogue, int8/kernels.py:114-144, int8_tensor.py:305-359) and e4m3 x e4m3 -> fp32 (aten::_scaled_mm rowwise,
+// float8/inference.py:104-123).  "NT": a [M][K], b [N][K], both K-contiguous.
+//
+// Structure (the CDNA4 guide's 8-phase idea re-derived for byte operands; one workgroup per CU):
+//   * 8 waves = 2 (m) x 4 (n); a wave owns 128 x 64 outputs = 8 x 4 MFMA tiles of 16 x 16 (128 accumulator VGPRs), visited as
+//     four QUADRANTS of 64 x 32 per 128-byte K tile: q0 (m-lo, n-lo), q1 (m-lo, n-hi), q2 (m-hi, n-hi), q3 (m-hi, n-lo).  Its B
+//     fragments (all 64 columns) and the m-lo A fragments are read in q0, the m-hi A fragments in q2 (16, 0, 8, 0 ds_read_b128).
+//   * a PHASE = [LDS fragment reads + 2 LDS-DMA issues + counted vmcnt | barrier | 16 int8 (8 fp8) MFMAs = 256 matrix cycles |
+//     barrier].  The two wave rows run one barrier apart, so on every SIMD one wave multiplies while the other reads / issues:
+//     the matrix pipe never waits for LDS, and no wave drains its DMA queue in the steady state (vmcnt(4) once per K tile).
+//   * operands are staged by LDS-DMA in HALF tiles (128 rows x 128 B = 16 KiB, two 1 KiB DMA instructions per wave), two K
+//     tiles of four half tiles resident (128 KiB).  A wave row reads its A half tile in q0 and q2, a wave column pair its B
+//     half tile in q0 only, so per K tile t the phases issue: q0 A-lo(t+1), q1 A-hi(t+1), q2 B-lo(t+2), q3 B-hi(t+2) -- every slot
+//     has then been unread for two phases when it is refilled (with the one-barrier stagger a slot's last reader can be a phase
+//     behind its writer), and the wait for tile t+1 (vmcnt(4) in q3, one phase before its first read: the other wave row's
+//     wait is a barrier later) finds its youngest half tile two phases old.
+//   * bank conflicts: the DMA writes lane-linear, so the SOURCE is swizzled (LDS chunk position c of row r holds global chunk
+//     c ^ ((r >> 1) & 7)) and fragment reads apply the same involution.
+//   * epilogue: scales applied in registers with the reference's rounding sequence, tile transposed through the (now free)
+//     LDS so that every lane stores 16 contiguous bytes (128-byte rows per 8 lanes) instead of 2.
+#include "common.h"
+#include "lds_dma.h"
+
+namespace ao {
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+enum P8Epi { P8_INT8_SCALED = 0, P8_INT32 = 1, P8_FP8_ROWWISE = 2, P8_FP8_RAW = 3 };
+
+struct P8Args {
+  const uint8_t* a;        // [M][K]
+  const uint8_t* b;        // [N][K]
+  const float* row_scale;  // [M]
+  const float* col_scale;  // [N]
+  const uint16_t* bias;    // [N] bf16 or null
+  void* out;               // bf16 / int32 / fp32 [M][N]
+  int M, N, K;
+  int tiles_m, tiles_n;
+};
+
+constexpr int kHalf = 16384;          // one half tile: 128 rows x 128 B
+constexpr int kBuf = 4 * kHalf;       // A-lo, A-hi, B-lo, B-hi of one K tile
+constexpr int kEpiStride = 144;       // bytes per row of a wave's 128 x 64 bf16 staging region (128 + 16: conflict-free b16 writes)
+constexpr int kSmem = 8 * 128 * kEpiStride;  // 147456 B >= 2 * kBuf
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
+  constexpr bool IS_INT = (EPI == P8_INT8_SCALED || EPI == P8_INT32);
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nl = lane & 15, kq = lane >> 4;
+
+  // workgroup -> tile: blocks of one XCD (id % 8) take consecutive tiles, tiles ordered in groups of 8 tile rows that walk
+  // the N direction together (a group shares its A panels in the XCD's L2 and streams B once)
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const int group = 8 * p.tiles_n;
+  const int g0 = (wg / group) * 8;
+  const int gsz = min(8, p.tiles_m - g0);
+  const int tm = g0 + (wg % group) % gsz, tn = (wg % group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int ktiles = p.K >> 7;
+
+  // DMA sources.  Half tile rows 16 w + 8 i + (lane >> 3), i = 0, 1; lane lands at chunk position lane & 7.
+  uint32_t aoff[2][2], boff[2][2];  // [half][i]: byte offset from the tile's first row, k = 0
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 16 * wave + 8 * i + (lane >> 3);
+      const uint32_t chunk = (uint32_t)(((lane & 7) ^ (row >> 1)) & 7) << 4;
+      aoff[h][i] = (uint32_t)(min(m0 + h * 128 + row, p.M - 1) - m0) * (uint32_t)p.K + chunk;
+      boff[h][i] = (uint32_t)(min(n0 + h * 128 + row, p.N - 1) - n0) * (uint32_t)p.K + chunk;
+    }
+  const uint8_t* abase = p.a + (size_t)m0 * p.K;
+  const uint8_t* bbase = p.b + (size_t)n0 * p.K;
+  const uint32_t lds0 = lds_offset(smem);
+  // half tile j of the stream: tile j / 4; order A-lo, B-hi, B-lo, A-hi; slots [A-lo, A-hi, B-lo, B-hi]
+  auto issue = [&](int tile, int which) {  // which: 0 A-lo, 1 B-hi, 2 B-lo, 3 A-hi
+    if (tile >= ktiles) return;
+    const bool is_a = (which == 0 || which == 3);
+    const int half = (which == 1 || which == 3) ? 1 : 0;
+    const uint32_t dst = lds0 + (tile & 1) * kBuf + ((is_a ? 0 : 2) + half) * kHalf + wave * 2048;
+    const uint8_t* src = (is_a ? abase : bbase) + (size_t)tile * 128;
+    if (is_a) {
+      dma_b128_s(src, aoff[half][0], dst);
+      dma_b128_s(src, aoff[half][1], dst + 1024);
+    } else {
+      dma_b128_s(src, boff[half][0], dst);
+      dma_b128_s(src, boff[half][1], dst + 1024);
+    }
+  };
+
+  // fragment addresses inside a buffer: A rows of wave row wr (half tile wr), B rows of wave column wc (half tile wc >> 1)
+  const int pos_lo = ((kq ^ (nl >> 1)) & 7) << 4;  // chunk kq of row nl (+ 16 row steps keep (row >> 1) & 7); chunk 4 + kq: ^ 64
+  const int a_frag = wr * kHalf + nl * 128 + pos_lo;
+  const int b_frag = (2 + (wc >> 1)) * kHalf + ((wc & 1) * 64 + nl) * 128 + pos_lo;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 af[4][2], bf[4][2];  // A: the current 64-row half of the wave's rows (4 m-tiles x {chunk kq, chunk 4 + kq}); B: all 4 n-tiles
+
+  auto load_a = [&](const char* buf, int mi) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int off = a_frag + (mi * 64 + mt * 16) * 128;
+      af[mt][0] = *reinterpret_cast<const u32x4*>(buf + off);
+      af[mt][1] = *reinterpret_cast<const u32x4*>(buf + (off ^ 64));
+    }
+  };
+  auto load_b = [&](const char* buf) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int off = b_frag + (nt * 16) * 128;
+      bf[nt][0] = *reinterpret_cast<const u32x4*>(buf + off);
+      bf[nt][1] = *reinterpret_cast<const u32x4*>(buf + (off ^ 64));
+    }
+  };
+  auto multiply = [&](int mi, int nj) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+        const int nt = nj * 2 + n2;
+        f32x4& c = acc[mi * 4 + mt][nt];
+        if constexpr (IS_INT) {
+          // (the second k half of every tile follows in a second sweep below: back-to-back MFMAs on one accumulator would wait for each other)
+          c = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[mt][0]), __builtin_bit_cast(i32x4, bf[nt][0]),
+                                                                             __builtin_bit_cast(i32x4, c), 0, 0, 0));
+        } else {
+          const i32x8 av = {(int)af[mt][0].x, (int)af[mt][0].y, (int)af[mt][0].z, (int)af[mt][0].w,
+                            (int)af[mt][1].x, (int)af[mt][1].y, (int)af[mt][1].z, (int)af[mt][1].w};
+          const i32x8 bv = {(int)bf[nt][0].x, (int)bf[nt][0].y, (int)bf[nt][0].z, (int)bf[nt][0].w,
+                            (int)bf[nt][1].x, (int)bf[nt][1].y, (int)bf[nt][1].z, (int)bf[nt][1].w};
+          c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, 127, 0, 127);
+        }
+      }
+    if constexpr (IS_INT) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int nt = nj * 2 + n2;
+          f32x4& c = acc[mi * 4 + mt][nt];
+          c = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[mt][1]), __builtin_bit_cast(i32x4, bf[nt][1]),
+                                                                             __builtin_bit_cast(i32x4, c), 0, 0, 0));
+        }
+    }
+  };
+  // the barrier between a load segment and a multiply segment (and back): LDS reads retired, nothing moves across
+  auto seam = [&] {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: K tile 0 entirely and the B halves of tile 1 (as if issued in q2 / q3 of a tile -1); wait for tile 0
+  issue(0, 0); issue(0, 3); issue(0, 2); issue(0, 1); issue(1, 2); issue(1, 1);
+  if (ktiles > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+  asm volatile("s_barrier" ::: "memory");
+  if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the stagger: wave row 1 runs one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int t = 0; t < ktiles; ++t) {
+    const char* buf = smem + (t & 1) * kBuf;
+    // ---- q0: m-lo x n-lo; reads the wave's B fragments and its m-lo A fragments; refills A-lo of the other buffer ----------
+    load_b(buf); __builtin_amdgcn_sched_barrier(0); load_a(buf, 0);
+    issue(t + 1, 0);
+    seam();
+    __builtin_amdgcn_s_setprio(1); multiply(0, 0); __builtin_amdgcn_s_setprio(0);
+    seam();
+    // ---- q1: m-lo x n-hi ------------------------------------------------------------------------------------------------
+    issue(t + 1, 3);
+    seam();
+    __builtin_amdgcn_s_setprio(1); multiply(0, 1); __builtin_amdgcn_s_setprio(0);
+    seam();
+    // ---- q2: m-hi x n-hi; B of this buffer was last read two phases ago: refill B-lo for tile t + 2 ---------------------------
+    load_a(buf, 1);
+    issue(t + 2, 2);
+    seam();
+    __builtin_amdgcn_s_setprio(1); multiply(1, 1); __builtin_amdgcn_s_setprio(0);
+    seam();
+    // ---- q3: m-hi x n-lo; tile t + 1 must have landed before the next phase reads it (its B halves are older than its A halves)
+    issue(t + 2, 1);
+    if (t + 2 < ktiles) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    seam();
+    __builtin_amdgcn_s_setprio(1); multiply(1, 0); __builtin_amdgcn_s_setprio(0);
+    seam();
+  }
+  if (wr == 0) asm volatile("s_barrier" ::: "memory");  // wave row 0 catches up: from here on the LDS is free for every wave
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue --------------------------------------------------------------------------------------------------------
+  // D layout of the 16 x 16 MFMA: lane (col = nl, kq) holds rows 4 kq + {0..3}
+  const int rbase = m0 + wr * 128, cbase = n0 + wc * 64;
+  if constexpr (EPI == P8_INT32 || EPI == P8_FP8_RAW) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = rbase + mt * 16 + kq * 4 + r, n = cbase + nt * 16 + nl;
+          if (m < p.M && n < p.N) reinterpret_cast<uint32_t*>(p.out)[(size_t)m * p.N + n] = __builtin_bit_cast(u32x4, acc[mt][nt])[r];
+        }
+  } else {
+    float cs[4], bias[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = min(cbase + nt * 16 + nl, p.N - 1);
+      cs[nt] = p.col_scale[n];
+      bias[nt] = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
+    }
+    char* region = smem + wave * (128 * kEpiStride);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      float rs[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[r] = p.row_scale[min(rbase + mt * 16 + kq * 4 + r, p.M - 1)];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v;
+          if constexpr (EPI == P8_INT8_SCALED) {
+            // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+            v = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt][nt])[r] * rs[r]) * cs[nt];
+          } else {
+            v = acc[mt][nt][r] * rs[r] * cs[nt];
+          }
+          if (p.bias != nullptr) v += bias[nt];
+          *reinterpret_cast<uint16_t*>(region + (mt * 16 + kq * 4 + r) * kEpiStride + (nt * 16 + nl) * 2) = f32_to_bf16_bits(v);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own writes (DS ops of a wave complete in order)
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = i * 8 + (lane >> 3), piece = lane & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * kEpiStride + piece * 16);
+      const int m = rbase + row, n = cbase + piece * 8;
+      if (m < p.M && n + 8 <= p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.N + n) = v;
+    }
+  }
+}
+
+template <int EPI>
+int launch_p8(P8Args p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8_kernel<EPI>), kSmem, "hipFuncSetAttribute(gemm8_p8_kernel)")) return rc;
+  ao::launch(gemm8_p8_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kSmem, stream, p);
+  AO_LAUNCH_CHECK("gemm8_p8_kernel launch");
+  return AO_OK;
+}
+
+}  // namespace
+
+// epi: 0 int8 scaled (bf16 out), 1 int32 out, 2 fp8 rowwise (bf16 out), 3 fp8 raw fp32 out.  K % 128 == 0, N % 8 == 0,
+// 256 * K < 4 GiB (32-bit in-tile offsets).
+bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K) { return K % 128 == 0 && N % 8 == 0 && 256 * K < (1ll << 32) && M > 0 && N > 0; }
+
+int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
+             int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+  P8Args p{a, b, row_scale, col_scale, bias, out, (int)M, (int)N, (int)K, 0, 0};
+  switch (epi) {
+    case P8_INT8_SCALED: return launch_p8<P8_INT8_SCALED>(p, stream);
+    case P8_INT32: return launch_p8<P8_INT32>(p, stream);
+    case P8_FP8_ROWWISE: return launch_p8<P8_FP8_ROWWISE>(p, stream);
+    default: return launch_p8<P8_FP8_RAW>(p, stream);
+  }
+}
+
+}  // namespace ao

@@ -15,7 +15,7 @@ in the same run and reported in config.merged_tokens_per_s.
 The same line carries `configs`, one object per other BASELINE.json config, each with its own value, roofline and
 cpu_baseline (rank 0, N = 1 runs):
   int4_bs128          configs[1]'s second half (bs = 128): same weights, 128-row activations (MFMA-bound)
-  int8_dyn_bs128x2048 configs[2]: int8 dynamic-activation / int8-weight, M = 128 x 2048 = 262144 rows in 2048-row chunks
+  int8_dyn_bs128x2048 configs[2]: int8 dynamic-activation / int8-weight, M = 128 x 2048 = 262144 rows in 16384-row chunks
   fp8_tp8_shards      configs[3], one GPU's share: Float8 rowwise, the Llama-3-70B TP=8 shard linears, M in {1, 128, 2048}
   mxfp8_mixtral_bs64  configs[4]: MXFP8 grouped GEMM, Mixtral-8x7B expert shapes, 64 tokens x top-2
 With N > 1 ranks: the headline runs one replica per GPU (the decode path partitions by token stream, no data-path
@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--configs", default="int4_bs128,int8,fp8,mx,tp", help="comma list of secondary configs to run")
     ap.add_argument("--wpb", type=int, default=0, help="tuning: waves per workgroup override")
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="tuning: ao_gemm8_set_variant for the 8-bit configs (profiling only)")
     return ap.parse_args()
 
 
@@ -330,16 +331,17 @@ def config_int4_bs128(model, stream, device, args):
 
 
 def config_int8(stream, device, args):
-    """configs[2]: Int8DynamicActivationInt8WeightConfig, Llama-3-8B shapes, M = 128 x 2048 rows as 128 chunks of 2048."""
+    """configs[2]: Int8DynamicActivationInt8WeightConfig, Llama-3-8B shapes, M = 128 x 2048 = 262144 rows as 16 chunks of 16384 (the
+    chunking only bounds the activation buffers: x of one chunk is 470 MB at K = 14336)."""
     from ao_amd import _lib, ops
     lib = _lib.lib()
-    chunk, nchunk, rot = 2048, 128, 8
+    chunk, nchunk, rot = 16384, 16, 2
     gen = torch.Generator(device=device).manual_seed(1)
     ws, xs = [], {}
     for name, n, k in LLAMA3_8B_UNMERGED:
         w = torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02
         ws.append((name, n, k) + ops.int8_quantize_rowwise(w))
-        if k not in xs:  # `rot` distinct activation chunks per K (rot x 2048 x K x 2 B >> the 256 MiB Infinity Cache at K = 14336)
+        if k not in xs:  # `rot` distinct activation chunks per K (2 x 16384 x K x 2 B >= 268 MB: beyond the 256 MiB Infinity Cache)
             xs[k] = [torch.randn(chunk, k, device=device, dtype=torch.bfloat16, generator=gen) for _ in range(rot)]
     def layer():
         for name, n, k, wq, wsc in ws:
@@ -352,7 +354,7 @@ def config_int8(stream, device, args):
     M = chunk * nchunk
     flops = sum(2.0 * M * n * k for _, n, k, _, _ in ws)
     cast_ms, gemm_ms = float(prof[0::2].sum()), float(prof[1::2].sum())
-    out = {"workload": "Int8DynamicActivationInt8WeightConfig Llama-3-8B linear shapes, M = 128 x 2048 = 262144 rows in 2048-row chunks, "
+    out = {"workload": "Int8DynamicActivationInt8WeightConfig Llama-3-8B linear shapes, M = 128 x 2048 = 262144 rows in 16384-row chunks, "
                        "1 of 32 layers timed (x32 = one forward; every layer does the same work)",
            "value": M / (t * N_LAYERS), "unit": "tokens/s", "ms_per_layer": t * 1e3, "dtype": "int8 x int8 -> int32, bf16 out",
            "launch": "hipGraph replay" if graphed else "eager", "launches_per_layer": 2 * nchunk * len(ws),
@@ -562,6 +564,8 @@ def main():
     lib = _lib.lib()
     if args.wpb or args.mode:
         lib.ao_int4_set_tuning(args.wpb, args.mode)
+    if args.gemm_variant:
+        lib.ao_gemm8_set_variant(args.gemm_variant)
 
     merged = args.merged and not args.unmerged
     shapes = LLAMA3_8B_MERGED if merged else LLAMA3_8B_UNMERGED

@@ -396,8 +396,8 @@ def test_fp8_weight_streaming_mid_m(m, n, k, bias):
     assert _rel(np_from_torch_bf16(y_gemm), yn) <= 1e-3  # the GEMM kernels agree up to accumulation order
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 8, 16])
-@pytest.mark.parametrize("m,n,k", [(130, 208, 1152), (300, 528, 256), (513, 384, 4096)])  # N % 16 == 0 (fp8 requirement)
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 16, 32])
+@pytest.mark.parametrize("m,n,k", [(130, 208, 1152), (300, 528, 256), (513, 384, 4096), (257, 272, 128)])  # N % 16 == 0 (fp8 requirement)
 def test_gemm8_every_kernel_variant(variant, m, n, k):
     """register-staged, 128x128 / 256x128 / 256x256 LDS-DMA kernels: same bits for int8 (integer GEMM + the
     reference's rounding sequence), <= 1e-3 for fp8; ragged M and N against every tile shape."""
@@ -421,3 +421,34 @@ def test_gemm8_every_kernel_variant(variant, m, n, k):
     assert np.array_equal(np_from_torch_bf16(y8), I.linear(x.float().numpy(), w.float().numpy(), b.float().numpy()))
     assert np.array_equal(c.cpu().numpy(), I.int_mm(xq.cpu().numpy(), wq.cpu().numpy()))
     assert _rel(np_from_torch_bf16(yf), F.linear(x.float().numpy(), w.float().numpy(), b.float().numpy())) <= 1e-3
+
+
+@pytest.mark.parametrize("m,n,k", [(2048, 4096, 4096), (4096, 1024, 14336), (1000, 784, 2048)])
+def test_gemm8_phase_interleaved_kernel_race_screen(m, n, k):
+    """gemm8_p8_kernel (variant 32): staggered wave rows, counted vmcnt, LDS slots refilled two phases after their last read --
+    an ordering mistake would show as rare wrong tiles.  The int8 GEMM is exact, so ANY difference from the two-stage kernel
+    (variant 8) in any of 6 runs on fresh random operands is a failure; fp8 within accumulation order."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    for run in range(6):
+        g = torch.Generator(device=DEV).manual_seed(1000 * run + m)
+        a = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+        b = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+        f = torch.randn(m, k, device=DEV, generator=g).to(torch.bfloat16)
+        h = (torch.randn(n, k, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+        fq, fs = ops.fp8_quantize_rowwise(f)
+        hq, hs = ops.fp8_quantize_rowwise(h)
+        try:
+            lib.ao_gemm8_set_variant(8)
+            want = ops.int_mm(a, b.t())
+            want_f = ops.fp8_scaled_mm(fq, hq.t(), fs, hs.t())
+            lib.ao_gemm8_set_variant(32)
+            got = ops.int_mm(a, b.t())
+            got_f = ops.fp8_scaled_mm(fq, hq.t(), fs, hs.t())
+            raw = ops.fp8_mm_f32(fq, hq.t())
+        finally:
+            lib.ao_gemm8_set_variant(0)
+        assert torch.equal(got, want), (run, int((got != want).sum()))
+        assert _rel(np_from_torch_bf16(got_f), np_from_torch_bf16(want_f)) <= 1e-3
+        assert _rel(np_from_torch_bf16((raw * fs * hs.t()).to(torch.bfloat16)), np_from_torch_bf16(want_f)) <= 2e-3

@@ -103,6 +103,15 @@ def main():
                 b = n * k + m * k + m * n * 2
                 rec(kernel="fp8_scaled_mm", shape=name, M=m, N=n, K=k, us=t * 1e6, TFLOPs=f / t / 1e12, frac_mfma=f / t / PEAK_FP8,
                     GBps=b / t / 1e9, frac_hbm=b / t / PEAK_HBM)
+    if "fp8l" in which:  # fp8 rowwise on the Llama-3-8B shapes at one M (GEMM tile-shape A/B)
+        for name, n, k in LLAMA8B:
+            x = torch.randn(M, k, device=dev, dtype=torch.bfloat16)
+            w = torch.randn(n, k, device=dev, dtype=torch.bfloat16) * 0.02
+            wq, ws = ops.fp8_quantize_rowwise(w)
+            xq, xs = ops.fp8_quantize_rowwise(x)
+            t = timeit(lambda: ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t()), args.iters)
+            f = 2.0 * M * n * k
+            rec(kernel="fp8_scaled_mm", shape=name, M=M, N=n, K=k, us=t * 1e6, TFLOPs=f / t / 1e12, frac_mfma=f / t / PEAK_FP8)
     if "mx" in which:
         E, rows = 8, 128
         sizes = [32, 0, 32, 16, 16, 0, 32, 0]
