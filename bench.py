@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--configs", default="int4_bs128,int8,fp8,mx,tp", help="comma list of secondary configs to run")
     ap.add_argument("--wpb", type=int, default=0, help="tuning: waves per workgroup override")
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
+    ap.add_argument("--force-tp", action="store_true", help="run the TP-linear config even with one rank (exercises the RCCL path on a 1-GPU box)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning: ao_gemm8_set_variant for the 8-bit configs (profiling only)")
     return ap.parse_args()
 
@@ -542,6 +543,11 @@ def config_fp8_tp(stream, device, args, dist, world):
 
 # ----------------------------------------------------------------------------------------------------------------------
 def main():
+    # stdout carries exactly ONE line (the JSON): RCCL / HIP libraries print banners to the C-level stdout ("RCCL version : ...")
+    # whenever they like, so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -553,10 +559,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_tp:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
 
     from ao_amd import _lib
@@ -571,7 +580,7 @@ def main():
     shapes = LLAMA3_8B_MERGED if merged else LLAMA3_8B_UNMERGED
     stream = torch.cuda.Stream(device=device)
     model = Int4Linears(device, args.layers, shapes)
-    elapsed, graphed = run_int4(model, args.batch, args.steps, args.warmup, stream, device, not args.no_graph, dist)
+    elapsed, graphed = run_int4(model, args.batch, args.steps, args.warmup, stream, device, not args.no_graph, dist if world > 1 else None)
     ms_per_step = elapsed * 1e3 / args.steps
     tokens_per_s = args.batch * world * args.steps / elapsed
 
@@ -601,7 +610,7 @@ def main():
                 except Exception as e:  # noqa: BLE001 -- a secondary config must not take the headline line down
                     configs[name] = {"error": repr(e)}
                 torch.cuda.empty_cache()
-    if world > 1 and "tp" in want and args.batch == 1:
+    if (world > 1 or args.force_tp) and "tp" in want and args.batch == 1:
         model.io = {}
         try:
             tp = config_fp8_tp(stream, device, args, dist, world)
@@ -643,10 +652,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline_int4(args.batch)
         if configs:
             out["configs"] = configs
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
