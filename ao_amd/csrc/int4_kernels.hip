@@ -441,7 +441,16 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 //     queue in the texture path and hold the wave ~120 cycles each; spreading them further or staggering them
 //     between waves measured 7 % slower).
 // ---------------------------------------------------------------------------
-constexpr int kRbStages = 3;
+constexpr int kRbStages = 3;  // x ring (shared by the workgroup): filled two k-blocks ahead
+// weight ring (per wave), filled kW - 1 k-blocks ahead.  Its depth is independent of the x ring's; deepening it to 6 - 8 stages
+// (what fixed the 8-bit weight-streaming kernel, rb8_kernels.hip) measured 0.96x here (bs = 128: 31.9k -> 30.8k tok/s,
+// profiles/int4_bs_sweep_r02.txt): at one wave per SIMD the k-block is bound by what the wave itself issues (10 LDS-DMAs, 32
+// ds_read_b128, ~70 VALU, 32 MFMAs, one after the other), not by the HBM stream's latency.  So: 3 stages.
+constexpr int kRbWeightStages = 3;
+constexpr int rb_wstages(int waves, int mt, int wst) {
+  const int room = (160 * 1024 - kRbStages * mt * 4096) / (waves * wst);
+  return room >= kRbWeightStages ? kRbWeightStages : (room < 3 ? 3 : room);
+}
 
 // ABL (profiling builds only): 1 no 16x16x32 MFMAs, 2 no dequant, 3 no A reads, 4 no DMAs, 5 product + s_memtime stamps of wave 0
 // (16 u64 per workgroup: entry, ring primed, barrier of k-blocks 0..7 passed, loop done, meeting done, exit)
@@ -460,7 +469,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   constexpr int ABUF = MT * 4096;         // one x stage: 16 MT rows x 256 B
   constexpr int LPS = ADMA + NT * (1 + NG);  // DMAs per wave and stage
   constexpr int SLOTS = 16 * NT;          // schedule slots per k-block (MT / 4 MFMAs each)
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][128 rows][256 B] x | [WAVES][3][WST]
+  constexpr int KW = rb_wstages(WAVES, MT, WST);  // weight ring stages
+  constexpr int WDMAS = NT * (1 + NG);    // weight DMAs per wave and stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][128 rows][256 B] x | [WAVES][KW][WST]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -483,19 +494,21 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     aoff[i] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)K * 2u + (((lane & 15) ^ (row & 15)) << 4);
   }
   const uint32_t a_lds = lds_offset(smem);
-  const uint32_t w_lds = a_lds + kRbStages * ABUF + wave * (kRbStages * WST);
-  // One DMA of the stage's LPS (compile-time index): the x rows first, then per n-tile the packed block and its
-  // scale/zero words.  kb clamped: the fill past the end re-reads the last block (unused)
-  auto issue_one = [&](auto idx_c, int stage, int kb) {
+  const uint32_t w_lds = a_lds + kRbStages * ABUF + wave * (KW * WST);
+  // One DMA of a k-block's LPS (compile-time index): the x rows first (into x stage `stage`, k-block kb), then per n-tile the
+  // packed block and its scale/zero words (into weight stage `wstage`, k-block kbw).  k-blocks past the end are clamped: the fill
+  // re-reads the last block (unused)
+  auto issue_one = [&](auto idx_c, int stage, int kb, int wstage, int kbw) {
     constexpr int idx = decltype(idx_c)::value;
     if (ABL == 4) return;
-    const int k = kb0 + min(kb, nkb - 1);
     if constexpr (idx < ADMA) {
+      const int k = kb0 + min(kb, nkb - 1);
       dma_b128_s(x + (size_t)k * 128, aoff[idx], a_lds + stage * ABUF + (ADMA * wave + idx) * 1024);
     } else {
+      const int k = kb0 + min(kbw, nkb - 1);
       constexpr int t = (idx - ADMA) / (1 + NG), part = (idx - ADMA) % (1 + NG);
       const int tile = min(tile0 + t, ntiles - 1);  // tiles past N alias the last one; their columns are never stored
-      const uint32_t dst = w_lds + stage * WST + t * WBLK;
+      const uint32_t dst = w_lds + wstage * WST + t * WBLK;
       if constexpr (part == 0) {
         dma_b128_nt_s(qdata + ((size_t)tile * kblocks + k) * 64, lane * 16, dst);
       } else {
@@ -504,9 +517,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
       }
     }
   };
-  auto issue_all = [&](int stage, int kb) {
-    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, I>{}, stage, kb), ...); }
-    (std::make_integer_sequence<int, LPS>{});
+  auto issue_x = [&](int stage, int kb) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, I>{}, stage, kb, 0, 0), ...); }
+    (std::make_integer_sequence<int, ADMA>{});
+  };
+  auto issue_w = [&](int wstage, int kbw) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, ADMA + I>{}, 0, 0, wstage, kbw), ...); }
+    (std::make_integer_sequence<int, WDMAS>{});
   };
 
   f32x4 acc[MT * NT];  // [n-tile][m-tile]
@@ -521,9 +538,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   // scale/zero word of word j = 2a + e
   const int zg0 = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga, zg1 = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga + 1;
 
-  auto kblock = [&](int stage, int refill, int kb) {
+  auto kblock = [&](int stage, int refill, int wstage, int wrefill, int kb) {
     const char* A = smem + stage * ABUF;
-    const char* Wst = smem + kRbStages * ABUF + (wave * kRbStages + stage) * WST;
+    const char* Wst = smem + kRbStages * ABUF + (wave * KW + wstage) * WST;
     uint32_t word[NT][2][2];  // [tile][e][which packed lane]
     float sc[NT][2], zp[NT][2];
 #pragma unroll
@@ -581,7 +598,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
            (([&] {
               constexpr int c = C, t = c / 4, slot = p * 4 * NT + c;
               __builtin_amdgcn_sched_barrier(0);
-              if constexpr (slot < LPS) issue_one(std::integral_constant<int, slot>{}, refill, kb + 2);
+              if constexpr (slot < LPS) issue_one(std::integral_constant<int, slot>{}, refill, kb + 2, wrefill, kb + KW - 1);
               if constexpr (e == 0) {  // the 8 NT slots of phases 0, 1 carry the 2 NT words of e = 1, four stages each
                 constexpr int q = h * 4 * NT + c, w = q / 4;
                 stage_of(std::integral_constant<int, q % 4>{}, dq[w / 2][w % 2], w / 2, 1, w % 2);
@@ -606,23 +623,31 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     }(std::make_integer_sequence<int, 4>{});
     // DMAs left over when a stage has more of them than the k-block has slots
     if constexpr (LPS > SLOTS) {
-      [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, SLOTS + I>{}, refill, kb + 2), ...); }
+      [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, SLOTS + I>{}, refill, kb + 2, wrefill, kb + KW - 1), ...); }
       (std::make_integer_sequence<int, LPS - SLOTS>{});
     }
   };
 
-  issue_all(0, 0);
-  issue_all(1, 1);
+  // issue order: w(0 .. KW-3) | x(0) w(KW-2) | x(1) ... then per k-block kb: x(kb + 2), w(kb + KW - 1).  When k-block kb starts, the
+  // requests younger than x(kb) are w(kb + KW - 3) (issued right behind it), x(kb + 1) and w(kb + KW - 2): LPS + WDMAS of them may
+  // still be in flight; everything this k-block reads -- x(kb), w(kb) -- is older and has landed.
+#pragma unroll
+  for (int i = 0; i < KW - 2; ++i) issue_w(i, i);
+  issue_x(0, 0); issue_w(KW - 2, KW - 2);
+  issue_x(1, 1);
   if (ABL == 5) ts[1] = __builtin_amdgcn_s_memtime();
-  int stage = 0;
+  int stage = 0, wstage = 0;
   for (int kb = 0; kb < nkb; ++kb) {
-    if (ABL != 4) wait_vmcnt<LPS>();  // this wave's share of stage kb has landed (stage kb + 1 may still be in flight)
+    // (k-blocks 0 and 1: x(kb + 1) follows x(kb) directly or with one weight stage between -- only LPS younger requests exist)
+    if (ABL != 4) { if (kb < 2) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + WDMAS>(); }
     // everyone's share has landed, and everyone has finished reading stage kb - 1 (its LDS reads have returned)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ABL == 5 && kb < 8) ts[2 + kb] = __builtin_amdgcn_s_memtime();
-    const int refill = (stage == 0) ? 2 : stage - 1;  // (kb + 2) % 3 == (kb - 1) % 3
-    kblock(stage, refill, kb);
+    const int refill = (stage == 0) ? 2 : stage - 1;          // (kb + 2) % 3 == (kb - 1) % 3
+    const int wrefill = (wstage == 0) ? KW - 1 : wstage - 1;  // (kb + KW - 1) % KW == (kb - 1) % KW
+    kblock(stage, refill, wstage, wrefill, kb);
     stage = (stage == 2) ? 0 : stage + 1;
+    wstage = (wstage == KW - 1) ? 0 : wstage + 1;
   }
   wait_vmcnt<0>();  // the clamped fills past the end still write LDS
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -666,7 +691,8 @@ int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, ui
   constexpr int BN = WAVES * NT * 16;
   constexpr int BM = 16 * MT;
   dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)split), block(64 * WAVES);
-  constexpr size_t smem = (size_t)kRbStages * MT * 4096 + (size_t)WAVES * kRbStages * NT * (1024 + NG * 256);
+  constexpr int KW = rb_wstages(WAVES, MT, NT * (1024 + NG * 256));
+  constexpr size_t smem = (size_t)kRbStages * MT * 4096 + (size_t)WAVES * KW * NT * (1024 + NG * 256);
   static_assert(smem <= 160 * 1024, "int4_mm_rb_kernel: LDS");
   float* ws = nullptr;
   unsigned* tickets = nullptr;
