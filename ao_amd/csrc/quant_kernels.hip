@@ -118,6 +118,90 @@ __global__ __launch_bounds__(kThreads) void scale_epilogue_kernel(const void* __
   }
 }
 
+// ---- int8 per-row ASYMMETRIC (Int8DynamicActivationInt8WeightConfig(act_mapping_type=ASYMMETRIC)) --------------------
+// choose_qparams_affine's ASYMMETRIC branch on a bf16 row (quant_primitives.py:1568-1574; every tensor op rounds to bf16):
+//   mn = min(min(row), 0), mx = max(max(row), 0)
+//   scale = max(bf16(bf16(mx - mn) / 255), bf16(f32_eps));  zp = clamp(-128 - rint(bf16(mn / scale)), -128, 127)
+//   q = clamp(rint(x * (1 / scale)) + zp, -128, 127)                                       (quantize_affine, :463-485)
+__global__ __launch_bounds__(kThreads) void int8_quant_rowwise_asym_kernel(const uint16_t* __restrict__ x, int8_t* __restrict__ q,
+                                                                           float* __restrict__ scale, int8_t* __restrict__ zero_point,
+                                                                           int64_t K) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * K);
+  const int64_t nvec = K >> 3;
+  float mx = 0.f, mn = 0.f;  // the zero each is clamped against is the identity here
+  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) {
+    const u32x4 v = xr[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf16_lo_to_f32(w[j]), b = bf16_hi_to_f32(w[j]);
+      mx = fmaxf(mx, fmaxf(a, b));
+      mn = fminf(mn, fminf(a, b));
+    }
+  }
+  mx = block_max(mx, red);
+  mn = -block_max(-mn, red);
+  const float s = fmaxf(round_bf16(round_bf16(mx - mn) / 255.0f), 1.1920928955078125e-07f);
+  const float zp = fminf(fmaxf(-128.0f - rintf(round_bf16(mn / s)), -128.0f), 127.0f);
+  const float inv = 1.0f / s;
+  if (threadIdx.x == 0) {
+    scale[row] = s;
+    zero_point[row] = (int8_t)(int)zp;
+  }
+  u32x2* qr = reinterpret_cast<u32x2*>(q + row * K);
+  for (int64_t i = threadIdx.x; i < nvec; i += kThreads) {
+    const u32x4 v = xr[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t out[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = fminf(fmaxf(rintf(bf16_lo_to_f32(w[j]) * inv) + zp, -128.f), 127.f);
+      const float b = fminf(fmaxf(rintf(bf16_hi_to_f32(w[j]) * inv) + zp, -128.f), 127.f);
+      out[j >> 1] |= (((uint32_t)(int)a & 0xffu) | (((uint32_t)(int)b & 0xffu) << 8)) << ((j & 1) * 16);
+    }
+    qr[i] = u32x2{out[0], out[1]};
+  }
+}
+
+// row sums of an int8 [N][K] weight (the zero-point correction's rowsum(W), int8_tensor.py:326): one wave per row
+__global__ __launch_bounds__(kThreads) void int8_row_sums_kernel(const int8_t* __restrict__ q, int32_t* __restrict__ sums, int64_t N, int64_t K) {
+  const int64_t row = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  const u32x4* qr = reinterpret_cast<const u32x4*>(q + row * K);
+  int32_t acc = 0;
+  for (int64_t i = lane; i < (K >> 4); i += 64) {
+    const u32x4 v = qr[i];
+    acc = __builtin_amdgcn_sdot4((int)v.x, 0x01010101, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)v.y, 0x01010101, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)v.z, 0x01010101, acc, false);
+    acc = __builtin_amdgcn_sdot4((int)v.w, 0x01010101, acc, false);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) sums[row] = acc;
+}
+
+// the Int8Tensor linear's epilogue with an asymmetric activation (int8_tensor.py:305-346):
+//   t = bf16(f32(c) * sx[m]);  corr = bf16((f32(zp[m]) * sx[m]) * f32(wsum[n]));  t = bf16(t - corr);  y = bf16(t * sw[n] (+ bias))
+__global__ __launch_bounds__(kThreads) void scale_epilogue_asym_kernel(const int32_t* __restrict__ acc, const float* __restrict__ x_scale,
+                                                                       const int8_t* __restrict__ x_zp, const int32_t* __restrict__ w_sums,
+                                                                       const float* __restrict__ w_scale, const uint16_t* __restrict__ bias,
+                                                                       uint16_t* __restrict__ y, int64_t N) {
+  const int64_t row = blockIdx.y;
+  const float xs = x_scale[row];
+  const float zs = (float)x_zp[row] * xs;
+  for (int64_t n = (int64_t)blockIdx.x * kThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kThreads) {
+    float t = round_bf16((float)acc[row * N + n] * xs);
+    t = round_bf16(t - round_bf16(zs * (float)w_sums[n]));
+    float v = t * w_scale[n];
+    if (bias != nullptr) v += bf16_lo_to_f32(bias[n]);
+    y[row * N + n] = f32_to_bf16_bits(v);
+  }
+}
+
 // ---- MXFP8: one E8M0 scale per 32 elements along the row -------------------------
 // 4 lanes own one 32-element block (8 elements each); 64 blocks per 256-thread group.
 template <int MODE>  // AO_MX_SCALE_FLOOR / AO_MX_SCALE_RCEIL
@@ -379,6 +463,50 @@ extern "C" int ao_int8_scale_epilogue(const int32_t* acc, const float* x_scale, 
 extern "C" int ao_fp8_scale_epilogue(const float* acc, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                                      int64_t M, int64_t N, void* stream) {
   return scale_epilogue<false>(__func__, acc, scale_a, scale_b, bias, y, M, N, stream);
+}
+
+extern "C" int ao_int8_quantize_rowwise_asym(const uint16_t* x, int8_t* q, float* scale, int8_t* zero_point, int64_t M, int64_t K,
+                                             void* stream) {
+  if (int rc = check_rows(__func__, M, K, 8)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(q);
+  AO_REQUIRE_PTR(scale);
+  AO_REQUIRE_PTR(zero_point);
+  ao::launch(int8_quant_rowwise_asym_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, q, scale, zero_point, K);
+  AO_LAUNCH_CHECK("int8_quant_rowwise_asym_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_int8_row_sums(const int8_t* q, int32_t* sums, int64_t N, int64_t K, void* stream) {
+  if (int rc = check_rows(__func__, N, K, 16)) return rc;
+  if (N == 0) return AO_OK;
+  AO_REQUIRE_PTR(q);
+  AO_REQUIRE_PTR(sums);
+  AO_REQUIRE(K <= (1ll << 24), "%s: K=%lld too large for an int32 row sum", __func__, (long long)K);
+  ao::launch(int8_row_sums_kernel, dim3((unsigned)((N + 3) / 4)), dim3(kThreads), 0, (hipStream_t)stream, q, sums, N, K);
+  AO_LAUNCH_CHECK("int8_row_sums_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_int8_scale_epilogue_asym(const int32_t* acc, const float* x_scale, const int8_t* x_zero_point, const int32_t* w_row_sums,
+                                           const float* w_scale, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, void* stream) {
+  AO_REQUIRE(M >= 0 && N > 0 && M <= 65535ll * 65535ll, "%s: bad shape M=%lld N=%lld", __func__, (long long)M, (long long)N);
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(acc);
+  AO_REQUIRE_PTR(x_scale);
+  AO_REQUIRE_PTR(x_zero_point);
+  AO_REQUIRE_PTR(w_row_sums);
+  AO_REQUIRE_PTR(w_scale);
+  AO_REQUIRE_PTR(y);
+  for (int64_t m0 = 0; m0 < M; m0 += 65535) {
+    const int64_t rows = std::min<int64_t>(65535, M - m0);
+    dim3 grid((unsigned)std::min<int64_t>((N + kThreads - 1) / kThreads, 64), (unsigned)rows);
+    ao::launch(scale_epilogue_asym_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, acc + m0 * N, x_scale + m0, x_zero_point + m0,
+               w_row_sums, w_scale, bias, y + m0 * N, N);
+  }
+  AO_LAUNCH_CHECK("scale_epilogue_asym_kernel launch");
+  return AO_OK;
 }
 
 extern "C" int ao_mxfp8_quantize_rowwise(const uint16_t* x, uint8_t* q, uint8_t* scale_e8m0, int64_t R,

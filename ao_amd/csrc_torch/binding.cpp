@@ -9,10 +9,10 @@
 //     Schemas are defined by whoever imports first: torchao's Python, or ao_amd/torch_ops.py when torchao is absent.
 //   * TORCH_LIBRARY_IMPL(aten, CUDA), only when AO_MI355_OVERRIDE_ATEN=1 is set when the library is loaded:
 //     aten::_weight_int4pack_mm, aten::_convert_weight_to_int4pack (int4_tile_packed_to_4d_tensor.py:202,287),
-//     aten::_int_mm (int8/kernels.py:38-40,70), aten::_scaled_mm with rowwise scales (float8/inference.py:104-123),
+//     aten::_int_mm (int8/kernels.py:38-40,70), aten::_scaled_mm with rowwise or tensorwise scales (float8/inference.py:104-123),
 //     aten::_scaled_grouped_mm with MXFP8 operands (mxfp8_grouped_mm.py:541) -- so that an UNMODIFIED torchao's
 //     Int4TilePackedTo4dTensor / Int8Tensor / Float8Tensor reach these kernels through PyTorch-ROCm's dispatcher.
-//     Variants of those ops outside the low-bit path (per-tensor scales, fp16 outputs, ...) raise instead of silently
+//     Variants of those ops outside the low-bit path (blockwise scales, fp16 outputs, ...) raise instead of silently
 //     computing something else: the override is opt-in for exactly that reason.
 //   * TORCH_LIBRARY(ao_mi355_c, ...): the same kernels under their own namespace, always registered (tests, opcheck).
 //
@@ -96,7 +96,7 @@ Tensor int_mm(const Tensor& self, const Tensor& mat2) {
 Tensor scaled_mm(const Tensor& self, const Tensor& mat2, const Tensor& scale_a, const Tensor& scale_b,
                  const std::optional<Tensor>& bias, const std::optional<Tensor>& scale_result,
                  std::optional<c10::ScalarType> out_dtype, bool use_fast_accum) {
-  const char* op = "_scaled_mm (MI355X rowwise e4m3)";
+  const char* op = "_scaled_mm (MI355X e4m3)";
   (void)use_fast_accum;  // fp32 accumulation on the scaled MFMA either way
   check_gpu(self, op, "self"); check_gpu(mat2, op, "mat2");
   TORCH_CHECK(self.scalar_type() == at::kFloat8_e4m3fn && mat2.scalar_type() == at::kFloat8_e4m3fn,
@@ -105,11 +105,15 @@ Tensor scaled_mm(const Tensor& self, const Tensor& mat2, const Tensor& scale_a, 
   TORCH_CHECK(!scale_result.has_value(), op, ": scale_result is not implemented");
   TORCH_CHECK(!out_dtype.has_value() || *out_dtype == at::kBFloat16, op, ": only bfloat16 outputs are implemented");
   const int64_t M = self.size(0), K = self.size(1), N = mat2.size(1);
-  TORCH_CHECK(scale_a.numel() == M && scale_b.numel() == N && scale_a.scalar_type() == at::kFloat && scale_b.scalar_type() == at::kFloat,
-              op, ": only rowwise fp32 scales (scale_a [M,1], scale_b [1,N]) are implemented");
+  TORCH_CHECK(scale_a.scalar_type() == at::kFloat && scale_b.scalar_type() == at::kFloat, op, ": scales must be float32");
+  const bool rowwise = scale_a.numel() == M && scale_b.numel() == N;
+  const bool tensorwise = scale_a.numel() == 1 && scale_b.numel() == 1;
+  TORCH_CHECK(rowwise || tensorwise, op, ": scales must be rowwise (scale_a [M,1], scale_b [1,N]) or tensorwise ([1,1] both); blockwise is not implemented");
   c10::DeviceGuard guard(self.device());
   const Tensor a = self.contiguous(), bt = mat2.t().contiguous();  // mat2 is column-major [K,N] = row-major [N,K]: no copy
-  const Tensor sa = scale_a.reshape({-1}).contiguous(), sb = scale_b.reshape({-1}).contiguous();
+  // tensorwise: the same epilogue with the two scalars broadcast over rows / columns (M + N floats)
+  const Tensor sa = (rowwise ? scale_a.reshape({-1}) : scale_a.reshape({1}).expand({M})).contiguous();
+  const Tensor sb = (rowwise ? scale_b.reshape({-1}) : scale_b.reshape({1}).expand({N})).contiguous();
   Tensor bb;
   if (bias.has_value() && bias->defined()) {
     TORCH_CHECK(bias->numel() == N, op, ": bias must have N elements");

@@ -495,6 +495,84 @@ def fp8_scale_epilogue(acc, scale_a, scale_b, bias=None):
     return _scale_epilogue("fp8_scale_epilogue", _lib.lib().ao_fp8_scale_epilogue, acc, torch.float32, scale_a, scale_b, bias)
 
 
+# ---- granularity / mapping variants of the dynamic-activation formats (PerTensor; int8 ASYMMETRIC activations) ----------
+def _tensor_amax_rows(x):
+    """[M] fp32 filled with max |x| over the WHOLE matrix (PerTensor granularity: block_size = shape)."""
+    return rowwise_amax(x).amax().expand(x.shape[0])
+
+
+def int8_quantize_tensorwise(x: torch.Tensor):
+    """Int8Tensor.from_hp(x, PerTensor()) (int8_tensor.py:191-230 with block_size = shape): bf16 [M, K] ->
+    (qdata int8 [M, K], scale fp32 [1, 1])."""
+    q, s = int8_quantize_rowwise_amax(x, _tensor_amax_rows(x))
+    return q, s[:1].reshape(1, 1)
+
+
+def fp8_quantize_tensorwise(x: torch.Tensor):
+    """Float8Tensor.from_hp(x, e4m3, PerTensor()) (float8_tensor.py:167-253 with block_size = shape): bf16 [M, K] ->
+    (qdata e4m3fn [M, K], scale fp32 [1, 1])."""
+    q, s = fp8_quantize_rowwise_amax(x, _tensor_amax_rows(x))
+    return q, s[:1].reshape(1, 1)
+
+
+def int8_quantize_rowwise_asym(x: torch.Tensor):
+    """Int8Tensor.from_hp(x, PerRow(), mapping_type=ASYMMETRIC) (int8_tensor.py:191-236): bf16 [M, K] ->
+    (qdata int8 [M, K], scale fp32 [M, 1], zero_point int8 [M, 1])."""
+    dev = _require_gpu("int8_quantize_rowwise_asym", x)
+    x = _as_rows("int8_quantize_rowwise_asym", x, torch.bfloat16)
+    m, k = x.shape
+    q = torch.empty((m, k), dtype=torch.int8, device=dev)
+    s = torch.empty((m, 1), dtype=torch.float32, device=dev)
+    zp = torch.empty((m, 1), dtype=torch.int8, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_int8_quantize_rowwise_asym(_ptr(x), _ptr(q), _ptr(s), _ptr(zp), m, k, _stream()))
+    return q, s, zp
+
+
+def int8_row_sums(wq: torch.Tensor) -> torch.Tensor:
+    """rowsum of an int8 [N, K] weight as int32 [N]: the zero-point correction's `weight_tensor.qdata.sum(dim=-1)` (int8_tensor.py:326)."""
+    dev = _require_gpu("int8_row_sums", wq)
+    wq = _as_rows("int8_row_sums", wq, torch.int8)
+    n, k = wq.shape
+    out = torch.empty((n,), dtype=torch.int32, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_int8_row_sums(_ptr(wq), _ptr(out), n, k, _stream()))
+    return out
+
+
+def int8_scale_epilogue_asym(acc, x_scale, x_zero_point, w_row_sums, w_scale, bias=None):
+    """bf16(bf16(bf16(acc * sx[m]) - bf16((zp[m] * sx[m]) * wsum[n])) * sw[n] (+ bias)) over int32 accumulators
+    (int8_tensor.py:305-346)."""
+    name = "int8_scale_epilogue_asym"
+    dev = _require_gpu(name, acc, x_scale, x_zero_point, w_row_sums, w_scale, bias)
+    if acc.dtype != torch.int32 or acc.dim() != 2:
+        raise RuntimeError(f"{name}: expected a 2-D int32 accumulator, got {acc.dim()}-D {acc.dtype}")
+    acc = acc.contiguous()
+    m, n = acc.shape
+    x_scale = x_scale.reshape(-1).to(torch.float32).contiguous()
+    x_zero_point = x_zero_point.reshape(-1).to(torch.int8).contiguous()
+    w_scale = w_scale.reshape(-1).to(torch.float32).contiguous()
+    w_row_sums = w_row_sums.reshape(-1).to(torch.int32).contiguous()
+    if x_scale.numel() != m or x_zero_point.numel() != m or w_scale.numel() != n or w_row_sums.numel() != n:
+        raise RuntimeError(f"{name}: x_scale / x_zero_point must have M = {m} entries, w_scale / w_row_sums N = {n}")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+        if bias.numel() != n:
+            raise RuntimeError(f"{name}: bias must have N elements")
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_int8_scale_epilogue_asym(_ptr(acc), _ptr(x_scale), _ptr(x_zero_point), _ptr(w_row_sums), _ptr(w_scale),
+                                                          _ptr(bias), _ptr(y), m, n, _stream()))
+    return y
+
+
+def int8_linear_asym(x2, wq, w_scale, w_row_sums, bias=None):
+    """The Int8Tensor F.linear with ASYMMETRIC per-row activation quantization (int8_tensor.py:266-359): cast, int32 GEMM,
+    zero-point-corrected scale epilogue (three launches; the symmetric default keeps the fused epilogue)."""
+    xq, xs, zp = int8_quantize_rowwise_asym(x2)
+    return int8_scale_epilogue_asym(int_mm(xq, wq.t()), xs, zp, w_row_sums, w_scale, bias)
+
+
 # ---------------------------------------------------------------------------
 # MXFP8
 # ---------------------------------------------------------------------------

@@ -8,6 +8,7 @@ from .config import (  # noqa: F401
     Int8DynamicActivationInt8WeightConfig,
 )
 from .granularity import PerGroup, PerRow, PerTensor  # noqa: F401
+from .quant_primitives import MappingType  # noqa: F401
 from .float8_tensor import Float8Tensor, QuantizeTensorToFloat8Kwargs  # noqa: F401
 from .int4_plain_tensor import Int4Tensor  # noqa: F401
 from .int4_tensor import Int4TilePackedTo4dTensor  # noqa: F401

@@ -2,9 +2,10 @@
 torchao/quantization/quant_api.py:502,808,1112)."""
 import enum
 from dataclasses import dataclass, field
-from typing import Optional
+from typing import List, Optional, Union
 
-from .granularity import Granularity, PerRow
+from .granularity import Granularity, PerRow, PerTensor
+from .quant_primitives import MappingType
 
 
 class AOBaseConfig:
@@ -44,24 +45,60 @@ class Int4WeightOnlyConfig(AOBaseConfig):
         self.int4_choose_qparams_algorithm = Int4ChooseQParamsAlgorithm(self.int4_choose_qparams_algorithm)
 
 
+def _normalize_granularity(granularity, default, what):
+    """(activation, weight) granularities from None / one Granularity / a list of two (reference Int8Tensor._normalize_granularity
+    int8_tensor.py:140-174; quantization/utils.py _normalize_granularity for float8)."""
+    if granularity is None:
+        return default(), default()
+    if isinstance(granularity, Granularity):
+        pair = (granularity, granularity)
+    elif isinstance(granularity, (list, tuple)):
+        if len(granularity) != 2:
+            raise ValueError(f"Granularity list must have exactly 2 elements, got {len(granularity)}: {granularity}")
+        pair = tuple(granularity)
+    else:
+        raise ValueError(f"Invalid granularity type: {granularity}. Expected None, Granularity, or list of 2 Granularities.")
+    for g in pair:
+        if not isinstance(g, (PerRow, PerTensor)):
+            raise ValueError(f"{what}: only PerTensor and PerRow are supported, got {g}")
+    return pair
+
+
 @dataclass
 class Int8DynamicActivationInt8WeightConfig(AOBaseConfig):
-    """int8 per-token dynamic activation x int8 per-row weight (reference
-    quant_api.py:808-884; defaults PerRow symmetric)."""
+    """int8 dynamic activation x int8 weight (reference quant_api.py:808-884): granularity PerRow (default) or PerTensor, one
+    value for both operands or [activation, weight]; act_mapping_type SYMMETRIC (default) or ASYMMETRIC."""
 
-    granularity: Granularity = field(default_factory=PerRow)
+    act_mapping_type: MappingType = MappingType.SYMMETRIC
+    granularity: Optional[Union[Granularity, List[Granularity]]] = field(default_factory=PerRow)
     set_inductor_config: bool = False
     version: int = 2
+    reduce_range: bool = False
+
+    def __post_init__(self):
+        if self.version == 1:
+            raise ValueError("version 1 of Int8DynamicActivationInt8WeightConfig has been removed, please use version 2")
+        if self.reduce_range:
+            raise NotImplementedError("reduce_range is a CPU-without-VNNI option; the MI355X int8 MFMA path uses the full range")
+        if self.act_mapping_type not in (MappingType.SYMMETRIC, MappingType.ASYMMETRIC):
+            raise ValueError(f"act_mapping_type must be SYMMETRIC or ASYMMETRIC, got {self.act_mapping_type}")
+        self.granularity = list(_normalize_granularity(self.granularity, PerRow, "Int8DynamicActivationInt8WeightConfig"))
 
 
 @dataclass
 class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
-    """float8 e4m3 rowwise dynamic activation x float8 weight (reference
-    quant_api.py:1112-1297).  Only PerRow granularity is implemented."""
+    """float8 e4m3 dynamic activation x float8 weight (reference quant_api.py:1112-1297).  granularity: None = PerTensor for
+    both (the reference's default), PerRow() (the BASELINE configuration), or [activation, weight] of the same type."""
 
-    granularity: Granularity = field(default_factory=PerRow)
+    granularity: Optional[Union[Granularity, List[Granularity]]] = None
     set_inductor_config: bool = False
     version: int = 2
+
+    def __post_init__(self):
+        act, weight = _normalize_granularity(self.granularity, PerTensor, "Float8DynamicActivationFloat8WeightConfig")
+        if type(act) is not type(weight):
+            raise ValueError(f"Different granularities for activation and weight are not supported: {act}, {weight}")
+        self.granularity = [act, weight]
 
 
 @dataclass

@@ -1,4 +1,4 @@
-"""Float8Tensor: float8 e4m3 rowwise weight with dynamic rowwise activations, MI355X-native.
+"""Float8Tensor: float8 e4m3 weight (PerRow or PerTensor scales) with dynamic activations of the same granularity, MI355X-native.
 
 Host-side mirror of torchao/quantization/quantize_/workflows/float8/float8_tensor.py for the branch
 SURVEY.md 8(a9, a10) scopes -- PerRow, KernelPreference TORCH/AUTO on AMD, i.e. what
@@ -14,22 +14,24 @@ import torch.nn.functional as F
 
 from .. import ops
 from .base_tensor import LowBitTensorBase, aten
-from .granularity import Granularity, PerRow
+from .granularity import Granularity, PerRow, PerTensor
 
 __all__ = ["Float8Tensor", "QuantizeTensorToFloat8Kwargs"]
 
 
 @dataclass
 class QuantizeTensorToFloat8Kwargs:
-    """reference float8_tensor.py:50-81 (PerRow / e4m3fn only)"""
+    """reference float8_tensor.py:50-81 (PerRow / PerTensor, e4m3fn)"""
 
     float8_dtype: torch.dtype = torch.float8_e4m3fn
     granularity: Granularity = field(default_factory=PerRow)
 
 
 def _check(granularity, float8_dtype):
-    if not isinstance(granularity, PerRow):
-        raise NotImplementedError(f"Float8Tensor on MI355X implements PerRow only, got {granularity}")
+    if not isinstance(granularity, (PerRow, PerTensor)):
+        raise NotImplementedError(f"Float8Tensor on MI355X implements PerRow / PerTensor, got {granularity} (blockwise scaling is outside SURVEY.md section 8)")
+    if isinstance(granularity, PerRow) and granularity.dim != -1:
+        raise NotImplementedError(f"Float8Tensor on MI355X implements PerRow(dim=-1) only, got {granularity}")
     if float8_dtype != torch.float8_e4m3fn:
         raise NotImplementedError(f"Float8Tensor on MI355X implements float8_e4m3fn only, got {float8_dtype}")
 
@@ -71,12 +73,18 @@ class Float8Tensor(LowBitTensorBase):
         granularity = PerRow() if granularity is None else granularity
         _check(granularity, float8_dtype)
         if hp_tensor.dtype != torch.bfloat16:
-            # reference quant_api.py:1211-1216: PerRow quantization only works for bfloat16 precision
+            # reference quant_api.py:1211-1216: PerRow quantization only works for bfloat16 precision; the MI355X kernels take
+            # bfloat16 for PerTensor too
             raise AssertionError("PerRow quantization only works for bfloat16 precision input weight")
         if hp_tensor.dim() not in (2, 3):
             raise NotImplementedError("Float8Tensor.from_hp on MI355X takes 2-D weights or 3-D [E, N, K] expert weights")
         k = hp_tensor.shape[-1]
-        qdata, scale = ops.fp8_quantize_rowwise(hp_tensor.contiguous().reshape(-1, k))  # PerRow: one scale per row of every expert
+        rows = hp_tensor.contiguous().reshape(-1, k)
+        if isinstance(granularity, PerTensor):  # one scale for the whole tensor (block_size = shape)
+            qdata, scale = ops.fp8_quantize_tensorwise(rows)
+            return cls(qdata.reshape(hp_tensor.shape), scale.reshape([1] * hp_tensor.dim()), list(hp_tensor.shape), hp_tensor.dtype,
+                       act_quant_kwargs=act_quant_kwargs)
+        qdata, scale = ops.fp8_quantize_rowwise(rows)  # PerRow: one scale per row of every expert
         qdata, scale = qdata.reshape(hp_tensor.shape), scale.reshape(*hp_tensor.shape[:-1], 1)
         return cls(qdata, scale, [1] * (hp_tensor.dim() - 1) + [k], hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs)
 
@@ -108,8 +116,18 @@ def _(func, types, args, kwargs):
     _check(w.act_quant_kwargs.granularity, w.act_quant_kwargs.float8_dtype)
     x2 = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
     n = w.qdata.shape[0]
+    w_tensorwise = w.scale.numel() == 1
+    if isinstance(w.act_quant_kwargs.granularity, PerTensor) != w_tensorwise:
+        # reference quant_api.py:1123: "Currently both quantizations need to be the same type"
+        raise NotImplementedError("Float8Tensor linear: activation and weight granularities must both be PerRow or both PerTensor")
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
+    elif w_tensorwise:
+        # tensorwise-scaled _scaled_mm (float8/inference.py:68-123 with [1, 1] scales): the same epilogue with the two
+        # scalars broadcast over rows / columns
+        xq, xs = ops.fp8_quantize_tensorwise(x2)
+        y = ops.fp8_scaled_mm(xq, w.qdata.t(), xs.reshape(-1).expand(x2.shape[0]), w.scale.reshape(-1).expand(n), bias)
+        bias = None
     else:
         from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
         y = kernels(x2).fp8_linear(x2, w.qdata, w.scale, bias)
@@ -131,13 +149,15 @@ def _(func, types, args, kwargs):
     assert step == 1 and dim in (0, 1)
     end = min(end, self.shape[dim])
     pre = self.act_pre_scale
+    per_tensor = self.scale.numel() == 1
     if dim == 0:
-        q, s = self.qdata[start:end].contiguous(), self.scale[start:end].contiguous()
+        q = self.qdata[start:end].contiguous()
+        s = self.scale if per_tensor else self.scale[start:end].contiguous()
     else:
         q, s = self.qdata[:, start:end].contiguous(), self.scale
         if pre is not None and pre.numel() == self.shape[1]:  # per-input-feature pre-scale follows the K slice
             pre = pre.reshape(-1)[start:end]
-    return Float8Tensor(q, s, [1, q.shape[1]], self.dtype_, self.act_quant_kwargs, pre)
+    return Float8Tensor(q, s, list(q.shape) if per_tensor else [1, q.shape[1]], self.dtype_, self.act_quant_kwargs, pre)
 
 
 @implements(aten.transpose.int)

@@ -1,9 +1,10 @@
-"""Int8Tensor: int8 per-row weight with dynamic per-token int8 activations, MI355X-native.
+"""Int8Tensor: int8 weight with dynamic int8 activations, MI355X-native.
 
-Host-side mirror of torchao/quantization/quantize_/workflows/int8/int8_tensor.py
-(same attribute names, from_hp / linear / slice semantics for the path SURVEY.md 8(a7, a8) scopes:
-PerRow symmetric weight, optional PerRow symmetric dynamic activation).  Arithmetic: the HIP
-kernels behind ao_amd.ops (ao_int8_quantize_rowwise, ao_int8_scaled_mm).
+Host-side mirror of torchao/quantization/quantize_/workflows/int8/int8_tensor.py (same attribute names, from_hp / linear /
+slice semantics for the path SURVEY.md 8(a7, a8) scopes): PerRow (default) or PerTensor symmetric weights; dynamic
+activations PerRow / PerTensor symmetric, or PerRow ASYMMETRIC with the zero-point correction of :318-331.  Arithmetic: the
+HIP kernels behind ao_amd.ops (ao_int8_quantize_rowwise[_amax|_asym], ao_int8_scaled_mm, ao_int8_int_mm +
+ao_int8_scale_epilogue_asym).
 """
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -13,74 +14,106 @@ import torch.nn.functional as F
 
 from .. import ops
 from .base_tensor import LowBitTensorBase, aten
-from .granularity import Granularity, PerRow
+from .granularity import Granularity, PerRow, PerTensor
+from .quant_primitives import MappingType
 
 __all__ = ["Int8Tensor", "QuantizeTensorToInt8Kwargs"]
 
 
 @dataclass
 class QuantizeTensorToInt8Kwargs:
-    """reference int8_tensor.py:41-56 (only the PerRow / symmetric defaults are implemented)"""
+    """reference int8_tensor.py:41-56"""
 
     granularity: Granularity = field(default_factory=PerRow)
-    mapping_type: str = "symmetric"
+    mapping_type: MappingType = MappingType.SYMMETRIC
     reduce_range: bool = False
 
 
-def _check_per_row(granularity, what):
-    if not isinstance(granularity, PerRow):
+def _mapping(mapping_type) -> MappingType:
+    if isinstance(mapping_type, str):  # round-1 checkpoints stored the lowercase name
+        return MappingType[mapping_type.upper()]
+    return mapping_type
+
+
+def _check_granularity(granularity, what):
+    if not isinstance(granularity, (PerRow, PerTensor)):
         raise NotImplementedError(
-            f"Int8Tensor on MI355X implements PerRow {what} quantization only, got {granularity} "
-            "(per-tensor / per-group are outside the SURVEY.md section 8 path)"
+            f"Int8Tensor on MI355X implements PerRow / PerTensor {what} quantization, got {granularity} "
+            "(per-group int8 is outside the SURVEY.md section 8 path)"
         )
+    if isinstance(granularity, PerRow) and granularity.dim not in (-1,):
+        raise NotImplementedError(f"Int8Tensor on MI355X implements PerRow(dim=-1) only, got {granularity}")
 
 
 class Int8Tensor(LowBitTensorBase):
     """
     Tensor attributes (reference :59-88):
-      qdata  int8 [N, K]
-      scale  fp32 [N, 1]   (reference keeps the scale in the hp dtype widened on use; values are
-                            bf16-representable, computed in bf16 like the reference -- oracle A.3)
-    Non-tensor attributes: block_size ([1, K]), dtype (the original hp dtype),
-    act_quant_kwargs (None = weight only).
+      qdata       int8 [N, K]
+      scale       fp32 [N, 1] (PerRow) or [1, 1] (PerTensor)   (values are bf16-representable, computed in bf16 like the
+                                                                reference -- oracle A.3)
+      zero_point  int8, same shape as scale, or None (symmetric)
+    Non-tensor attributes: block_size ([1, K] or [N, K]), dtype (the original hp dtype), act_quant_kwargs (None = weight only).
     """
 
     tensor_data_names = ["qdata", "scale"]
     tensor_attribute_names = ["block_size", "dtype_", "act_quant_kwargs"]
-    optional_tensor_data_names = ["act_pre_scale"]
+    optional_tensor_data_names = ["act_pre_scale", "zero_point"]
 
-    def __new__(cls, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None):
+    def __new__(cls, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None):
         kwargs = dict(device=qdata.device, dtype=dtype_, requires_grad=False)
         return torch.Tensor._make_wrapper_subclass(cls, qdata.shape, **kwargs)
 
-    def __init__(self, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None):
+    def __init__(self, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None):
         self.qdata = qdata
         self.scale = scale
         self.block_size = list(block_size)
         self.dtype_ = dtype_
         self.act_quant_kwargs = act_quant_kwargs
         self.act_pre_scale = act_pre_scale
+        self.zero_point = zero_point
+        self._row_sums = None  # int32 [N], built on first asymmetric-activation linear (the correction's rowsum(W))
 
     def _quantization_type(self):
         return (f"act_quant_kwargs={self.act_quant_kwargs}, block_size={self.block_size}, "
                 f"shape={tuple(self.shape)}, device={self.device}, dtype={self.dtype}")
 
     @classmethod
-    def from_hp(cls, hp_tensor: torch.Tensor, granularity: Granularity = None,
+    def from_hp(cls, hp_tensor: torch.Tensor, granularity: Granularity = None, mapping_type=MappingType.SYMMETRIC,
                 act_quant_kwargs: Optional[QuantizeTensorToInt8Kwargs] = None):
-        """reference from_hp (:176-248): symmetric, scale = amax / 127.5 clamped at fp32 eps."""
+        """reference from_hp (:176-248).  SYMMETRIC: scale = amax / 127.5 clamped at fp32 eps, over the row or the whole
+        tensor; ASYMMETRIC (PerRow): scale = (max - min) / 255, integer zero-point."""
         granularity = PerRow() if granularity is None else granularity
-        _check_per_row(granularity, "weight")
+        mapping_type = _mapping(mapping_type)
+        _check_granularity(granularity, "tensor")
         if hp_tensor.dtype != torch.bfloat16:
             raise NotImplementedError(f"Int8Tensor.from_hp on MI355X takes bfloat16, got {hp_tensor.dtype}")
         if hp_tensor.dim() != 2:
             raise NotImplementedError("Int8Tensor.from_hp on MI355X takes 2-D tensors")
-        qdata, scale = ops.int8_quantize_rowwise(hp_tensor.contiguous())
-        return cls(qdata, scale, [1, hp_tensor.shape[-1]], hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs)
+        x = hp_tensor.contiguous()
+        zero_point = None
+        if mapping_type == MappingType.ASYMMETRIC:
+            if not isinstance(granularity, PerRow):
+                raise NotImplementedError("Int8Tensor on MI355X implements ASYMMETRIC quantization per row only")
+            qdata, scale, zero_point = ops.int8_quantize_rowwise_asym(x)
+        elif mapping_type != MappingType.SYMMETRIC:
+            raise NotImplementedError(f"Int8Tensor on MI355X implements SYMMETRIC / ASYMMETRIC mapping, got {mapping_type}")
+        elif isinstance(granularity, PerTensor):
+            qdata, scale = ops.int8_quantize_tensorwise(x)
+        else:
+            qdata, scale = ops.int8_quantize_rowwise(x)
+        block_size = list(hp_tensor.shape) if isinstance(granularity, PerTensor) else [1, hp_tensor.shape[-1]]
+        return cls(qdata, scale, block_size, hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs, zero_point=zero_point)
 
     def dequantize(self, output_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """reference :250-263: qdata * scale in fp32, then cast"""
-        return (self.qdata.to(torch.float32) * self.scale.to(torch.float32)).to(output_dtype or self.dtype)
+        """reference :250-263: (qdata - zero_point) * scale in fp32, then cast"""
+        q = self.qdata.to(torch.float32)
+        if self.zero_point is not None:
+            q = q - self.zero_point.to(torch.float32)
+        return (q * self.scale.to(torch.float32)).to(output_dtype or self.dtype)
+
+    def _row_scale(self) -> torch.Tensor:
+        """fp32 [N]: the per-row view of the scale (a PerTensor scale is broadcast)"""
+        return self.scale.reshape(-1).expand(self.qdata.shape[0]) if self.scale.numel() == 1 else self.scale.reshape(-1)
 
 
 implements = Int8Tensor.implements
@@ -103,14 +136,28 @@ def _(func, types, args, kwargs):
             "Int8Tensor weight-only linear is not on the MI355X hot path (SURVEY.md section 8): "
             "use Int8DynamicActivationInt8WeightConfig"
         )
-    _check_per_row(w.act_quant_kwargs.granularity, "activation")
+    act = w.act_quant_kwargs
+    _check_granularity(act.granularity, "activation")
+    if w.zero_point is not None:
+        raise NotImplementedError("Int8Tensor linear on MI355X takes symmetric weights (asymmetric is an ACTIVATION option in the reference)")
     x2 = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
     n = w.qdata.shape[0]
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
+    elif _mapping(act.mapping_type) == MappingType.ASYMMETRIC:
+        if not isinstance(act.granularity, PerRow):
+            raise NotImplementedError("Int8Tensor on MI355X implements ASYMMETRIC activation quantization per row only")
+        if w._row_sums is None:
+            w._row_sums = ops.int8_row_sums(w.qdata)
+        y = ops.int8_linear_asym(x2, w.qdata, w._row_scale(), w._row_sums, bias)
+        bias = None
+    elif isinstance(act.granularity, PerTensor):
+        xq, xs = ops.int8_quantize_tensorwise(x2)
+        y = ops.int8_scaled_mm(xq, xs.reshape(-1).expand(x2.shape[0]), w.qdata, w._row_scale(), bias)
+        bias = None
     else:
         from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
-        y = kernels(x2).int8_linear(x2, w.qdata, w.scale, bias)
+        y = kernels(x2).int8_linear(x2, w.qdata, w._row_scale(), bias)
         bias = None
     y = y.reshape(*x.shape[:-1], n)
     if bias is not None:
@@ -129,13 +176,18 @@ def _(func, types, args, kwargs):
     assert step == 1 and dim in (0, 1)
     end = min(end, self.shape[dim])
     pre = self.act_pre_scale
+    per_tensor = self.scale.numel() == 1
+    zp = self.zero_point
     if dim == 0:
-        q, s = self.qdata[start:end].contiguous(), self.scale[start:end].contiguous()
+        q = self.qdata[start:end].contiguous()
+        s = self.scale if per_tensor else self.scale[start:end].contiguous()
+        zp = zp if (zp is None or per_tensor) else zp[start:end].contiguous()
     else:
         q, s = self.qdata[:, start:end].contiguous(), self.scale
         if pre is not None and pre.numel() == self.shape[1]:  # per-input-feature pre-scale follows the K slice
             pre = pre.reshape(-1)[start:end]
-    return Int8Tensor(q, s, [1, q.shape[1]], self.dtype_, self.act_quant_kwargs, pre)
+    block_size = list(q.shape) if per_tensor else [1, q.shape[1]]
+    return Int8Tensor(q, s, block_size, self.dtype_, self.act_quant_kwargs, pre, zp)
 
 
-torch.serialization.add_safe_globals([Int8Tensor, QuantizeTensorToInt8Kwargs])
+torch.serialization.add_safe_globals([Int8Tensor, QuantizeTensorToInt8Kwargs, MappingType])

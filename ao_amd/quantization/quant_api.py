@@ -151,10 +151,11 @@ def _int8_dynamic_activation_int8_weight_transform(module, config, *, parameter_
         f"applying int8 dynamic activation int8 weight quant requires module to have {parameter_name} attribute"
     )
     weight = getattr(module, parameter_name)
+    act_granularity, weight_granularity = config.granularity
     new_weight = Int8Tensor.from_hp(
         weight,
-        granularity=config.granularity,
-        act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=config.granularity),
+        granularity=weight_granularity,
+        act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=act_granularity, mapping_type=config.act_mapping_type),
     )
     setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
     return module
@@ -184,10 +185,11 @@ def _float8_dynamic_activation_float8_weight_transform(module, config, *, parame
     weight = getattr(module, parameter_name)
     if not _fp8_mm_compat(weight):
         return module
+    act_granularity, weight_granularity = config.granularity
     new_weight = Float8Tensor.from_hp(
         weight,
-        granularity=config.granularity,
-        act_quant_kwargs=QuantizeTensorToFloat8Kwargs(granularity=config.granularity),
+        granularity=weight_granularity,
+        act_quant_kwargs=QuantizeTensorToFloat8Kwargs(granularity=act_granularity),
     )
     setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
     return module

@@ -359,7 +359,7 @@ def config_int8(stream, device, args):
                        "1 of 32 layers timed (x32 = one forward; every layer does the same work)",
            "value": M / (t * N_LAYERS), "unit": "tokens/s", "ms_per_layer": t * 1e3, "dtype": "int8 x int8 -> int32, bf16 out",
            "launch": "hipGraph replay" if graphed else "eager", "launches_per_layer": 2 * nchunk * len(ws),
-           "roofline": {"kernel": "gemm8_dma_kernel", "bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_8BIT_PEAK_TOPS,
+           "roofline": {"kernel": "gemm8_p8_kernel<int8> (256x256 phase-interleaved; gemm8_dma_kernel below 160 tiles)", "bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_8BIT_PEAK_TOPS,
                         "unit": "TOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_8BIT_PEAK_TOPS, "traffic": None,
                         "timing": "HIP extension events, one eager layer", "gemm_ms_per_layer": gemm_ms, "act_cast_ms_per_layer": cast_ms,
                         "end_to_end_TOPs": flops / t / 1e12}}
@@ -420,7 +420,7 @@ def config_fp8_shards(stream, device, args):
                        "(qkv 1280x8192, o 8192x1024, gate_up 7168x8192, down 8192x3584), 80 layers, activation cast + scaled mm per linear",
            "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (per GPU, M = 2048, before the all-reduce)", "dtype": "e4m3 x e4m3 -> fp32, bf16 out",
            "by_M": res,
-           "roofline": {"kernel": "gemm8_dma_kernel", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
+           "roofline": {"kernel": "gemm8_p8_kernel<fp8> / gemm8_dma_kernel / rb8_kernel by shard shape", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": res["M2048"]["frac"], "traffic": None, "timing": "hipGraph replay wall time of the whole step (casts included)"}}
     if not args.no_cpu_baseline:
         from oracle import c_ref
@@ -494,7 +494,7 @@ def config_mx(stream, device, args):
 def config_fp8_tp(stream, device, args, dist, world):
     """configs[3] for real when N > 1: Llama-3-70B linears sharded TP = N over RCCL (ao_amd/parallel.py)."""
     from ao_amd import parallel
-    from ao_amd.quantization import Float8DynamicActivationFloat8WeightConfig, quantize_
+    from ao_amd.quantization import Float8DynamicActivationFloat8WeightConfig, PerRow, quantize_
     gen = torch.Generator(device=device).manual_seed(4)
     layers = 8  # of 80: the same four linears per layer; tokens/s is extrapolated x10 (weights of 8 layers are 2.7 GB per GPU at TP=8)
     mods = []
@@ -503,7 +503,7 @@ def config_fp8_tp(stream, device, args, dist, world):
             lin = torch.nn.Linear(k, n, bias=False, device=device, dtype=torch.bfloat16)
             with torch.no_grad():
                 lin.weight.copy_(torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02)
-            quantize_(lin, Float8DynamicActivationFloat8WeightConfig())
+            quantize_(lin, Float8DynamicActivationFloat8WeightConfig(granularity=PerRow()))
             mods.append((name, style, parallel.shard_linear_(lin, "colwise" if style == "col" else "rowwise", reduce="exact")))
             del lin
     torch.cuda.empty_cache()

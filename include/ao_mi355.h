@@ -141,6 +141,24 @@ int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const int8_t* wq,
 int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, int64_t M,
                    int64_t N, int64_t K, void* stream);
 
+/* Asymmetric per-row activation quantization: Int8Tensor.from_hp(x, PerRow(), mapping_type=ASYMMETRIC), the activation side
+ * of Int8DynamicActivationInt8WeightConfig(act_mapping_type=ASYMMETRIC) (int8_tensor.py:191-236; choose_qparams_affine's
+ * ASYMMETRIC branch quant_primitives.py:1568-1574; quantize_affine :463-485), bf16 input:
+ *   mn = min(row, 0), mx = max(row, 0); scale = max(bf16(bf16(mx - mn) / 255), f32_eps);
+ *   zero_point = clamp(-128 - rint(bf16(mn / scale)), -128, 127); q = clamp(rint(x / scale) + zero_point, -128, 127)
+ *   x bf16 [M][K] -> q int8 [M][K], scale fp32 [M], zero_point int8 [M] */
+int ao_int8_quantize_rowwise_asym(const uint16_t* x, int8_t* q, float* scale, int8_t* zero_point,
+                                  int64_t M, int64_t K, void* stream);
+/* rowsum(W_int8) of the zero-point correction (int8_tensor.py:326 `weight_tensor.qdata.sum(dim=-1)`): q int8 [N][K] ->
+ * sums int32 [N].  K % 16 == 0.  Computed once per weight by the host mirror. */
+int ao_int8_row_sums(const int8_t* q, int32_t* sums, int64_t N, int64_t K, void* stream);
+/* The Int8Tensor linear's epilogue with an asymmetric activation (int8_tensor.py:305-346) over the int32 accumulator of
+ * ao_int8_int_mm:  t = bf16(f32(acc) * x_scale[m]);  t = bf16(t - bf16((zp[m] * x_scale[m]) * w_row_sums[n]));
+ *   y = bf16(t * w_scale[n] (+ bias[n])). */
+int ao_int8_scale_epilogue_asym(const int32_t* acc, const float* x_scale, const int8_t* x_zero_point,
+                                const int32_t* w_row_sums, const float* w_scale, const uint16_t* bias,
+                                uint16_t* y, int64_t M, int64_t N, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * float8 (OCP e4m3fn) rowwise
  * ------------------------------------------------------------------------- */

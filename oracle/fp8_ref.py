@@ -97,3 +97,12 @@ def grouped_mm(a, b, scale_a, scale_b, offs):
             out[start:end] = scaled_mm(a[start:end], b[e], np.asarray(scale_a)[start:end], np.asarray(scale_b)[e])
         start = end
     return out
+
+
+def quantize_tensorwise(x):
+    """Float8Tensor.from_hp(x, e4m3, PerTensor()): one amax over the whole tensor, scale = f32(bf16(amax / 448))
+    (quant_primitives.py:2192-2212 with block_size = shape).  Returns (codes uint8 [M,K], scale fp32 scalar)."""
+    x = np.asarray(x, dtype=np.float32)
+    amax = np.float32(np.abs(x).max())
+    q, s = quantize_rowwise(x, amax=np.full((x.shape[0],), amax, dtype=np.float32))
+    return q, s[0]

@@ -229,8 +229,53 @@ def make_hqq():
     print("hqq.npz:", len(out), "arrays")
 
 
+def make_int8_fp8_variants():
+    """PerTensor granularity (int8, fp8) and the ASYMMETRIC activation mapping of Int8Tensor, by the reference's own from_hp and its
+    own F.linear dispatch on CPU tensors (int8_tensor.py:176-359)."""
+    import torch.nn.functional as F
+    from torchao.quantization.granularity import PerRow, PerTensor
+    from torchao.quantization.quant_primitives import MappingType
+    from torchao.quantization.quantize_.workflows.float8.float8_tensor import Float8Tensor
+    from torchao.quantization.quantize_.workflows.int8.int8_tensor import Int8Tensor, QuantizeTensorToInt8Kwargs
+
+    gen = torch.Generator().manual_seed(91)
+    m, n, k = 21, 64, 384
+    x = torch.randn(m, k, generator=gen).to(torch.bfloat16)
+    x[1] = x[1].abs() + 0.5       # all-positive row: min_val_neg = 0, zero_point = -128
+    x[2] = -x[2].abs() - 0.25     # all-negative row: max_val_pos = 0, zero_point = 127
+    x[3] *= 250.0
+    x[4] *= 2e-3
+    x[5] = 0                      # scale clamps to eps, zero_point = -128
+    x[6] = x[6] + 3.0             # skewed
+    x[7, 0] = 1000.0              # one outlier
+    w = (torch.randn(n, k, generator=gen) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(n, generator=gen).to(torch.bfloat16)
+    out = {"x": bits(x), "w": bits(w), "bias": bits(bias)}
+    # --- int8 asymmetric per-row activation
+    xa = Int8Tensor.from_hp(x, PerRow(), mapping_type=MappingType.ASYMMETRIC)
+    out.update(asym_xq=xa.qdata.numpy(), asym_xs=xa.scale.flatten().numpy(), asym_xzp=xa.zero_point.flatten().numpy().astype(np.int8))
+    wt = Int8Tensor.from_hp(w, PerRow(), act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=PerRow(), mapping_type=MappingType.ASYMMETRIC))
+    out.update(asym_wq=wt.qdata.numpy(), asym_ws=wt.scale.flatten().numpy())
+    out["asym_y"] = bits(F.linear(x, wt, bias))
+    out["asym_y_nobias"] = bits(F.linear(x, wt))
+    # --- int8 per-tensor (symmetric), both operands
+    xt = Int8Tensor.from_hp(x, PerTensor())
+    wtt = Int8Tensor.from_hp(w, PerTensor(), act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=PerTensor()))
+    out.update(pt_xq=xt.qdata.numpy(), pt_xs=xt.scale.flatten().numpy(), pt_wq=wtt.qdata.numpy(), pt_ws=wtt.scale.flatten().numpy())
+    out["pt_y"] = bits(F.linear(x, wtt, bias))
+    # --- fp8 per-tensor
+    xf = Float8Tensor.from_hp(x, torch.float8_e4m3fn, PerTensor())
+    wf = Float8Tensor.from_hp(w, torch.float8_e4m3fn, PerTensor())
+    out.update(fp8pt_xq=xf.qdata.view(torch.uint8).numpy(), fp8pt_xs=xf.scale.flatten().numpy(),
+               fp8pt_wq=wf.qdata.view(torch.uint8).numpy(), fp8pt_ws=wf.scale.flatten().numpy())
+    out["fp8pt_y_dequant_f32"] = ((xf.dequantize().float() @ wf.dequantize().float().t()) + bias.float()).numpy()
+    np.savez_compressed(os.path.join(HERE, "int8_fp8_variants.npz"), **out)
+    print("int8_fp8_variants.npz:", {k_: v.shape for k_, v in out.items()})
+
+
 def make_rest():
     make_int8_fp8()
+    make_int8_fp8_variants()
     make_mx()
     make_moe()
     make_int4_plain()

@@ -86,8 +86,13 @@ def test_cxx_aten_signature_ops_match_the_c_abi_wrappers():
     bias = _randn_bf16((n,), 7).to(DEV)
     y = torch.ops.ao_mi355_c._scaled_mm(aq, fq.t(), a_s, fs.t(), bias, None, torch.bfloat16, True)
     assert torch.equal(y, ops.fp8_scaled_mm(aq, fq.t(), a_s, fs.t(), bias))
-    with pytest.raises(RuntimeError, match="rowwise"):
-        torch.ops.ao_mi355_c._scaled_mm(aq, fq.t(), a_s[:1], fs.t()[:, :1], None, None, torch.bfloat16, True)
+    # tensorwise scales ([1, 1] both: the reference's default Float8DynamicActivationFloat8WeightConfig) broadcast in the binding
+    tq, ts = ops.fp8_quantize_tensorwise(w)
+    uq, us = ops.fp8_quantize_tensorwise(x)
+    y = torch.ops.ao_mi355_c._scaled_mm(uq, tq.t(), us, ts, bias, None, torch.bfloat16, True)
+    assert torch.equal(y, ops.fp8_scaled_mm(uq, tq.t(), us.reshape(-1).expand(3), ts.reshape(-1).expand(n), bias))
+    with pytest.raises(RuntimeError, match="rowwise"):  # anything else (here: 2 scales for 3 rows) is refused
+        torch.ops.ao_mi355_c._scaled_mm(aq, fq.t(), a_s[:2], fs.t(), None, None, torch.bfloat16, True)
     # grouped MXFP8: mat2 arrives [E, K, N] with K-major experts (the transpose of [E, N, K])
     E = 4
     we = _randn_bf16((E, 64, 512), 8, 0.1).to(DEV)
@@ -129,12 +134,12 @@ def test_torch_compile_fullgraph_through_the_subclass(kind):
     from torch._dynamo.utils import counters
 
     from ao_amd.quantization import (Float8DynamicActivationFloat8WeightConfig, Int4WeightOnlyConfig,
-                                     Int8DynamicActivationInt8WeightConfig, quantize_)
+                                     Int8DynamicActivationInt8WeightConfig, PerRow, quantize_)
 
     torch.manual_seed(0)
     lin = torch.nn.Linear(1024, 256, bias=True).to(torch.bfloat16).to(DEV)
     cfg = {"int4": Int4WeightOnlyConfig(group_size=128, int4_packing_format="tile_packed_to_4d"), "int8": Int8DynamicActivationInt8WeightConfig(),
-           "fp8": Float8DynamicActivationFloat8WeightConfig()}[kind]
+           "fp8": Float8DynamicActivationFloat8WeightConfig(granularity=PerRow())}[kind]
     quantize_(lin, cfg)
     x = _randn_bf16((5, 1024), 21).to(DEV)
     want = lin(x)

@@ -111,15 +111,30 @@ def test_fp8_skips_shapes_scaled_mm_cannot_take():
 
 
 def test_8bit_granularity_checks():
-    from ao_amd.quantization import Float8Tensor, Int8Tensor, PerTensor
+    from ao_amd.quantization import (Float8DynamicActivationFloat8WeightConfig, Float8Tensor, Int8DynamicActivationInt8WeightConfig,
+                                     Int8Tensor, MappingType, PerGroup, PerRow, PerTensor)
 
     w = torch.zeros(32, 64, dtype=torch.bfloat16)
     with pytest.raises(NotImplementedError):
-        Int8Tensor.from_hp(w, PerTensor())
+        Int8Tensor.from_hp(w, PerGroup(32))
     with pytest.raises(NotImplementedError):
-        Float8Tensor.from_hp(w, granularity=PerTensor())
+        Float8Tensor.from_hp(w, granularity=PerGroup(32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # PerTensor is implemented: it reaches the kernels
+        Int8Tensor.from_hp(w, PerTensor())
     with pytest.raises(AssertionError):
         Float8Tensor.from_hp(w.float())  # PerRow needs bf16 (reference quant_api.py:1211-1216)
+    # config normalisation mirrors the reference: fp8 defaults to PerTensor for both operands, int8 to PerRow
+    assert Float8DynamicActivationFloat8WeightConfig().granularity == [PerTensor(), PerTensor()]
+    assert Float8DynamicActivationFloat8WeightConfig(granularity=PerRow()).granularity == [PerRow(), PerRow()]
+    assert Int8DynamicActivationInt8WeightConfig().granularity == [PerRow(), PerRow()]
+    assert Int8DynamicActivationInt8WeightConfig(granularity=[PerTensor(), PerRow()]).granularity == [PerTensor(), PerRow()]
+    assert Int8DynamicActivationInt8WeightConfig(act_mapping_type=MappingType.ASYMMETRIC).act_mapping_type == MappingType.ASYMMETRIC
+    with pytest.raises(ValueError):
+        Float8DynamicActivationFloat8WeightConfig(granularity=[PerTensor(), PerRow()])  # reference: must be the same type
+    with pytest.raises(ValueError):
+        Int8DynamicActivationInt8WeightConfig(granularity=[PerRow()])
+    with pytest.raises(ValueError):
+        Int8DynamicActivationInt8WeightConfig(version=1)
 
 
 def test_mx_argument_checks():

@@ -1,0 +1,52 @@
+"""CPU: the PerTensor / ASYMMETRIC variants of the int8 and fp8 oracles against fixtures produced by the reference's own
+Int8Tensor / Float8Tensor from_hp and F.linear dispatch (tests/golden/make_golden.py:make_int8_fp8_variants)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bf16_bits_to_f32
+from oracle import bf16, fp8_ref as F, int8_ref as I
+
+
+@pytest.fixture(scope="module")
+def gv():
+    return np.load(os.path.join(GOLDEN, "int8_fp8_variants.npz"))
+
+
+def test_int8_asymmetric_quantize_bit_exact(gv):
+    q, s, zp = I.quantize_rowwise_asym(bf16_bits_to_f32(gv["x"]))
+    assert np.array_equal(q, gv["asym_xq"]) and np.array_equal(s, gv["asym_xs"]) and np.array_equal(zp, gv["asym_xzp"])
+    # the fixture covers the corner rows: all-positive (zp -128), all-negative (zp 127), all-zero (scale = eps)
+    assert gv["asym_xzp"][1] == -128 and gv["asym_xzp"][2] >= 126 and gv["asym_xzp"][5] == -128
+
+
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_int8_asymmetric_linear_bit_exact(gv, with_bias):
+    b = bf16_bits_to_f32(gv["bias"]) if with_bias else None
+    y = I.scaled_mm_asym(gv["asym_xq"], gv["asym_xs"], gv["asym_xzp"], gv["asym_wq"], gv["asym_ws"], b)
+    assert np.array_equal(bf16.to_bits(y), gv["asym_y" if with_bias else "asym_y_nobias"])
+    y2 = I.linear_asym(bf16_bits_to_f32(gv["x"]), bf16_bits_to_f32(gv["w"]), b)
+    assert np.array_equal(bf16.to_bits(y2), gv["asym_y" if with_bias else "asym_y_nobias"])
+
+
+def test_int8_per_tensor_bit_exact(gv):
+    x, w = bf16_bits_to_f32(gv["x"]), bf16_bits_to_f32(gv["w"])
+    xq, xs = I.quantize_tensorwise(x)
+    wq, ws = I.quantize_tensorwise(w)
+    assert np.array_equal(xq, gv["pt_xq"]) and xs == gv["pt_xs"][0]
+    assert np.array_equal(wq, gv["pt_wq"]) and ws == gv["pt_ws"][0]
+    y = I.scaled_mm(xq, np.full(x.shape[0], xs, np.float32), wq, np.full(w.shape[0], ws, np.float32), bf16_bits_to_f32(gv["bias"]))
+    assert np.array_equal(bf16.to_bits(y), gv["pt_y"])
+
+
+def test_fp8_per_tensor_bit_exact(gv):
+    for t in ("x", "w"):
+        q, s = F.quantize_tensorwise(bf16_bits_to_f32(gv[t]))
+        assert np.array_equal(q, gv[f"fp8pt_{t}q"]) and s == gv[f"fp8pt_{t}s"][0]
+    x, w = bf16_bits_to_f32(gv["x"]), bf16_bits_to_f32(gv["w"])
+    xq, xs = F.quantize_tensorwise(x)
+    wq, ws = F.quantize_tensorwise(w)
+    y = F.scaled_mm(xq, wq, np.full(x.shape[0], xs, np.float32), np.full(w.shape[0], ws, np.float32), bf16_bits_to_f32(gv["bias"]))
+    ref = gv["fp8pt_y_dequant_f32"]
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 3e-3  # bf16 output rounding only

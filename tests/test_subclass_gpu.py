@@ -17,6 +17,9 @@ from ao_amd.quantization import (  # noqa: E402
     Float8Tensor,
     Int8DynamicActivationInt8WeightConfig,
     Int8Tensor,
+    MappingType,
+    PerRow,
+    PerTensor,
     quantize_,
 )
 
@@ -69,7 +72,7 @@ def test_float8_dynamic_linear(n, k, bias):
     b = lin.bias.detach().float().numpy() if bias else None
     y_bf16 = lin(x)
     lin = lin.to(DEV)
-    quantize_(lin, Float8DynamicActivationFloat8WeightConfig())
+    quantize_(lin, Float8DynamicActivationFloat8WeightConfig(granularity=PerRow()))
     assert isinstance(lin.weight, Float8Tensor) and lin.weight.qdata.dtype == torch.float8_e4m3fn
     y = lin(x.to(DEV))
     y_ref = F8.linear(x.reshape(-1, k).float().numpy(), w, b)
