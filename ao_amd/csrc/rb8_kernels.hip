@@ -20,6 +20,7 @@
 #include "splitk.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ao {
 namespace {
@@ -29,7 +30,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
 // weight ring (per wave), filled kWStages - 1 steps ahead: the HBM stream needs the bytes in flight.  6 stages; 5 for the
 // 8-wave MX form, whose scale rings would otherwise push the workgroup past 160 KiB of LDS
-constexpr int w_stages(int waves, int kind) { return (waves == 8 && kind == 2) ? 5 : 6; }
+// (also 5 for the 64-row MX slab, which then fits two workgroups per CU)
+constexpr int w_stages(int waves, int kind, int mt) { return (kind == 2 && (waves == 8 || mt == 4)) ? 5 : 6; }
 
 // RB8_FP8_GROUPED: rowwise e4m3 like RB8_FP8, rows grouped by expert like RB8_MX (Float8Tensor's _grouped_mm, float8_tensor.py:1085-1122)
 enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2, RB8_FP8_GROUPED = 3 };
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   constexpr int BM = 16 * MT;
   constexpr int LPS = ADMA + 2 + (MX ? 2 : 0);
   constexpr int RPW = BM / WAVES;   // MX: activation-scale rows fetched per wave
-  constexpr int kWStages = w_stages(WAVES, KIND);
+  constexpr int kWStages = w_stages(WAVES, KIND, MT);
   // [3][128][128 B] a | [WAVES][6][2 KiB] b | MX: [3][WAVES][256 B] a scales | [WAVES][6][256 B] b scales
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -80,15 +82,48 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int S = gridDim.z, ks = blockIdx.z;
   const int k0 = (int)(((long long)ksteps * ks) / S);
   const int nk = (int)(((long long)ksteps * (ks + 1)) / S) - k0;
-  // rows of this workgroup: [m0, m_end) -- a 128-row slab of the matrix, or of one expert's token group
+  // rows of this workgroup: [m0, m_end) -- a slab of the matrix, or of one expert's token group.  Grouped kinds: blockIdx.y
+  // enumerates the NON-EMPTY slabs in (expert, slab) order -- the y-th one is found from the group ends on the device, so the
+  // grid needs ceil(M / BM) + E rows at most (not E x the slabs of the largest possible group) and an expert without tokens
+  // costs nothing.
   int m0 = blockIdx.y * BM, m_end = p.M, expert = 0;
   if constexpr (GROUPED) {
-    expert = blockIdx.y / p.slabs;
-    const int begin = (p.offs != nullptr && expert > 0) ? p.offs[expert - 1] : 0;
-    m_end = (p.offs != nullptr) ? p.offs[expert] : p.M;
-    m0 = begin + (blockIdx.y % p.slabs) * BM;
-    if (m0 >= m_end) return;  // uniform: empty group / slab past the group (before any DMA or barrier)
+    if (p.offs != nullptr) {
+      int y = blockIdx.y, found = -1, begin = 0, end = 0;
+      for (int e0 = 0; e0 < p.E && found < 0; e0 += 64) {  // 64 experts per pass: lane e owns expert e0 + e
+        const int e = e0 + lane;
+        const int lo = (e > 0 && e < p.E) ? p.offs[e - 1] : 0;
+        const int hi = (e < p.E) ? p.offs[e] : lo;
+        const int ns = (hi - lo + BM - 1) / BM;  // slabs of this expert (0 when it has no tokens)
+        int incl = ns;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d);
+          if (lane >= d) incl += t;
+        }
+        const unsigned long long hit = __ballot(incl > y);
+        if (hit != 0ull) {
+          const int l = __builtin_ctzll(hit);
+          found = e0 + l;
+          begin = __builtin_amdgcn_readlane(lo, l);
+          end = __builtin_amdgcn_readlane(hi, l);
+          y -= __builtin_amdgcn_readlane(incl - ns, l);
+        } else {
+          y -= __builtin_amdgcn_readlane(incl, 63);
+        }
+      }
+      if (found < 0) return;  // uniform: past the last non-empty slab (before any DMA or barrier)
+      expert = found;
+      m0 = begin + y * BM;
+      m_end = end;
+    } else if (m0 >= m_end) {
+      return;
+    }
   }
+  // m-tiles this slab really has, rounded up to a power of two: the k loop below is specialised on it, so a 32-row group in a
+  // 64- or 128-row slab reads and multiplies 32 rows (the DMA counts stay static for the hand-counted waits; rows past the
+  // group re-read its last row)
+  const int mt_have = (min(m_end - m0, BM) + 15) >> 4;
 
   uint32_t aoff[ADMA];
 #pragma unroll
@@ -142,6 +177,8 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   issue_a(0, 0); issue_w(kWStages - 3, kWStages - 3);
   issue_a(1, 1); issue_w(kWStages - 2, kWStages - 2);
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
+  auto k_loop = [&](auto mtc) {
+  constexpr int MTC = decltype(mtc)::value;
   int stage = 0, wstage = 0;
   for (int k = 0; k < nk; ++k) {
     wait_vmcnt<LPS + 2 + (MX ? 1 : 0)>();
@@ -162,7 +199,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + kStages * WAVES * 256 +
                                                     (wave * kWStages + wstage) * 256 + nl * 4) >> (8 * kq)) & 0xff;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MTC; ++mt) {
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
       const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + (pa ^ 64));
       if constexpr (INT8) {  // acc holds int32 bit patterns
@@ -182,6 +219,15 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     }
     stage = (stage == 2) ? 0 : stage + 1;
     wstage = (wstage == kWStages - 1) ? 0 : wstage + 1;
+  }
+  };
+  if constexpr (GROUPED && MT >= 4) {
+    if (mt_have <= 1) k_loop(std::integral_constant<int, 1>{});
+    else if (mt_have <= 2) k_loop(std::integral_constant<int, 2>{});
+    else if (MT == 4 || mt_have <= 4) k_loop(std::integral_constant<int, 4>{});
+    else k_loop(std::integral_constant<int, MT>{});
+  } else {
+    k_loop(std::integral_constant<int, MT>{});
   }
   wait_vmcnt<0>();  // the clamped fills past the end still write LDS
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -247,9 +293,12 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   constexpr int BN = WAVES * 16;
   constexpr int BM = 16 * MT;
   constexpr bool kGrouped = (KIND == RB8_MX || KIND == RB8_FP8_GROUPED);
-  const unsigned gy = kGrouped ? (unsigned)(p.slabs * (p.offs != nullptr ? p.E : 1)) : (unsigned)((p.M + BM - 1) / BM);
+  // grouped: at most ceil(M / BM) + E non-empty slabs exist whatever the group sizes are (and no more than E x slabs-per-group)
+  const unsigned gy = !kGrouped ? (unsigned)((p.M + BM - 1) / BM)
+                      : (p.offs == nullptr) ? (unsigned)p.slabs
+                                            : (unsigned)std::min<int64_t>((int64_t)p.slabs * p.E, (p.M + BM - 1) / BM + p.E);
   dim3 grid((unsigned)((p.N + BN - 1) / BN), gy, (unsigned)split), block(64 * WAVES);
-  constexpr int kWStages = w_stages(WAVES, KIND);
+  constexpr int kWStages = w_stages(WAVES, KIND, MT);
   constexpr size_t smem = (size_t)kStages * MT * 2048 + (size_t)WAVES * kWStages * 2048 +
                           ((KIND == RB8_MX) ? (size_t)(kStages + kWStages) * WAVES * 256 : 0);
   static_assert(smem <= 160 * 1024, "rb8_kernel: LDS");
@@ -326,13 +375,13 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
   Rb8Args p{};
   p.a = a; p.b = b; p.y = out; p.a_mx = a_scale; p.b_mx = b_scale; p.offs = offs;
   p.M = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
-  // Slab height from the average group size (the sizes themselves live on the device): 32 rows for decode-size groups, else
-  // 128; the grid provides enough slabs per group for the largest group `rows_hint` allows, empty ones exit at once.
+  // Slab capacity from the average group size (the sizes themselves live on the device): 64 rows for decode-size groups (two
+  // workgroups per CU; a group's real m-tile count is found on the device), else 128.
   const int64_t groups = (offs != nullptr ? E : 1);
-  const int bm = (M_total <= 24 * groups) ? 32 : 128;
+  const int bm = (M_total <= 48 * groups) ? 64 : 128;
   p.slabs = (int)std::max<int64_t>(1, (std::min(rows_hint, M_total) + bm - 1) / bm);
   // 64-column tiles when 128-column ones would not give every CU a workgroup even if every group had tokens
-  if (bm == 32) return launch_rb8<4, RB8_MX, 2>(p, 1, stream);
+  if (bm == 64) return launch_rb8<4, RB8_MX, 4>(p, 1, stream);
   return (((N + 127) / 128) * groups * p.slabs < 400) ? launch_rb8<4, RB8_MX, 8>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);
 }
 
@@ -343,9 +392,9 @@ int fp8_rowwise_grouped_rb(const uint8_t* a, const uint8_t* b, const float* scal
   Rb8Args p{};
   p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.y = out; p.offs = offs;
   p.M = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
-  const int bm = (M_total <= 24 * E) ? 32 : 128;
+  const int bm = (M_total <= 48 * E) ? 64 : 128;
   p.slabs = (int)std::max<int64_t>(1, (M_total + bm - 1) / bm);
-  if (bm == 32) return launch_rb8<4, RB8_FP8_GROUPED, 2>(p, 1, stream);
+  if (bm == 64) return launch_rb8<4, RB8_FP8_GROUPED, 4>(p, 1, stream);
   return (((N + 127) / 128) * E * p.slabs < 400) ? launch_rb8<4, RB8_FP8_GROUPED, 8>(p, 1, stream) : launch_rb8<8, RB8_FP8_GROUPED, 8>(p, 1, stream);
 }
 

@@ -412,8 +412,8 @@ extern "C" int ao_fp8_grouped_mm(const uint8_t* a, const float* scale_a, const u
   AO_REQUIRE(M_total >= 0 && N > 0 && K > 0 && E > 0, "ao_fp8_grouped_mm: bad shape M_total=%lld N=%lld K=%lld E=%lld", (long long)M_total,
              (long long)N, (long long)K, (long long)E);
   AO_REQUIRE(K % 128 == 0 && N % 16 == 0, "ao_fp8_grouped_mm: K=%lld must be a multiple of 128 and N=%lld of 16", (long long)K, (long long)N);
-  const int64_t bm = (M_total <= 24 * E) ? 32 : 128;
-  AO_REQUIRE(M_total * K < (1ll << 32) && N * K < (1ll << 32) && E * ((M_total + bm - 1) / bm) <= 65535 && E < 65536,
+  const int64_t bm = (M_total <= 48 * E) ? 64 : 128;
+  AO_REQUIRE(M_total * K < (1ll << 32) && N * K < (1ll << 32) && E + (M_total + bm - 1) / bm <= 65535,
              "ao_fp8_grouped_mm: tensor too large for one launch (M_total * K and N * K must stay below 4 Gi elements)");
   if (M_total == 0) return AO_OK;
   AO_REQUIRE_PTR(a);
@@ -449,9 +449,9 @@ extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, con
   // LDS-staged 89 / 110; 128 rows per expert -- 381 / 474 (the A-stationary kernel re-streams the weights per 64-row pass) vs
   // 211 / 172.  Variant 111 keeps the older kernels reachable for A/B runs.
   // (it addresses activation rows with 32-bit byte offsets and puts experts x slabs on grid.y: tensors beyond either bound --
-  // M_total * K >= 4 GiB, or more than 65535 (expert, slab) pairs -- take the per-tile kernels below, which have neither limit)
-  const int64_t rb_bm = (M_total <= 24 * (offs != nullptr ? E : 1)) ? 32 : 128;
-  const bool rb_ok = M_total * K < (1ll << 32) && N * K < (1ll << 32) && (offs != nullptr ? E : 1) * ((M_total + rb_bm - 1) / rb_bm) <= 65535;
+  // M_total * K >= 4 GiB, or more than 65535 possible non-empty (expert, slab) pairs -- take the per-tile kernels below, which have neither limit)
+  const int64_t rb_bm = (M_total <= 48 * (offs != nullptr ? E : 1)) ? 64 : 128;
+  const bool rb_ok = M_total * K < (1ll << 32) && N * K < (1ll << 32) && (offs != nullptr ? E : 0) + (M_total + rb_bm - 1) / rb_bm <= 65535;
   if (g_mx_variant != 2 && rb_ok) return mxfp8_grouped_rb(a, a_scale, b, b_scale, offs, out, M_total, N, K, E, M_total, (hipStream_t)stream);
   if (offs != nullptr && K % 2048 == 0) {
     // Group sizes live on the device.  Size the m-tiling for twice the AVERAGE group: a larger group

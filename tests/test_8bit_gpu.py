@@ -328,7 +328,11 @@ def test_mxfp8_grouped_mm_a_stationary_kernel(sizes, n, k):
 @pytest.mark.parametrize(
     "sizes,n,k",
     [([8, 8, 8, 8], 80, 2048), ([16, 16, 16, 16], 256, 4096), ([40, 0, 5, 27], 80, 512), ([200, 1, 3, 0], 144, 1024), ([0, 0, 130], 4096, 384),
-     ([16, 32, 16, 0, 32, 0, 16, 16], 2048, 2048)],
+     ([16, 32, 16, 0, 32, 0, 16, 16], 2048, 2048),
+     # the device-side slab enumeration: every m-tile count of a 64-row slab (1, 17, 33, 49 rows), a group that straddles
+     # two slabs next to empty ones, and more than 64 experts (second pass of the 64-lane scan) with the tokens at the far end
+     ([1, 17, 33, 49, 0, 64, 65, 0], 80, 512), ([0] * 66 + [5, 0, 70, 3], 64, 256), ([2] * 70, 48, 384),
+     ([130, 0, 0, 257, 1], 96, 256)],
 )
 def test_mxfp8_grouped_mm_lds_staged_kernel(sizes, n, k):
     """The LDS-staged weight-streaming form (rb8_kernel<RB8_MX>, forced with variant 110): groups larger than one 128-row

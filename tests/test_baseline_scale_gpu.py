@@ -207,6 +207,7 @@ def test_row_parallel_blocks_match_unsharded_oracle(kind, world):
 
 # ---- Float8Tensor _grouped_mm (rowwise) and the cached MXFP8 expert weights ------------------------------------------------
 @pytest.mark.parametrize("sizes,n,k", [([16, 16, 16, 16], 64, 512), ([32, 0, 5, 27], 256, 2048), ([1, 70, 3, 0], 144, 4096),
+                                       ([0] * 65 + [40, 0, 9], 64, 256), ([1, 17, 33, 49, 0, 64, 65, 0], 80, 512),
                                        ([128, 0, 64, 200, 0, 0, 8, 0], 1024, 1024)])
 def test_fp8_grouped_mm_vs_oracle(sizes, n, k):
     """torch._grouped_mm(x, Float8Tensor weight.transpose(-2, -1), offs) -- float8_tensor.py:1085-1122 -- against the numpy oracle
