@@ -628,9 +628,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     }
   };
 
-  // issue order: w(0 .. KW-3) | x(0) w(KW-2) | x(1) ... then per k-block kb: x(kb + 2), w(kb + KW - 1).  When k-block kb starts, the
-  // requests younger than x(kb) are w(kb + KW - 3) (issued right behind it), x(kb + 1) and w(kb + KW - 2): LPS + WDMAS of them may
-  // still be in flight; everything this k-block reads -- x(kb), w(kb) -- is older and has landed.
+  // issue order: w(0 .. KW-3) | x(0) w(KW-2) | x(1) ... then per k-block kb: x(kb + 2), w(kb + KW - 1).  With KW >= 4, when k-block kb
+  // starts the requests younger than x(kb) are w(kb + KW - 3) (issued right behind it), x(kb + 1) and w(kb + KW - 2): LPS + WDMAS of
+  // them may still be in flight; everything this k-block reads -- x(kb), w(kb) -- is older and has landed.
 #pragma unroll
   for (int i = 0; i < KW - 2; ++i) issue_w(i, i);
   issue_x(0, 0); issue_w(KW - 2, KW - 2);
@@ -639,7 +639,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   int stage = 0, wstage = 0;
   for (int kb = 0; kb < nkb; ++kb) {
     // (k-blocks 0 and 1: x(kb + 1) follows x(kb) directly or with one weight stage between -- only LPS younger requests exist)
-    if (ABL != 4) { if (kb < 2) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + WDMAS>(); }
+    // (KW = 3: w(kb) is issued right BEHIND x(kb), in k-block kb - 2, so only x(kb + 1) and w(kb + 1) -- LPS requests -- are younger
+    // than what this k-block reads; a deeper weight ring issues w(kb) earlier and one more weight stage may be in flight)
+    if (ABL != 4) { if (kb < 2 || KW < 4) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + WDMAS>(); }
     // everyone's share has landed, and everyone has finished reading stage kb - 1 (its LDS reads have returned)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ABL == 5 && kb < 8) ts[2 + kb] = __builtin_amdgcn_s_memtime();

@@ -27,13 +27,13 @@ LLAMA70B = [("qkv_proj", 10240, 8192), ("o_proj", 8192, 8192), ("gate_up_proj", 
 def timeit(fn, iters, warmup=3):
     """Seconds per call.  The calls are captured into one hipGraph and replayed (like bench.py), so that kernels of a
     few microseconds are not hidden behind ~18 us of eager Python + launch overhead per call."""
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
+        for _ in range(warmup):  # on the capture stream: the library's split-K workspace is per stream, allocated on first use
+            fn()
+        side.synchronize()
         with torch.cuda.graph(g, stream=side):
             for _ in range(iters):
                 fn()
