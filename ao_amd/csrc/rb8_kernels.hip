@@ -65,7 +65,6 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   static_assert(ADMA >= 1, "every wave issues the same number of DMAs per stage");
   constexpr int kABuf = MT * 2048;      // one activation stage: 16 MT rows x 128 k bytes
   constexpr int BM = 16 * MT;
-  constexpr int LPS = ADMA + 2 + (MX ? 2 : 0);
   constexpr int RPW = BM / WAVES;   // MX: activation-scale rows fetched per wave
   constexpr int kWStages = w_stages(WAVES, KIND, MT);
   // [3][128][128 B] a | [WAVES][6][2 KiB] b | MX: [3][WAVES][256 B] a scales | [WAVES][6][256 B] b scales
@@ -125,12 +124,6 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // group re-read its last row)
   const int mt_have = (min(m_end - m0, BM) + 15) >> 4;
 
-  uint32_t aoff[ADMA];
-#pragma unroll
-  for (int i = 0; i < ADMA; ++i) {
-    const int row = 8 * (ADMA * wave + i) + (lane >> 3);
-    aoff[i] = (uint32_t)min(m0 + row, m_end - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
-  }
   // weight DMA i (0, 1) of a step fetches rows 8 i + (lane >> 3) of the n-tile as FULL 128-byte lines (chunk position lane & 7,
   // same swizzle as the activations); half-line requests -- one lane group per 64 bytes -- ran the stream at 3.7 TB/s
   uint32_t boff[2];
@@ -150,13 +143,6 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const uint8_t* bsrows = MX ? p.b_mx + ((size_t)expert * p.N + (size_t)tile_c * 16) * kb32 : nullptr;
   const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (kWStages * 2048);
   const uint32_t bs_lds = as_lds + kStages * WAVES * 256 + wave * (kWStages * 256);
-  // k clamped: the fills past the end re-read the last step (unused)
-  auto issue_a = [&](int stage, int k) {
-    const int kk = k0 + min(k, nk - 1);
-#pragma unroll
-    for (int i = 0; i < ADMA; ++i) dma_b128_s(p.a + (size_t)kk * 128, aoff[i], a_lds + stage * kABuf + (ADMA * wave + i) * 1024);
-    if constexpr (MX) dma_b32_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (stage * WAVES + wave) * 256);
-  };
   auto issue_w = [&](int stage, int k) {
     const int kk = k0 + min(k, nk - 1);
     dma_b128_nt_s(brows + (size_t)kk * 128, boff[0], w_lds + stage * 2048);
@@ -171,17 +157,34 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int pa = nl * 128 + (((kq ^ (nl >> 1)) & 7) << 4);  // second half: ^ 64; + 2048 per m-tile
 
   // Issue order (6 stages) is w(0..2) | a(0) w(3) | a(1) w(4), then per step a(k+2) w(k+5): when step k starts, the youngest requests
-  // are a(k+1), w(k+4) (one stage: LPS) and w(k+3) (2 DMAs, 3 with MX scales); everything older -- a(k), w(k) .. w(k+2) -- has landed.
+  // are a(k+1), w(k+4) (one stage: LPSC) and w(k+3) (2 DMAs, 3 with MX scales); everything older -- a(k), w(k) .. w(k+2) -- has landed.
+  auto k_loop = [&](auto mtc) {
+  constexpr int MTC = decltype(mtc)::value;
+  // activation DMAs per wave and stage for the m-tiles this slab really has (8 rows each; with fewer 8-row blocks than waves
+  // the last waves re-fetch the group's last row into rows nobody reads): a 32-row group in a 64-row slab costs the workgroup
+  // 4 activation DMAs per step, not 8 -- the activation tile is half of what a CU's texture path moves per step
+  constexpr int AD = (2 * MTC >= WAVES) ? 2 * MTC / WAVES : 1;
+  constexpr int LPSC = AD + 2 + (MX ? 2 : 0);
+  uint32_t aoff[AD];
+#pragma unroll
+  for (int i = 0; i < AD; ++i) {
+    const int row = 8 * (AD * wave + i) + (lane >> 3);
+    aoff[i] = (uint32_t)min(m0 + row, m_end - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
+  }
+  auto issue_a = [&](int stage, int k) {  // k clamped: the fills past the end re-read the last step (unused)
+    const int kk = k0 + min(k, nk - 1);
+#pragma unroll
+    for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)kk * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
+    if constexpr (MX) dma_b32_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (stage * WAVES + wave) * 256);
+  };
 #pragma unroll
   for (int i = 0; i < kWStages - 3; ++i) issue_w(i, i);
   issue_a(0, 0); issue_w(kWStages - 3, kWStages - 3);
   issue_a(1, 1); issue_w(kWStages - 2, kWStages - 2);
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
-  auto k_loop = [&](auto mtc) {
-  constexpr int MTC = decltype(mtc)::value;
   int stage = 0, wstage = 0;
   for (int k = 0; k < nk; ++k) {
-    wait_vmcnt<LPS + 2 + (MX ? 1 : 0)>();
+    wait_vmcnt<LPSC + 2 + (MX ? 1 : 0)>();
     // everyone's share of the activation tile has landed, and everyone has finished reading step k - 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (TRACE && k < 8) ts[2 + k] = __builtin_amdgcn_s_memtime();
