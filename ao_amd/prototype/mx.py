@@ -104,6 +104,13 @@ def _to_mxfp8_then_scaled_grouped_mm(
     B_t may also be an MXFP8ExpertWeights (cast once, MXFP8ExpertWeights.from_hp(B_t)); `cache_weights=True` memoises that
     cast per weight tensor (keyed on its storage and version counter: an in-place update re-casts) -- inference only.
     Raises like the reference for unsupported arguments (:167-200)."""
+    from .ep import MXFP8Tokens
+    if isinstance(A, MXFP8Tokens):
+        # pre-quantized tokens (the output of the EP dispatch; reference: MXTensor input, mxfp8_grouped_mm.py:173-178, 482-486)
+        assert block_size == BLOCK and offs is not None and A.shape[-1] == B_t.shape[-2], f"shape {A.shape} and {B_t.shape} are not compatible"
+        w = B_t if isinstance(B_t, MXFP8ExpertWeights) else (
+            _cached_expert_weights(B_t, scale_calculation_mode) if cache_weights else MXFP8ExpertWeights.from_hp(B_t, scale_calculation_mode))
+        return ops.mxfp8_grouped_mm(A.data, A.scale, w.data, w.scale, offs.to(torch.int32))
     assert A.ndim == 2, "A must be 2D"
     if isinstance(B_t, MXFP8ExpertWeights):
         assert block_size == BLOCK, "Only block_size=32 is supported"
