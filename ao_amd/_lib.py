@@ -49,6 +49,7 @@ _SIGNATURES = {
     "ao_fp8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_mxfp8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _INT, _P],
     "ao_mxfp8_quantize_colwise": [_P, _P, _P, _I64, _I64, _INT, _P],
+    "ao_mxfp8_quantize_colwise_3d": [_P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_fp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "ao_mxfp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "ao_dyn_linear_fits": [_I64, _I64, _I64],

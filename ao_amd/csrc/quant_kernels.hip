@@ -288,6 +288,10 @@ __global__ __launch_bounds__(kThreads) void mxfp8_quant_colwise_kernel(const uin
                                                                        uint8_t* __restrict__ scale, int64_t R, int64_t C) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[kColTile * kColLdsStride];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // blockIdx.z: the matrix of a batch (expert) -- each [R][C] matrix is cast on its own, outputs laid out per matrix
+  x += (int64_t)blockIdx.z * R * C;
+  qt += (int64_t)blockIdx.z * R * C;
+  scale += (int64_t)blockIdx.z * (R >> 5) * C;
   const int64_t r0 = (int64_t)blockIdx.y * kColTile, c0 = (int64_t)blockIdx.x * kColTile;
   const int64_t rb = r0 + wave * 32, c = c0 + 2 * lane;
   if (rb < R && c < C) {
@@ -368,25 +372,39 @@ extern "C" int ao_fp8_quantize_rowwise(const uint16_t* x, uint8_t* q, float* sca
   return AO_OK;
 }
 
-extern "C" int ao_mxfp8_quantize_colwise(const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0, int64_t R, int64_t C, int scaling_mode,
-                                         void* stream) {
-  if (int rc = check_rows(__func__, R, C, 32)) return rc;
-  AO_REQUIRE(R % 32 == 0, "ao_mxfp8_quantize_colwise: R=%lld must be a multiple of 32", (long long)R);
+namespace {
+int mxfp8_colwise(const char* fn, const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0, int64_t E, int64_t R, int64_t C, int scaling_mode,
+                  void* stream) {
+  if (int rc = check_rows(fn, R, C, 32)) return rc;
+  AO_REQUIRE(R % 32 == 0, "%s: R=%lld must be a multiple of 32", fn, (long long)R);
+  AO_REQUIRE(E >= 0 && E <= 65535, "%s: E=%lld must be in [0, 65535]", fn, (long long)E);
   AO_REQUIRE(scaling_mode == AO_MX_SCALE_FLOOR || scaling_mode == AO_MX_SCALE_RCEIL,
-             "ao_mxfp8_quantize_colwise: scaling_mode must be AO_MX_SCALE_FLOOR or AO_MX_SCALE_RCEIL, got %d", scaling_mode);
-  if (R == 0) return AO_OK;
+             "%s: scaling_mode must be AO_MX_SCALE_FLOOR or AO_MX_SCALE_RCEIL, got %d", fn, scaling_mode);
+  if (R == 0 || E == 0) return AO_OK;
   AO_REQUIRE_PTR(x);
   AO_REQUIRE_PTR(q_t);
   AO_REQUIRE_PTR(scale_e8m0);
   const int64_t gx = (C + kColTile - 1) / kColTile, gy = (R + kColTile - 1) / kColTile;
-  AO_REQUIRE(gy <= 65535, "ao_mxfp8_quantize_colwise: R=%lld too large for one launch", (long long)R);
+  AO_REQUIRE(gy <= 65535, "%s: R=%lld too large for one launch", fn, (long long)R);
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)E);
   if (scaling_mode == AO_MX_SCALE_RCEIL)
-    ao::launch(mxfp8_quant_colwise_kernel<AO_MX_SCALE_RCEIL>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, x, q_t, scale_e8m0, R, C);
+    ao::launch(mxfp8_quant_colwise_kernel<AO_MX_SCALE_RCEIL>, grid, dim3(kThreads), 0, s, x, q_t, scale_e8m0, R, C);
   else
-    ao::launch(mxfp8_quant_colwise_kernel<AO_MX_SCALE_FLOOR>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, x, q_t, scale_e8m0, R, C);
+    ao::launch(mxfp8_quant_colwise_kernel<AO_MX_SCALE_FLOOR>, grid, dim3(kThreads), 0, s, x, q_t, scale_e8m0, R, C);
   AO_LAUNCH_CHECK("mxfp8_quant_colwise_kernel launch");
   return AO_OK;
+}
+}  // namespace
+
+extern "C" int ao_mxfp8_quantize_colwise(const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0, int64_t R, int64_t C, int scaling_mode,
+                                         void* stream) {
+  return mxfp8_colwise(__func__, x, q_t, scale_e8m0, 1, R, C, scaling_mode, stream);
+}
+
+extern "C" int ao_mxfp8_quantize_colwise_3d(const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0, int64_t E, int64_t R, int64_t C,
+                                            int scaling_mode, void* stream) {
+  return mxfp8_colwise(__func__, x, q_t, scale_e8m0, E, R, C, scaling_mode, stream);
 }
 
 namespace {

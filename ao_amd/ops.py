@@ -645,6 +645,29 @@ def mxfp8_quantize_colwise(x: torch.Tensor, scaling_mode: str = "rceil"):
     return qt.view(torch.float8_e4m3fn).t(), st.view(torch.float8_e8m0fnu).t()
 
 
+def mxfp8_quantize_3d(x: torch.Tensor, block_size: int = 32, scale_block_dim1: int = 32, scale_block_dim2: int = 1,
+                      scaling_mode: str = "rceil"):
+    """mxfp8_quantize_cuda_3d with logical (un-blocked) scales (prototype/moe_training/kernels/mxfp8/quant.py:1413-1440): x bf16
+    [E, N, K] -> (data float8_e4m3fn {E, N, K} column-major per expert, i.e. strides {N K, 1, N}; scale float8_e8m0fnu
+    {E, K, N/32} with strides {N/32 * K, 1, K}): one scale per 32 values of the MIDDLE dimension.  Only the (32, 1) scale block."""
+    dev = _require_gpu("mxfp8_quantize_3d", x)
+    if x.dtype != torch.bfloat16 or x.dim() != 3 or not x.is_contiguous():
+        raise RuntimeError("mxfp8_quantize_3d: expected a contiguous 3-D bfloat16 tensor")
+    if block_size != 32 or (scale_block_dim1, scale_block_dim2) != (32, 1):
+        raise NotImplementedError("mxfp8_quantize_3d on MI355X implements block_size 32 with (scale_block_dim1, scale_block_dim2) = (32, 1)")
+    mode = MX_SCALE_MODES.get(str(getattr(scaling_mode, "value", scaling_mode)).lower())
+    if mode is None:
+        raise RuntimeError(f"mxfp8_quantize_3d: unsupported scaling mode {scaling_mode!r} (floor | rceil)")
+    e, r, c = x.shape
+    if r % 32 != 0 or c % 32 != 0:
+        raise RuntimeError(f"mxfp8_quantize_3d: shape {tuple(x.shape)}: N and K must be multiples of 32")
+    qt = torch.empty((e, c, r), dtype=torch.uint8, device=dev)
+    st = torch.empty((e, r // 32, c), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_mxfp8_quantize_colwise_3d(_ptr(x), _ptr(qt), _ptr(st), e, r, c, mode, _stream()))
+    return qt.view(torch.float8_e4m3fn).transpose(-2, -1), st.view(torch.float8_e8m0fnu).transpose(-2, -1)
+
+
 def mxfp8_grouped_mm(a, a_scale, b, b_scale, offs):
     """aten::_scaled_grouped_mm for MXFP8 (mxfp8_grouped_mm.py:541), numerics of the
     emulated path (:959-1023).  a e4m3 [M, K]; a_scale e8m0 [M, K/32]; b e4m3

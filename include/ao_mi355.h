@@ -221,6 +221,13 @@ int ao_mxfp8_quantize_rowwise(const uint16_t* x, uint8_t* q, uint8_t* scale_e8m0
 int ao_mxfp8_quantize_colwise(const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0,
                               int64_t R, int64_t C, int scaling_mode, void* stream);
 
+/* The 3-D (per-expert) form: mxfp8_quantize_cuda_3d with (scale_block_dim1, scale_block_dim2) = (32, 1), logical scales
+ * (torchao/prototype/moe_training/kernels/mxfp8/quant.py:1413-1440; csrc/cuda/mx_kernels/mxfp8_quantize.cuh:822-1290) --
+ * every [R][C] matrix of the batch cast on its own, "column-major-per-expert" data.
+ *   x bf16 [E][R][C] -> q_t e4m3fn [E][C][R], scale e8m0 [E][R/32][C]. */
+int ao_mxfp8_quantize_colwise_3d(const uint16_t* x, uint8_t* q_t, uint8_t* scale_e8m0,
+                                 int64_t E, int64_t R, int64_t C, int scaling_mode, void* stream);
+
 /* Replaces aten::_scaled_grouped_mm as called from _compute_fwd_sm100
  * (torchao/prototype/moe_training/mxfp8_grouped_mm.py:541), with the numerics of
  * _emulated_mxfp8_scaled_grouped_mm_2d_3d (:959-1023):

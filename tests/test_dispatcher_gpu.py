@@ -60,6 +60,21 @@ def test_torchao_mxfp8_quantize_rowwise_and_colwise_vs_oracle(r, c, mode):
         torch.ops.torchao.mxfp8_quantize(xd, True, False, 32, 32, "e5m2", mode)
 
 
+@pytest.mark.parametrize("mode", ["rceil", "floor"])
+def test_mxfp8_quantize_3d_is_the_colwise_cast_per_expert(mode):
+    """mxfp8_quantize_cuda_3d, (32, 1) scale blocks (quant.py:1413-1440): every expert's [N, K] matrix cast along N."""
+    E, N, K = 3, 96, 160
+    x = _randn_bf16((E, N, K), 17)
+    x[1, :32, 5] = 0
+    x[2, 32:64, 7] *= 1e4
+    q, s = ops.mxfp8_quantize_3d(x.to(DEV), scaling_mode=mode)
+    assert tuple(q.shape) == (E, N, K) and q.stride() == (N * K, 1, N) and tuple(s.shape) == (E, K, N // 32)
+    for e in range(E):
+        qo, so = MX.to_mx(x[e].t().contiguous().float().numpy(), MX.RCEIL if mode == "rceil" else MX.FLOOR)  # [K, N], blocks along N
+        assert np.array_equal(q[e].t().contiguous().view(torch.uint8).cpu().numpy(), qo)
+        assert np.array_equal(s[e].contiguous().view(torch.uint8).cpu().numpy(), so)
+
+
 def test_torchao_pad_unpad_ops_match_python_wrappers():
     x = _randn_bf16((100, 256), 3).to(DEV)
     offs = torch.tensor([10, 10, 57, 100], dtype=torch.int32, device=DEV)
