@@ -573,6 +573,22 @@ def int8_linear_asym(x2, wq, w_scale, w_row_sums, bias=None):
     return int8_scale_epilogue_asym(int_mm(xq, wq.t()), xs, zp, w_row_sums, w_scale, bias)
 
 
+def int8_linear_tensorwise(x2, wq, w_scale, bias=None):
+    """The Int8Tensor F.linear with a PerTensor activation (int8_tensor.py:266-359): one amax over the whole activation, the
+    fused two-rounding epilogue with that scalar broadcast over the rows.  `w_scale` fp32 [N] (a PerTensor weight scale already
+    broadcast)."""
+    xq, xs = int8_quantize_tensorwise(x2)
+    return int8_scaled_mm(xq, xs.reshape(-1).expand(x2.shape[0]), wq, w_scale, bias)
+
+
+def fp8_linear_tensorwise(x2, wq, w_scale, bias=None):
+    """The Float8Tensor F.linear with PerTensor scales on both operands (tensorwise aten::_scaled_mm, float8/inference.py:68-123):
+    `w_scale` is the weight's [1, 1] scale."""
+    xq, xs = fp8_quantize_tensorwise(x2)
+    n = wq.shape[0]
+    return fp8_scaled_mm(xq, wq.t(), xs.reshape(-1).expand(x2.shape[0]), w_scale.reshape(-1).expand(n), bias)
+
+
 # ---------------------------------------------------------------------------
 # MXFP8
 # ---------------------------------------------------------------------------

@@ -122,15 +122,11 @@ def _(func, types, args, kwargs):
         raise NotImplementedError("Float8Tensor linear: activation and weight granularities must both be PerRow or both PerTensor")
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
-    elif w_tensorwise:
-        # tensorwise-scaled _scaled_mm (float8/inference.py:68-123 with [1, 1] scales): the same epilogue with the two
-        # scalars broadcast over rows / columns
-        xq, xs = ops.fp8_quantize_tensorwise(x2)
-        y = ops.fp8_scaled_mm(xq, w.qdata.t(), xs.reshape(-1).expand(x2.shape[0]), w.scale.reshape(-1).expand(n), bias)
-        bias = None
     else:
         from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
-        y = kernels(x2).fp8_linear(x2, w.qdata, w.scale, bias)
+        # tensorwise-scaled _scaled_mm (float8/inference.py:68-123 with [1, 1] scales) is the rowwise epilogue with the two
+        # scalars broadcast over rows / columns
+        y = (kernels(x2).fp8_linear_tensorwise if w_tensorwise else kernels(x2).fp8_linear)(x2, w.qdata, w.scale, bias)
         bias = None
     y = y.reshape(*x.shape[:-1], n)
     if bias is not None:

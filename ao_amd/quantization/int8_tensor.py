@@ -57,13 +57,15 @@ class Int8Tensor(LowBitTensorBase):
 
     tensor_data_names = ["qdata", "scale"]
     tensor_attribute_names = ["block_size", "dtype_", "act_quant_kwargs"]
-    optional_tensor_data_names = ["act_pre_scale", "zero_point"]
+    # w_row_sums (int32 [N]): rowsum(qdata), the operand of the asymmetric-activation correction (int8_tensor.py:326 recomputes it
+    # on every call); kept next to the weight, built at from_hp when the activation mapping is ASYMMETRIC
+    optional_tensor_data_names = ["act_pre_scale", "zero_point", "w_row_sums"]
 
-    def __new__(cls, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None):
+    def __new__(cls, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None, w_row_sums=None):
         kwargs = dict(device=qdata.device, dtype=dtype_, requires_grad=False)
         return torch.Tensor._make_wrapper_subclass(cls, qdata.shape, **kwargs)
 
-    def __init__(self, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None):
+    def __init__(self, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None, w_row_sums=None):
         self.qdata = qdata
         self.scale = scale
         self.block_size = list(block_size)
@@ -71,7 +73,7 @@ class Int8Tensor(LowBitTensorBase):
         self.act_quant_kwargs = act_quant_kwargs
         self.act_pre_scale = act_pre_scale
         self.zero_point = zero_point
-        self._row_sums = None  # int32 [N], built on first asymmetric-activation linear (the correction's rowsum(W))
+        self.w_row_sums = w_row_sums
 
     def _quantization_type(self):
         return (f"act_quant_kwargs={self.act_quant_kwargs}, block_size={self.block_size}, "
@@ -102,7 +104,10 @@ class Int8Tensor(LowBitTensorBase):
         else:
             qdata, scale = ops.int8_quantize_rowwise(x)
         block_size = list(hp_tensor.shape) if isinstance(granularity, PerTensor) else [1, hp_tensor.shape[-1]]
-        return cls(qdata, scale, block_size, hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs, zero_point=zero_point)
+        w_row_sums = None
+        if act_quant_kwargs is not None and _mapping(act_quant_kwargs.mapping_type) == MappingType.ASYMMETRIC:
+            w_row_sums = ops.int8_row_sums(qdata)
+        return cls(qdata, scale, block_size, hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs, zero_point=zero_point, w_row_sums=w_row_sums)
 
     def dequantize(self, output_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """reference :250-263: (qdata - zero_point) * scale in fp32, then cast"""
@@ -144,20 +149,19 @@ def _(func, types, args, kwargs):
     n = w.qdata.shape[0]
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
-    elif _mapping(act.mapping_type) == MappingType.ASYMMETRIC:
-        if not isinstance(act.granularity, PerRow):
-            raise NotImplementedError("Int8Tensor on MI355X implements ASYMMETRIC activation quantization per row only")
-        if w._row_sums is None:
-            w._row_sums = ops.int8_row_sums(w.qdata)
-        y = ops.int8_linear_asym(x2, w.qdata, w._row_scale(), w._row_sums, bias)
-        bias = None
-    elif isinstance(act.granularity, PerTensor):
-        xq, xs = ops.int8_quantize_tensorwise(x2)
-        y = ops.int8_scaled_mm(xq, xs.reshape(-1).expand(x2.shape[0]), w.qdata, w._row_scale(), bias)
-        bias = None
     else:
         from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
-        y = kernels(x2).int8_linear(x2, w.qdata, w._row_scale(), bias)
+        k = kernels(x2)
+        if _mapping(act.mapping_type) == MappingType.ASYMMETRIC:
+            if not isinstance(act.granularity, PerRow):
+                raise NotImplementedError("Int8Tensor on MI355X implements ASYMMETRIC activation quantization per row only")
+            if w.w_row_sums is None:  # a weight built without from_hp (e.g. loaded from a reference checkpoint): once, eagerly
+                w.w_row_sums = ops.int8_row_sums(w.qdata)
+            y = k.int8_linear_asym(x2, w.qdata, w._row_scale(), w.w_row_sums, bias)
+        elif isinstance(act.granularity, PerTensor):
+            y = k.int8_linear_tensorwise(x2, w.qdata, w._row_scale(), bias)
+        else:
+            y = k.int8_linear(x2, w.qdata, w._row_scale(), bias)
         bias = None
     y = y.reshape(*x.shape[:-1], n)
     if bias is not None:
@@ -182,12 +186,14 @@ def _(func, types, args, kwargs):
         q = self.qdata[start:end].contiguous()
         s = self.scale if per_tensor else self.scale[start:end].contiguous()
         zp = zp if (zp is None or per_tensor) else zp[start:end].contiguous()
+        sums = None if self.w_row_sums is None else self.w_row_sums[start:end].contiguous()
     else:
         q, s = self.qdata[:, start:end].contiguous(), self.scale
+        sums = None if self.w_row_sums is None else ops.int8_row_sums(q)  # a K slice has its own row sums
         if pre is not None and pre.numel() == self.shape[1]:  # per-input-feature pre-scale follows the K slice
             pre = pre.reshape(-1)[start:end]
     block_size = list(q.shape) if per_tensor else [1, q.shape[1]]
-    return Int8Tensor(q, s, block_size, self.dtype_, self.act_quant_kwargs, pre, zp)
+    return Int8Tensor(q, s, block_size, self.dtype_, self.act_quant_kwargs, pre, zp, sums)
 
 
 torch.serialization.add_safe_globals([Int8Tensor, QuantizeTensorToInt8Kwargs, MappingType])

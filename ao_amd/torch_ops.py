@@ -54,6 +54,9 @@ _lib_def.define("int8_dynamic_linear(Tensor x, Tensor wq, Tensor w_scale, Tensor
 _lib_def.define("fp8_dynamic_linear(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("int8_linear(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("fp8_linear(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
+_lib_def.define("int8_linear_asym(Tensor x, Tensor wq, Tensor w_scale, Tensor w_row_sums, Tensor? bias) -> Tensor")
+_lib_def.define("int8_linear_tensorwise(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
+_lib_def.define("fp8_linear_tensorwise(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("int8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("fp8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("mxfp8_quantize(Tensor x, str scaling_mode) -> (Tensor, Tensor)")
@@ -73,6 +76,9 @@ _lib_impl.impl("int8_dynamic_linear", ops.int8_dynamic_linear)
 _lib_impl.impl("fp8_dynamic_linear", ops.fp8_dynamic_linear)
 _lib_impl.impl("int8_linear", ops.int8_linear)
 _lib_impl.impl("fp8_linear", ops.fp8_linear)
+_lib_impl.impl("int8_linear_asym", ops.int8_linear_asym)
+_lib_impl.impl("int8_linear_tensorwise", ops.int8_linear_tensorwise)
+_lib_impl.impl("fp8_linear_tensorwise", ops.fp8_linear_tensorwise)
 _lib_impl.impl("int8_quantize_rowwise", ops.int8_quantize_rowwise)
 _lib_impl.impl("fp8_quantize_rowwise", ops.fp8_quantize_rowwise)
 _lib_impl.impl("mxfp8_quantize", lambda x, mode: ops.mxfp8_quantize(x, mode))
@@ -118,6 +124,21 @@ def _(x, wq, w_scale, bias):
 
 
 @torch.library.register_fake("ao_mi355::fp8_linear")
+def _(x, wq, w_scale, bias):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::int8_linear_asym")
+def _(x, wq, w_scale, w_row_sums, bias):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::int8_linear_tensorwise")
+def _(x, wq, w_scale, bias):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::fp8_linear_tensorwise")
 def _(x, wq, w_scale, bias):
     return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
 
