@@ -83,6 +83,55 @@ __global__ __launch_bounds__(kThreads) void fp8_quant_rowwise_kernel(const uint1
   for (int64_t i = threadIdx.x; i < nvec; i += kThreads) qr[i] = fp8_quant8(xr[i], s);
 }
 
+// ---- the same two casts with the row held in registers between the amax reduction and the cast (K <= 16384): one read of x
+// instead of a second sweep through L2.  NV = 16-byte vectors per thread.
+template <bool INT8, int NV>
+__global__ __launch_bounds__(kThreads) void quant_rowwise_reg_kernel(const uint16_t* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ amax_in, uint8_t* __restrict__ q,
+                                                                     float* __restrict__ scale, int64_t K) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
+  const int nvec = (int)(K >> 3);
+  u32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = threadIdx.x + i * kThreads;
+    v[i] = (idx < nvec) ? xr[idx] : u32x4{0u, 0u, 0u, 0u};
+  }
+  float m = 0.f;
+  if (amax_in != nullptr) {
+    m = amax_in[row];
+  } else {
+    bool has_nan = false;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, amax8(v[i], has_nan));
+    m = block_max(has_nan ? INFINITY : m, red);  // (NaN rows are outside the contract)
+  }
+  const float s = INT8 ? int8_row_scale(m) : fp8_row_scale(m);
+  const float inv = 1.0f / s;
+  if (threadIdx.x == 0) scale[row] = s;
+  u32x2* qr = reinterpret_cast<u32x2*>(q + row * K);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = threadIdx.x + i * kThreads;
+    if (idx < nvec) qr[idx] = INT8 ? int8_quant8(v[i], inv) : fp8_quant8(v[i], s);
+  }
+}
+
+template <bool INT8>
+bool launch_quant_rowwise_reg(const uint16_t* x, int64_t ldx, const float* amax, void* q, float* scale, int64_t M, int64_t K, hipStream_t s) {
+  const int64_t per_thread = ((K >> 3) + kThreads - 1) / kThreads;
+  const dim3 grid((unsigned)M), block(kThreads);
+  uint8_t* qb = reinterpret_cast<uint8_t*>(q);
+  if (per_thread <= 1) ao::launch(quant_rowwise_reg_kernel<INT8, 1>, grid, block, 0, s, x, ldx, amax, qb, scale, K);
+  else if (per_thread <= 2) ao::launch(quant_rowwise_reg_kernel<INT8, 2>, grid, block, 0, s, x, ldx, amax, qb, scale, K);
+  else if (per_thread <= 4) ao::launch(quant_rowwise_reg_kernel<INT8, 4>, grid, block, 0, s, x, ldx, amax, qb, scale, K);
+  else if (per_thread <= 8) ao::launch(quant_rowwise_reg_kernel<INT8, 8>, grid, block, 0, s, x, ldx, amax, qb, scale, K);
+  else return false;  // longer rows: the two-sweep kernels
+  return true;
+}
+
 // ---- per-row amax of a (possibly strided) bf16 matrix: the local half of a full-K activation scale under K sharding -----
 __global__ __launch_bounds__(kThreads) void rowwise_amax_kernel(const uint16_t* __restrict__ x, int64_t ldx, float* __restrict__ amax,
                                                                 int64_t K) {
@@ -355,7 +404,8 @@ extern "C" int ao_int8_quantize_rowwise(const uint16_t* x, int8_t* q, float* sca
   AO_REQUIRE_PTR(x);
   AO_REQUIRE_PTR(q);
   AO_REQUIRE_PTR(scale);
-  ao::launch(int8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, K, (const float*)nullptr, q, scale, K);
+  if (!launch_quant_rowwise_reg<true>(x, K, nullptr, q, scale, M, K, (hipStream_t)stream))
+    ao::launch(int8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, K, (const float*)nullptr, q, scale, K);
   AO_LAUNCH_CHECK("int8_quant_rowwise_kernel launch");
   return AO_OK;
 }
@@ -367,7 +417,8 @@ extern "C" int ao_fp8_quantize_rowwise(const uint16_t* x, uint8_t* q, float* sca
   AO_REQUIRE_PTR(x);
   AO_REQUIRE_PTR(q);
   AO_REQUIRE_PTR(scale);
-  ao::launch(fp8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, K, (const float*)nullptr, q, scale, K);
+  if (!launch_quant_rowwise_reg<false>(x, K, nullptr, q, scale, M, K, (hipStream_t)stream))
+    ao::launch(fp8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, K, (const float*)nullptr, q, scale, K);
   AO_LAUNCH_CHECK("fp8_quant_rowwise_kernel launch");
   return AO_OK;
 }
@@ -433,7 +484,8 @@ extern "C" int ao_int8_quantize_rowwise_amax(const uint16_t* x, int64_t ldx, con
   AO_REQUIRE_PTR(amax);
   AO_REQUIRE_PTR(q);
   AO_REQUIRE_PTR(scale);
-  ao::launch(int8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, amax, q, scale, K);
+  if (!launch_quant_rowwise_reg<true>(x, ldx, amax, q, scale, M, K, (hipStream_t)stream))
+    ao::launch(int8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, amax, q, scale, K);
   AO_LAUNCH_CHECK("int8_quant_rowwise_kernel launch");
   return AO_OK;
 }
@@ -446,7 +498,8 @@ extern "C" int ao_fp8_quantize_rowwise_amax(const uint16_t* x, int64_t ldx, cons
   AO_REQUIRE_PTR(amax);
   AO_REQUIRE_PTR(q);
   AO_REQUIRE_PTR(scale);
-  ao::launch(fp8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, amax, q, scale, K);
+  if (!launch_quant_rowwise_reg<false>(x, ldx, amax, q, scale, M, K, (hipStream_t)stream))
+    ao::launch(fp8_quant_rowwise_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, ldx, amax, q, scale, K);
   AO_LAUNCH_CHECK("fp8_quant_rowwise_kernel launch");
   return AO_OK;
 }
