@@ -50,3 +50,26 @@ def test_fp8_per_tensor_bit_exact(gv):
     y = F.scaled_mm(xq, wq, np.full(x.shape[0], xs, np.float32), np.full(w.shape[0], ws, np.float32), bf16_bits_to_f32(gv["bias"]))
     ref = gv["fp8pt_y_dequant_f32"]
     assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 3e-3  # bf16 output rounding only
+
+
+def test_fp8_cast_residual_corrected_reciprocal_gives_the_division_codes():
+    """The fp8 cast kernels (csrc/quant_math.h fp8_quant8) replace x / s by q0 = x r, q = fma(fma(-q0, s, x), r, q0) with r = 1 / s.
+    Every finite bf16 x against bf16-valued scales over 2^-100 .. 2^100: the e4m3 codes are those of the division."""
+    old = np.seterr(all="ignore")
+    try:
+        xs = (np.arange(0x0080, 0x7F80, dtype=np.uint32) << 16).view(np.float32)
+        xs = np.concatenate([xs, -xs[::5], np.float32([0.0, -0.0, np.inf, -np.inf])])
+        rng = np.random.default_rng(1)
+        sc = (rng.integers(0x0D80, 0x7180, size=160, dtype=np.uint32) << 16).view(np.float32)
+        sc = np.concatenate([sc, np.float32([1.0, 448.0, 2.0 ** -7, 3.0])])
+        for s in sc:
+            want = F.f32_to_e4m3(np.clip((xs / s).astype(np.float32), -448, 448))
+            r = (np.float32(1.0) / s).astype(np.float32)
+            q0 = (xs * r).astype(np.float32)
+            e = (xs.astype(np.float64) - q0.astype(np.float64) * np.float64(s)).astype(np.float32)   # fma: one rounding
+            q = (q0.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
+            q = np.where(np.isfinite(q0) & (q0 != 0), q, q0)
+            got = F.f32_to_e4m3(np.clip(q, -448, 448))
+            assert np.array_equal(got, want), float(s)
+    finally:
+        np.seterr(**old)
