@@ -27,7 +27,50 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
-__all__ = ["shard_bounds", "shard_unit", "ColumnParallelLinear", "RowParallelLinear", "shard_linear_", "tp_mlp"]
+__all__ = ["shard_bounds", "shard_unit", "ColumnParallelLinear", "RowParallelLinear", "shard_linear_", "tp_mlp", "OneShotAllReduce"]
+
+
+class OneShotAllReduce:
+    """SUM all-reduce of SMALL float tensors (decode: a bf16 [1, 8192] partial is 16 KiB) in one hop: every rank publishes its
+    vector in a peer-mapped symmetric buffer, one signal round, every rank reads all peers' buffers over xGMI and adds
+    (`torch.distributed._symmetric_memory` + `symm_mem::one_shot_all_reduce`; SURVEY.md 8(e): "direct / one-shot algorithm for
+    S <= ~1 MiB, never a ring on the fully connected 8-GPU xGMI mesh").  RCCL's all_reduce stays the path for anything larger, for
+    integer / MAX reductions, and whenever symmetric memory cannot be set up (the constructor then leaves `ok` False and the
+    call falls through to RCCL).  PROTOTYPE: exercised here on a world of one GPU only -- no 2-GPU node was available to this build.
+    """
+
+    def __init__(self, group=None, max_bytes: int = 1 << 20, device=None):
+        self.group = dist.group.WORLD if group is None else group
+        self.max_bytes = max_bytes
+        self.ok = False
+        self.why = None
+        try:
+            import torch.distributed._symmetric_memory as symm_mem
+
+            device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+            self.group_name = self.group.group_name
+            if hasattr(symm_mem, "enable_symm_mem_for_group"):
+                symm_mem.enable_symm_mem_for_group(self.group_name)
+            self.buf = symm_mem.empty(max_bytes, dtype=torch.uint8, device=device)
+            self.handle = symm_mem.rendezvous(self.buf, self.group_name)
+            self.ok = True
+        except Exception as e:  # noqa: BLE001 -- any failure means "use RCCL"
+            self.why = f"{type(e).__name__}: {e}"
+
+    def fits(self, t: torch.Tensor) -> bool:
+        return (self.ok and t.is_cuda and t.dtype in (torch.bfloat16, torch.float32)
+                and t.numel() * t.element_size() <= self.max_bytes and (t.numel() * t.element_size()) % 16 == 0)
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place SUM over the group; returns t."""
+        if not self.fits(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t
+        nbytes = t.numel() * t.element_size()
+        stage = self.buf[:nbytes].view(t.dtype).view(t.shape)
+        stage.copy_(t)
+        t.copy_(torch.ops.symm_mem.one_shot_all_reduce(stage, "sum", self.group_name))
+        return t
 
 
 def shard_bounds(size: int, world: int, rank: int, unit: int = 1) -> Tuple[int, int]:
@@ -103,7 +146,7 @@ class RowParallelLinear(nn.Module):
     tensors) all-reduces the bf16 partial of F.linear."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], group=None, input_is_parallel: bool = True,
-                 reduce: str = "exact", blocks=None):
+                 reduce: str = "exact", blocks=None, one_shot: Optional["OneShotAllReduce"] = None):
         super().__init__()
         if reduce not in ("exact", "bf16"):
             raise ValueError(f"reduce must be 'exact' or 'bf16', got {reduce!r}")
@@ -120,6 +163,7 @@ class RowParallelLinear(nn.Module):
             self.kind = None
         self.exact = reduce == "exact" and self.kind is not None
         self.blocks = blocks or _GpuBlocks
+        self.one_shot = one_shot  # float SUM all-reduces of <= 1 MiB go through it when given (decode-size partials)
         # act_pre_scale (AWQ / SmoothQuant, per input feature): the full vector for a replicated input, the K shard's part else
         self.pre_full = getattr(weight, "act_pre_scale", None)
         self.pre_shard = self.pre_full
@@ -143,7 +187,7 @@ class RowParallelLinear(nn.Module):
             x_sh = x2[:, k0:k1]
         xq, xs = self.blocks.quantize(self.kind, x_sh, amax)  # the shard of the unsharded qdata, the unsharded scale
         acc = self.blocks.partial_mm(self.kind, xq, w)        # int32 / fp32 [M, N], unscaled
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(acc)
         y = self.blocks.epilogue(self.kind, acc, xs, w, self.bias)
         return y.reshape(*x.shape[:-1], y.shape[-1]).to(out_dtype)
 
@@ -156,13 +200,20 @@ class RowParallelLinear(nn.Module):
         # one exchange step per row-parallel linear: bf16 [M, N] partial sums.  On 8 MI355X over
         # xGMI RCCL picks a direct (all links) algorithm for these sizes; the call is asynchronous
         # on the current stream, the next kernel on that stream orders behind it.
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(y)
         if self.bias is not None:
             y = y + self.bias.to(y.dtype)
         return y
 
+    def _sum(self, t):
+        if self.one_shot is not None:
+            self.one_shot(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-def shard_linear_(module: nn.Linear, style: str, group=None, input_is_parallel: bool = True, reduce: str = "exact") -> nn.Module:
+
+def shard_linear_(module: nn.Linear, style: str, group=None, input_is_parallel: bool = True, reduce: str = "exact",
+                  one_shot: Optional["OneShotAllReduce"] = None) -> nn.Module:
     """Replace an (already quantized or plain) nn.Linear by its TP shard; style "colwise" | "rowwise"
     (the names of torchao/testing/utils.py:370-467's DTensor harness)."""
     bias = module.bias.detach() if module.bias is not None else None
@@ -170,7 +221,7 @@ def shard_linear_(module: nn.Linear, style: str, group=None, input_is_parallel: 
     if style == "colwise":
         return ColumnParallelLinear(w, bias, group)
     if style == "rowwise":
-        return RowParallelLinear(w, bias, group, input_is_parallel, reduce)
+        return RowParallelLinear(w, bias, group, input_is_parallel, reduce, one_shot=one_shot)
     raise ValueError(f"unknown TP style {style!r} (colwise | rowwise)")
 
 

@@ -76,6 +76,7 @@ def parse_args():
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
     ap.add_argument("--force-tp", action="store_true", help="run the TP-linear config even with one rank (exercises the RCCL path on a 1-GPU box)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning: ao_gemm8_set_variant for the 8-bit configs (profiling only)")
+    ap.add_argument("--tp-one-shot", action="store_true", help="TP config: accumulator all-reduces of <= 1 MiB through the symmetric-memory one-shot path (prototype; default RCCL)")
     return ap.parse_args()
 
 
@@ -495,6 +496,7 @@ def config_fp8_tp(stream, device, args, dist, world):
     """configs[3] for real when N > 1: Llama-3-70B linears sharded TP = N over RCCL (ao_amd/parallel.py)."""
     from ao_amd import parallel
     from ao_amd.quantization import Float8DynamicActivationFloat8WeightConfig, PerRow, quantize_
+    one_shot = parallel.OneShotAllReduce() if args.tp_one_shot else None
     gen = torch.Generator(device=device).manual_seed(4)
     layers = 8  # of 80: the same four linears per layer; tokens/s is extrapolated x10 (weights of 8 layers are 2.7 GB per GPU at TP=8)
     mods = []
@@ -504,7 +506,7 @@ def config_fp8_tp(stream, device, args, dist, world):
             with torch.no_grad():
                 lin.weight.copy_(torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02)
             quantize_(lin, Float8DynamicActivationFloat8WeightConfig(granularity=PerRow()))
-            mods.append((name, style, parallel.shard_linear_(lin, "colwise" if style == "col" else "rowwise", reduce="exact")))
+            mods.append((name, style, parallel.shard_linear_(lin, "colwise" if style == "col" else "rowwise", reduce="exact", one_shot=one_shot)))
             del lin
     torch.cuda.empty_cache()
     res = {}

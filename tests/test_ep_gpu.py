@@ -59,3 +59,23 @@ def test_dispatch_then_grouped_mm_matches_the_unexchanged_path(world1):
     assert torch.equal(back, y_tok)
     sq = 20 * torch.log10(torch.linalg.norm(x.float()) / torch.linalg.norm(x.float() - toks.dequantize().float()))
     assert float(sq) > 30.0  # reference bar, test_a2a_dispatch.py:107
+
+
+def test_one_shot_all_reduce_world1_or_clean_fallback(world1):
+    """The symmetric-memory one-shot all-reduce (ao_amd.parallel.OneShotAllReduce) on a world of one GPU: either the symmetric
+    buffer is set up and the op returns the input (sum over one rank), or set-up fails cleanly and the call falls through to
+    RCCL -- never a wrong result, never a hang."""
+    from ao_amd.parallel import OneShotAllReduce, RowParallelLinear
+
+    red = OneShotAllReduce(max_bytes=1 << 16)
+    print("one-shot all-reduce available:", red.ok, red.why)
+    for dtype, n in ((torch.bfloat16, 8192), (torch.float32, 4096), (torch.float32, 1 << 20), (torch.int32, 64)):
+        t = torch.arange(n, device=DEV).to(dtype) if dtype != torch.bfloat16 else torch.randn(n, device=DEV).to(dtype)
+        want = t.clone()
+        assert red(t) is t and torch.equal(t, want)
+    # through a row-parallel linear (plain bf16 weight: the partial is all-reduced, bias added after)
+    w = torch.randn(64, 256, device=DEV, dtype=torch.bfloat16)
+    b = torch.randn(64, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(3, 256, device=DEV, dtype=torch.bfloat16)
+    lin = RowParallelLinear(w, b, one_shot=red)
+    assert torch.allclose(lin(x).float(), torch.nn.functional.linear(x, w, b).float(), atol=2e-2, rtol=2e-2)
