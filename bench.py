@@ -76,6 +76,7 @@ def parse_args():
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
     ap.add_argument("--force-tp", action="store_true", help="run the TP-linear config even with one rank (exercises the RCCL path on a 1-GPU box)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning: ao_gemm8_set_variant for the 8-bit configs (profiling only)")
+    ap.add_argument("--tp-graph", action="store_true", help="TP config: capture each step (kernels + RCCL collectives) into a hipGraph")
     ap.add_argument("--tp-one-shot", action="store_true", help="TP config: accumulator all-reduces of <= 1 MiB through the symmetric-memory one-shot path (prototype; default RCCL)")
     return ap.parse_args()
 
@@ -522,7 +523,12 @@ def config_fp8_tp(stream, device, args, dist, world):
         with torch.cuda.stream(stream):
             for _ in range(3):
                 step()
-            t = time_steps(step, stream, device, steps, 2, dist) / steps
+        # decode-size steps are launch-bound in eager mode (six launches + two collectives per row-parallel linear): replay them
+        # from a hipGraph when --tp-graph asks for it (RCCL collectives are capturable; kept opt-in because a failed capture
+        # cannot be retried safely on a multi-rank run)
+        run, graphed = capture(step, stream, use_graph=True) if args.tp_graph else (step, False)
+        with torch.cuda.stream(stream):
+            t = time_steps(run, stream, device, steps, 2, dist) / steps
             # the collectives alone, same sizes and order: amax MAX [M] + fp32 SUM [M, 8192] per row-parallel linear
             bufs = [(torch.zeros(m, device=device), torch.zeros(m, 8192, device=device)) for _ in range(2)]
             def comm():
@@ -535,11 +541,11 @@ def config_fp8_tp(stream, device, args, dist, world):
                 comm()
             tc = time_steps(comm, stream, device, steps, 2, dist) / steps
         flops = sum(2.0 * m * n * k for _, n, k, _ in LLAMA3_70B) * layers / world
-        res[f"M{m}"] = {"tokens_per_s": m / (t * 80 / layers), "ms_per_8_layers": t * 1e3, "allreduce_ms_per_8_layers": tc * 1e3,
+        res[f"M{m}"] = {"tokens_per_s": m / (t * 80 / layers), "launch": "hipGraph replay" if graphed else "eager", "ms_per_8_layers": t * 1e3, "allreduce_ms_per_8_layers": tc * 1e3,
                         "allreduce_bytes_per_row_linear": m * 8192 * 4 + m * 4, "per_gpu_TFLOPs": flops / t / 1e12,
                         "per_gpu_frac_of_fp8_mfma_peak": flops / t / 1e12 / MFMA_8BIT_PEAK_TOPS}
     return {"workload": f"Float8 rowwise Llama-3-70B linears, TP={world} over RCCL (column-parallel qkv / gate_up, row-parallel o / down with the "
-                        "exact protocol: amax all-reduce(MAX) + fp32 accumulator all-reduce(SUM) + one scale epilogue), 8 of 80 layers timed, eager launches",
+                        "exact protocol: amax all-reduce(MAX) + fp32 accumulator all-reduce(SUM) + one scale epilogue), 8 of 80 layers timed",
             "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (M = 2048, x10 extrapolated to 80 layers)", "by_M": res}
 
 
