@@ -701,6 +701,7 @@ int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, ui
   if (split > 1) {
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
+    AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "int4_mm_rb: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
     if (int rc = splitk_workspace(stream, &ws, &tickets)) return rc;
   }
   auto kern = int4_mm_rb_kernel<G, WAVES, NT, MT, ABL>;

@@ -94,14 +94,14 @@ int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets) {
              "reuse streams (a captured graph keeps using the workspace of the stream it was captured on)", kSplitSlots, dev,
              (kSplitSlotFloats * sizeof(float)) >> 20);
   if (w->part == nullptr) {
-    const size_t bytes = kSplitSlotFloats * sizeof(float) + kSplitMaxTiles * sizeof(unsigned);
+    const size_t bytes = kSplitSlotFloats * sizeof(float) + kSplitMaxTickets * sizeof(unsigned);
     char* p = nullptr;
     e = hipMalloc(&p, bytes);
     if (e != hipSuccess)
       return hip_failed(e, "hipMalloc(split-K workspace); call the op with this shape once on this stream outside stream capture "
                            "before capturing it into a graph");
     unsigned* t = reinterpret_cast<unsigned*>(p + kSplitSlotFloats * sizeof(float));
-    e = hipMemset(t, 0, kSplitMaxTiles * sizeof(unsigned));
+    e = hipMemset(t, 0, kSplitMaxTickets * sizeof(unsigned));
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(split-K tickets)"); }
     w->part = reinterpret_cast<float*>(p);

@@ -4,11 +4,15 @@
 
 namespace ao {
 
-// Workspace: one per (device, stream), at most kSplitSlots streams per device, each kSplitMaxTiles fp32 tiles of 128 x 128
-// + one ticket per output tile.  Allocated on the first split-K launch on a stream (outside stream capture); runtime.hip.
+// Workspace: one per (device, stream), at most kSplitSlots streams per device: kSplitSlotFloats fp32 of parked partial tiles
+// (kSplitMaxTiles tiles of 128 x 128; smaller tiles pack more of them) + kSplitMaxTickets tickets, one per output tile -- the
+// smallest tile a kernel parks is 64 x 16, two parts at least, so 4096 tickets cover every launch the float budget admits only
+// if the budget stays <= 4096 * 2 * 1024 floats; launchers check both.  Allocated on the first split-K launch on a stream
+// (outside stream capture); runtime.hip.
 constexpr int kSplitSlots = 8;
-constexpr int kSplitMaxTiles = 256;
-constexpr size_t kSplitSlotFloats = (size_t)kSplitMaxTiles * 128 * 128;
+constexpr int kSplitMaxTiles = 2048;
+constexpr int kSplitMaxTickets = 16384;
+constexpr size_t kSplitSlotFloats = (size_t)kSplitMaxTiles * 128 * 128;  // 128 MiB
 int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets);
 
 // ---------------------------------------------------------------------------
