@@ -455,8 +455,11 @@ constexpr int rb_wstages(int waves, int mt, int wst) {
 // ABL (profiling builds only): 1 no 16x16x32 MFMAs, 2 no dequant, 3 no A reads, 4 no DMAs, 5 product + s_memtime stamps of wave 0
 // (16 u64 per workgroup: entry, ring primed, barrier of k-blocks 0..7 passed, loop done, meeting done, exit)
 // MT = 16-row m-tiles per slab (8, 4, 2, 1): batches below 128 rows stage, read and multiply only the rows they have.
-template <int G, int WAVES, int NT, int MT = 8, int ABL = 0>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_kernel(
+// PROD: WAVES more waves that do nothing but issue the ring's DMAs (producer wave WAVES + w feeds consumer wave w: its weight ring and
+// its quarter of the x tile).  A global_load_lds issue holds its wave for 50 - 120 cycles, ten of them per k-block; with one or two
+// in-order waves per SIMD nothing else of that wave issues meanwhile -- on their own waves they cost the consumers nothing.
+template <int G, int WAVES, int NT, int MT = 8, int ABL = 0, bool PROD = false>
+__global__ __launch_bounds__(64 * WAVES * (PROD ? 2 : 1), (WAVES == 4 && !PROD) ? 2 : 1) void int4_mm_rb_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M,
     int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets, unsigned long long* __restrict__ trace) {
   unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -475,7 +478,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = PROD && wave_id >= WAVES;
+  const int wave = producer ? wave_id - WAVES : wave_id;  // the consumer this wave is, or feeds
   const int nl = lane & 15, grp = lane >> 4;
   const int m0 = blockIdx.y * (16 * MT);
   const int ntiles = N >> 4;
@@ -525,6 +530,30 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, ADMA + I>{}, 0, 0, wstage, kbw), ...); }
     (std::make_integer_sequence<int, WDMAS>{});
   };
+
+  if (producer) {
+    // same issue order and waits as the fused form below: w(0 .. KW-3) | x(0) w(KW-2) | x(1), then per k-block x(kb + 2), w(kb + KW - 1)
+#pragma unroll
+    for (int i = 0; i < KW - 2; ++i) issue_w(i, i);
+    issue_x(0, 0); issue_w(KW - 2, KW - 2);
+    issue_x(1, 1);
+    int stage = 0, wstage = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+      if (kb < 2 || KW < 4) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + WDMAS>();
+      asm volatile("s_barrier" ::: "memory");  // stage kb has landed (every producer waited), the consumers are done with stage kb - 1
+      issue_x((stage == 0) ? 2 : stage - 1, kb + 2);
+      issue_w((wstage == 0) ? KW - 1 : wstage - 1, kb + KW - 1);
+      stage = (stage == 2) ? 0 : stage + 1;
+      wstage = (wstage == KW - 1) ? 0 : wstage + 1;
+    }
+    wait_vmcnt<0>();  // the clamped fills past the end still write LDS
+    asm volatile("s_barrier" ::: "memory");
+    if (S > 1) {
+      f32x4 none[MT * NT];
+      (void)split_k_meet<MT * NT, 64 * WAVES>(none, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem), false);
+    }
+    return;
+  }
 
   f32x4 acc[MT * NT];  // [n-tile][m-tile]
 #pragma unroll
@@ -598,7 +627,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
            (([&] {
               constexpr int c = C, t = c / 4, slot = p * 4 * NT + c;
               __builtin_amdgcn_sched_barrier(0);
-              if constexpr (slot < LPS) issue_one(std::integral_constant<int, slot>{}, refill, kb + 2, wrefill, kb + KW - 1);
+              if constexpr (slot < LPS && !PROD) issue_one(std::integral_constant<int, slot>{}, refill, kb + 2, wrefill, kb + KW - 1);
               if constexpr (e == 0) {  // the 8 NT slots of phases 0, 1 carry the 2 NT words of e = 1, four stages each
                 constexpr int q = h * 4 * NT + c, w = q / 4;
                 stage_of(std::integral_constant<int, q % 4>{}, dq[w / 2][w % 2], w / 2, 1, w % 2);
@@ -622,7 +651,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
        ...);
     }(std::make_integer_sequence<int, 4>{});
     // DMAs left over when a stage has more of them than the k-block has slots
-    if constexpr (LPS > SLOTS) {
+    if constexpr (LPS > SLOTS && !PROD) {
       [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, SLOTS + I>{}, refill, kb + 2, wrefill, kb + KW - 1), ...); }
       (std::make_integer_sequence<int, LPS - SLOTS>{});
     }
@@ -631,17 +660,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
   // issue order: w(0 .. KW-3) | x(0) w(KW-2) | x(1) ... then per k-block kb: x(kb + 2), w(kb + KW - 1).  With KW >= 4, when k-block kb
   // starts the requests younger than x(kb) are w(kb + KW - 3) (issued right behind it), x(kb + 1) and w(kb + KW - 2): LPS + WDMAS of
   // them may still be in flight; everything this k-block reads -- x(kb), w(kb) -- is older and has landed.
+  if constexpr (!PROD) {
 #pragma unroll
-  for (int i = 0; i < KW - 2; ++i) issue_w(i, i);
-  issue_x(0, 0); issue_w(KW - 2, KW - 2);
-  issue_x(1, 1);
+    for (int i = 0; i < KW - 2; ++i) issue_w(i, i);
+    issue_x(0, 0); issue_w(KW - 2, KW - 2);
+    issue_x(1, 1);
+  }
   if (ABL == 5) ts[1] = __builtin_amdgcn_s_memtime();
   int stage = 0, wstage = 0;
   for (int kb = 0; kb < nkb; ++kb) {
     // (k-blocks 0 and 1: x(kb + 1) follows x(kb) directly or with one weight stage between -- only LPS younger requests exist)
     // (KW = 3: w(kb) is issued right BEHIND x(kb), in k-block kb - 2, so only x(kb + 1) and w(kb + 1) -- LPS requests -- are younger
     // than what this k-block reads; a deeper weight ring issues w(kb) earlier and one more weight stage may be in flight)
-    if (ABL != 4) { if (kb < 2 || KW < 4) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + WDMAS>(); }
+    if (ABL != 4 && !PROD) { if (kb < 2 || KW < 4) wait_vmcnt<LPS>(); else wait_vmcnt<LPS + WDMAS>(); }
     // everyone's share has landed, and everyone has finished reading stage kb - 1 (its LDS reads have returned)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (ABL == 5 && kb < 8) ts[2 + kb] = __builtin_amdgcn_s_memtime();
@@ -651,7 +682,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
     stage = (stage == 2) ? 0 : stage + 1;
     wstage = (wstage == KW - 1) ? 0 : wstage + 1;
   }
-  wait_vmcnt<0>();  // the clamped fills past the end still write LDS
+  if constexpr (!PROD) wait_vmcnt<0>();  // the clamped fills past the end still write LDS
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (ABL == 5) ts[10] = __builtin_amdgcn_s_memtime();
   auto dump = [&] {
@@ -686,13 +717,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4) ? 2 : 1) void int4_mm_rb_k
 
 thread_local unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
 
-template <int G, int WAVES, int NT, int MT = 8, int ABL = 0>
+template <int G, int WAVES, int NT, int MT = 8, int ABL = 0, bool PROD = false>
 int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
                  hipStream_t stream) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
   constexpr int BN = WAVES * NT * 16;
   constexpr int BM = 16 * MT;
-  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)split), block(64 * WAVES);
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)split), block(64 * WAVES * (PROD ? 2 : 1));
   constexpr int KW = rb_wstages(WAVES, MT, NT * (1024 + NG * 256));
   constexpr size_t smem = (size_t)kRbStages * MT * 4096 + (size_t)WAVES * KW * NT * (1024 + NG * 256);
   static_assert(smem <= 160 * 1024, "int4_mm_rb_kernel: LDS");
@@ -704,7 +735,7 @@ int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, ui
     AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "int4_mm_rb: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
     if (int rc = splitk_workspace(stream, &ws, &tickets)) return rc;
   }
-  auto kern = int4_mm_rb_kernel<G, WAVES, NT, MT, ABL>;
+  auto kern = int4_mm_rb_kernel<G, WAVES, NT, MT, ABL, PROD>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_rb_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)M,
              (int)N, (int)K, ws, tickets, g_mm_trace);
@@ -948,6 +979,13 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
       if (abl == 5) return launch_mm_rb<G, 8, 1, 8, 5>(x, qdata, sz, y, M, N, K, sp, stream);
       if (abl == 6) return launch_mm_rb<G, 4, 2>(x, qdata, sz, y, M, N, K, sp, stream);
     }
+  } else if (g_tune_mode >= 900 && g_tune_mode < 910 && M > 64) {
+    // profiling: the producer-wave form (4 consumers + 4 DMA producers, 128-row slabs), 90S = S K-parts (900: as the product picks)
+    const int64_t base9 = ((N + 63) / 64) * ((M + 127) / 128);
+    const int64_t fit9 = (int64_t)kSplitMaxTiles * 128 * 128 / (base9 * 64 * 128);
+    const int sp = (g_tune_mode == 900) ? (int)std::max<int64_t>(1, std::min<int64_t>({256 / base9, fit9, 8, kblocks / 8}))
+                                        : (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode - 900), kblocks, fit9}));
+    return launch_mm_rb<G, 4, 1, 8, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
   } else if (g_tune_mode >= 700 && g_tune_mode < 800) {
     mt = 1 << std::min(3, (g_tune_mode - 700) / 10);
     waves = (g_tune_wpb == 8 && mt >= 2) ? 8 : 4;
@@ -967,7 +1005,13 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     if (mt == 4) return launch_mm_rb<G, 8, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
     return launch_mm_rb<G, 8, 1, 2>(x, qdata, sz, y, M, N, K, split, stream);
   }
-  if (mt == 8) return launch_mm_rb<G, 4, 1, 8>(x, qdata, sz, y, M, N, K, split, stream);
+  if (mt == 8) {
+    // one 128-row slab (65 .. 128 rows: the "bs = 128" half of the BASELINE metric): the form with DMA-producer waves -- Llama-3-8B
+    // at bs = 128 32.3k -> 35.4k tok/s (gate_proj 28.2 -> 25.5 us, same bits); with two or more slabs the two forms measure the
+    // same (bs = 256) or the fused form wins (bs = 2048: 57k vs 50k tok/s).  Mode 910: never.
+    if (slabs == 1 && g_tune_mode != 910) return launch_mm_rb<G, 4, 1, 8, 0, true>(x, qdata, sz, y, M, N, K, split, stream);
+    return launch_mm_rb<G, 4, 1, 8>(x, qdata, sz, y, M, N, K, split, stream);
+  }
   if (mt == 4) return launch_mm_rb<G, 4, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
   if (mt == 2) return launch_mm_rb<G, 4, 1, 2>(x, qdata, sz, y, M, N, K, split, stream);
   return launch_mm_rb<G, 4, 1, 1>(x, qdata, sz, y, M, N, K, split, stream);

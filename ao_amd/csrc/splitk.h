@@ -25,15 +25,19 @@ int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets);
 // ---------------------------------------------------------------------------
 // INT: the registers hold int32 partial sums (exact integer adds) instead of fp32.
 template <int NREG, int NTHR, bool INT = false>
-__device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
+__device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag,
+                                             bool active = true) {
   constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
   constexpr int kRegBytes = NTHR * 16;
   constexpr int kPartBytes = NREG * kRegBytes;
   const __amdgpu_buffer_rsrc_t rws =
       __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * S * (kPartBytes / 4), 0, S * kPartBytes, 0x00020000);
+  // `active` = false: a wave that holds no accumulators (a DMA-producer wave) only takes part in the workgroup barriers
+  if (active) {
 #pragma unroll
-  for (int r = 0; r < NREG; ++r)
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kSc1);
+    for (int r = 0; r < NREG; ++r)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kSc1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
   __syncthreads();
   if (tid == 0) {
@@ -43,7 +47,7 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
     if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (!*flag) return false;
+  if (!*flag || !active) return false;
   // parts are read in batches (<= 32 loads in flight per thread; indices past S re-read the last part and are
   // not added), summed in part order
   constexpr int U = (NREG >= 16) ? 2 : 4;
