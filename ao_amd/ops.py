@@ -589,6 +589,22 @@ def fp8_linear_tensorwise(x2, wq, w_scale, bias=None):
     return fp8_scaled_mm(xq, wq.t(), xs.reshape(-1).expand(x2.shape[0]), w_scale.reshape(-1).expand(n), bias)
 
 
+def fp8_linear_clamped(x2, wq, w_scale, bias=None, lb: float = -1.0, ub: float = -1.0, tensorwise: bool = False):
+    """The Float8Tensor F.linear with activation-value bounds (Float8DynamicActivationFloat8WeightConfig(activation_value_lb / _ub) ->
+    hp_value_lb / hp_value_ub of _choose_scale_float8, quant_primitives.py:2203-2204): the amax (per row, or over the whole
+    activation) is clamped to [lb, ub] before the scale is taken from it; values beyond ub saturate at +-448 in the cast.
+    A negative bound means "not set" (the dispatcher schema has no optional floats)."""
+    amax = rowwise_amax(x2)
+    if tensorwise:
+        amax = amax.amax().expand(x2.shape[0])
+    amax = amax.clamp(min=lb if lb >= 0 else None, max=ub if ub >= 0 else None)
+    amax = amax.to(torch.bfloat16).to(torch.float32)  # torch.clamp on the bf16 amax rounds the bound to bf16
+    xq, xs = fp8_quantize_rowwise_amax(x2, amax)
+    n = wq.shape[0]
+    sb = w_scale.reshape(-1).expand(n) if w_scale.numel() == 1 else w_scale.t()
+    return fp8_scaled_mm(xq, wq.t(), xs, sb, bias)
+
+
 # ---------------------------------------------------------------------------
 # MXFP8
 # ---------------------------------------------------------------------------

@@ -91,6 +91,8 @@ class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
     both (the reference's default), PerRow() (the BASELINE configuration), or [activation, weight] of the same type."""
 
     granularity: Optional[Union[Granularity, List[Granularity]]] = None
+    activation_value_lb: Optional[float] = None  # bounds on the activation amax the scale is calculated from (reference :1126-1127)
+    activation_value_ub: Optional[float] = None
     set_inductor_config: bool = False
     version: int = 2
 

@@ -25,6 +25,8 @@ class QuantizeTensorToFloat8Kwargs:
 
     float8_dtype: torch.dtype = torch.float8_e4m3fn
     granularity: Granularity = field(default_factory=PerRow)
+    hp_value_lb: Optional[float] = None  # bounds on the amax the activation scale is taken from (reference :64-66)
+    hp_value_ub: Optional[float] = None
 
 
 def _check(granularity, float8_dtype):
@@ -126,7 +128,14 @@ def _(func, types, args, kwargs):
         from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
         # tensorwise-scaled _scaled_mm (float8/inference.py:68-123 with [1, 1] scales) is the rowwise epilogue with the two
         # scalars broadcast over rows / columns
-        y = (kernels(x2).fp8_linear_tensorwise if w_tensorwise else kernels(x2).fp8_linear)(x2, w.qdata, w.scale, bias)
+        act = w.act_quant_kwargs
+        if act.hp_value_lb is not None or act.hp_value_ub is not None:
+            lb = -1.0 if act.hp_value_lb is None else float(act.hp_value_lb)
+            ub = -1.0 if act.hp_value_ub is None else float(act.hp_value_ub)
+            assert lb >= 0 or act.hp_value_lb is None, "hp_value_lb bounds an absolute value: it cannot be negative"
+            y = kernels(x2).fp8_linear_clamped(x2, w.qdata, w.scale, bias, lb, ub, w_tensorwise)
+        else:
+            y = (kernels(x2).fp8_linear_tensorwise if w_tensorwise else kernels(x2).fp8_linear)(x2, w.qdata, w.scale, bias)
         bias = None
     y = y.reshape(*x.shape[:-1], n)
     if bias is not None:

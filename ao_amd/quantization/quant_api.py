@@ -189,7 +189,8 @@ def _float8_dynamic_activation_float8_weight_transform(module, config, *, parame
     new_weight = Float8Tensor.from_hp(
         weight,
         granularity=weight_granularity,
-        act_quant_kwargs=QuantizeTensorToFloat8Kwargs(granularity=act_granularity),
+        act_quant_kwargs=QuantizeTensorToFloat8Kwargs(granularity=act_granularity, hp_value_lb=config.activation_value_lb,
+                                                      hp_value_ub=config.activation_value_ub),
     )
     setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
     return module

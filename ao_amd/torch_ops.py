@@ -57,6 +57,7 @@ _lib_def.define("fp8_linear(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -
 _lib_def.define("int8_linear_asym(Tensor x, Tensor wq, Tensor w_scale, Tensor w_row_sums, Tensor? bias) -> Tensor")
 _lib_def.define("int8_linear_tensorwise(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("fp8_linear_tensorwise(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
+_lib_def.define("fp8_linear_clamped(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias, float lb, float ub, bool tensorwise) -> Tensor")
 _lib_def.define("int8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("fp8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("mxfp8_quantize(Tensor x, str scaling_mode) -> (Tensor, Tensor)")
@@ -79,6 +80,7 @@ _lib_impl.impl("fp8_linear", ops.fp8_linear)
 _lib_impl.impl("int8_linear_asym", ops.int8_linear_asym)
 _lib_impl.impl("int8_linear_tensorwise", ops.int8_linear_tensorwise)
 _lib_impl.impl("fp8_linear_tensorwise", ops.fp8_linear_tensorwise)
+_lib_impl.impl("fp8_linear_clamped", ops.fp8_linear_clamped)
 _lib_impl.impl("int8_quantize_rowwise", ops.int8_quantize_rowwise)
 _lib_impl.impl("fp8_quantize_rowwise", ops.fp8_quantize_rowwise)
 _lib_impl.impl("mxfp8_quantize", lambda x, mode: ops.mxfp8_quantize(x, mode))
@@ -140,6 +142,11 @@ def _(x, wq, w_scale, bias):
 
 @torch.library.register_fake("ao_mi355::fp8_linear_tensorwise")
 def _(x, wq, w_scale, bias):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::fp8_linear_clamped")
+def _(x, wq, w_scale, bias, lb, ub, tensorwise):
     return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
 
 

@@ -106,3 +106,14 @@ def quantize_tensorwise(x):
     amax = np.float32(np.abs(x).max())
     q, s = quantize_rowwise(x, amax=np.full((x.shape[0],), amax, dtype=np.float32))
     return q, s[0]
+
+
+def clamp_amax(amax, lb=None, ub=None):
+    """hp_value_lb / hp_value_ub of _choose_scale_float8 (quant_primitives.py:2203-2204): torch.clamp of the bf16 amax with Python
+    floats -- compared in fp32, the result rounded back to bf16."""
+    a = np.asarray(amax, dtype=np.float32)
+    if lb is not None:
+        a = np.maximum(a, np.float32(lb))
+    if ub is not None:
+        a = np.minimum(a, np.float32(ub))
+    return bf16.bf16_round(a.astype(np.float32))

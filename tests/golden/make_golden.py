@@ -269,6 +269,10 @@ def make_int8_fp8_variants():
     out.update(fp8pt_xq=xf.qdata.view(torch.uint8).numpy(), fp8pt_xs=xf.scale.flatten().numpy(),
                fp8pt_wq=wf.qdata.view(torch.uint8).numpy(), fp8pt_ws=wf.scale.flatten().numpy())
     out["fp8pt_y_dequant_f32"] = ((xf.dequantize().float() @ wf.dequantize().float().t()) + bias.float()).numpy()
+    # --- fp8 per-row with the activation-value bounds of Float8DynamicActivationFloat8WeightConfig(activation_value_lb / _ub)
+    lb, ub = 0.37, 900.0  # lb is not bf16-representable on purpose; ub cuts the amax of rows 3 and 7
+    xc = Float8Tensor.from_hp(x, torch.float8_e4m3fn, PerRow(), hp_value_lb=lb, hp_value_ub=ub)
+    out.update(fp8clamp_xq=xc.qdata.view(torch.uint8).numpy(), fp8clamp_xs=xc.scale.flatten().numpy(), fp8clamp_bounds=np.float64([lb, ub]))
     np.savez_compressed(os.path.join(HERE, "int8_fp8_variants.npz"), **out)
     print("int8_fp8_variants.npz:", {k_: v.shape for k_, v in out.items()})
 

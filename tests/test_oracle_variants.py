@@ -73,3 +73,14 @@ def test_fp8_cast_residual_corrected_reciprocal_gives_the_division_codes():
             assert np.array_equal(got, want), float(s)
     finally:
         np.seterr(**old)
+
+
+def test_fp8_activation_value_bounds_bit_exact(gv):
+    """hp_value_lb / hp_value_ub (Float8DynamicActivationFloat8WeightConfig(activation_value_lb / _ub)): the clamped amax, then the
+    usual per-row cast -- against Float8Tensor.from_hp(..., hp_value_lb, hp_value_ub) of the reference."""
+    x = bf16_bits_to_f32(gv["x"])
+    lb, ub = (float(v) for v in gv["fp8clamp_bounds"])
+    amax = F.clamp_amax(np.abs(x).max(axis=1), lb, ub)
+    q, s = F.quantize_rowwise(x, amax=amax)
+    assert np.array_equal(q, gv["fp8clamp_xq"]) and np.array_equal(s, gv["fp8clamp_xs"])
+    assert s[5] == bf16.div(bf16.bf16_round(np.float32(lb)), np.float32(448.0))  # the all-zero row takes the (bf16-rounded) lower bound

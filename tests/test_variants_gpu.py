@@ -176,3 +176,25 @@ def test_per_tensor_slices_keep_the_scalar_scale():
         top, left = t[:32], t[:, :128]
         assert top.scale.numel() == 1 and left.scale.numel() == 1 and top.block_size == [32, 256] and left.block_size == [64, 128]
         assert torch.equal(top.qdata.view(torch.uint8), t.qdata[:32].view(torch.uint8))
+
+
+def test_fp8_activation_value_bounds_through_the_config(gv):
+    """Float8DynamicActivationFloat8WeightConfig(granularity=PerRow(), activation_value_lb, activation_value_ub): the activation codes
+    the linear multiplies are the reference's (fixture), and the output is the oracle's scaled mm on them."""
+    lb, ub = (float(v) for v in gv["fp8clamp_bounds"])
+    w = _t(gv, "w")
+    lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=True, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+        lin.bias.copy_(_t(gv, "bias"))
+    quantize_(lin, Float8DynamicActivationFloat8WeightConfig(granularity=PerRow(), activation_value_lb=lb, activation_value_ub=ub))
+    assert lin.weight.act_quant_kwargs.hp_value_lb == lb and lin.weight.act_quant_kwargs.hp_value_ub == ub
+    x = _t(gv, "x")
+    y = np_from_torch_bf16(lin(x))
+    # the cast the handler runs, on its own: bit-exact against the reference fixture
+    amax = ops.rowwise_amax(x).clamp(min=lb, max=ub).to(torch.bfloat16).float()
+    xq, xs = ops.fp8_quantize_rowwise_amax(x, amax)
+    assert np.array_equal(xq.view(torch.uint8).cpu().numpy(), gv["fp8clamp_xq"]) and np.array_equal(xs.flatten().cpu().numpy(), gv["fp8clamp_xs"])
+    wq, ws = F.quantize_rowwise(bf16_bits_to_f32(gv["w"]))
+    y_ref = F.scaled_mm(gv["fp8clamp_xq"], wq, gv["fp8clamp_xs"], ws, bf16_bits_to_f32(gv["bias"]))
+    assert _rel(y, y_ref) <= 1e-3
