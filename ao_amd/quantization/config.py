@@ -71,11 +71,14 @@ class Int8DynamicActivationInt8WeightConfig(AOBaseConfig):
 
     act_mapping_type: MappingType = MappingType.SYMMETRIC
     granularity: Optional[Union[Granularity, List[Granularity]]] = field(default_factory=PerRow)
+    weight_only_decode: bool = False
     set_inductor_config: bool = False
     version: int = 2
     reduce_range: bool = False
 
     def __post_init__(self):
+        if self.weight_only_decode:
+            raise NotImplementedError("weight_only_decode (int8 weight-only at decode sizes) is outside the SURVEY.md section 8 path")
         if self.version == 1:
             raise ValueError("version 1 of Int8DynamicActivationInt8WeightConfig has been removed, please use version 2")
         if self.reduce_range:
@@ -93,6 +96,10 @@ class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
     granularity: Optional[Union[Granularity, List[Granularity]]] = None
     activation_value_lb: Optional[float] = None  # bounds on the activation amax the scale is calculated from (reference :1126-1127)
     activation_value_ub: Optional[float] = None
+    # accepted for source compatibility with the reference's call sites; there is one kernel family on MI355X (fp32 accumulation on
+    # the scaled MFMA whatever use_fast_accum says, no mslk / torch choice to make), so neither changes what runs
+    mm_config: Optional[object] = None
+    kernel_preference: object = "auto"
     set_inductor_config: bool = False
     version: int = 2
 
