@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ao_int8_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_fp8_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_int8_quantize_rowwise_asym": [_P, _P, _P, _P, _I64, _I64, _P],
+    "ao_int8_quantize_static": [_P, _P, _P, _INT, _P, _I64, _I64, _P],
     "ao_int8_row_sums": [_P, _P, _I64, _I64, _P],
     "ao_int8_scale_epilogue_asym": [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P],
     "ao_rowwise_amax": [_P, _I64, _P, _I64, _I64, _P],

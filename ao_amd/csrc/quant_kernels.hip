@@ -214,6 +214,30 @@ __global__ __launch_bounds__(kThreads) void int8_quant_rowwise_asym_kernel(const
   }
 }
 
+// static activation quantization (Int8StaticActivationInt8WeightConfig: Int8Tensor.from_hp(x, scale=..., zero_point=...), int8_tensor.py:
+// 212-231): q = clamp(rint(x * (1 / scale)) + zp, -128, 127) with the GIVEN scale / zero-point, one per tensor (stride 0) or per row
+__global__ __launch_bounds__(kThreads) void int8_quant_static_kernel(const uint16_t* __restrict__ x, const float* __restrict__ scale,
+                                                                     const int8_t* __restrict__ zero_point, int stride,
+                                                                     int8_t* __restrict__ q, int64_t K) {
+  const int64_t row = blockIdx.x;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * K);
+  const float inv = 1.0f / scale[row * stride];
+  const float zp = zero_point != nullptr ? (float)zero_point[row * stride] : 0.0f;
+  u32x2* qr = reinterpret_cast<u32x2*>(q + row * K);
+  for (int64_t i = threadIdx.x; i < (K >> 3); i += kThreads) {
+    const u32x4 v = xr[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t out[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = fminf(fmaxf(rintf(bf16_lo_to_f32(w[j]) * inv) + zp, -128.f), 127.f);
+      const float b = fminf(fmaxf(rintf(bf16_hi_to_f32(w[j]) * inv) + zp, -128.f), 127.f);
+      out[j >> 1] |= (((uint32_t)(int)a & 0xffu) | (((uint32_t)(int)b & 0xffu) << 8)) << ((j & 1) * 16);
+    }
+    qr[i] = u32x2{out[0], out[1]};
+  }
+}
+
 // row sums of an int8 [N][K] weight (the zero-point correction's rowsum(W), int8_tensor.py:326): one wave per row
 __global__ __launch_bounds__(kThreads) void int8_row_sums_kernel(const int8_t* __restrict__ q, int32_t* __restrict__ sums, int64_t N, int64_t K) {
   const int64_t row = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
@@ -546,6 +570,18 @@ extern "C" int ao_int8_quantize_rowwise_asym(const uint16_t* x, int8_t* q, float
   AO_REQUIRE_PTR(zero_point);
   ao::launch(int8_quant_rowwise_asym_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, q, scale, zero_point, K);
   AO_LAUNCH_CHECK("int8_quant_rowwise_asym_kernel launch");
+  return AO_OK;
+}
+
+extern "C" int ao_int8_quantize_static(const uint16_t* x, const float* scale, const int8_t* zero_point, int per_row, int8_t* q, int64_t M,
+                                       int64_t K, void* stream) {
+  if (int rc = check_rows(__func__, M, K, 8)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(scale);
+  AO_REQUIRE_PTR(q);
+  ao::launch(int8_quant_static_kernel, dim3((unsigned)M), dim3(kThreads), 0, (hipStream_t)stream, x, scale, zero_point, per_row ? 1 : 0, q, K);
+  AO_LAUNCH_CHECK("int8_quant_static_kernel launch");
   return AO_OK;
 }
 

@@ -5,6 +5,8 @@ borrowed) and error behaviour as the ops they replace; each docstring cites the
 reference call site.  Tensors must live on the GPU ("cuda" == HIP device on
 ROCm); there is no CPU fallback.
 """
+from typing import Optional
+
 import torch
 
 from . import _lib
@@ -527,6 +529,41 @@ def int8_quantize_rowwise_asym(x: torch.Tensor):
     with _on(dev):
         _lib.check(_lib.lib().ao_int8_quantize_rowwise_asym(_ptr(x), _ptr(q), _ptr(s), _ptr(zp), m, k, _stream()))
     return q, s, zp
+
+
+def int8_quantize_static(x: torch.Tensor, scale: torch.Tensor, zero_point: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Int8Tensor.from_hp(x, ..., scale=scale, zero_point=zero_point) (static quantization, int8_tensor.py:212-231): bf16 [M, K] with an fp32
+    scale of 1 or M elements (and an int8 zero-point of the same shape, or None) -> qdata int8 [M, K]."""
+    dev = _require_gpu("int8_quantize_static", x, scale, zero_point)
+    x = _as_rows("int8_quantize_static", x, torch.bfloat16)
+    m, k = x.shape
+    scale = scale.reshape(-1).to(torch.float32).contiguous()
+    if scale.numel() not in (1, m):
+        raise RuntimeError(f"int8_quantize_static: scale must have 1 or M = {m} elements, got {scale.numel()}")
+    if zero_point is not None:
+        zero_point = zero_point.reshape(-1).to(torch.int8).contiguous()
+        if zero_point.numel() != scale.numel():
+            raise RuntimeError("int8_quantize_static: zero_point must have the shape of scale")
+    q = torch.empty((m, k), dtype=torch.int8, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_int8_quantize_static(_ptr(x), _ptr(scale), _ptr(zero_point), int(scale.numel() == m and m > 1), _ptr(q), m, k, _stream()))
+    return q
+
+
+def int8_linear_static(x2, wq, w_scale, act_scale, act_zero_point=None, w_row_sums=None, bias=None):
+    """The Int8Tensor F.linear with STATIC activation qparams (Int8StaticActivationInt8WeightConfig): cast with the given scale /
+    zero-point, then the dynamic path's GEMM + epilogue (zero-point-corrected when one is given)."""
+    m = x2.shape[0]
+    xq = int8_quantize_static(x2, act_scale, act_zero_point)
+    xs = act_scale.reshape(-1).to(torch.float32)
+    xs = xs.expand(m) if xs.numel() == 1 else xs
+    if act_zero_point is None:
+        return int8_scaled_mm(xq, xs, wq, w_scale, bias)
+    zp = act_zero_point.reshape(-1)
+    zp = zp.expand(m) if zp.numel() == 1 else zp
+    if w_row_sums is None:
+        w_row_sums = int8_row_sums(wq)
+    return int8_scale_epilogue_asym(int_mm(xq, wq.t()), xs, zp, w_row_sums, w_scale, bias)
 
 
 def int8_row_sums(wq: torch.Tensor) -> torch.Tensor:

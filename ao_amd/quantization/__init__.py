@@ -6,6 +6,7 @@ from .config import (  # noqa: F401
     Int4PackingFormat,
     Int4WeightOnlyConfig,
     Int8DynamicActivationInt8WeightConfig,
+    Int8StaticActivationInt8WeightConfig,
 )
 from .granularity import PerGroup, PerRow, PerTensor  # noqa: F401
 from .quant_primitives import MappingType  # noqa: F401

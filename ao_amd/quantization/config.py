@@ -89,6 +89,31 @@ class Int8DynamicActivationInt8WeightConfig(AOBaseConfig):
 
 
 @dataclass
+class Int8StaticActivationInt8WeightConfig(AOBaseConfig):
+    """int8 STATIC activation (calibrated scale / zero-point given) x int8 weight (reference quant_api.py:919-1012)."""
+
+    act_quant_scale: Optional[object] = None        # torch.Tensor, fp32, one element (PerTensor) or one per activation row
+    act_quant_zero_point: Optional[object] = None   # torch.Tensor, int8, same shape (asymmetric only)
+    granularity: Optional[Union[Granularity, List[Granularity]]] = field(default_factory=PerRow)
+    act_mapping_type: MappingType = MappingType.SYMMETRIC
+    set_inductor_config: bool = False
+    version: int = 1
+    reduce_range: bool = False
+
+    def __post_init__(self):
+        if self.reduce_range:
+            raise NotImplementedError("reduce_range is a CPU-without-VNNI option; the MI355X int8 MFMA path uses the full range")
+        assert self.act_mapping_type in (MappingType.SYMMETRIC, MappingType.ASYMMETRIC), (
+            "Int8StaticActivationInt8WeightConfig requires `act_mapping_type` in (MappingType.SYMMETRIC, MappingType.ASYMMETRIC)."
+        )
+        self.granularity = list(_normalize_granularity(self.granularity, PerRow, "Int8StaticActivationInt8WeightConfig"))
+
+    def get_act_quant_kwargs(self):
+        from .int8_tensor import QuantizeTensorToInt8Kwargs
+        return QuantizeTensorToInt8Kwargs(granularity=self.granularity[0], mapping_type=self.act_mapping_type, reduce_range=self.reduce_range)
+
+
+@dataclass
 class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
     """float8 e4m3 dynamic activation x float8 weight (reference quant_api.py:1112-1297).  granularity: None = PerTensor for
     both (the reference's default), PerRow() (the BASELINE configuration), or [activation, weight] of the same type."""

@@ -59,13 +59,15 @@ class Int8Tensor(LowBitTensorBase):
     tensor_attribute_names = ["block_size", "dtype_", "act_quant_kwargs"]
     # w_row_sums (int32 [N]): rowsum(qdata), the operand of the asymmetric-activation correction (int8_tensor.py:326 recomputes it
     # on every call); kept next to the weight, built at from_hp when the activation mapping is ASYMMETRIC
-    optional_tensor_data_names = ["act_pre_scale", "zero_point", "w_row_sums"]
+    optional_tensor_data_names = ["act_pre_scale", "zero_point", "w_row_sums", "act_quant_scale", "act_quant_zero_point"]
 
-    def __new__(cls, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None, w_row_sums=None):
+    def __new__(cls, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None, w_row_sums=None,
+                act_quant_scale=None, act_quant_zero_point=None):
         kwargs = dict(device=qdata.device, dtype=dtype_, requires_grad=False)
         return torch.Tensor._make_wrapper_subclass(cls, qdata.shape, **kwargs)
 
-    def __init__(self, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None, w_row_sums=None):
+    def __init__(self, qdata, scale, block_size, dtype_, act_quant_kwargs=None, act_pre_scale=None, zero_point=None, w_row_sums=None,
+                 act_quant_scale=None, act_quant_zero_point=None):
         self.qdata = qdata
         self.scale = scale
         self.block_size = list(block_size)
@@ -74,6 +76,8 @@ class Int8Tensor(LowBitTensorBase):
         self.act_pre_scale = act_pre_scale
         self.zero_point = zero_point
         self.w_row_sums = w_row_sums
+        self.act_quant_scale = act_quant_scale              # static activation quantization: given, not measured (reference :80-84)
+        self.act_quant_zero_point = act_quant_zero_point
 
     def _quantization_type(self):
         return (f"act_quant_kwargs={self.act_quant_kwargs}, block_size={self.block_size}, "
@@ -81,7 +85,8 @@ class Int8Tensor(LowBitTensorBase):
 
     @classmethod
     def from_hp(cls, hp_tensor: torch.Tensor, granularity: Granularity = None, mapping_type=MappingType.SYMMETRIC,
-                act_quant_kwargs: Optional[QuantizeTensorToInt8Kwargs] = None):
+                act_quant_kwargs: Optional[QuantizeTensorToInt8Kwargs] = None, act_quant_scale: Optional[torch.Tensor] = None,
+                act_quant_zero_point: Optional[torch.Tensor] = None):
         """reference from_hp (:176-248).  SYMMETRIC: scale = amax / 127.5 clamped at fp32 eps, over the row or the whole
         tensor; ASYMMETRIC (PerRow): scale = (max - min) / 255, integer zero-point."""
         granularity = PerRow() if granularity is None else granularity
@@ -105,9 +110,10 @@ class Int8Tensor(LowBitTensorBase):
             qdata, scale = ops.int8_quantize_rowwise(x)
         block_size = list(hp_tensor.shape) if isinstance(granularity, PerTensor) else [1, hp_tensor.shape[-1]]
         w_row_sums = None
-        if act_quant_kwargs is not None and _mapping(act_quant_kwargs.mapping_type) == MappingType.ASYMMETRIC:
+        if act_quant_kwargs is not None and (_mapping(act_quant_kwargs.mapping_type) == MappingType.ASYMMETRIC or act_quant_zero_point is not None):
             w_row_sums = ops.int8_row_sums(qdata)
-        return cls(qdata, scale, block_size, hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs, zero_point=zero_point, w_row_sums=w_row_sums)
+        return cls(qdata, scale, block_size, hp_tensor.dtype, act_quant_kwargs=act_quant_kwargs, zero_point=zero_point, w_row_sums=w_row_sums,
+                   act_quant_scale=act_quant_scale, act_quant_zero_point=act_quant_zero_point)
 
     def dequantize(self, output_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """reference :250-263: (qdata - zero_point) * scale in fp32, then cast"""
@@ -152,7 +158,12 @@ def _(func, types, args, kwargs):
     else:
         from ..torch_ops import kernels  # dispatcher ops (with fake kernels) while tracing, the direct C-ABI calls otherwise
         k = kernels(x2)
-        if _mapping(act.mapping_type) == MappingType.ASYMMETRIC:
+        if w.act_quant_scale is not None:  # static: the activation qparams were calibrated, not measured per call
+            zp = w.act_quant_zero_point
+            if zp is not None and w.w_row_sums is None:
+                w.w_row_sums = ops.int8_row_sums(w.qdata)
+            y = k.int8_linear_static(x2, w.qdata, w._row_scale(), w.act_quant_scale, zp, w.w_row_sums, bias)
+        elif _mapping(act.mapping_type) == MappingType.ASYMMETRIC:
             if not isinstance(act.granularity, PerRow):
                 raise NotImplementedError("Int8Tensor on MI355X implements ASYMMETRIC activation quantization per row only")
             if w.w_row_sums is None:  # a weight built without from_hp (e.g. loaded from a reference checkpoint): once, eagerly
@@ -193,7 +204,7 @@ def _(func, types, args, kwargs):
         if pre is not None and pre.numel() == self.shape[1]:  # per-input-feature pre-scale follows the K slice
             pre = pre.reshape(-1)[start:end]
     block_size = list(q.shape) if per_tensor else [1, q.shape[1]]
-    return Int8Tensor(q, s, block_size, self.dtype_, self.act_quant_kwargs, pre, zp, sums)
+    return Int8Tensor(q, s, block_size, self.dtype_, self.act_quant_kwargs, pre, zp, sums, self.act_quant_scale, self.act_quant_zero_point)
 
 
 torch.serialization.add_safe_globals([Int8Tensor, QuantizeTensorToInt8Kwargs, MappingType])

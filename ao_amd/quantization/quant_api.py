@@ -18,6 +18,7 @@ from .config import (
     Int4PackingFormat,
     Int4WeightOnlyConfig,
     Int8DynamicActivationInt8WeightConfig,
+    Int8StaticActivationInt8WeightConfig,
 )
 
 logger = logging.getLogger(__name__)
@@ -156,6 +157,26 @@ def _int8_dynamic_activation_int8_weight_transform(module, config, *, parameter_
         weight,
         granularity=weight_granularity,
         act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=act_granularity, mapping_type=config.act_mapping_type),
+    )
+    setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
+    return module
+
+
+@register_quantize_module_handler(Int8StaticActivationInt8WeightConfig)
+def _int8_static_activation_int8_weight_transform(module, config, *, parameter_name="weight"):
+    """reference quant_api.py:970-1012: int8 weight; the activation is cast with the calibrated scale (and zero-point) of the config."""
+    from .int8_tensor import Int8Tensor
+
+    assert hasattr(module, parameter_name), f"Expected module to have attribute `{parameter_name}` but not found"
+    assert config.act_quant_scale is not None, "Int8StaticActivationInt8WeightConfig needs act_quant_scale"
+    act_granularity, weight_granularity = config.granularity
+    zp = None if config.act_quant_zero_point is None else config.act_quant_zero_point.detach()
+    new_weight = Int8Tensor.from_hp(
+        getattr(module, parameter_name),
+        granularity=weight_granularity,
+        act_quant_kwargs=config.get_act_quant_kwargs(),
+        act_quant_scale=config.act_quant_scale.detach(),
+        act_quant_zero_point=zp,
     )
     setattr(module, parameter_name, nn.Parameter(new_weight, requires_grad=False))
     return module

@@ -58,6 +58,7 @@ _lib_def.define("int8_linear_asym(Tensor x, Tensor wq, Tensor w_scale, Tensor w_
 _lib_def.define("int8_linear_tensorwise(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("fp8_linear_tensorwise(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias) -> Tensor")
 _lib_def.define("fp8_linear_clamped(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias, float lb, float ub, bool tensorwise) -> Tensor")
+_lib_def.define("int8_linear_static(Tensor x, Tensor wq, Tensor w_scale, Tensor act_scale, Tensor? act_zero_point, Tensor? w_row_sums, Tensor? bias) -> Tensor")
 _lib_def.define("int8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("fp8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("mxfp8_quantize(Tensor x, str scaling_mode) -> (Tensor, Tensor)")
@@ -81,6 +82,7 @@ _lib_impl.impl("int8_linear_asym", ops.int8_linear_asym)
 _lib_impl.impl("int8_linear_tensorwise", ops.int8_linear_tensorwise)
 _lib_impl.impl("fp8_linear_tensorwise", ops.fp8_linear_tensorwise)
 _lib_impl.impl("fp8_linear_clamped", ops.fp8_linear_clamped)
+_lib_impl.impl("int8_linear_static", ops.int8_linear_static)
 _lib_impl.impl("int8_quantize_rowwise", ops.int8_quantize_rowwise)
 _lib_impl.impl("fp8_quantize_rowwise", ops.fp8_quantize_rowwise)
 _lib_impl.impl("mxfp8_quantize", lambda x, mode: ops.mxfp8_quantize(x, mode))
@@ -147,6 +149,11 @@ def _(x, wq, w_scale, bias):
 
 @torch.library.register_fake("ao_mi355::fp8_linear_clamped")
 def _(x, wq, w_scale, bias, lb, ub, tensorwise):
+    return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
+
+
+@torch.library.register_fake("ao_mi355::int8_linear_static")
+def _(x, wq, w_scale, act_scale, act_zero_point, w_row_sums, bias):
     return x.new_empty((x.shape[0], wq.shape[0]), dtype=torch.bfloat16)
 
 

@@ -149,6 +149,11 @@ int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, int64_t M,
  *   x bf16 [M][K] -> q int8 [M][K], scale fp32 [M], zero_point int8 [M] */
 int ao_int8_quantize_rowwise_asym(const uint16_t* x, int8_t* q, float* scale, int8_t* zero_point,
                                   int64_t M, int64_t K, void* stream);
+/* Static activation quantization: Int8Tensor.from_hp(x, granularity, mapping_type, scale=..., zero_point=...) with the qparams GIVEN
+ * (Int8StaticActivationInt8WeightConfig, quant_api.py:919-1012; int8_tensor.py:212-231): q = clamp(rint(x / scale) + zp, -128, 127).
+ *   x bf16 [M][K]; scale fp32 [1] (per_row = 0) or [M] (per_row = 1); zero_point int8, same shape, or NULL (symmetric) -> q int8 [M][K] */
+int ao_int8_quantize_static(const uint16_t* x, const float* scale, const int8_t* zero_point, int per_row,
+                            int8_t* q, int64_t M, int64_t K, void* stream);
 /* rowsum(W_int8) of the zero-point correction (int8_tensor.py:326 `weight_tensor.qdata.sum(dim=-1)`): q int8 [N][K] ->
  * sums int32 [N].  K % 16 == 0.  Computed once per weight by the host mirror. */
 int ao_int8_row_sums(const int8_t* q, int32_t* sums, int64_t N, int64_t K, void* stream);

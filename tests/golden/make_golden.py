@@ -273,6 +273,18 @@ def make_int8_fp8_variants():
     lb, ub = 0.37, 900.0  # lb is not bf16-representable on purpose; ub cuts the amax of rows 3 and 7
     xc = Float8Tensor.from_hp(x, torch.float8_e4m3fn, PerRow(), hp_value_lb=lb, hp_value_ub=ub)
     out.update(fp8clamp_xq=xc.qdata.view(torch.uint8).numpy(), fp8clamp_xs=xc.scale.flatten().numpy(), fp8clamp_bounds=np.float64([lb, ub]))
+    # --- int8 STATIC activation quantization (Int8StaticActivationInt8WeightConfig): the activation scale (and zero-point) are given
+    s_static = torch.tensor([[0.0625]], dtype=torch.float32)          # PerTensor activation scale
+    ws_ = Int8Tensor.from_hp(w, PerRow(), act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=PerTensor()), act_quant_scale=s_static)
+    out["static_sym_scale"] = s_static.numpy()
+    out["static_sym_xq"] = Int8Tensor.from_hp(x, PerTensor(), scale=s_static).qdata.numpy()
+    out["static_sym_y"] = bits(F.linear(x, ws_, bias))
+    s_asym, zp_asym = torch.tensor([[0.04]], dtype=torch.float32), torch.tensor([[-19]], dtype=torch.int8)
+    wa_ = Int8Tensor.from_hp(w, PerRow(), act_quant_kwargs=QuantizeTensorToInt8Kwargs(granularity=PerTensor(), mapping_type=MappingType.ASYMMETRIC),
+                             act_quant_scale=s_asym, act_quant_zero_point=zp_asym)
+    out["static_asym_scale"], out["static_asym_zp"] = s_asym.numpy(), zp_asym.numpy()
+    out["static_asym_xq"] = Int8Tensor.from_hp(x, PerTensor(), mapping_type=MappingType.ASYMMETRIC, scale=s_asym, zero_point=zp_asym).qdata.numpy()
+    out["static_asym_y"] = bits(F.linear(x, wa_, bias))
     np.savez_compressed(os.path.join(HERE, "int8_fp8_variants.npz"), **out)
     print("int8_fp8_variants.npz:", {k_: v.shape for k_, v in out.items()})
 

@@ -142,14 +142,15 @@ def test_opcheck_custom_ops():
     opcheck(torch.ops.torchao.fused_pad_token_groups.default, (x32, offs, 32), test_utils=utils)
 
 
-@pytest.mark.parametrize("kind", ["int4", "int8", "fp8", "int8_asym", "int8_pt", "fp8_pt"])
+@pytest.mark.parametrize("kind", ["int4", "int8", "fp8", "int8_asym", "int8_pt", "fp8_pt", "int8_static", "fp8_clamped"])
 def test_torch_compile_fullgraph_through_the_subclass(kind):
     """torch.compile(fullgraph=True) traces F.linear on the quantized weight to ONE extern call of the ao_mi355:: op (the
     reference asserts the same shape of graph: extern_kernels._int_mm, test_int8_tensor.py:276-278) and reproduces eager."""
     from torch._dynamo.utils import counters
 
     from ao_amd.quantization import (Float8DynamicActivationFloat8WeightConfig, Int4WeightOnlyConfig,
-                                     Int8DynamicActivationInt8WeightConfig, MappingType, PerRow, PerTensor, quantize_)
+                                     Int8DynamicActivationInt8WeightConfig, Int8StaticActivationInt8WeightConfig, MappingType, PerRow,
+                                     PerTensor, quantize_)
 
     torch.manual_seed(0)
     lin = torch.nn.Linear(1024, 256, bias=True).to(torch.bfloat16).to(DEV)
@@ -157,7 +158,9 @@ def test_torch_compile_fullgraph_through_the_subclass(kind):
            "fp8": Float8DynamicActivationFloat8WeightConfig(granularity=PerRow()),
            "int8_asym": Int8DynamicActivationInt8WeightConfig(act_mapping_type=MappingType.ASYMMETRIC),
            "int8_pt": Int8DynamicActivationInt8WeightConfig(granularity=PerTensor()),
-           "fp8_pt": Float8DynamicActivationFloat8WeightConfig()}[kind]
+           "fp8_pt": Float8DynamicActivationFloat8WeightConfig(),
+           "int8_static": Int8StaticActivationInt8WeightConfig(act_quant_scale=torch.tensor([[0.05]], device=DEV), granularity=[PerTensor(), PerRow()]),
+           "fp8_clamped": Float8DynamicActivationFloat8WeightConfig(granularity=PerRow(), activation_value_lb=0.5, activation_value_ub=3.0)}[kind]
     quantize_(lin, cfg)
     x = _randn_bf16((5, 1024), 21).to(DEV)
     want = lin(x)
@@ -174,7 +177,8 @@ def test_torch_compile_fullgraph_through_the_subclass(kind):
     got = torch.compile(lin, fullgraph=True, backend=aot_autograd(fw_compiler=fw_compiler))(x)
     assert torch.equal(got, want)
     opname = {"int4": "ao_mi355.weight_int4pack_mm", "int8": "ao_mi355.int8_linear.", "fp8": "ao_mi355.fp8_linear.",
-              "int8_asym": "ao_mi355.int8_linear_asym", "int8_pt": "ao_mi355.int8_linear_tensorwise", "fp8_pt": "ao_mi355.fp8_linear_tensorwise"}[kind]
+              "int8_asym": "ao_mi355.int8_linear_asym", "int8_pt": "ao_mi355.int8_linear_tensorwise", "fp8_pt": "ao_mi355.fp8_linear_tensorwise",
+              "int8_static": "ao_mi355.int8_linear_static", "fp8_clamped": "ao_mi355.fp8_linear_clamped"}[kind]
     assert sum(opname in t for t in seen) == 1, seen
     assert counters["graph_break"] == {} or sum(counters["graph_break"].values()) == 0
     # and through inductor (the op becomes an extern kernel call)

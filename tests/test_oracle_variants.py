@@ -84,3 +84,22 @@ def test_fp8_activation_value_bounds_bit_exact(gv):
     q, s = F.quantize_rowwise(x, amax=amax)
     assert np.array_equal(q, gv["fp8clamp_xq"]) and np.array_equal(s, gv["fp8clamp_xs"])
     assert s[5] == bf16.div(bf16.bf16_round(np.float32(lb)), np.float32(448.0))  # the all-zero row takes the (bf16-rounded) lower bound
+
+
+def _quantize_static(x, scale, zp=0):
+    """Int8Tensor.from_hp(x, ..., scale=, zero_point=): quantize_affine with given qparams (quant_primitives.py:463-485)."""
+    inv = (np.float32(1.0) / np.float32(scale)).astype(np.float32)
+    return np.clip(np.rint(x * inv).astype(np.float32) + np.float32(zp), -128, 127).astype(np.int8)
+
+
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_int8_static_activation_bit_exact(gv, kind):
+    x, w, b = bf16_bits_to_f32(gv["x"]), bf16_bits_to_f32(gv["w"]), bf16_bits_to_f32(gv["bias"])
+    s = float(gv[f"static_{kind}_scale"].reshape(-1)[0])
+    zp = int(gv["static_asym_zp"].reshape(-1)[0]) if kind == "asym" else 0
+    q = _quantize_static(x, s, zp)
+    assert np.array_equal(q, gv[f"static_{kind}_xq"])
+    wq, ws = I.quantize_rowwise(w)
+    xs = np.full(x.shape[0], s, np.float32)
+    y = I.scaled_mm(q, xs, wq, ws, b) if kind == "sym" else I.scaled_mm_asym(q, xs, np.full(x.shape[0], zp, np.int8), wq, ws, b)
+    assert np.array_equal(bf16.to_bits(y), gv[f"static_{kind}_y"])

@@ -16,6 +16,7 @@ from ao_amd.quantization import (  # noqa: E402
     Float8DynamicActivationFloat8WeightConfig,
     Float8Tensor,
     Int8DynamicActivationInt8WeightConfig,
+    Int8StaticActivationInt8WeightConfig,
     Int8Tensor,
     MappingType,
     PerRow,
@@ -198,3 +199,25 @@ def test_fp8_activation_value_bounds_through_the_config(gv):
     wq, ws = F.quantize_rowwise(bf16_bits_to_f32(gv["w"]))
     y_ref = F.scaled_mm(gv["fp8clamp_xq"], wq, gv["fp8clamp_xs"], ws, bf16_bits_to_f32(gv["bias"]))
     assert _rel(y, y_ref) <= 1e-3
+
+
+@pytest.mark.parametrize("kind", ["sym", "asym"])
+def test_int8_static_activation_golden_through_the_config(gv, kind):
+    """Int8StaticActivationInt8WeightConfig: calibrated activation scale (and zero-point); bit-exact against the reference's F.linear."""
+    scale = torch.from_numpy(gv[f"static_{kind}_scale"]).to(DEV)
+    zp = torch.from_numpy(gv["static_asym_zp"]).to(DEV) if kind == "asym" else None
+    x = _t(gv, "x")
+    assert np.array_equal(ops.int8_quantize_static(x, scale, zp).cpu().numpy(), gv[f"static_{kind}_xq"])
+    lin = torch.nn.Linear(gv["w"].shape[1], gv["w"].shape[0], bias=True, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        lin.weight.copy_(_t(gv, "w"))
+        lin.bias.copy_(_t(gv, "bias"))
+    quantize_(lin, Int8StaticActivationInt8WeightConfig(act_quant_scale=scale, act_quant_zero_point=zp, granularity=[PerTensor(), PerRow()],
+                                                         act_mapping_type=MappingType.ASYMMETRIC if kind == "asym" else MappingType.SYMMETRIC))
+    assert isinstance(lin.weight, Int8Tensor) and lin.weight.act_quant_scale is not None
+    assert np.array_equal(_bits(lin(x)), gv[f"static_{kind}_y"])
+    # per-row static scales (one per activation row) take the same kernel with stride 1
+    rs = torch.linspace(0.03, 0.09, x.shape[0], device=DEV)
+    q = ops.int8_quantize_static(x, rs).cpu().numpy()
+    ref = np.clip(np.rint(bf16_bits_to_f32(gv["x"]) * (np.float32(1.0) / rs.cpu().numpy())[:, None]), -128, 127).astype(np.int8)
+    assert np.array_equal(q, ref)
