@@ -2,11 +2,13 @@ from .config import (  # noqa: F401
     AOBaseConfig,
     Float8DynamicActivationFloat8WeightConfig,
     Float8DynamicActivationInt4WeightConfig,
+    FqnToConfig,
     Int4ChooseQParamsAlgorithm,
     Int4PackingFormat,
     Int4WeightOnlyConfig,
     Int8DynamicActivationInt8WeightConfig,
     Int8StaticActivationInt8WeightConfig,
+    ModuleFqnToConfig,
 )
 from .granularity import PerGroup, PerRow, PerTensor  # noqa: F401
 from .quant_primitives import MappingType  # noqa: F401

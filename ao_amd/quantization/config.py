@@ -145,3 +145,28 @@ class Float8DynamicActivationInt4WeightConfig(AOBaseConfig):
 
     def __post_init__(self):
         self.int4_packing_format = Int4PackingFormat(self.int4_packing_format)
+
+
+@dataclass
+class FqnToConfig(AOBaseConfig):
+    """Different configs for different parts of a model, keyed by fully qualified name (reference quant_api.py:1515-1596).
+
+    Keys of `fqn_to_config`, in order of precedence: the fqn of a parameter ("model.layers.0.q_proj.weight"), the fqn of a module,
+    "re:<regex>" matched in full against parameter fqns, "re:<regex>" against module fqns (the first matching key wins), and
+    "_default" (every other nn.Linear).  A value of None leaves the match unquantized.  `module_fqn_to_config` is the old name of
+    the same field."""
+
+    fqn_to_config: dict = field(default_factory=dict)
+    module_fqn_to_config: dict = field(default_factory=dict)
+    version: int = 1
+
+    def __post_init__(self):
+        if self.fqn_to_config and self.module_fqn_to_config and self.fqn_to_config != self.module_fqn_to_config:
+            raise ValueError("`fqn_to_config` and `module_fqn_to_config` are both specified and are not equal!")
+        if self.module_fqn_to_config and not self.fqn_to_config:
+            self.fqn_to_config = self.module_fqn_to_config
+        if self.fqn_to_config and not self.module_fqn_to_config:
+            self.module_fqn_to_config = self.fqn_to_config
+
+
+ModuleFqnToConfig = FqnToConfig  # the reference keeps the old name (quant_api.py:1598)

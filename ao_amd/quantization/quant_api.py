@@ -18,6 +18,7 @@ from .config import (
     Int4PackingFormat,
     Int4WeightOnlyConfig,
     Int8DynamicActivationInt8WeightConfig,
+    FqnToConfig,
     Int8StaticActivationInt8WeightConfig,
 )
 
@@ -67,6 +68,10 @@ def quantize_(model: nn.Module, config: AOBaseConfig, filter_fn: Optional[Callab
     filter_fn(module, fqn) -> bool selects modules (default: every nn.Linear).
     Raises AssertionError for configs without a registered handler, like the
     reference (quant_api.py:307-317)."""
+    if isinstance(config, FqnToConfig):
+        if filter_fn is not None:
+            raise ValueError("Custom filter_fn and FqnToConfig were both specified. Only filter_fn=None is supported when FqnToConfig is specified.")
+        return _quantize_by_fqn(model, config, device)
     filter_fn = _is_linear if filter_fn is None else filter_fn
     if not isinstance(config, AOBaseConfig):
         raise AssertionError(
@@ -76,6 +81,67 @@ def quantize_(model: nn.Module, config: AOBaseConfig, filter_fn: Optional[Callab
     if handler is None:
         raise AssertionError(f"unexpected config type: {type(config)}")
     _replace_with_custom_fn_if_matches_filter(model, lambda m: handler(m, config), filter_fn, device=device)
+
+
+def _pick_config(fqn: str, table: dict, regex_only: bool = False):
+    """(found, config) for an fqn: the exact key unless regex_only, else the first "re:" key whose pattern matches it in full."""
+    import re
+
+    if not regex_only:
+        if fqn in table:
+            assert not fqn.startswith("re:"), f"Error: Exact match but regex {fqn} specified."
+            return True, table[fqn]
+        return False, None
+    for key, cfg in table.items():
+        if key.startswith("re:") and re.fullmatch(key[3:], fqn):
+            return True, cfg
+    return False, None
+
+
+def _apply(module, cfg, parameter_name=None):
+    if cfg is None:
+        return module
+    handler = _QUANTIZE_CONFIG_HANDLER.get(type(cfg))
+    if handler is None:
+        raise AssertionError(f"unexpected config type: {type(cfg)}")
+    return handler(module, cfg) if parameter_name is None else handler(module, cfg, parameter_name=parameter_name)
+
+
+def _quantize_by_fqn(model, config, device):
+    """quantize_ with an FqnToConfig (reference quant_api.py:286-306, 1610-1703).  Per module: parameters named exactly, then the
+    module named exactly, then parameter regexes, then module regexes, then "_default" for plain nn.Linear modules."""
+    table = config.fqn_to_config
+    modules = dict(model.named_modules())
+    for fqn, module in modules.items():
+        params = [(n, f"{fqn}.{n}" if fqn else n) for n, _ in module.named_parameters(recurse=False)]
+        replacement, decided = module, False
+        hits = [(n, _pick_config(pf, table)) for n, pf in params]
+        if any(found for _, (found, _c) in hits):  # parameters named exactly (possibly several of one module)
+            for n, (found, cfg) in hits:
+                if found:
+                    replacement = _apply(replacement, cfg, parameter_name=n)
+            decided = True
+        if not decided:
+            found, cfg = _pick_config(fqn, table)
+            if found:
+                replacement, decided = _apply(module, cfg), True
+        if not decided:
+            for n, pf in params:
+                found, cfg = _pick_config(pf, table, regex_only=True)
+                if found:
+                    replacement, decided = _apply(replacement, cfg, parameter_name=n), True
+        if not decided:
+            found, cfg = _pick_config(fqn, table, regex_only=True)
+            if found:
+                replacement, decided = _apply(module, cfg), True
+        if not decided and "_default" in table and _is_linear(module):
+            replacement, decided = _apply(module, table["_default"]), True
+        if decided and device is not None:
+            replacement = replacement.to(device=device)
+        if decided and replacement is not module and fqn != "":
+            parent, _, child = fqn.rpartition(".")
+            setattr(modules[parent], child, replacement)
+    return model
 
 
 def _int4_weight_only_quantize_tensor(weight, config):

@@ -150,3 +150,39 @@ def test_mx_argument_checks():
         _to_mxfp8_then_scaled_grouped_mm(a, b, offs=None)
     with pytest.raises(AssertionError):
         _to_mxfp8_then_scaled_grouped_mm(a, b[0], offs=torch.zeros(2, dtype=torch.int32))
+
+
+def test_fqn_to_config_precedence(monkeypatch):
+    """FqnToConfig (reference quant_api.py:1515-1703): exact parameter fqn > exact module fqn > parameter regex > module regex > _default;
+    None leaves a match alone.  The handlers are stubbed (no GPU here): what is under test is which config reaches which module."""
+    from ao_amd.quantization import FqnToConfig, Int4WeightOnlyConfig, Int8DynamicActivationInt8WeightConfig, ModuleFqnToConfig, quant_api
+
+    seen = []
+    for cfg_type in (Int4WeightOnlyConfig, Int8DynamicActivationInt8WeightConfig):
+        monkeypatch.setitem(quant_api._QUANTIZE_CONFIG_HANDLER, cfg_type,
+                            lambda m, c, parameter_name="weight", _t=cfg_type: (seen.append((id(m), _t.__name__, parameter_name)), m)[1])
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.o_proj, self.gate = torch.nn.Linear(8, 8), torch.nn.Linear(8, 8), torch.nn.Linear(8, 8)
+            self.norm = torch.nn.LayerNorm(8)
+
+    model = torch.nn.Sequential(Block(), Block(), torch.nn.Linear(8, 4))
+    i4, i8 = Int4WeightOnlyConfig(group_size=32), Int8DynamicActivationInt8WeightConfig()
+    cfg = FqnToConfig({"0.q_proj.weight": i8, "0.o_proj": None, r"re:\d\.q_proj": i4, r"re:.*\.gate\.weight": i8, "_default": i4})
+    quantize_(model, cfg)
+    got = {(name, t, p) for name, mod in model.named_modules() for mid, t, p in seen if mid == id(mod)}
+    assert got == {
+        ("0.q_proj", "Int8DynamicActivationInt8WeightConfig", "weight"),   # exact parameter fqn beats the module regex
+        ("1.q_proj", "Int4WeightOnlyConfig", "weight"),                    # module regex
+        ("0.gate", "Int8DynamicActivationInt8WeightConfig", "weight"),     # parameter regex
+        ("1.gate", "Int8DynamicActivationInt8WeightConfig", "weight"),
+        ("1.o_proj", "Int4WeightOnlyConfig", "weight"),                    # _default: plain linears only ...
+        ("2", "Int4WeightOnlyConfig", "weight"),
+    }  # ... 0.o_proj (None) and the LayerNorms untouched
+    assert ModuleFqnToConfig is FqnToConfig
+    with pytest.raises(ValueError):
+        quantize_(model, cfg, filter_fn=lambda m, f: True)
+    with pytest.raises(ValueError):
+        FqnToConfig({"a": i4}, {"b": i4})
