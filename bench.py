@@ -544,7 +544,7 @@ def config_fp8_tp(stream, device, args, dist, world):
         res[f"M{m}"] = {"tokens_per_s": m / (t * 80 / layers), "launch": "hipGraph replay" if graphed else "eager", "ms_per_8_layers": t * 1e3, "allreduce_ms_per_8_layers": tc * 1e3,
                         "allreduce_bytes_per_row_linear": m * 8192 * 4 + m * 4, "per_gpu_TFLOPs": flops / t / 1e12,
                         "per_gpu_frac_of_fp8_mfma_peak": flops / t / 1e12 / MFMA_8BIT_PEAK_TOPS}
-    return {"workload": f"Float8 rowwise Llama-3-70B linears, TP={world} over RCCL (column-parallel qkv / gate_up, row-parallel o / down with the "
+    return {"workload": f"Float8 rowwise Llama-3-70B linears, TP={world} over {dist.get_backend()} (nccl = RCCL over xGMI; column-parallel qkv / gate_up, row-parallel o / down with the "
                         "exact protocol: amax all-reduce(MAX) + fp32 accumulator all-reduce(SUM) + one scale epilogue), 8 of 80 layers timed",
             "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (M = 2048, x10 extrapolated to 80 layers)", "by_M": res}
 
@@ -564,6 +564,10 @@ def main():
         print(f"warning: --gpus {args.gpus} != WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    # AO_BENCH_SHARE_GPU=1 (+ AO_BENCH_BACKEND=gloo): every rank on cuda:0 -- a dry run of the N > 1 code path on a one-GPU box (RCCL refuses
+    # two ranks on one device, gloo moves device tensors through the host); numbers from such a run mean nothing
+    if os.environ.get("AO_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -574,7 +578,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("AO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from ao_amd import _lib
 
