@@ -102,3 +102,57 @@ def test_tp_linears_two_ranks_one_gpu_vs_unsharded_oracle():
         # int4 weight-only: the op's contract is a bf16 output, so each rank's partial sum is rounded to bf16 before the all-reduce adds
         # them in bf16 -- what a caller of the reference's F.linear(x_shard, w_shard) + all_reduce gets too; one bf16 ulp is 3.9e-3
         assert r["int4"][0] <= 1e-3 and r["int4"][1] <= 4e-3, r["int4"]
+
+
+def _ep_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ao_amd.prototype.ep import a2a_combine_hp_fwd, a2a_dispatch_mxfp8_fwd, exchange_split_sizes
+        from ao_amd.prototype.mx import MXFP8ExpertWeights, _to_mxfp8_then_scaled_grouped_mm
+        from oracle import mx_ref as MX
+
+        dev = "cuda"
+        torch.manual_seed(5 + rank)
+        tokens, dim, n_out = 96, 256, 128
+        x = torch.randn(tokens, dim).to(torch.bfloat16).to(dev)
+        per_expert = torch.tensor([[32, 0, 40, 24], [16, 48, 0, 32]][rank], device=dev)  # 4 global experts, 2 per rank; rows sorted by expert
+        input_splits, output_splits, per_group = exchange_split_sizes(per_expert)
+        toks = a2a_dispatch_mxfp8_fwd(x, output_splits, input_splits)           # HIP cast, then the byte exchange
+        ref = torch.empty(sum(output_splits), dim, dtype=torch.bfloat16, device=dev)
+        dist.all_to_all_single(ref, x, output_splits, input_splits)
+        rq, rs = MX.to_mx(ref.float().cpu().numpy(), MX.RCEIL)
+        same = bool(np.array_equal(toks.data.view(torch.uint8).cpu().numpy(), rq) and np.array_equal(toks.scale.view(torch.uint8).cpu().numpy(), rs))
+        # local experts: received rows are ordered (source rank, local expert); with ONE local expert per call the groups are the sources
+        g = torch.Generator().manual_seed(9)
+        w = (torch.randn(world, n_out, dim, generator=g) * 0.1).to(torch.bfloat16).to(dev)  # treat each source chunk as a group
+        offs = torch.tensor(np.cumsum(output_splits), dtype=torch.int32, device=dev)
+        y = _to_mxfp8_then_scaled_grouped_mm(toks, MXFP8ExpertWeights.from_hp(w.transpose(-2, -1)), offs)
+        y_hp = _to_mxfp8_then_scaled_grouped_mm(ref, w.transpose(-2, -1), offs)
+        back = a2a_combine_hp_fwd(y, input_splits, output_splits)
+        q.put((rank, same, bool(torch.equal(y, y_hp)), tuple(back.shape), per_group.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ep_dispatch_two_ranks_one_gpu():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_ep_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        if p.is_alive():
+            p.kill()
+            pytest.fail("EP worker did not finish")
+        assert p.exitcode == 0
+    res = sorted(q.get() for _ in range(world))
+    for rank, same, same_mm, back_shape, per_group in res:
+        assert same, f"rank {rank}: HIP cast + exchange differs from exchange + oracle cast"
+        assert same_mm, f"rank {rank}: grouped GEMM on dispatched MXFP8 tokens differs from the bf16-input path"
+        assert back_shape == (96, 128)
+    assert res[0][4] == [32, 0, 16, 48] and res[1][4] == [40, 24, 0, 32]
