@@ -156,3 +156,37 @@ def test_ep_dispatch_two_ranks_one_gpu():
         assert same_mm, f"rank {rank}: grouped GEMM on dispatched MXFP8 tokens differs from the bf16-input path"
         assert back_shape == (96, 128)
     assert res[0][4] == [32, 0, 16, 48] and res[1][4] == [40, 24, 0, 32]
+
+
+def _oneshot_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ao_amd.parallel import OneShotAllReduce
+
+        red = OneShotAllReduce(max_bytes=1 << 16)  # symmetric memory refuses two ranks on one device: ok must come back False, not raise
+        t = torch.arange(4096, device="cuda", dtype=torch.float32) + 1000.0 * rank
+        red(t)                                      # ... and the call must fall through to the group's all_reduce
+        want = torch.arange(4096, device="cuda", dtype=torch.float32) * 2 + 1000.0
+        q.put((rank, red.ok, bool(torch.equal(t, want)), red.why))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_all_reduce_falls_back_cleanly_when_symmetric_memory_is_unavailable():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        if p.is_alive():
+            p.kill()
+            pytest.fail("one-shot worker did not finish")
+        assert p.exitcode == 0
+    for rank, ok, summed, why in sorted(q.get() for _ in range(world)):
+        assert summed, f"rank {rank}: wrong sum (one-shot ok={ok}, {why})"
