@@ -159,10 +159,16 @@ struct XRegs {
 //   3  profiling only: no dequant at all
 //   2  as 1, and software-pipelined across blocks: the four products of block b-1 are issued between the mask / convert /
 //      multiply VALU work of block b (x slab double-buffered so that block b-1's A fragments are still in LDS)
-template <int G, int MAXM, int DEPTH, int SCHED = 0>
+// TILES (round 3 A/B): a workgroup walks TILES consecutive n-tiles with the register ring carried across them (each wave's run per
+//   tile is exactly DEPTH blocks, so one pass of the unrolled ring = one tile): wide weights at small K give a wave 4 blocks per
+//   workgroup otherwise.
+// grid.z = S > 1 (round 3 A/B): cross-workgroup split-K -- part ks owns k-blocks [kblocks ks / S, kblocks (ks + 1) / S); the parts'
+//   fp32 tiles meet in the split-K workspace (sc1 stores / loads, one ticket per output tile), the last arriver adds them in part
+//   order and stores the tile.
+template <int G, int MAXM, int DEPTH, int SCHED = 0, int TILES = 1, bool SPLITK = false>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
-    const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K) {
+    const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);              // groups per 128-k block
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;          // bytes, padded vs bank conflicts
   constexpr int NSLAB = (SCHED == 2) ? 2 : 1;                 // x slabs per wave (rows 0..MAXM-1 each) + one shared zero row
@@ -172,12 +178,15 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  const int ntile = blockIdx.x;
+  const int ntile = blockIdx.x * TILES;
   const int m0 = blockIdx.y * 16;
   const int rows = min(16, M - m0);
   const int kblocks = K >> 7;
-  const int kb0 = (kblocks * wave) / nwaves;
-  const int kb1 = (kblocks * (wave + 1)) / nwaves;
+  const int S = SPLITK ? (int)gridDim.z : 1, ks = SPLITK ? (int)blockIdx.z : 0;
+  const int pb0 = SPLITK ? (int)(((long long)kblocks * ks) / S) : 0;  // this part's k-blocks
+  const int pbn = SPLITK ? (int)(((long long)kblocks * (ks + 1)) / S) - pb0 : kblocks;
+  const int kb0 = pb0 + (pbn * wave) / nwaves;
+  const int kb1 = pb0 + (pbn * (wave + 1)) / nwaves;
 
   char* slab = smem + wave * SLAB;
   float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
@@ -223,11 +232,11 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   // LDS copy of such a row is never read) so that the steady-state loop is
   // straight-line code and the compiler can use counted s_waitcnt vmcnt(N).
   const int last_row = rows - 1;
-  auto issue = [&](Stage& s, int kb) {
-    s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
+  auto issue = [&](Stage& s, int kb, int t = 0) {
+    s.w = __builtin_nontemporal_load(wp + ((size_t)t * kblocks + kb) * 64);
     const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
 #pragma unroll
-    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
+    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n + 16 * t];
     if (MAXM <= 4) {
 #pragma unroll
       for (int r = 0; r < MAXM; ++r) {
@@ -359,11 +368,28 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
 
-  int kb = kb0;
   // ring slots as compile-time indices (the slot's parity picks the x slab under SCHED 2)
   auto for_slots = [&](auto&& f) {
     [&]<int... D>(std::integer_sequence<int, D...>) { (f(std::integral_constant<int, D>{}), ...); }(std::make_integer_sequence<int, DEPTH>{});
   };
+  if constexpr (TILES > 1) {
+    // the host guarantees kb1 - kb0 == DEPTH for every wave: one pass of the ring per tile, refilled with the next tile's blocks
+    static_assert(SCHED == 0, "TILES > 1 is built on the word-by-word schedule");
+    [&]<int... T>(std::integer_sequence<int, T...>) {
+      (([&] {
+         for_slots([&](auto dc) {
+           constexpr int d = decltype(dc)::value;
+           consume(st[d], std::integral_constant<int, (d & 1)>{});
+           if constexpr (T + 1 < TILES) issue(st[d], kb0 + d, T + 1);
+         });
+         float* r = red + (T * nwaves + wave) * 256 + (kq * 4) * 16 + (lane & 15);
+         r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
+         acc = f32x4{0.f, 0.f, 0.f, 0.f};
+       }()),
+       ...);
+    }(std::make_integer_sequence<int, TILES>{});
+  } else {
+  int kb = kb0;
   // steady state: every consumed stage is refilled, no branches in the body
   for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
     for_slots([&](auto dc) {
@@ -396,22 +422,50 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
       mma(a[0], prev[0], acc); mma(a[1], prev[1], acc2); mma(a[2], prev[2], acc); mma(a[3], prev[3], acc2);
     }
   }
+  }
   acc += acc2;
 
-  // cross-wave reduction: red[wave][row][col]
-  {
+  // cross-wave reduction: red[tile][wave][row][col]
+  if constexpr (TILES == 1) {
     float* r = red + wave * 256 + (kq * 4) * 16 + (lane & 15);
     r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
   }
   __syncthreads();
   const int tid = threadIdx.x;
-  if (tid < 256) {
-    const int row = tid >> 4, col = tid & 15;
-    if (row < rows) {
-      float sum = 0.f;
-      for (int w = 0; w < nwaves; ++w) sum += red[w * 256 + tid];
-      y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(sum);
+  const int row = tid >> 4, col = tid & 15;
+  if (!SPLITK || S == 1) {
+    if (tid < 256 && row < rows) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        float sum = 0.f;
+        for (int w = 0; w < nwaves; ++w) sum += red[(t * nwaves + w) * 256 + tid];
+        y[(size_t)(m0 + row) * N + (ntile + t) * 16 + col] = f32_to_bf16_bits(sum);
+      }
     }
+    return;
+  }
+  // split-K meeting (TILES == 1): 256 fp32 per part and output tile
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  float* mine = ws + ((size_t)tile * S + ks) * 256;
+  if (tid < 256 && row < rows) {
+    float sum = 0.f;
+    for (int w = 0; w < nwaves; ++w) sum += red[w * 256 + tid];
+    __hip_atomic_store(mine + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: written through
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(smem);
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == (unsigned)S - 1);
+    if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!*flag) return;
+  if (tid < 256 && row < rows) {
+    float sum = 0.f;
+    for (int p = 0; p < S; ++p) sum += __hip_atomic_load(ws + ((size_t)tile * S + p) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(sum);
   }
 }
 
@@ -716,6 +770,241 @@ __global__ __launch_bounds__(64 * WAVES * (PROD ? 2 : 1), (WAVES == 4 && !PROD) 
 }
 
 thread_local unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
+thread_local int g_tune_wpb = 0;
+
+// ---------------------------------------------------------------------------
+// Round 3: int4_mm_kh_kernel -- the batched kernel with two symmetric, software-pipelined waves per SIMD ("K-half waves").
+//
+// What the round-3 measurements say about a SIMD of gfx950 (profiles/kh_trace_r03.txt, profiles/int4_kh_ablation_r03.txt):
+//   * instructions of the waves of a SIMD issue one at a time (~4.4 cycles each); a v_mfma_f32_16x16x32_bf16 keeps the matrix pipe
+//     for 16 cycles, and in that shadow 2 - 3 OTHER instructions can issue -- but only if they are next in some wave's stream.  A wave
+//     whose next instruction is another MFMA stalls at the issue port and the other waves' VALU work waits behind it: a
+//     "multiplying" wave next to a "dequantising" wave on one SIMD simply add up (measured: 64 x 128 tile, VALU + MFMA time = the sum);
+//   * so the exact dequant (92 VALU per packed n-tile block), the A-fragment reads and the MFMAs only overlap when ONE instruction
+//     stream interleaves them, and a lone wave per SIMD then stalls on every LDS / barrier latency (the round-2 kernel: ~1650
+//     cycles per k-block for 512 cycles of MFMA);
+//   * a DMA-producer wave pays ~170 cycles per global_load_lds while the LDS is busy with fragment reads: 10 per producer and
+//     k-block made the producers the critical path.
+// Hence: 8 waves = (n-tile t, K-half e): wave (t, e) owns n-tile t and the phases 2e, 2e + 1 (64 of the 128 k) of every k-block --
+// per k-block 2 MT MFMAs, two packed words to dequantise, 2 MT A-fragment reads, and its share of the stage's DMAs (x rows +
+// the tile's packed block (e = 0) or scale / zero words (e = 1)).  Every wave runs the SAME hand-interleaved stream: slot i =
+// one MFMA of k-block kb + one ds_read (the other phase's / the next k-block's A fragment) + one chunk of the dequant of k-block
+// kb + 1 + now and then one DMA of stage kb + 3; two such waves per SIMD fill each other's stalls.  Rings are 4 deep (x and w):
+// stage kb + 1 is in LDS when k-block kb starts ("all but the youngest stage's DMAs have landed" before each barrier).
+// The K-halves' accumulators meet in LDS after the loop (e = 0 + e = 1, fixed order), then the usual split-K meeting / store.
+// ---------------------------------------------------------------------------
+constexpr int kKhStages = 4;  // x and w rings
+// VAR (profiling): 0 product; 1 every DMA behind its own M0 write, dealt one per slot; 6 no DMAs at all (wrong results)
+template <int G, int MT, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void int4_mm_kh_kernel(
+    const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M,
+    int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets) {
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);
+  constexpr int WBLK = 1024 + NG * 256;    // one n-tile's share of a stage: packed block + NG x 64 scale/zero words
+  constexpr int KS = kKhStages;
+  constexpr int XD = 4 * MT / 8;           // x DMAs per wave and stage (4 rows each)
+  constexpr int ABUF = MT * 4096;          // one x stage: 16 MT rows x 256 B
+  constexpr int XRING = KS * ABUF;
+  constexpr int NSLOT = 2 * MT;            // MFMAs per wave and k-block
+  constexpr int LPS0 = XD + 1, LPS1 = XD + NG;  // DMAs per stage of an e = 0 / e = 1 wave
+  static_assert(LPS1 <= NSLOT / (MT == 8 ? 2 : 1), "every DMA piece of a stage gets a slot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [KS][16 MT rows][256 B] x | [4 tiles][KS][WBLK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = wave_id & 3, e = wave_id >> 2;
+  const int nl = lane & 15, grp = lane >> 4;
+  const int m0 = blockIdx.y * (16 * MT);
+  const int ntiles = N >> 4;
+  const int kblocks = K >> 7;
+  const int tile = blockIdx.x * 4 + t;
+  const int wtile = min(tile, ntiles - 1);  // tiles past N alias the last one; their columns are never stored
+  const int S = gridDim.z, ks = blockIdx.z;
+  const int kb0 = (int)(((long long)kblocks * ks) / S);
+  const int nkb = (int)(((long long)kblocks * (ks + 1)) / S) - kb0;
+  const uint32_t a_lds = lds_offset(smem);
+  const uint32_t w_lds = a_lds + XRING + t * (KS * WBLK);
+  const int out_tile = blockIdx.y * gridDim.x + blockIdx.x;
+  int* flag = reinterpret_cast<int*>(smem + XRING);  // a weight-ring word: free once the loop is over
+
+  // x DMA i of this wave fills rows 4 (XD wave + i) + (lane >> 4), chunk position lane & 15 (source-swizzled, see int4_mm_rb_kernel)
+  uint32_t aoff[XD];
+#pragma unroll
+  for (int i = 0; i < XD; ++i) {
+    const int row = 4 * (XD * wave_id + i) + (lane >> 4);
+    aoff[i] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)K * 2u + (((lane & 15) ^ (row & 15)) << 4);
+  }
+  // DMA piece d of k-block kb into ring slot `slot`: x pieces first, then the tile's packed block (e = 0) or scale/zero words (e = 1)
+  auto issue_piece = [&](auto d_c, int slot, int kb) {
+    constexpr int d = decltype(d_c)::value;
+    if (VAR == 6) return;
+    const int k = kb0 + min(kb, nkb - 1);  // k-blocks past the end re-read the last one (unused)
+    if constexpr (d < XD) {
+      if constexpr (VAR == 1) {
+        dma_b128_s(x + (size_t)k * 128, aoff[d], a_lds + slot * ABUF + (XD * wave_id + d) * 1024);
+      } else if constexpr (d == 0) {  // the wave's x pieces of the stage: one M0 write
+        const char* src = reinterpret_cast<const char*>(x + (size_t)k * 128);
+        if constexpr (XD == 4) dma_b128_x4(src, aoff[0], aoff[1], aoff[2], aoff[3], a_lds + slot * ABUF + (XD * wave_id) * 1024);
+        else dma_b128_x2(src, aoff[0], aoff[1], a_lds + slot * ABUF + (XD * wave_id) * 1024);
+      }
+    } else {
+      const uint32_t dst = w_lds + slot * WBLK;
+      if (e == 0) {
+        if constexpr (d == XD) dma_b128_nt_s(qdata + ((size_t)wtile * kblocks + k) * 64, lane * 16, dst);
+      } else {
+        if constexpr (d - XD < NG) {
+          const int kg0 = (G >= 128) ? ((k * 128) / G) : (k * NG);
+          dma_b32_s(sz + (size_t)(kg0 + (d - XD)) * N + wtile * 16, nl * 4, dst + 1024 + (d - XD) * 256);
+        }
+      }
+    }
+  };
+  auto issue_stage = [&](int slot, int kb) {
+    [&]<int... D>(std::integer_sequence<int, D...>) { (issue_piece(std::integral_constant<int, D>{}, slot, kb), ...); }
+    (std::make_integer_sequence<int, (LPS1 > LPS0 ? LPS1 : LPS0)>{});
+  };
+  auto wait_stage = [&] {  // everything but this wave's youngest stage has landed
+    if (VAR == 6) return;
+    if (e == 0) wait_vmcnt<LPS0>(); else wait_vmcnt<LPS1>();
+  };
+
+  const s16x4 ident = identity_fragment(lane);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // lane (row r = nl, group g = 2a + t'): A operand of phase p = 2e + h: chunk 2p ^ (8a | t') of row r, at position chunk ^ r
+  const int ga = grp >> 1, gt = grp & 1;
+  const int pbase = (nl * 256 + ((((ga << 3) | gt) ^ nl) << 4)) ^ (e << 6);  // ^ (h << 5) per phase, + 4096 per m-tile
+  const int wbase = ((2 * gt) * 16 + nl) * 16 + 8 * ga + 4 * e;              // word 2a + e of packed lane (n, 2t'); second piece: + 256
+  const int zg = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga + e;
+  const char* Wring = smem + XRING + t * (KS * WBLK);
+  auto a_frag = [&](int slot, int h, int mt) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(smem + slot * ABUF + (pbase ^ (h << 5)) + mt * 4096);
+  };
+
+  issue_stage(0, 0); issue_stage(1, 1); issue_stage(2, 2);
+  wait_stage();
+  asm volatile("s_barrier" ::: "memory");  // stages 0 and 1 are in LDS
+
+  u32x4 a0[MT], a1[MT];     // A fragments of the wave's two phases (h = 0, 1)
+  u32x4 bcur[2], bnext[2];  // B operands of h = 0, 1: this k-block's, the next one's (being dequantised)
+  uint32_t wq[2], wz;       // the next k-block's two packed words and its scale / zero word
+  DequantPipe dq[2];
+  auto load_words = [&](int slot) {
+    const char* Wst = Wring + slot * WBLK;
+    wq[0] = *reinterpret_cast<const uint32_t*>(Wst + wbase);
+    wq[1] = *reinterpret_cast<const uint32_t*>(Wst + wbase + 256);
+    wz = *reinterpret_cast<const uint32_t*>(Wst + 1024 + zg * 256 + nl * 4);
+  };
+  // chunk c = (stage c / 2, word c & 1) of the dequant pipeline
+  auto dequant_chunk = [&](auto c_c) {
+    constexpr int cc = decltype(c_c)::value;
+    const float sc = bf16_lo_to_f32(wz), zp = bf16_hi_to_f32(wz);
+    dequant_stage<cc / 2>(dq[cc & 1], wq[cc & 1], sc, -8.0f * sc, zp, ident);
+  };
+  auto take_next = [&] {
+    bnext[0] = u32x4{dq[0].out[0], dq[0].out[1], dq[1].out[0], dq[1].out[1]};
+    bnext[1] = u32x4{dq[0].out[2], dq[0].out[3], dq[1].out[2], dq[1].out[3]};
+  };
+  // k-block 0's operands, not overlapped with anything (once per launch)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a0[mt] = a_frag(0, 0, mt);
+  load_words(0);
+  [&]<int... C>(std::integer_sequence<int, C...>) { (dequant_chunk(std::integral_constant<int, C>{}), ...); }(std::make_integer_sequence<int, 8>{});
+  take_next();
+  bcur[0] = bnext[0]; bcur[1] = bnext[1];
+
+  // slot of dequant chunk c, of DMA piece d
+  constexpr int CH0 = (MT == 8) ? 3 : 1;  // first slot with dequant work (the words are read in slot 0)
+  auto chunk_slot = [](int cc) constexpr { return CH0 + (cc * (NSLOT - 1 - CH0)) / 7; };
+  auto piece_slot = [](int d) constexpr { return (MT == 8) ? 2 * d : d; };
+
+  int stage = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int next = (stage == KS - 1) ? 0 : stage + 1;
+    const int fill = (stage == 0) ? KS - 1 : stage - 1;  // (kb + 3) % KS
+    [&]<int... SL>(std::integer_sequence<int, SL...>) {
+      (([&] {
+         constexpr int sl = SL;
+         __builtin_amdgcn_sched_barrier(0);
+         if constexpr (sl == 0) load_words(next);
+         // one DMA of stage kb + 3
+         [&]<int... D>(std::integer_sequence<int, D...>) {
+           (([&] { if constexpr (piece_slot(D) == sl) issue_piece(std::integral_constant<int, D>{}, fill, kb + 3); }()), ...);
+         }(std::make_integer_sequence<int, (LPS1 > LPS0 ? LPS1 : LPS0)>{});
+         // one A fragment: this k-block's second phase, then the next k-block's first
+         if constexpr (sl < MT) a1[sl] = a_frag(stage, 1, sl); else a0[sl - MT] = a_frag(next, 0, sl - MT);
+         // dequant of k-block kb + 1
+         [&]<int... C>(std::integer_sequence<int, C...>) {
+           (([&] { if constexpr (chunk_slot(C) == sl) dequant_chunk(std::integral_constant<int, C>{}); }()), ...);
+         }(std::make_integer_sequence<int, 8>{});
+         if constexpr (sl < MT)
+           acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[sl]), __builtin_bit_cast(bf16x8, bcur[0]), acc[sl], 0, 0, 0);
+         else
+           acc[sl - MT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[sl - MT]), __builtin_bit_cast(bf16x8, bcur[1]), acc[sl - MT], 0, 0, 0);
+       }()),
+       ...);
+    }(std::make_integer_sequence<int, NSLOT>{});
+    __builtin_amdgcn_sched_barrier(0);
+    take_next();
+    bcur[0] = bnext[0]; bcur[1] = bnext[1];
+    stage = next;
+    wait_stage();  // stage kb + 2 of this wave's DMAs has landed (only stage kb + 3's may be in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // k-block kb is done everywhere; stages kb + 1, kb + 2 are in LDS
+  }
+  wait_vmcnt<0>();  // the clamped fills past the end still write LDS
+  asm volatile("s_barrier" ::: "memory");
+
+  // the two K-halves meet: e = 1 parks its tile in LDS, e = 0 adds it (fixed order)
+  f32x4* park = reinterpret_cast<f32x4*>(smem) + (t * MT) * 64 + lane;
+  if (e == 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) park[i * 64] = acc[i];
+  }
+  __syncthreads();
+  if (e == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] += park[i * 64];
+  }
+  if (S > 1) {
+    if (!split_k_meet<MT, 256>(acc, ws, tickets, out_tile, S, ks, tid, flag, e == 0)) return;
+  }
+  if (e != 0 || tile >= ntiles) return;
+  // D layout of the 16x16 tile: lane (col = nl, group g) holds rows 4 g + {0..3}
+  const int nn = tile * 16 + nl;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + mt * 16 + grp * 4 + r;
+      if (m < M) y[(size_t)m * N + nn] = f32_to_bf16_bits(acc[mt][r]);
+    }
+}
+
+template <int G, int MT, int VAR = 0>
+int launch_mm_kh(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
+                 hipStream_t stream) {
+  constexpr int NG = (G >= 128) ? 1 : (128 / G);
+  constexpr int BN = 64, BM = 16 * MT;
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)split), block(512);
+  constexpr size_t smem = (size_t)kKhStages * MT * 4096 + (size_t)4 * kKhStages * (1024 + NG * 256);
+  static_assert(smem <= 160 * 1024, "int4_mm_kh_kernel: LDS");
+  float* ws = nullptr;
+  unsigned* tickets = nullptr;
+  if (split > 1) {
+    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "int4_mm_kh: %u x %u tiles x %d parts exceed the split-K workspace",
+               grid.x, grid.y, split);
+    AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "int4_mm_kh: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
+  }
+  auto kern = int4_mm_kh_kernel<G, MT, VAR>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_kh_kernel)")) return rc;
+  ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)M,
+             (int)N, (int)K, ws, tickets);
+  AO_LAUNCH_CHECK("int4_mm_kh_kernel launch");
+  return AO_OK;
+}
 
 template <int G, int WAVES, int NT, int MT = 8, int ABL = 0, bool PROD = false>
 int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
@@ -733,7 +1022,7 @@ int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, ui
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "int4_mm_rb: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &ws, &tickets)) return rc;
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
   }
   auto kern = int4_mm_rb_kernel<G, WAVES, NT, MT, ABL, PROD>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_rb_kernel)")) return rc;
@@ -903,29 +1192,51 @@ __global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __res
   }
 }
 
-thread_local int g_tune_wpb = 0;
 thread_local int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 95-99 small-M A/B builds, 600-699 batched kernel (parts, ablation / trace builds)
 
-template <int G, int MAXM, int DEPTH = 4, int SCHED = 0>
+template <int G, int MAXM, int DEPTH = 4, int SCHED = 0, int TILES = 1>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
-              int64_t N, int64_t K, hipStream_t stream) {
+              int64_t N, int64_t K, hipStream_t stream, int split = 1) {
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;
   constexpr int SLAB = (((SCHED == 2) ? 2 : 1) * MAXM + 1) * ROWSTRIDE;
   const int kblocks = (int)(K >> 7);
   const int64_t ntiles = N >> 4;
   const int64_t mslabs = (M + 15) / 16;
+  split = std::max(1, std::min(split, kblocks));
+  const int kpart = kblocks / split;  // k-blocks of the smallest part
   // waves per workgroup: 8 once a wave still gets >= 2 weight blocks (measured at M = 1 on the Llama-3-8B shapes:
   // 4 waves 800, 8 waves 868, 16 waves 705 tok/s), else 4 (>= 256 threads for the epilogue)
-  int wpb = (kblocks >= 16) ? 8 : 4;
+  int wpb = (kpart >= 16) ? 8 : 4;
   if (ntiles * mslabs >= 2048 && wpb > 4 && MAXM > 1) wpb /= 2;
   if (g_tune_wpb >= 4 && g_tune_wpb <= 16) wpb = g_tune_wpb;
   if (MAXM > 4 && wpb > 8) wpb = 8;  // 16-row variant is built for <= 512 threads
-  if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
-  const size_t smem = (size_t)wpb * (SLAB + 1024);
-  dim3 grid((unsigned)ntiles, (unsigned)mslabs), block(wpb * 64);
-  ao::launch((int4_mm_kernel<G, MAXM, DEPTH, SCHED>), grid, block, smem, stream, x,
-                     reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
-                     (int)M, (int)N, (int)K);
+  if (wpb > kpart) wpb = kpart < 4 ? 4 : kpart;
+  if (TILES > 1) {
+    // the multi-tile form needs every wave's run to be exactly the ring depth; anything else takes the plain kernel
+    if (kblocks != wpb * DEPTH || ntiles % TILES != 0 || split != 1) return launch_mm<G, MAXM, DEPTH, SCHED, 1>(x, qdata, sz, y, M, N, K, stream, split);
+  }
+  float* ws = nullptr;
+  unsigned* tickets = nullptr;
+  if (split > 1) {
+    AO_REQUIRE(ntiles * mslabs <= kSplitMaxTickets && ntiles * mslabs * split * 256 <= (int64_t)kSplitSlotFloats, "int4_mm: %lld tiles x %d parts exceed the split-K workspace",
+               (long long)(ntiles * mslabs), split);
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)(ntiles * mslabs) * split * 256)) return rc;
+  }
+  const size_t smem = (size_t)wpb * (SLAB + 1024 * TILES);
+  dim3 grid((unsigned)(ntiles / TILES), (unsigned)mslabs, (unsigned)split), block(wpb * 64);
+  auto go = [&](auto kern) {
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_kernel)")) return rc;
+    ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
+               (int)M, (int)N, (int)K, ws, tickets);
+    return (int)AO_OK;
+  };
+  if constexpr (MAXM == 1 && DEPTH == 4 && SCHED == 0 && TILES == 1) {
+    if (split > 1) { if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, true>)) return rc; }
+    else if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false>)) return rc;
+  } else {
+    AO_REQUIRE(split == 1, "int4_mm: split-K is built for the single-row kernel only");
+    if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false>)) return rc;
+  }
   AO_LAUNCH_CHECK("int4_mm_kernel launch");
   return AO_OK;
 }
@@ -951,6 +1262,17 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   if (M == 1 && g_tune_mode == 96) return launch_mm<G, 1, 8>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 95) return launch_mm<G, 1, 6>(x, qdata, sz, y, M, N, K, stream);
   if (g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
+  // round-3 A/Bs at M = 1 (profiles/int4_modes_r03.jsonl): 20S = cross-workgroup split-K, S parts, for weights of < 512 n-tiles
+  // (o, qkv, down); 21T = T n-tiles per workgroup for weights of >= 512 n-tiles (gate, up); 22x = both (S = 2, T = x)
+  if (M == 1 && g_tune_mode >= 200 && g_tune_mode < 230) {
+    const int kind = (g_tune_mode - 200) / 10, v = g_tune_mode % 10;
+    const bool narrow = (N >> 4) < 512;
+    const int sp = narrow ? (kind == 0 ? v : kind == 2 ? 2 : 1) : 1;
+    const int tl = narrow ? 1 : (kind == 1 || kind == 2 ? v : 1);
+    if (tl == 2) return launch_mm<G, 1, 4, 0, 2>(x, qdata, sz, y, M, N, K, stream);
+    if (tl == 4) return launch_mm<G, 1, 4, 0, 4>(x, qdata, sz, y, M, N, K, stream);
+    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, sp);
+  }
   if (M <= 16 && g_tune_mode < 600 && !(wide && (M > 4 || g_tune_mode == 93))) {
     if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
     if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
@@ -986,6 +1308,32 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     const int sp = (g_tune_mode == 900) ? (int)std::max<int64_t>(1, std::min<int64_t>({256 / base9, fit9, 8, kblocks / 8}))
                                         : (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode - 900), kblocks, fit9}));
     return launch_mm_rb<G, 4, 1, 8, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
+  } else if (g_tune_mode >= 800 && g_tune_mode < 840 && M > 16) {
+    // profiling (round 3): two n-tiles per wave -- every A fragment read from LDS feeds two MFMAs.  80S / 81S: 64-row slabs x 128
+    // columns (4 waves, fused / with DMA-producer waves), 82S / 83S: 128-row slabs x 128 columns; S = K parts (0: fill ~256 workgroups)
+    const int kind = (g_tune_mode - 800) / 10, s_req = g_tune_mode % 10;
+    const int rows = (kind < 2) ? 64 : 128;
+    const int64_t base8 = ((N + 127) / 128) * ((M + rows - 1) / rows);
+    const int64_t fit8 = (int64_t)kSplitMaxTiles * 128 * 128 / (base8 * 128 * rows);
+    const int sp = (int)std::max<int64_t>(1, s_req == 0 ? std::min<int64_t>({256 / base8, fit8, 8, kblocks / 8}) : std::min<int64_t>({(int64_t)s_req, kblocks, fit8}));
+    if (kind == 0) return launch_mm_rb<G, 4, 2, 4>(x, qdata, sz, y, M, N, K, sp, stream);
+    if (kind == 1) return launch_mm_rb<G, 4, 2, 4, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
+    if (kind == 2) return launch_mm_rb<G, 4, 2, 8>(x, qdata, sz, y, M, N, K, sp, stream);
+    return launch_mm_rb<G, 4, 2, 8, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
+  } else if (g_tune_mode >= 840 && g_tune_mode < 860 && M > 16) {
+    // profiling (round 3): the K-half-wave kernel.  84S: 128-row slabs, 85S: 64-row slabs; S = K parts (0: fill ~256 workgroups)
+    const int rows = (g_tune_mode < 850) ? 128 : 64, s_req = g_tune_mode % 10;
+    const int64_t base8 = ((N + 63) / 64) * ((M + rows - 1) / rows);
+    const int64_t fit8 = (int64_t)kSplitMaxTiles * 128 * 128 / (base8 * 64 * rows);
+    const int sp = (int)std::max<int64_t>(1, s_req == 0 ? std::min<int64_t>({256 / base8, fit8, 8, kblocks / 8}) : std::min<int64_t>({(int64_t)s_req, kblocks, fit8}));
+    if (rows == 128) return launch_mm_kh<G, 8>(x, qdata, sz, y, M, N, K, sp, stream);
+    return launch_mm_kh<G, 4>(x, qdata, sz, y, M, N, K, sp, stream);
+  } else if (g_tune_mode >= 860 && g_tune_mode < 880 && M > 16) {
+    const int64_t base8 = ((N + 63) / 64) * ((M + 127) / 128);
+    const int64_t fit8 = (int64_t)kSplitMaxTiles * 128 * 128 / (base8 * 64 * 128);
+    const int sp = (int)std::max<int64_t>(1, std::min<int64_t>({256 / base8, fit8, 8, kblocks / 8}));
+    if (g_tune_mode < 870) return launch_mm_kh<G, 8, 1>(x, qdata, sz, y, M, N, K, sp, stream);
+    return launch_mm_kh<G, 8, 6>(x, qdata, sz, y, M, N, K, sp, stream);
   } else if (g_tune_mode >= 700 && g_tune_mode < 800) {
     mt = 1 << std::min(3, (g_tune_mode - 700) / 10);
     waves = (g_tune_wpb == 8 && mt >= 2) ? 8 : 4;

@@ -30,6 +30,30 @@ __device__ __forceinline__ void dma_b32_s(const void* sbase, uint32_t voff, uint
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// N consecutive 1 KiB pieces with ONE M0 write: piece i lands at LDS[lds_dst + i * 1024 + lane * 16] and reads sbase + voff[i] (the
+// instruction's offset field moves BOTH addresses, so piece i's scalar base is lowered by the same i * 1024).  Back-to-back
+// global_load_lds behind separate M0 writes cost a wave ~170 cycles each in the batched kernels (round-3 trace); the M0 write has
+// to wait for the previous DMA's address phase.
+__device__ __forceinline__ void dma_b128_x4(const char* sbase, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %9\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %5\n\t"
+               "global_load_lds_dwordx4 %2, %6 offset:1024\n\t"
+               "global_load_lds_dwordx4 %3, %7 offset:2048\n\t"
+               "global_load_lds_dwordx4 %4, %8 offset:3072\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(sbase - 1024), "s"(sbase - 2048), "s"(sbase - 3072), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void dma_b128_x2(const char* sbase, uint32_t v0, uint32_t v1, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %3\n\t"
+               "global_load_lds_dwordx4 %2, %4 offset:1024\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(v0), "v"(v1), "s"(sbase), "s"(sbase - 1024), "s"(lds_dst) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -309,7 +309,7 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "rb8: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets)) return rc;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
   }
   p.trace = g_fp8_rb_trace;
   auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true> : rb8_kernel<WAVES, KIND, MT, false>;

@@ -64,55 +64,90 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
 }
 
 // ---- split-K workspace (splitk.h): the library's only device-side state ----------------------------------------------
-// One workspace (fp32 / int32 parts + tickets) per (device, stream), allocated on the first split-K launch on that stream.
-// Launches on ONE stream are ordered, and the last arriver of a launch leaves every ticket at zero, so consecutive launches
-// on a stream share their workspace safely; launches on different streams never share one.  (Round 1 rotated 4
-// process-wide slots with no tie to streams: more than 4 split-K kernels in flight across streams aliased a slot.)
+// One workspace (fp32 / int32 parts + tickets) per (device, stream), allocated on the first split-K launch on that stream and
+// sized to what the launches on it have asked for so far (power-of-two steps from 8 MiB up to the kSplitSlotFloats cap; growing
+// re-allocates after a device synchronise).  Launches on ONE stream are ordered, and the last arriver of a launch leaves every
+// ticket at zero, so consecutive launches on a stream share their workspace safely; launches on different streams never share
+// one.  At most kSplitSlots streams per device hold a workspace at a time: a further stream EVICTS the least recently used slot
+// (device synchronise first -- nothing of the evicted stream's launches may still be using the memory -- then the slot, memory
+// and all, changes owner).  Allocation, growth and eviction cannot happen inside stream capture (hipMalloc / synchronise are
+// illegal there): run the op once on the stream, outside capture, with the largest shape first.  A graph captured on a stream
+// whose slot is later evicted must be re-captured (its launches would share the buffer with the new owner).
 namespace {
 struct SplitWs {
   hipStream_t stream = nullptr;
   bool used = false;
-  float* part = nullptr;
-  unsigned* tickets = nullptr;
+  char* base = nullptr;       // [floats fp32][kSplitMaxTickets unsigned]
+  size_t floats = 0;          // capacity of the parts area
+  unsigned long long last_use = 0;
 };
 std::mutex g_split_mu;
 SplitWs g_split_ws[64][kSplitSlots];
+unsigned long long g_split_clock = 0;
+std::vector<char*> g_split_retired;  // outgrown buffers, kept alive for graphs captured before the growth
+constexpr size_t kSplitMinFloats = (size_t)2 << 20;  // 8 MiB
+
+int split_alloc(SplitWs* w, size_t floats) {
+  char* p = nullptr;
+  hipError_t e = hipMalloc(&p, floats * sizeof(float) + kSplitMaxTickets * sizeof(unsigned));
+  if (e != hipSuccess)
+    return hip_failed(e, "hipMalloc(split-K workspace); call the op with this shape once on this stream outside stream capture "
+                         "before capturing it into a graph");
+  e = hipMemset(p + floats * sizeof(float), 0, kSplitMaxTickets * sizeof(unsigned));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(split-K tickets)"); }
+  w->base = p;
+  w->floats = floats;
+  return AO_OK;
+}
 }  // namespace
 
-int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets) {
+int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_t need_floats) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return hip_failed(e, "hipGetDevice");
   AO_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  AO_REQUIRE(need_floats <= kSplitSlotFloats, "split-K workspace request of %zu floats exceeds the %zu-float cap", need_floats, kSplitSlotFloats);
   std::lock_guard<std::mutex> lock(g_split_mu);
   SplitWs* w = nullptr;
   for (int i = 0; i < kSplitSlots && w == nullptr; ++i)
     if (g_split_ws[dev][i].used && g_split_ws[dev][i].stream == stream) w = &g_split_ws[dev][i];
   for (int i = 0; i < kSplitSlots && w == nullptr; ++i)
     if (!g_split_ws[dev][i].used) w = &g_split_ws[dev][i];
-  AO_REQUIRE(w != nullptr, "split-K kernels were launched on more than %d streams of device %d: each stream owns a %zu MB workspace; "
-             "reuse streams (a captured graph keeps using the workspace of the stream it was captured on)", kSplitSlots, dev,
-             (kSplitSlotFloats * sizeof(float)) >> 20);
-  if (w->part == nullptr) {
-    const size_t bytes = kSplitSlotFloats * sizeof(float) + kSplitMaxTickets * sizeof(unsigned);
-    char* p = nullptr;
-    e = hipMalloc(&p, bytes);
+  if (w == nullptr) {
+    // every slot has an owner: the least recently used one changes hands once the device is idle
+    e = hipDeviceSynchronize();
     if (e != hipSuccess)
-      return hip_failed(e, "hipMalloc(split-K workspace); call the op with this shape once on this stream outside stream capture "
-                           "before capturing it into a graph");
-    unsigned* t = reinterpret_cast<unsigned*>(p + kSplitSlotFloats * sizeof(float));
-    e = hipMemset(t, 0, kSplitMaxTickets * sizeof(unsigned));
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(split-K tickets)"); }
-    w->part = reinterpret_cast<float*>(p);
-    w->tickets = t;
+      return hip_failed(e, "hipDeviceSynchronize (evicting a split-K workspace: more than kSplitSlots streams of this device run split-K "
+                           "kernels; not possible inside stream capture)");
+    w = &g_split_ws[dev][0];
+    for (int i = 1; i < kSplitSlots; ++i)
+      if (g_split_ws[dev][i].last_use < w->last_use) w = &g_split_ws[dev][i];
+  }
+  size_t want = kSplitMinFloats;
+  while (want < need_floats) want <<= 1;
+  if (want > kSplitSlotFloats) want = kSplitSlotFloats;
+  if (w->base == nullptr) {
+    if (int rc = split_alloc(w, want)) return rc;
+  } else if (w->floats < need_floats) {
+    e = hipDeviceSynchronize();  // earlier launches on this stream may still be meeting in the old buffer
+    if (e != hipSuccess) return hip_failed(e, "hipDeviceSynchronize (growing the split-K workspace; run the largest shape once outside stream capture)");
+    // the outgrown buffer is RETIRED, not freed: a hipGraph captured on this stream earlier keeps launching into it (each launch
+    // is self-contained -- it leaves its tickets at zero), so freeing it would pull memory from under such a graph.  At most
+    // log2(cap / 8 MiB) retirements per slot, < the cap in total.
+    g_split_retired.push_back(w->base);
+    w->base = nullptr;
+    w->floats = 0;
+    if (int rc = split_alloc(w, want)) return rc;
   }
   w->used = true;
   w->stream = stream;
-  *part = w->part;
-  *tickets = w->tickets;
+  w->last_use = ++g_split_clock;
+  *part = reinterpret_cast<float*>(w->base);
+  *tickets = reinterpret_cast<unsigned*>(w->base + w->floats * sizeof(float));
   return AO_OK;
 }
+
 }  // namespace ao
 
 extern "C" int ao_abi_version(void) { return AO_MI355_ABI_VERSION; }

@@ -4,7 +4,8 @@
 
 namespace ao {
 
-// Workspace: one per (device, stream), at most kSplitSlots streams per device: kSplitSlotFloats fp32 of parked partial tiles
+// Workspace: one per (device, stream); at most kSplitSlots streams per device hold one at a time (a further stream evicts the least
+// recently used slot after a device synchronise); sized on demand (8 MiB steps of two) up to kSplitSlotFloats fp32 of parked partial tiles
 // (kSplitMaxTiles tiles of 128 x 128; smaller tiles pack more of them) + kSplitMaxTickets tickets, one per output tile -- the
 // smallest tile a kernel parks is 64 x 16, two parts at least, so 4096 tickets cover every launch the float budget admits only
 // if the budget stays <= 4096 * 2 * 1024 floats; launchers check both.  Allocated on the first split-K launch on a stream
@@ -13,7 +14,8 @@ constexpr int kSplitSlots = 8;
 constexpr int kSplitMaxTiles = 2048;
 constexpr int kSplitMaxTickets = 16384;
 constexpr size_t kSplitSlotFloats = (size_t)kSplitMaxTiles * 128 * 128;  // 128 MiB
-int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets);
+// need_floats: what this launch parks (tiles x parts x tile floats); the slot grows to the largest request seen on its stream
+int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_t need_floats);
 
 // ---------------------------------------------------------------------------
 // Split-K meeting: every part parks its fp32 tile in the workspace

@@ -137,6 +137,26 @@ class _GpuBlocks:
         return (ops.int8_scale_epilogue if kind == "int8" else ops.fp8_scale_epilogue)(acc, xs, w.scale, bias)
 
 
+def _exact_protocol_blocker(weight) -> Optional[str]:
+    """None when `weight`'s activation recipe is the one RowParallelLinear._forward_exact implements, else the reason it is not."""
+    act = weight.act_quant_kwargs
+    gran = getattr(act, "granularity", None)
+    if type(gran).__name__ != "PerRow":
+        return f"activation granularity {gran} is not PerRow"
+    mapping = getattr(act, "mapping_type", None)
+    if mapping is not None and str(getattr(mapping, "name", mapping)).upper() != "SYMMETRIC":
+        return f"activation mapping_type {mapping} is not SYMMETRIC"
+    if getattr(weight, "act_quant_scale", None) is not None:
+        return "static activation scale (act_quant_scale) is set"
+    if getattr(act, "hp_value_lb", None) is not None or getattr(act, "hp_value_ub", None) is not None:
+        return "activation value bounds (hp_value_lb / hp_value_ub) are set"
+    if getattr(weight, "zero_point", None) is not None:
+        return "asymmetric weight (zero_point)"
+    if weight.scale.numel() != weight.shape[0]:
+        return f"weight scale has {weight.scale.numel()} elements, not one per output row (PerTensor / blockwise weights)"
+    return None
+
+
 class RowParallelLinear(nn.Module):
     """y = all_reduce_sum_r( x[..., k0:k1] @ W[:, k0:k1].T ) + b.  `input_is_parallel`: x already
     holds only this rank's K shard (the output of a ColumnParallelLinear).
@@ -162,6 +182,18 @@ class RowParallelLinear(nn.Module):
         if self.kind is not None and getattr(weight, "act_quant_kwargs", None) is None:
             self.kind = None
         self.exact = reduce == "exact" and self.kind is not None
+        if self.exact:
+            # the exact protocol reproduces ONE activation recipe: dynamic, symmetric, one scale per row, no value bounds, per-row
+            # weight scales.  Every other variant the subclasses accept (ASYMMETRIC mapping, PerTensor granularity on either operand,
+            # static act_quant_scale, hp_value_lb / _ub) would silently compute something else than the unsharded linear -- those
+            # take the reference callers' protocol instead (F.linear on the shard + bf16 all-reduce) and say so.
+            why = _exact_protocol_blocker(weight)
+            if why is not None:
+                import warnings
+
+                warnings.warn(f"RowParallelLinear(reduce='exact'): {why}; falling back to reduce='bf16' (locally quantized activation "
+                              "shard, bf16 partial sums)", stacklevel=2)
+                self.exact = False
         self.blocks = blocks or _GpuBlocks
         self.one_shot = one_shot  # float SUM all-reduces of <= 1 MiB go through it when given (decode-size partials)
         # act_pre_scale (AWQ / SmoothQuant, per input feature): the full vector for a replicated input, the K shard's part else

@@ -196,12 +196,20 @@ class Int4Linears:
             self.io[batch] = (keep, lst)
         return self.io[batch][1]
 
-    def step(self, batch, stream_ptr):
+    def step(self, batch, stream_ptr, side_stream=None):
+        """One token through every linear.  side_stream (tools/int4_branches.py): launch every `up` projection on it, forked after the
+        previous launch and joined before the next one -- gate and up read the same activation and are independent in a real layer."""
         f = self.lib.ao_int4_weight_int4pack_mm
-        for (xp, qp, sp, yp, m, n, k, _) in self.launches(batch):
-            rc = f(xp, qp, sp, yp, m, n, k, GROUP, stream_ptr)
+        cur = torch.cuda.current_stream()
+        for (xp, qp, sp, yp, m, n, k, name) in self.launches(batch):
+            forked = side_stream is not None and name == "up"
+            if side_stream is not None and name == "gate":
+                side_stream.wait_stream(cur)  # fork: up may start as soon as what precedes gate is done
+            rc = f(xp, qp, sp, yp, m, n, k, GROUP, side_stream.cuda_stream if forked else stream_ptr)
             if rc != 0:
                 self.check(rc)
+            if forked:
+                cur.wait_stream(side_stream)  # join before down
 
     def bytes_per_step(self, batch):
         return sum(algorithmic_bytes(batch, n, k, GROUP) for (_, _, n, k, _) in self.weights)

@@ -15,6 +15,16 @@
  * torchao/csrc/cuda/mx_kernels/mxfp8_extension.cpp:95-134).  The library never
  * calls exit().
  *
+ * Library state: the only device memory the library owns is a split-K scratch
+ * buffer per (device, stream) that launches split-K shapes (batched int4 on
+ * narrow N, 8-bit linears with few output tiles).  It is allocated on that
+ * stream's first such launch and grows in powers of two (8 MiB .. 128 MiB) to the
+ * largest request seen on the stream; at most 8 streams per device hold one at a
+ * time -- a ninth evicts the least recently used one after a device
+ * synchronise.  Allocation, growth and eviction are impossible inside stream
+ * capture: call the op once on the stream with its largest shape before
+ * capturing, and re-capture graphs of a stream that lost its buffer.
+ *
  * Each entry point cites the reference interface it replaces
  * (paths relative to the torchao checkout, lines from the 0.19.0 snapshot).
  * bf16 tensors are passed as uint16_t*, fp8 e4m3fn / e8m0 as uint8_t*.

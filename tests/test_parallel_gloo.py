@@ -167,3 +167,27 @@ def test_tp_mlp_world2_gloo():
     results = sorted(q.get(timeout=10) for _ in range(world))
     assert [r[0] for r in results] == [0, 1]
     assert all(r[1] for r in results), results
+
+
+def test_exact_protocol_is_only_taken_for_the_recipe_it_reproduces():
+    """ASYMMETRIC / PerTensor / static / bounded activation variants (and PerTensor weights) must not enter the exact
+    row-parallel protocol silently -- `_exact_protocol_blocker` names the reason and RowParallelLinear falls back to reduce='bf16'."""
+    from ao_amd.parallel import _exact_protocol_blocker
+    from ao_amd.quantization.float8_tensor import Float8Tensor, QuantizeTensorToFloat8Kwargs
+    from ao_amd.quantization.granularity import PerRow, PerTensor
+    from ao_amd.quantization.int8_tensor import Int8Tensor, QuantizeTensorToInt8Kwargs
+    from ao_amd.quantization.quant_primitives import MappingType
+
+    n, k = 32, 256
+    q8, s8 = torch.zeros(n, k, dtype=torch.int8), torch.ones(n, 1)
+    mk8 = lambda kw, **extra: Int8Tensor(q8, extra.pop("scale", s8), [1, k], torch.bfloat16, act_quant_kwargs=kw, **extra)  # noqa: E731
+    assert _exact_protocol_blocker(mk8(QuantizeTensorToInt8Kwargs())) is None
+    assert "SYMMETRIC" in _exact_protocol_blocker(mk8(QuantizeTensorToInt8Kwargs(mapping_type=MappingType.ASYMMETRIC)))
+    assert "PerRow" in _exact_protocol_blocker(mk8(QuantizeTensorToInt8Kwargs(granularity=PerTensor())))
+    assert "static" in _exact_protocol_blocker(mk8(QuantizeTensorToInt8Kwargs(), act_quant_scale=torch.ones(1)))
+    assert "per output row" in _exact_protocol_blocker(mk8(QuantizeTensorToInt8Kwargs(), scale=torch.ones(1, 1)))
+    qf = torch.zeros(n, k, dtype=torch.float8_e4m3fn)
+    mkf = lambda kw, sc=s8: Float8Tensor(qf, sc, [1, k], torch.bfloat16, act_quant_kwargs=kw)  # noqa: E731
+    assert _exact_protocol_blocker(mkf(QuantizeTensorToFloat8Kwargs(granularity=PerRow()))) is None
+    assert "bounds" in _exact_protocol_blocker(mkf(QuantizeTensorToFloat8Kwargs(granularity=PerRow(), hp_value_lb=1e-3)))
+    assert "PerRow" in _exact_protocol_blocker(mkf(QuantizeTensorToFloat8Kwargs(granularity=PerTensor())))
