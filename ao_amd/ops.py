@@ -802,6 +802,58 @@ def fused_pad_token_groups(inputs, offsets, alignment_size=32):
     return padded, starts, ends
 
 
+def generate_permute_indices(tokens_per_expert_group, experts_per_rank, num_ranks, max_len, alignment):
+    """torchao.prototype.moe_training.ep.kernels.generate_permute_indices (kernels.py:132-214): expert-major gather indices with every
+    expert's group padded to `alignment` rows.  Returns (permuted_indices int32 [max_len] with -1 for padding, m_sizes int32 [E],
+    m_offsets int32 [E])."""
+    dev = _require_gpu("generate_permute_indices", tokens_per_expert_group)
+    counts = tokens_per_expert_group.to(torch.int32).contiguous()
+    if counts.numel() != experts_per_rank * num_ranks:
+        raise ValueError(f"generate_permute_indices: expected {experts_per_rank * num_ranks} counts, got {counts.numel()}")
+    idx = torch.empty(max_len, dtype=torch.int32, device=dev)
+    start = torch.empty(counts.numel(), dtype=torch.int32, device=dev)
+    m_sizes = torch.empty(experts_per_rank, dtype=torch.int32, device=dev)
+    m_offsets = torch.empty(experts_per_rank, dtype=torch.int32, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_moe_permute_indices(_ptr(counts), _ptr(start), _ptr(idx), _ptr(m_sizes), _ptr(m_offsets), experts_per_rank,
+                                                     num_ranks, max_len, alignment, _stream()))
+    return idx, m_sizes, m_offsets
+
+
+def _rows_u8(t):
+    """[rows, row_bytes] byte view of a 2-D tensor of any dtype"""
+    t = t.contiguous()
+    return t, t.shape[0], t.shape[1] * t.element_size()
+
+
+def gather_rows(x, indices, num_out=None):
+    """out[i] = x[indices[i]] for 0 <= indices[i] < rows(x), zeros otherwise (`vstack(x, 0)[indices]`, ep/permute.py:86-96)."""
+    dev = _require_gpu("gather_rows", x, indices)
+    if x.dim() != 2 or indices.dim() != 1 or indices.dtype != torch.int32:
+        raise ValueError("gather_rows: expected a 2-D tensor and int32 1-D indices")
+    x, rows, row_bytes = _rows_u8(x)
+    indices = indices.contiguous()
+    n_out = indices.numel() if num_out is None else num_out
+    out = torch.empty((n_out, x.shape[1]), dtype=x.dtype, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_moe_gather_rows(_ptr(x), _ptr(indices), _ptr(out), rows, n_out, row_bytes, _stream()))
+    return out
+
+
+def scatter_rows(y, indices, num_rows_out):
+    """out[indices[i]] = y[i] for 0 <= indices[i] < num_rows_out (`out = empty(rows + 1); out[indices] = y; out[:-1]`,
+    ep/unpermute.py:36-41).  Rows no index names are left uninitialised, like the reference's."""
+    dev = _require_gpu("scatter_rows", y, indices)
+    if y.dim() != 2 or indices.dim() != 1 or indices.dtype != torch.int32 or indices.numel() != y.shape[0]:
+        raise ValueError("scatter_rows: expected a 2-D tensor and one int32 index per row")
+    y, rows, row_bytes = _rows_u8(y)
+    indices = indices.contiguous()
+    out = torch.empty((num_rows_out, y.shape[1]), dtype=y.dtype, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_moe_scatter_rows(_ptr(y), _ptr(indices), _ptr(out), rows, num_rows_out, row_bytes, _stream()))
+    return out
+
+
 def fused_unpad_token_groups(inputs, offsets, padded_group_start_offsets, num_tokens, alignment_size=32):
     """torchao::fused_unpad_token_groups (kernels/mxfp8/quant.py:1319-1363; semantics torch_unpad_token_groups,
     quant.py:433-480): gathers the `num_tokens` real rows back out of a padded buffer."""

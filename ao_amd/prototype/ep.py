@@ -11,9 +11,10 @@ all-to-all of S bytes per peer moves over all 7 links at once: the exchange is s
 The result feeds `_to_mxfp8_then_scaled_grouped_mm` (ao_amd/prototype/mx.py) directly: pre-quantized tokens skip its cast,
 like the reference's MXTensor input (mxfp8_grouped_mm.py:173-178, 482-486).
 
-Not mirrored: the Triton permute / unpermute of ep/permute.py (regrouping the received tokens by local expert); callers
-with one local expert per rank, or tokens already sorted by expert within each source rank's chunk and E_local = 1, need
-none.  Backward passes are training-only (outside SURVEY.md section 8).
+  * permute.py / unpermute.py / kernels.py -- regrouping the received tokens from rank-major to expert-major order with aligned
+    groups (`generate_permute_indices`, `permute_and_pad`, `permute_mxfp8_fwd`) and back (`unpermute_hp_fwd`): HIP index + row
+    kernels (csrc/moe_permute_kernels.hip) instead of Triton.
+Backward passes are training-only (outside SURVEY.md section 8).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -22,7 +23,50 @@ import torch.distributed as dist
 
 from .mx import BLOCK, ScaleCalculationMode
 
-__all__ = ["MXFP8Tokens", "a2a_dispatch_mxfp8_fwd", "a2a_combine_hp_fwd", "exchange_split_sizes"]
+__all__ = ["MXFP8Tokens", "a2a_dispatch_mxfp8_fwd", "a2a_combine_hp_fwd", "exchange_split_sizes", "generate_permute_indices",
+           "permute_and_pad", "permute_mxfp8_fwd", "unpermute_hp_fwd"]
+
+
+def _round_up(x: int, y: int) -> int:
+    return (x + y - 1) // y * y
+
+
+def generate_permute_indices(tokens_per_expert_group: torch.Tensor, experts_per_rank: int, num_ranks: int, max_len: int, alignment: int):
+    """reference ep/kernels.py:132-214 -> (permuted_indices int32 [max_len], m_sizes int32 [E], m_offsets int32 [E])."""
+    from .. import ops
+    return ops.generate_permute_indices(tokens_per_expert_group, experts_per_rank, num_ranks, max_len, alignment)
+
+
+def permute_and_pad(x: torch.Tensor, num_tokens_per_expert: torch.Tensor, ep_degree: int, num_local_experts: int, alignment: int):
+    """reference permute_and_pad (ep/permute.py:170-204): bf16 tokens from rank-major to expert-major order, every expert's group padded
+    to `alignment` rows (padding rows are zero).  Returns (input_shape incl. the reference's dummy row, permuted x, permuted_indices,
+    num_tokens_per_expert_padded, group_offsets)."""
+    from .. import ops
+    padded_max_len = _round_up(x.shape[0] + num_local_experts * alignment, alignment)
+    idx, m_sizes, m_offsets = generate_permute_indices(num_tokens_per_expert, num_local_experts, ep_degree, padded_max_len, alignment)
+    input_shape = torch.Size((x.shape[0] + 1, x.shape[1]))
+    return input_shape, ops.gather_rows(x, idx), idx, m_sizes, m_offsets
+
+
+def permute_mxfp8_fwd(tokens: "MXFP8Tokens", num_tokens_per_expert: torch.Tensor, ep_degree: int, num_local_experts: int,
+                      group_size_multiple_of: int = 32):
+    """reference _PermuteMXFP8FwdHPBwd.forward (ep/permute.py:60-125): the same regrouping applied to the e4m3 bytes and the E8M0 scale
+    bytes separately.  Returns (padded_shape, MXFP8Tokens, permuted_indices, num_tokens_per_expert_padded, group_offsets)."""
+    from .. import ops
+    data, scale = tokens.data, tokens.scale
+    padded_max_len = _round_up(data.shape[0] + num_local_experts * group_size_multiple_of, group_size_multiple_of)
+    idx, m_sizes, m_offsets = generate_permute_indices(num_tokens_per_expert, num_local_experts, ep_degree, padded_max_len, group_size_multiple_of)
+    d = ops.gather_rows(data.view(torch.uint8), idx).view(data.dtype)
+    s = ops.gather_rows(scale.view(torch.uint8), idx).view(scale.dtype)
+    padded_shape = torch.Size((data.shape[0] + 1, data.shape[1]))
+    return padded_shape, MXFP8Tokens(d, s, tokens.orig_dtype), idx, m_sizes, m_offsets
+
+
+def unpermute_hp_fwd(input: torch.Tensor, permuted_indices: torch.Tensor, padded_shape) -> torch.Tensor:
+    """reference _UnpermuteHPFwdMXFP8Bwd.forward / _unpermute_bf16 (ep/unpermute.py:23-47, 140-158): scatter the expert-major rows back
+    to their rank-major positions; `padded_shape` is the shape WITH the dummy row, the result has padded_shape[0] - 1 rows."""
+    from .. import ops
+    return ops.scatter_rows(input, permuted_indices, int(padded_shape[0]) - 1)
 
 
 class MXFP8Tokens:

@@ -194,4 +194,14 @@ def _(func, types, args, kwargs):
     return ops.fp8_grouped_mm(aq, a_s, wq, ws, offs.to(torch.int32)).to(output_dtype)
 
 
+@implements(aten.select.int)
+def _(func, types, args, kwargs):
+    """reference float8_tensor.py:936-955: expert selection on a 3-D (MoE) weight"""
+    self, dim, index = args
+    assert dim == 0, f"Float8Tensor aten.select.int with {dim=} is not yet supported"
+    assert len(self.qdata.shape) == len(self.scale.shape), "unsupported"
+    assert len(self.qdata.shape) == len(self.block_size), "unsupported"
+    return Float8Tensor(self.qdata[index], self.scale[index], self.block_size[1:], self.dtype_, self.act_quant_kwargs, self.act_pre_scale)
+
+
 torch.serialization.add_safe_globals([Float8Tensor, QuantizeTensorToFloat8Kwargs])

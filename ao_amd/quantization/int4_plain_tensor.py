@@ -36,13 +36,19 @@ class Int4Tensor(LowBitTensorBase):
 
     tensor_data_names = ["qdata", "scale", "zero_point"]
     tensor_attribute_names = ["block_size", "shape_"]
-    optional_tensor_data_names = ["act_pre_scale"]
+    # tp_qdata / tp_scale_and_zero: the compute layout (tinygemm tile order, padded to N % 16 == 0 and K % 128 == 0).  They are
+    # inner tensors like the rest -- built at from_hp, carried through flatten / unflatten / detach / to(), so torch.compile and
+    # AOT tracing see ready buffers and never the re-layout.  A tensor built without them (a reference checkpoint)
+    # gets them at its first eager use.
+    optional_tensor_data_names = ["act_pre_scale", "tp_qdata", "tp_scale_and_zero"]
 
-    def __new__(cls, qdata, scale, zero_point, block_size, shape_, act_pre_scale=None, activation_dtype=None):
+    def __new__(cls, qdata, scale, zero_point, block_size, shape_, act_pre_scale=None, activation_dtype=None, tp_qdata=None,
+                tp_scale_and_zero=None):
         kwargs = dict(device=qdata.device, dtype=scale.dtype, requires_grad=False)
         return torch.Tensor._make_wrapper_subclass(cls, torch.Size(shape_), **kwargs)
 
-    def __init__(self, qdata, scale, zero_point, block_size, shape_, act_pre_scale=None, activation_dtype=None):
+    def __init__(self, qdata, scale, zero_point, block_size, shape_, act_pre_scale=None, activation_dtype=None, tp_qdata=None,
+                 tp_scale_and_zero=None):
         self.qdata = qdata
         self.scale = scale
         self.zero_point = zero_point
@@ -50,7 +56,8 @@ class Int4Tensor(LowBitTensorBase):
         self.shape_ = torch.Size(shape_)
         self.act_pre_scale = act_pre_scale
         self.activation_dtype = activation_dtype if activation_dtype is not None else torch.bfloat16
-        self._tile_packed = None  # (qdata int32 [N/8, K/128, 32, 4], scale_and_zero bf16 [K/g, N, 2]): built on first use
+        self.tp_qdata = tp_qdata                    # int32 [Np/8, Kp/128, 32, 4]
+        self.tp_scale_and_zero = tp_scale_and_zero  # bf16 [Kp/g, Np, 2]
 
     def __tensor_flatten__(self):
         return self._data_names(), [self.block_size, self.shape_, self.activation_dtype]
@@ -59,11 +66,21 @@ class Int4Tensor(LowBitTensorBase):
     def __tensor_unflatten__(cls, tensor_data_dict, tensor_attributes, outer_size, outer_stride):
         block_size, shape_, act_dtype = tensor_attributes
         return cls(tensor_data_dict["qdata"], tensor_data_dict["scale"], tensor_data_dict["zero_point"], block_size, shape_,
-                   act_pre_scale=tensor_data_dict.get("act_pre_scale"), activation_dtype=act_dtype)
+                   act_pre_scale=tensor_data_dict.get("act_pre_scale"), activation_dtype=act_dtype,
+                   tp_qdata=tensor_data_dict.get("tp_qdata"), tp_scale_and_zero=tensor_data_dict.get("tp_scale_and_zero"))
 
     def _apply_fn_to_data(self, fn):
-        pre = fn(self.act_pre_scale) if self.act_pre_scale is not None else None
-        return Int4Tensor(fn(self.qdata), fn(self.scale), fn(self.zero_point), self.block_size, self.shape_, pre, self.activation_dtype)
+        opt = lambda t: fn(t) if t is not None else None  # noqa: E731
+        return Int4Tensor(fn(self.qdata), fn(self.scale), fn(self.zero_point), self.block_size, self.shape_, opt(self.act_pre_scale),
+                          self.activation_dtype, opt(self.tp_qdata), opt(self.tp_scale_and_zero))
+
+    def release_plain_(self):
+        """Serving-only: drop the PLAIN nibbles (the checkpoint layout) and keep the compute layout -- the default keeps both, i.e.
+        2 x N K / 2 bytes per weight.  After this the tensor can still run F.linear and dequantize(); slicing and saving in the
+        reference's format need the PLAIN data and raise."""
+        self.tile_packed()
+        self.qdata = self.qdata.new_empty((0,))
+        return self
 
     def _quantization_type(self):
         s = f"shape={tuple(self.shape)}, block_size={self.block_size}, device={self.device}, activation_dtype={self.activation_dtype}"
@@ -85,8 +102,17 @@ class Int4Tensor(LowBitTensorBase):
             raise NotImplementedError(f"Int4Tensor.from_hp on MI355X takes bfloat16, got {w.dtype}")
         if w.dim() != 2:
             raise NotImplementedError("Int4Tensor.from_hp on MI355X takes 2-D weights (per-expert 3-D weights: quantize each expert)")
-        qdata, scale, zero = ops.int4_plain_quantize(w.contiguous(), block_size[-1], symmetric=activation_dtype == torch.float8_e4m3fn)
-        return cls(qdata, scale, zero, list(block_size), w.shape, act_pre_scale=None, activation_dtype=activation_dtype)
+        g = block_size[-1]
+        n, k = w.shape
+        assert k % g == 0, f"K={k} must be a multiple of the group size {g} (quantize_() leaves such weights unquantized)"
+        kpad = (-k) % 128  # the kernel walks 128-k runs; whole zero groups are appended and cut off again
+        wq = F.pad(w, (0, kpad)) if kpad else w
+        qdata, scale, zero = ops.int4_plain_quantize(wq.contiguous(), g, symmetric=activation_dtype == torch.float8_e4m3fn)
+        if kpad:
+            qdata, scale, zero = qdata[:, : k // 2].contiguous(), scale[: k // g].contiguous(), zero[: k // g].contiguous()
+        out = cls(qdata, scale, zero, list(block_size), w.shape, act_pre_scale=None, activation_dtype=activation_dtype)
+        out.tile_packed()  # the compute layout, now (not inside the first forward, which may be a trace)
+        return out
 
     def dequantize(self, output_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         """q.to(bf16) * scale + zero_point in the weight dtype (reference formula gptq/api.py:200-221)."""
@@ -96,19 +122,30 @@ class Int4Tensor(LowBitTensorBase):
 
     def tile_packed(self):
         """The compute layout: the same codes and (scale, zero_point) in the tinygemm tile-packed format (gfx950:
-        [N/16][K/128][64 lanes][16 B]) -- built once, kept beside the PLAIN data."""
-        if self._tile_packed is None:
+        [N/16][K/128][64 lanes][16 B]), N padded to a multiple of 16 and K to a multiple of 128 (padded codes / qparams are zero: they
+        meet zero activations or columns that are sliced off) -- built once, kept beside the PLAIN data."""
+        if self.tp_qdata is None:
+            from torch._subclasses.fake_tensor import is_fake
+
+            if torch.compiler.is_compiling() or is_fake(self.qdata):
+                raise RuntimeError("Int4Tensor: the compute layout is missing while tracing; build it eagerly first (from_hp does; for a "
+                                   "tensor loaded from a reference checkpoint call weight.tile_packed() once before torch.compile)")
+            if self.qdata.numel() == 0:
+                raise RuntimeError("Int4Tensor: PLAIN data was released (release_plain_) and no compute layout is present")
             n, k = self.shape
             g = self.block_size[-1]
-            if n % 16 != 0 or k % 128 != 0:
-                raise NotImplementedError(f"Int4Tensor linear on MI355X needs N % 16 == 0 and K % 128 == 0, got {tuple(self.shape)}")
+            npad, kpad = (-n) % 16, (-k) % max(128, g)
             b = self.qdata ^ 0x88                      # two's-complement nibble -> offset-8 code (0..15)
-            b = ((b << 4) | (b >> 4)).contiguous()     # tinygemm's nibble pack keeps even k in the HIGH nibble
-            qdata_tp = ops.convert_weight_to_int4pack(b, 8)
-            sz = torch.stack([self.scale, self.zero_point], dim=-1).to(torch.bfloat16).contiguous()
-            assert sz.shape == (k // g, n, 2)
-            self._tile_packed = (qdata_tp, sz)
-        return self._tile_packed
+            b = ((b << 4) | (b >> 4))                  # tinygemm's nibble pack keeps even k in the HIGH nibble
+            scale, zero = self.scale, self.zero_point
+            if npad or kpad:
+                b = F.pad(b, (0, kpad // 2, 0, npad), value=0x88)  # code 8 = value 0 * scale + zero_point
+                scale = F.pad(scale, (0, npad, 0, kpad // g))
+                zero = F.pad(zero, (0, npad, 0, kpad // g))
+            self.tp_qdata = ops.convert_weight_to_int4pack(b.contiguous(), 8)
+            self.tp_scale_and_zero = torch.stack([scale, zero], dim=-1).to(torch.bfloat16).contiguous()
+            assert self.tp_scale_and_zero.shape == ((k + kpad) // g, n + npad, 2)
+        return self.tp_qdata, self.tp_scale_and_zero
 
 
 implements = Int4Tensor.implements
@@ -133,6 +170,9 @@ def _(func, types, args, kwargs):
     x2 = input_tensor.reshape(-1, input_tensor.shape[-1]).to(torch.bfloat16)
     qdata_tp, sz = weight_tensor.tile_packed()
     g = weight_tensor.block_size[-1]
+    kp = qdata_tp.shape[1] * 128
+    if kp != x2.shape[-1]:  # the compute layout pads K to a multiple of 128
+        x2 = F.pad(x2, (0, kp - x2.shape[-1]))
     from ..torch_ops import kernels
 
     k = kernels(x2)
@@ -145,7 +185,7 @@ def _(func, types, args, kwargs):
         res = (res.float() * x_scale).to(torch.bfloat16)
     else:
         res = k.weight_int4pack_mm(x2.contiguous(), qdata_tp, g, sz)
-    res = res.reshape(*orig_act_size[:-1], n_out)
+    res = res[:, :n_out].reshape(*orig_act_size[:-1], n_out)
     if bias is not None:
         res = res + bias.to(res.dtype)
     return res.to(orig_dtype)
@@ -160,6 +200,8 @@ def _(func, types, args, kwargs):
     step = args[4] if len(args) > 4 else 1
     assert step == 1
     assert dim in (0, 1), f"Only dim==0 or 1 are supported, got: {dim}"
+    if self.qdata.numel() == 0:
+        raise RuntimeError("Int4Tensor: slicing needs the PLAIN data, which release_plain_() dropped")
     end = min(end, self.shape[dim])
     g = self.block_size[-1]
     pre = self.act_pre_scale
@@ -173,7 +215,11 @@ def _(func, types, args, kwargs):
         new_shape = (self.shape[0], end - start)
         if pre is not None and pre.numel() == self.shape[1]:
             pre = pre.reshape(-1)[start:end]
-    return Int4Tensor(qdata.contiguous(), scale.contiguous(), zero.contiguous(), self.block_size, new_shape, pre, self.activation_dtype)
+    out = Int4Tensor(qdata.contiguous(), scale.contiguous(), zero.contiguous(), self.block_size, new_shape, pre, self.activation_dtype)
+    from torch._subclasses.fake_tensor import is_fake
+    if not (torch.compiler.is_compiling() or is_fake(qdata)):
+        out.tile_packed()  # a shard is a weight like any other: its compute layout is built with it
+    return out
 
 
 torch.serialization.add_safe_globals([Int4Tensor])

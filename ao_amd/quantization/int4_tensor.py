@@ -66,10 +66,16 @@ class Int4TilePackedTo4dTensor(LowBitTensorBase):
         assert hp_tensor.dtype == torch.bfloat16, (
             f"Only bfloat16 is supported for Int4TilePackedTo4dTensor, got {hp_tensor.dtype}"
         )
-        assert hp_tensor.ndim == 2, "only 2-D weights are supported on the MI355X path"
+        assert hp_tensor.ndim in (2, 3), "2-D weights, or 3-D [experts, N, K] MoE weights (reference :206-217), are supported"
         if not hp_tensor.is_cuda:
             # reference: test_cant_initialize_in_cpu (needs a GPU device)
             raise RuntimeError("Int4TilePackedTo4dTensor.from_hp requires a GPU tensor")
+        if hp_tensor.ndim == 3:
+            # "for moe quant" (reference :206-217): every expert is packed on its own; qdata [E, N/8, K/128, 32, 4],
+            # scale_and_zero [E, K/g, N, 2]; aten.select.int(0, e) hands expert e to F.linear as a 2-D weight
+            per = [cls.from_hp(hp_tensor[i], list(block_size[1:]), int4_choose_qparams_algorithm, ntile_size) for i in range(hp_tensor.shape[0])]
+            return cls(torch.stack([p.qdata for p in per]), torch.stack([p.scale_and_zero for p in per]), list(block_size), hp_tensor.shape,
+                       act_pre_scale=None)
         group_size = block_size[-1]
         original_shape = hp_tensor.shape
         n0, k0 = original_shape
@@ -87,6 +93,8 @@ class Int4TilePackedTo4dTensor(LowBitTensorBase):
 
     def dequantize(self) -> torch.Tensor:
         """bf16 [N, K] (unpadded) with the reference dequant rounding."""
+        if self.qdata.dim() == 5:
+            return torch.stack([self[i].dequantize() for i in range(self.shape[0])])
         w = ops.int4_dequantize(self.qdata, self.scale_and_zero, self.block_size[-1])
         return w[: self.shape[0], : self.shape[1]]
 
@@ -101,6 +109,7 @@ def _(func, types, args, kwargs):
     """reference :243-299"""
     input_tensor, weight_tensor = args[0], args[1]
     bias = args[2] if len(args) > 2 else kwargs.get("bias", None)
+    assert weight_tensor.qdata.dim() == 4, "F.linear takes a 2-D weight: select an expert of a 3-D weight first (weight[e])"
     assert weight_tensor.qdata.is_contiguous(), "Expected qdata to be contiguous"
     assert weight_tensor.scale_and_zero.is_contiguous(), "Expected scale_and_zero to be contiguous"
     assert weight_tensor.block_size[0] == 1, (
@@ -171,6 +180,19 @@ def _(func, types, args, kwargs):
     block_size = list(self.block_size)
     block_size[dim] = min(block_size[dim], new_shape[dim])
     return Int4TilePackedTo4dTensor(qdata, sz, block_size, torch.Size(new_shape), act_pre_scale=self.act_pre_scale)
+
+
+@implements(aten.select.int)
+def _(func, types, args, kwargs):
+    """reference :363-385: expert selection on a 3-D (MoE) weight"""
+    self, dim, index = args
+    assert dim == 0, f"Int4TilePackedTo4dTensor aten.select.int with {dim=} is not yet supported"
+    assert self.qdata.dim() == 5, "aten.select.int needs a 3-D (per-expert) weight"
+    new_shape = list(self.shape)
+    new_shape.pop(dim)
+    block_size = list(self.block_size)
+    block_size.pop(dim)
+    return Int4TilePackedTo4dTensor(self.qdata[index], self.scale_and_zero[index], block_size, torch.Size(new_shape), act_pre_scale=self.act_pre_scale)
 
 
 torch.serialization.add_safe_globals([Int4TilePackedTo4dTensor])

@@ -94,8 +94,17 @@ class Int8Tensor(LowBitTensorBase):
         _check_granularity(granularity, "tensor")
         if hp_tensor.dtype != torch.bfloat16:
             raise NotImplementedError(f"Int8Tensor.from_hp on MI355X takes bfloat16, got {hp_tensor.dtype}")
+        if hp_tensor.dim() == 3:
+            # per-expert (MoE) weight: every expert quantized on its own, qdata [E, N, K], scale [E, N, 1] (PerRow) / [E, 1, 1];
+            # aten.select.int(0, e) (reference :492-517) hands expert e to F.linear
+            if act_quant_scale is not None or mapping_type != MappingType.SYMMETRIC:
+                raise NotImplementedError("3-D Int8Tensor weights on MI355X: symmetric, dynamic or weight-only")
+            per = [cls.from_hp(hp_tensor[i], granularity, mapping_type, act_quant_kwargs) for i in range(hp_tensor.shape[0])]
+            sums = None if per[0].w_row_sums is None else torch.stack([p.w_row_sums for p in per])
+            return cls(torch.stack([p.qdata for p in per]), torch.stack([p.scale for p in per]), [1] + per[0].block_size, hp_tensor.dtype,
+                       act_quant_kwargs=act_quant_kwargs, w_row_sums=sums)
         if hp_tensor.dim() != 2:
-            raise NotImplementedError("Int8Tensor.from_hp on MI355X takes 2-D tensors")
+            raise NotImplementedError("Int8Tensor.from_hp on MI355X takes 2-D tensors or 3-D [experts, N, K] weights")
         x = hp_tensor.contiguous()
         zero_point = None
         if mapping_type == MappingType.ASYMMETRIC:
@@ -151,6 +160,7 @@ def _(func, types, args, kwargs):
     _check_granularity(act.granularity, "activation")
     if w.zero_point is not None:
         raise NotImplementedError("Int8Tensor linear on MI355X takes symmetric weights (asymmetric is an ACTIVATION option in the reference)")
+    assert w.qdata.dim() == 2, "F.linear takes a 2-D weight: select an expert of a 3-D weight first (weight[e])"
     x2 = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
     n = w.qdata.shape[0]
     if x2.shape[0] == 0:
@@ -205,6 +215,19 @@ def _(func, types, args, kwargs):
             pre = pre.reshape(-1)[start:end]
     block_size = list(q.shape) if per_tensor else [1, q.shape[1]]
     return Int8Tensor(q, s, block_size, self.dtype_, self.act_quant_kwargs, pre, zp, sums, self.act_quant_scale, self.act_quant_zero_point)
+
+
+@implements(aten.select.int)
+def _(func, types, args, kwargs):
+    """reference :492-517: expert selection on a 3-D (MoE) weight"""
+    self, dim, index = args
+    assert dim == 0, f"Int8Tensor aten.select.int with {dim=} is not yet supported"
+    assert len(self.qdata.shape) == len(self.scale.shape), "unsupported"
+    assert len(self.qdata.shape) == len(self.block_size), "unsupported"
+    zp = None if self.zero_point is None else self.zero_point[index]
+    sums = None if self.w_row_sums is None else self.w_row_sums[index]
+    return Int8Tensor(self.qdata[index], self.scale[index], self.block_size[1:], self.dtype_, self.act_quant_kwargs, self.act_pre_scale, zp, sums,
+                      self.act_quant_scale, self.act_quant_zero_point)
 
 
 torch.serialization.add_safe_globals([Int8Tensor, QuantizeTensorToInt8Kwargs, MappingType])

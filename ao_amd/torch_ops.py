@@ -190,6 +190,20 @@ def _(inputs, offsets, padded_group_start_offsets, num_tokens, alignment_size):
     return inputs.new_empty((num_tokens, inputs.shape[1]))
 
 
+# ---- autograd: these are inference kernels ------------------------------------------------------------------------------------
+# Without an Autograd-key registration PyTorch warns on every call that sees a tensor requiring grad ("an autograd kernel was not
+# registered": 34 warnings in the round-2 GPU log).  The ops get an explicit FALLTHROUGH on the Autograd key: forward works on any
+# input, the outputs are cut off from the graph -- what the reference's inference subclasses do too (their aten kernels run on
+# `requires_grad=False` parameters).  (A backward stub that raises was tried first: AOT autograd traces the joint graph of a
+# module whose bias requires grad and would hit it at torch.compile time.)
+_lib_autograd = torch.library.Library("ao_mi355", "IMPL", "Autograd")
+for _name in ("weight_int4pack_mm", "convert_weight_to_int4pack", "int8_scaled_mm", "fp8_scaled_mm", "int8_dynamic_linear", "fp8_dynamic_linear",
+              "int8_linear", "fp8_linear", "int8_linear_asym", "int8_linear_tensorwise", "fp8_linear_tensorwise", "fp8_linear_clamped",
+              "int8_linear_static", "int8_quantize_rowwise", "fp8_quantize_rowwise", "mxfp8_quantize", "mxfp8_grouped_mm",
+              "fused_pad_token_groups", "fused_unpad_token_groups"):
+    _lib_autograd.impl(_name, torch.library.fallthrough_kernel)
+
+
 # ---- the C++ registrations (ao_amd/csrc_torch/binding.cpp -> _C_mi355_ops.so) ------------------------------------------
 # torchao::mxfp8_quantize / fused_pad_token_groups / fused_unpad_token_groups are IMPLEMENTED in the .so under the
 # reference's names (TORCH_LIBRARY_IMPL(torchao, CUDA)); their schemas are defined by torchao's Python when it is imported

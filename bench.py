@@ -40,10 +40,13 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
-MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA
-MFMA_8BIT_PEAK_TOPS = 5000.0     # dense fp8 / int8 MFMA (same guide: fp8 ~5 PF dense, int8 ~2x the bf16 rate)
-ROUND = "r02"                    # names of the committed rocprofv3 summaries under profiles/
+from ao_amd import roofline as _roofline  # noqa: E402  (the gfx950 entry of a roofline_utils.py-style spec table)
+
+_SPECS = _roofline.get_specs("AMD Instinct MI355X")
+HBM_PEAK_GBS = _SPECS["peak_mem_bw_bytes_sec"] / 1e9   # 8000: MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = _SPECS["bf16_peak_tops"] / 1e12  # 2500: dense bf16 MFMA
+MFMA_8BIT_PEAK_TOPS = _SPECS["fp8_peak_tops"] / 1e12     # 5000: dense fp8 / int8 MFMA (fp8 ~5 PF dense, int8 ~2x the bf16 rate)
+ROUND = "r03"                    # names of the committed rocprofv3 summaries under profiles/
 
 LLAMA3_8B_MERGED = [("qkv_proj", 6144, 4096), ("o_proj", 4096, 4096), ("gate_up_proj", 28672, 4096), ("down_proj", 4096, 14336)]
 LLAMA3_8B_UNMERGED = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate", 14336, 4096), ("up", 14336, 4096), ("down", 4096, 14336)]
@@ -76,7 +79,10 @@ def parse_args():
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
     ap.add_argument("--force-tp", action="store_true", help="run the TP-linear config even with one rank (exercises the RCCL path on a 1-GPU box)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning: ao_gemm8_set_variant for the 8-bit configs (profiling only)")
-    ap.add_argument("--tp-graph", action="store_true", help="TP config: capture each step (kernels + RCCL collectives) into a hipGraph")
+    ap.add_argument("--tp-graph", action="store_true", help=argparse.SUPPRESS)  # round 2's opt-in; graph replay is the default now
+    ap.add_argument("--no-tp-graph", action="store_true", help="TP config: launch eagerly (default: each step -- kernels + RCCL collectives -- replays from a hipGraph, eager if the capture fails)")
+    ap.add_argument("--no-stack-baseline", action="store_true", help="skip the PyTorch-core (what torchao-on-ROCm runs today) timing")
+    ap.add_argument("--no-subclass-graph", action="store_true", help="skip the quantize_()-subclass + F.linear graph timing (a13)")
     ap.add_argument("--tp-one-shot", action="store_true", help="TP config: accumulator all-reduces of <= 1 MiB through the symmetric-memory one-shot path (prototype; default RCCL)")
     return ap.parse_args()
 
@@ -146,6 +152,20 @@ def rocprof_avg_us(kernel_substr):
             if kernel_substr in row.get("Name", ""):
                 return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
     return None, None
+
+
+def pmc_traffic_of(config_key):
+    """HBM bytes per launch of a secondary config's dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/configs_pmc_<round>.json, scripts/gpu_profile.sh: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes)."""
+    path = os.path.join(ROOT, "profiles", f"configs_pmc_{ROUND}.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    e = d.get("configs", {}).get(config_key)
+    if not e:
+        return None, None
+    return e.get("hbm_bytes_per_launch"), f"{os.path.relpath(path, ROOT)}: {e.get('kernel', '?')}"
 
 
 def pmc_traffic(kernel):
@@ -275,7 +295,7 @@ def int4_roofline(model, batch, stream):
         out["peak_note"] = ("dense bf16 MFMA peak: the int4 weights are dequantised to bf16 (the oracle's arithmetic) and multiplied by "
                             "v_mfma_f32_16x16x32_bf16; the fp8 peak named by north_star does not bound this kernel")
         out["frac_of_fp8_mfma_peak"] = out["achieved"] / MFMA_8BIT_PEAK_TOPS
-        out["traffic"] = None
+        out["traffic"], out["traffic_source"] = pmc_traffic_of("int4_bs128")
     else:
         out["algorithmic_bytes_per_launch"] = kd["algorithmic_bytes_per_launch"]
         out["traffic"], out["traffic_source"] = pmc_traffic(dom)
@@ -284,6 +304,135 @@ def int4_roofline(model, batch, stream):
             out["rocprof"] = {"avg_kernel_us": avg, "achieved": kd["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9,
                               "frac": kd["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "source": src}
     return out
+
+
+def replay_stats(models, batch, stream, device, rounds=5, steps=10):
+    """Median / min / max tokens/s over `rounds` ALTERNATING graph replays of several weight layouts in one process: the pool's
+    boxes differ by a few per cent and a single timed region cannot tell a layout effect from a box effect."""
+    graphs = {}
+    for name, model in models.items():
+        run, graphed = capture(lambda m=model: m.step(batch, torch.cuda.current_stream().cuda_stream), stream)
+        graphs[name] = run
+    times = {name: [] for name in models}
+    with torch.cuda.stream(stream):
+        for _ in range(rounds):
+            for name, run in graphs.items():
+                run()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    run()
+                torch.cuda.synchronize(device)
+                times[name].append((time.perf_counter() - t0) / steps)
+    out = {}
+    for name, t in times.items():
+        t = sorted(t)
+        out[name] = {"tokens_per_s_median": batch / t[len(t) // 2], "tokens_per_s_best": batch / t[0], "tokens_per_s_worst": batch / t[-1],
+                     "rounds": rounds, "steps_per_round": steps}
+    return out
+
+
+def subclass_graph_tokens_per_s(model, stream, device, steps=20):
+    """SURVEY.md 8 row a13, measured: the SAME 160 packed weights wrapped as Int4TilePackedTo4dTensor parameters of nn.Linear
+    modules (what quantize_() leaves behind), one token through `module(x)` = F.linear -> __torch_function__ -> the kernel, the
+    whole token captured in a hipGraph (how a serving stack runs decode).  Eager tokens/s is reported beside it: the Python
+    dispatch + ctypes hop per linear is what the graph removes."""
+    from ao_amd.quantization.int4_tensor import Int4TilePackedTo4dTensor
+
+    mods, xs = [], []
+    for qdata, sz, n, k, _ in model.weights:
+        lin = torch.nn.Linear(k, n, bias=False, device="meta", dtype=torch.bfloat16)
+        lin.weight = torch.nn.Parameter(Int4TilePackedTo4dTensor(qdata, sz, [1, GROUP], torch.Size([n, k])), requires_grad=False)
+        mods.append(lin)
+    for (xp, qp, sp, yp, m, n, k, _), (x, _y) in zip(model.launches(1), model.io[1][0]):
+        xs.append(x)
+    def step():
+        for lin, x in zip(mods, xs):
+            lin(x)
+    with torch.no_grad():
+        eager = time_steps(step, stream, device, 5, 2) / 5
+        run, graphed = capture(step, stream)
+        t = time_steps(run, stream, device, steps, 3) / steps
+    return {"tokens_per_s": 1.0 / t, "eager_tokens_per_s": 1.0 / eager, "launch": "hipGraph replay" if graphed else "eager",
+            "path": "nn.Linear(weight=Int4TilePackedTo4dTensor).forward -> F.linear -> __torch_function__ -> ao_int4_weight_int4pack_mm"}
+
+
+def stack_baseline(model, stream, device, args):
+    """What torchao-on-ROCm runs TODAY on this box, timed beside our kernels (never the target): PyTorch core's own
+    aten::_weight_int4pack_mm (the op Int4TilePackedTo4dTensor calls, int4_tile_packed_to_4d_tensor.py:287) on the same packed
+    weights (the layouts are bit-identical) in the same 160-launch hipGraph, core's aten::_int_mm (int8/kernels.py:70) and
+    aten::_scaled_mm rowwise (float8/inference.py:104) on one representative shape each."""
+    out = {"note": "PyTorch-core kernels (hipBLASLt / core's hipified int4mm) on the same box and inputs; a same-node reference, not the target"}
+    if os.environ.get("AO_MI355_OVERRIDE_ATEN") == "1":
+        return {"skipped": "AO_MI355_OVERRIDE_ATEN=1: the aten ops ARE our kernels in this process"}
+    try:
+        ios = model.launches(1)
+        keep = model.io[1][0]
+        ws = model.weights
+        def step():
+            for (x, _y), (qdata, sz, n, k, _) in zip(keep, ws):
+                torch.ops.aten._weight_int4pack_mm(x, qdata, GROUP, sz)
+        with torch.no_grad():
+            run, graphed = capture(step, stream)
+            t = time_steps(run, stream, device, 10, 2) / 10
+        out["int4_bs1"] = {"op": "aten::_weight_int4pack_mm (PyTorch core)", "tokens_per_s": 1.0 / t, "launch": "hipGraph replay" if graphed else "eager"}
+        del ios
+    except Exception as e:  # noqa: BLE001
+        out["int4_bs1"] = {"error": repr(e)}
+    try:
+        m, n, k = 16384, 14336, 4096
+        a = torch.randint(-127, 127, (m, k), device=device, dtype=torch.int8)
+        b = torch.randint(-127, 127, (n, k), device=device, dtype=torch.int8)
+        fn = lambda: torch._int_mm(a, b.t())  # noqa: E731
+        with torch.no_grad():
+            run, graphed = capture(fn, stream)
+            t = time_steps(run, stream, device, 5, 2) / 5
+        out["int8_gemm"] = {"op": "aten::_int_mm (PyTorch core)", "shape": [m, n, k], "TOPs": 2.0 * m * n * k / t / 1e12, "ms": t * 1e3}
+        del a, b
+    except Exception as e:  # noqa: BLE001
+        out["int8_gemm"] = {"error": repr(e)}
+    try:
+        m, n, k = 2048, 7168, 8192
+        a = torch.randn(m, k, device=device).to(torch.float8_e4m3fn)
+        b = torch.randn(n, k, device=device).to(torch.float8_e4m3fn)
+        sa, sb = torch.rand(m, 1, device=device) + 0.5, torch.rand(1, n, device=device) + 0.5
+        fn = lambda: torch._scaled_mm(a, b.t(), scale_a=sa, scale_b=sb, out_dtype=torch.bfloat16, use_fast_accum=True)  # noqa: E731
+        with torch.no_grad():
+            run, graphed = capture(fn, stream)
+            t = time_steps(run, stream, device, 5, 2) / 5
+        out["fp8_rowwise_gemm"] = {"op": "aten::_scaled_mm rowwise (PyTorch core)", "shape": [m, n, k], "TFLOPs": 2.0 * m * n * k / t / 1e12, "ms": t * 1e3}
+    except Exception as e:  # noqa: BLE001
+        out["fp8_rowwise_gemm"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return out
+
+
+def reference_cpu_baseline_int4():
+    """BASELINE.md section 3 by the letter, when the reference checkout is reachable (the build container; never the GPU box):
+    torchao's own groupwise_affine_dequantize_tensor_from_qparams + bf16 F.linear on ONE layer's five linears at M = 1."""
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "torchao")):
+        return None
+    try:
+        sys.path.insert(0, ref)
+        from torchao.quantization.utils import groupwise_affine_dequantize_tensor_from_qparams, groupwise_affine_quantize_tensor_from_qparams, get_groupwise_affine_qparams  # noqa: E501
+        tt = 0.0
+        for _, n, k in LLAMA3_8B_UNMERGED:
+            w = torch.randn(n, k, dtype=torch.bfloat16) * 0.02
+            sc, zp = get_groupwise_affine_qparams(w, 4, GROUP, torch.bfloat16)
+            q = groupwise_affine_quantize_tensor_from_qparams(w, sc, zp, 4, GROUP)
+            x = torch.randn(1, k, dtype=torch.bfloat16)
+            t0 = time.perf_counter()
+            wd = groupwise_affine_dequantize_tensor_from_qparams(q, sc, zp, 4, GROUP)
+            torch.nn.functional.linear(x, wd)
+            tt += time.perf_counter() - t0
+        return {"value": 1.0 / (tt * N_LAYERS), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "reference",
+                "sample": "1 of 32 layers (5 linears) at M = 1 through torchao's groupwise_affine_dequantize_tensor_from_qparams + bf16 F.linear, x32"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+    finally:
+        if sys.path and sys.path[0] == ref:
+            sys.path.pop(0)
 
 
 def cpu_baseline_int4(batch):
@@ -370,7 +519,7 @@ def config_int8(stream, device, args):
            "value": M / (t * N_LAYERS), "unit": "tokens/s", "ms_per_layer": t * 1e3, "dtype": "int8 x int8 -> int32, bf16 out",
            "launch": "hipGraph replay" if graphed else "eager", "launches_per_layer": 2 * nchunk * len(ws),
            "roofline": {"kernel": "gemm8_p8_kernel<int8> (256x256 phase-interleaved; gemm8_dma_kernel below 160 tiles)", "bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_8BIT_PEAK_TOPS,
-                        "unit": "TOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_8BIT_PEAK_TOPS, "traffic": None,
+                        "unit": "TOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_8BIT_PEAK_TOPS, "traffic": pmc_traffic_of("int8")[0], "traffic_source": pmc_traffic_of("int8")[1],
                         "timing": "HIP extension events, one eager layer", "gemm_ms_per_layer": gemm_ms, "act_cast_ms_per_layer": cast_ms,
                         "end_to_end_TOPs": flops / t / 1e12}}
     if not args.no_cpu_baseline:
@@ -431,7 +580,8 @@ def config_fp8_shards(stream, device, args):
            "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (per GPU, M = 2048, before the all-reduce)", "dtype": "e4m3 x e4m3 -> fp32, bf16 out",
            "by_M": res,
            "roofline": {"kernel": "gemm8_p8_kernel<fp8> / gemm8_dma_kernel / rb8_kernel by shard shape", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
-                        "frac": res["M2048"]["frac"], "traffic": None, "timing": "hipGraph replay wall time of the whole step (casts included)"}}
+                        "frac": res["M2048"]["frac"], "traffic": pmc_traffic_of("fp8")[0], "traffic_source": pmc_traffic_of("fp8")[1],
+                        "timing": "hipGraph replay wall time of the whole step (casts included)"}}
     if not args.no_cpu_baseline:
         from oracle import c_ref
         rng = np.random.default_rng(2)
@@ -482,7 +632,8 @@ def config_mx(stream, device, args):
            "value": 64 / t, "unit": "tokens/s", "ms_per_step": t * 1e3, "dtype": "e4m3 x e4m3 with E8M0 1x32 block scales, bf16 out",
            "launch": "hipGraph replay" if graphed else "eager",
            "roofline": {"kernel": "rb8_kernel<RB8_MX>", "bound": "hbm", "achieved": bts / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bts / t / 1e9 / HBM_PEAK_GBS, "traffic": None, "timing": "hipGraph replay wall time of the whole step (activation casts included)",
+                        "frac": bts / t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_of("mx")[0], "traffic_source": pmc_traffic_of("mx")[1],
+                        "timing": "hipGraph replay wall time of the whole step (activation casts included)",
                         "bytes_note": "weights of the experts that received tokens only", "TFLOPs": flops / t / 1e12}}
     if not args.no_cpu_baseline:
         from oracle import c_ref
@@ -531,10 +682,10 @@ def config_fp8_tp(stream, device, args, dist, world):
         with torch.cuda.stream(stream):
             for _ in range(3):
                 step()
-        # decode-size steps are launch-bound in eager mode (six launches + two collectives per row-parallel linear): replay them
-        # from a hipGraph when --tp-graph asks for it (RCCL collectives are capturable; kept opt-in because a failed capture
-        # cannot be retried safely on a multi-rank run)
-        run, graphed = capture(step, stream, use_graph=True) if args.tp_graph else (step, False)
+        # decode-size steps are launch-bound in eager mode (six launches + two collectives per row-parallel linear: 27 tok/s eager vs
+        # 318 from a graph at M = 1, round 2): every step replays from a hipGraph (RCCL collectives are capturable) unless
+        # --no-tp-graph; a failed capture falls back to eager launches on every rank (capture() catches it)
+        run, graphed = (step, False) if args.no_tp_graph else capture(step, stream, use_graph=True)
         with torch.cuda.stream(stream):
             t = time_steps(run, stream, device, steps, 2, dist) / steps
             # the collectives alone, same sizes and order: amax MAX [M] + fp32 SUM [M, 8192] per row-parallel linear
@@ -610,15 +761,27 @@ def main():
 
     roof = int4_roofline(model, args.batch, stream) if rank == 0 else None
 
-    # the other module layout, for the record (rank 0 of a 1-GPU run only: it doubles resident weights)
-    other_tok_s = None
+    # the other module layout, for the record (rank 0 of a 1-GPU run only: it doubles resident weights); then both layouts
+    # replayed alternately (median / best / worst of 5 rounds), the subclass + F.linear path (a13) and the same-box stack baseline
+    other_tok_s, stats, subclass, stack = None, None, None, None
     if rank == 0 and world == 1 and not args.no_second_layout:
         m2 = Int4Linears(device, args.layers, LLAMA3_8B_UNMERGED if merged else LLAMA3_8B_MERGED)
         steps2 = min(args.steps, 20)
         e2, _ = run_int4(m2, args.batch, steps2, min(args.warmup, 3), stream, device, not args.no_graph)
         other_tok_s = args.batch * steps2 / e2
+        if not args.no_graph:
+            names = ("merged", "five") if merged else ("five", "merged")
+            stats = replay_stats({names[0]: model, names[1]: m2}, args.batch, stream, device)
         del m2
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.batch == 1 and not args.no_graph:
+        if not args.no_subclass_graph:
+            try:
+                subclass = subclass_graph_tokens_per_s(model, stream, device)
+            except Exception as e:  # noqa: BLE001
+                subclass = {"error": repr(e)}
+        if not args.no_stack_baseline:
+            stack = stack_baseline(model, stream, device, args)
 
     configs = {}
     want = set() if args.no_configs else set(args.configs.split(","))
@@ -669,13 +832,51 @@ def main():
                 "hbm_roofline_tokens_per_s": roofline_tok_s,
                 "frac_of_hbm_roofline_end_to_end": (tokens_per_s / world) / roofline_tok_s,
                 ("unmerged_tokens_per_s" if merged else "merged_tokens_per_s"): other_tok_s,
+                "replay_stats": stats,
+                "subclass_graph": subclass,
+                "subclass_graph_tokens_per_s": None if not subclass else subclass.get("tokens_per_s"),
             },
             "roofline": roof,
         }
+        if stack is not None:
+            out["stack_baseline"] = stack
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_int4(args.batch)
+            out["cpu_baseline"]["reference_checkout_reachable"] = os.path.isdir("/root/reference/torchao")
+            ref = reference_cpu_baseline_int4() if args.batch == 1 else None
+            if ref is not None:  # the build container only: the GPU box has no /root/reference (kind stays "port" there)
+                out["cpu_baseline_reference"] = ref
         if configs:
             out["configs"] = configs
+        # the driver's parser keeps top-level scalars only: every config's value / fraction again as flat keys
+        flat = {"roofline_frac": roof["frac"] if roof else None, "merged_tokens_per_s": other_tok_s if not merged else None,
+                "subclass_graph_tokens_per_s": None if not subclass else subclass.get("tokens_per_s")}
+        if stats:
+            for lay, st in stats.items():
+                flat[f"{lay}_tokens_per_s_median"] = st["tokens_per_s_median"]
+                flat[f"{lay}_tokens_per_s_best"] = st["tokens_per_s_best"]
+        if stack and "int4_bs1" in stack:
+            flat["stack_int4_bs1_tokens_per_s"] = stack["int4_bs1"].get("tokens_per_s")
+        c = configs
+        if "int4_bs128" in c and "value" in c["int4_bs128"]:
+            flat["int4_bs128_tokens_per_s"] = c["int4_bs128"]["value"]
+            flat["int4_bs128_frac_of_bf16_mfma_peak"] = c["int4_bs128"]["roofline"]["frac"]
+        if "int8_dyn_bs128x2048" in c and "value" in c["int8_dyn_bs128x2048"]:
+            flat["int8_dyn_tokens_per_s"] = c["int8_dyn_bs128x2048"]["value"]
+            flat["int8_dyn_gemm_frac_of_int8_mfma_peak"] = c["int8_dyn_bs128x2048"]["roofline"]["frac"]
+            flat["int8_dyn_end_to_end_frac_of_int8_mfma_peak"] = c["int8_dyn_bs128x2048"]["roofline"]["end_to_end_TOPs"] / MFMA_8BIT_PEAK_TOPS
+        if "fp8_tp8_shards" in c and "by_M" in c["fp8_tp8_shards"]:
+            for mk, r in c["fp8_tp8_shards"]["by_M"].items():
+                flat[f"fp8_shards_{mk}_tokens_per_s"] = r["tokens_per_s"]
+                flat[f"fp8_shards_{mk}_frac_of_{r['bound']}_peak"] = r["frac"]
+        if "mxfp8_mixtral_bs64" in c and "value" in c["mxfp8_mixtral_bs64"]:
+            flat["mxfp8_mixtral_tokens_per_s"] = c["mxfp8_mixtral_bs64"]["value"]
+            flat["mxfp8_mixtral_frac_of_hbm_peak"] = c["mxfp8_mixtral_bs64"]["roofline"]["frac"]
+        if "fp8_tp" in c and "by_M" in c["fp8_tp"]:
+            for mk, r in c["fp8_tp"]["by_M"].items():
+                flat[f"fp8_tp_{mk}_tokens_per_s"] = r["tokens_per_s"]
+                flat[f"fp8_tp_{mk}_allreduce_ms_per_8_layers"] = r["allreduce_ms_per_8_layers"]
+        out.update({k_: v for k_, v in flat.items() if v is not None})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

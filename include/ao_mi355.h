@@ -291,6 +291,34 @@ int ao_moe_unpad_token_groups(const void* padded, const int32_t* offsets,
                               int64_t dim, int elem_bytes, int64_t num_groups, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Expert-parallel token regrouping (between the all-to-all and the grouped GEMM)
+ * ------------------------------------------------------------------------- */
+
+/* Replaces generate_permute_indices (torchao/prototype/moe_training/ep/kernels.py:132-214; Triton `_fill_indices_kernel` :13-60,
+ * semantics of fill_indices_cpu :94-129).
+ *   tokens_per_expert_group int32 [num_ranks * experts_per_rank], rank-major counts of the tokens this rank received;
+ *   start_workspace         int32 [num_ranks * experts_per_rank] scratch (exclusive prefix sum of the counts);
+ *   permuted_indices        int32 [max_len]: source row of every expert-major position, -1 for alignment padding and the tail;
+ *   m_sizes / m_offsets     int32 [experts_per_rank]: align_up(max(tokens of expert, alignment), alignment) and its inclusive cumsum. */
+int ao_moe_permute_indices(const int32_t* tokens_per_expert_group, int32_t* start_workspace,
+                           int32_t* permuted_indices, int32_t* m_sizes, int32_t* m_offsets,
+                           int64_t experts_per_rank, int64_t num_ranks, int64_t max_len,
+                           int alignment, void* stream);
+
+/* Replaces the row gather `vstack(x, 0)[permuted_indices]` of permute_and_pad / _PermuteMXFP8FwdHPBwd.forward (ep/permute.py:86-96,
+ * 195-198) and of _UnpermuteHPFwdMXFP8Bwd.backward (ep/unpermute.py:57-98): out[i] = inputs[indices[i]] when 0 <= indices[i] <
+ * num_rows_in, else zeros (index -1 and index num_rows_in are the reference's appended zero row).  Rows are row_bytes bytes of any
+ * dtype (bf16 tokens, e4m3 data, e8m0 scales). */
+int ao_moe_gather_rows(const void* inputs, const int32_t* indices, void* out, int64_t num_rows_in,
+                       int64_t num_rows_out, int64_t row_bytes, void* stream);
+
+/* Replaces the row scatter `out[permuted_indices] = y; out[:-1]` of _UnpermuteHPFwdMXFP8Bwd.forward / _unpermute_bf16
+ * (ep/unpermute.py:36-41, 152-158): out[indices[i]] = inputs[i] when 0 <= indices[i] < num_rows_out (rows sent to the dummy row are
+ * dropped; rows of `out` no index names are left untouched, as in the reference's new_empty). */
+int ao_moe_scatter_rows(const void* inputs, const int32_t* indices, void* out, int64_t num_rows_in,
+                        int64_t num_rows_out, int64_t row_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Dynamic-activation linears with the activation cast fused in (decode sizes)
  * ------------------------------------------------------------------------- */
 

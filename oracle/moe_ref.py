@@ -37,3 +37,41 @@ def unpad_token_groups(padded, group_offsets, padded_group_start_offsets, num_to
     if out.shape[0] != num_tokens:
         raise RuntimeError(f"Unpad output size mismatch: expected {num_tokens} tokens but got {out.shape[0]} tokens. ")
     return out
+
+
+# ---- expert-parallel regrouping (torchao/prototype/moe_training/ep/) ------------------------------------------------------------
+def generate_permute_indices(tokens_per_expert_group, experts_per_rank, num_ranks, max_len, alignment):
+    """numpy restatement of generate_permute_indices + fill_indices_cpu (ep/kernels.py:94-129, 132-214): tokens arrive rank-major
+    (for rank r: expert 0's tokens, expert 1's, ...); the result lists, expert-major and with every expert's group padded to
+    `alignment` rows (an empty expert gets one aligned block), the source row of each position, -1 for padding.
+    Pinned by tests/golden/moe_permute.npz (make_golden.py:make_moe_permute)."""
+    c = np.asarray(tokens_per_expert_group, dtype=np.int64)
+    start = np.cumsum(c) - c                                              # :166-168
+    total = np.maximum(c.reshape(num_ranks, -1).sum(0), alignment)        # :171-174
+    m_sizes = ((total + alignment - 1) // alignment * alignment).astype(np.int32)  # :177-179
+    m_offsets = np.cumsum(m_sizes).astype(np.int32)                       # :183
+    write = m_offsets - m_sizes
+    idx = np.full(max_len, -1, dtype=np.int32)
+    for e in range(experts_per_rank):                                     # fill_indices_cpu :110-128
+        w = int(write[e])
+        for r in range(num_ranks):
+            i = r * experts_per_rank + e
+            n = int(c[i])
+            if n > 0:
+                end = min(w + n, max_len)
+                idx[w:end] = np.arange(start[i], start[i] + (end - w), dtype=np.int32)
+            w += n
+    return idx, m_sizes, m_offsets
+
+
+def gather_rows(x, idx):
+    """`vstack(x, 0)[idx]` (ep/permute.py:86-96, 195-198): index -1 (or len(x)) is the appended zero row."""
+    xp = np.concatenate([x, np.zeros((1,) + x.shape[1:], x.dtype)], axis=0)
+    return xp[np.asarray(idx, dtype=np.int64)]
+
+
+def scatter_rows(y, idx, num_rows):
+    """`out = empty(num_rows + 1); out[idx] = y; out[:-1]` (ep/unpermute.py:36-41, 152-158); rows nothing names stay zero here."""
+    out = np.zeros((num_rows + 1,) + y.shape[1:], y.dtype)
+    out[np.asarray(idx, dtype=np.int64)] = y
+    return out[:-1]

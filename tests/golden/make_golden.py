@@ -289,11 +289,43 @@ def make_int8_fp8_variants():
     print("int8_fp8_variants.npz:", {k_: v.shape for k_, v in out.items()})
 
 
+def make_moe_permute():
+    """ep/kernels.py generate_permute_indices (its own CPU restatement, use_cpu=True) + ep/permute.py permute_and_pad +
+    ep/unpermute.py _unpermute_bf16 on seeded routing tables: the fixtures of the HIP regrouping kernels."""
+    from torchao.prototype.moe_training.ep.kernels import generate_permute_indices
+    from torchao.prototype.moe_training.ep.permute import permute_and_pad as _unused  # noqa: F401  (import check: same module the mirror cites)
+
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    cases = [(4, 2, 32, 24), (3, 5, 16, 16), (8, 1, 32, 8), (2, 8, 32, 40)]  # (experts per rank, ranks, alignment, dim)
+    for ci, (E, R, align, dim) in enumerate(cases):
+        counts = torch.randint(0, 9, (R * E,), generator=g, dtype=torch.int32)
+        if ci == 1:
+            counts.view(R, E)[:, 2] = 0  # an expert nobody routed to: one aligned block of padding
+        T = int(counts.sum())
+        max_len = (T + E * align + align - 1) // align * align
+        idx, m_sizes, m_offsets = generate_permute_indices(counts, E, R, max_len, align, use_cpu=True)
+        x = torch.randn(T, dim, generator=g).to(torch.bfloat16)
+        xp = torch.vstack((x, x.new_zeros((1, dim))))
+        permuted = xp[idx.long(), :]
+        y = torch.randn(max_len, dim, generator=g).to(torch.bfloat16)
+        un = y.new_zeros((T + 1, dim))
+        un[idx.long(), :] = y
+        out[f"c{ci}_meta"] = np.array([E, R, align, dim, T, max_len], dtype=np.int64)
+        out[f"c{ci}_counts"] = counts.numpy()
+        out[f"c{ci}_idx"], out[f"c{ci}_m_sizes"], out[f"c{ci}_m_offsets"] = idx.numpy(), m_sizes.numpy(), m_offsets.numpy()
+        out[f"c{ci}_x"], out[f"c{ci}_permuted"] = bits(x), bits(permuted)
+        out[f"c{ci}_y"], out[f"c{ci}_unpermuted"] = bits(y), bits(un[:-1])
+    np.savez_compressed(os.path.join(HERE, "moe_permute.npz"), **out)
+    print("moe_permute.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
 def make_rest():
     make_int8_fp8()
     make_int8_fp8_variants()
     make_mx()
     make_moe()
+    make_moe_permute()
     make_int4_plain()
     make_hqq()
 

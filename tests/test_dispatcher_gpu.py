@@ -142,7 +142,7 @@ def test_opcheck_custom_ops():
     opcheck(torch.ops.torchao.fused_pad_token_groups.default, (x32, offs, 32), test_utils=utils)
 
 
-@pytest.mark.parametrize("kind", ["int4", "int8", "fp8", "int8_asym", "int8_pt", "fp8_pt", "int8_static", "fp8_clamped"])
+@pytest.mark.parametrize("kind", ["int4", "int4_plain", "int8", "fp8", "int8_asym", "int8_pt", "fp8_pt", "int8_static", "fp8_clamped"])
 def test_torch_compile_fullgraph_through_the_subclass(kind):
     """torch.compile(fullgraph=True) traces F.linear on the quantized weight to ONE extern call of the ao_mi355:: op (the
     reference asserts the same shape of graph: extern_kernels._int_mm, test_int8_tensor.py:276-278) and reproduces eager."""
@@ -154,7 +154,9 @@ def test_torch_compile_fullgraph_through_the_subclass(kind):
 
     torch.manual_seed(0)
     lin = torch.nn.Linear(1024, 256, bias=True).to(torch.bfloat16).to(DEV)
-    cfg = {"int4": Int4WeightOnlyConfig(group_size=128, int4_packing_format="tile_packed_to_4d"), "int8": Int8DynamicActivationInt8WeightConfig(),
+    cfg = {"int4": Int4WeightOnlyConfig(group_size=128, int4_packing_format="tile_packed_to_4d"),
+           "int4_plain": Int4WeightOnlyConfig(group_size=128),  # the DEFAULT packing format (PLAIN): its compute layout is an inner tensor
+           "int8": Int8DynamicActivationInt8WeightConfig(),
            "fp8": Float8DynamicActivationFloat8WeightConfig(granularity=PerRow()),
            "int8_asym": Int8DynamicActivationInt8WeightConfig(act_mapping_type=MappingType.ASYMMETRIC),
            "int8_pt": Int8DynamicActivationInt8WeightConfig(granularity=PerTensor()),
@@ -176,7 +178,7 @@ def test_torch_compile_fullgraph_through_the_subclass(kind):
 
     got = torch.compile(lin, fullgraph=True, backend=aot_autograd(fw_compiler=fw_compiler))(x)
     assert torch.equal(got, want)
-    opname = {"int4": "ao_mi355.weight_int4pack_mm", "int8": "ao_mi355.int8_linear.", "fp8": "ao_mi355.fp8_linear.",
+    opname = {"int4": "ao_mi355.weight_int4pack_mm", "int4_plain": "ao_mi355.weight_int4pack_mm", "int8": "ao_mi355.int8_linear.", "fp8": "ao_mi355.fp8_linear.",
               "int8_asym": "ao_mi355.int8_linear_asym", "int8_pt": "ao_mi355.int8_linear_tensorwise", "fp8_pt": "ao_mi355.fp8_linear_tensorwise",
               "int8_static": "ao_mi355.int8_linear_static", "fp8_clamped": "ao_mi355.fp8_linear_clamped"}[kind]
     assert sum(opname in t for t in seen) == 1, seen

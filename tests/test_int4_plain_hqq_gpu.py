@@ -155,3 +155,31 @@ def test_hqq_vs_oracle_and_beats_tinygemm(n, k, g):
     y = np_from_torch_bf16(torch.nn.functional.linear(x.to(DEV), t))
     y_ref = bf16.bf16_round((x.float().numpy().astype(np.float64) @ dq_hqq.astype(np.float64).T).astype(np.float32))
     assert _rel(y, y_ref) <= 1e-3
+
+
+@pytest.mark.gpu
+def test_plain_int4_ragged_shapes_and_release():
+    """the default (PLAIN) format must not defer failures to the first forward: N % 16 != 0 and K % 128 != 0 are padded
+    inside the compute layout (built at from_hp), detach / clone keep it, and release_plain_() halves the resident bytes."""
+    import torch
+    from ao_amd.quantization import Int4WeightOnlyConfig, quantize_
+
+    torch.manual_seed(3)
+    n, k, g = 40, 192, 64  # N % 16 = 8, K % 128 = 64
+    lin = torch.nn.Linear(k, n, bias=False).to(torch.bfloat16).cuda()
+    w = lin.weight.detach().clone()
+    quantize_(lin, Int4WeightOnlyConfig(group_size=g))
+    wt = lin.weight
+    assert type(wt).__name__ == "Int4Tensor" and wt.tp_qdata is not None, "compute layout must exist right after quantize_"
+    assert wt.tp_qdata.shape[0] * 8 == 48 and wt.tp_qdata.shape[1] * 128 == 256
+    x = torch.randn(3, k, dtype=torch.bfloat16, device="cuda")
+    y = lin(x)
+    ref = torch.nn.functional.linear(x, wt.dequantize())
+    assert y.shape == (3, n) and torch.allclose(y.float(), ref.float(), rtol=2e-2, atol=2e-2)
+    assert (y.float() - torch.nn.functional.linear(x, w).float()).norm() / torch.nn.functional.linear(x, w).float().norm() < 0.2
+    d = wt.detach()
+    assert d.tp_qdata is not None and d.tp_qdata.data_ptr() == wt.tp_qdata.data_ptr()
+    wt.release_plain_()
+    assert wt.qdata.numel() == 0 and torch.equal(lin(x), y)
+    with pytest.raises(RuntimeError):
+        wt[:16]

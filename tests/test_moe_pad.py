@@ -7,6 +7,7 @@ import torch
 
 from conftest import GOLDEN, np_from_torch_bf16, torch_bf16_from_f32  # noqa: F401
 from oracle import moe_ref as R
+M = R  # the regrouping tests below name it M (R is a rank count there)
 
 CASES = ["ragged", "aligned16", "single", "odd_dim"]
 
@@ -126,3 +127,67 @@ def test_argument_errors():
         ops.fused_pad_token_groups(x.cpu(), offs.cpu(), 32)
     p, s, e = ops.fused_pad_token_groups(x[:0], torch.tensor([0], dtype=torch.int32, device="cuda"), 32)  # no tokens
     assert p.shape == (32, 8) and not p.any() and s.item() == 0 and e.item() == 0
+
+
+# ---- expert-parallel regrouping: generate_permute_indices / permute / unpermute (ep/kernels.py, permute.py, unpermute.py) -------------
+def _permute_cases():
+    d = np.load(os.path.join(GOLDEN, "moe_permute.npz"))
+    ci = 0
+    while f"c{ci}_meta" in d:
+        E, R, align, dim, T, max_len = (int(v) for v in d[f"c{ci}_meta"])
+        yield ci, d, E, R, align, dim, T, max_len
+        ci += 1
+
+
+def test_permute_oracle_matches_the_reference_fixtures():
+    """oracle/moe_ref.py vs outputs of the reference's own generate_permute_indices(use_cpu=True) / row gather / row scatter"""
+    n = 0
+    for ci, d, E, R, align, dim, T, max_len in _permute_cases():
+        idx, m_sizes, m_offsets = M.generate_permute_indices(d[f"c{ci}_counts"], E, R, max_len, align)
+        assert np.array_equal(idx, d[f"c{ci}_idx"]) and np.array_equal(m_sizes, d[f"c{ci}_m_sizes"]) and np.array_equal(m_offsets, d[f"c{ci}_m_offsets"])
+        assert np.array_equal(M.gather_rows(d[f"c{ci}_x"], idx), d[f"c{ci}_permuted"])
+        assert np.array_equal(M.scatter_rows(d[f"c{ci}_y"], idx, T), d[f"c{ci}_unpermuted"])
+        # properties: a permutation of the real rows plus padding; group sizes aligned and >= alignment
+        real = idx[idx >= 0]
+        assert sorted(real.tolist()) == list(range(T)) and (m_sizes % align == 0).all() and (m_sizes >= align).all()
+        n += 1
+    assert n >= 4
+
+
+@pytest.mark.gpu
+def test_permute_kernels_match_oracle_and_fixtures():
+    import torch
+    from ao_amd import ops
+    from ao_amd.prototype import ep
+
+    dev = torch.device("cuda", 0)
+    for ci, d, E, R, align, dim, T, max_len in _permute_cases():
+        counts = torch.from_numpy(d[f"c{ci}_counts"]).to(dev)
+        idx, m_sizes, m_offsets = ops.generate_permute_indices(counts, E, R, max_len, align)
+        assert np.array_equal(idx.cpu().numpy(), d[f"c{ci}_idx"])
+        assert np.array_equal(m_sizes.cpu().numpy(), d[f"c{ci}_m_sizes"]) and np.array_equal(m_offsets.cpu().numpy(), d[f"c{ci}_m_offsets"])
+        x = torch.from_numpy(d[f"c{ci}_x"].view(np.int16)).view(torch.bfloat16).to(dev)
+        shape, xp, idx2, sizes2, offs2 = ep.permute_and_pad(x, counts, R, E, align)
+        assert tuple(shape) == (T + 1, dim) and torch.equal(idx2, idx)
+        assert np.array_equal(xp.view(torch.int16).cpu().numpy().view(np.uint16), d[f"c{ci}_permuted"])
+        y = torch.from_numpy(d[f"c{ci}_y"].view(np.int16)).view(torch.bfloat16).to(dev)
+        un = ep.unpermute_hp_fwd(y, idx, shape)
+        assert np.array_equal(un.view(torch.int16).cpu().numpy().view(np.uint16), d[f"c{ci}_unpermuted"])
+        # round trip: unpermute(permute(x)) == x
+        assert torch.equal(ep.unpermute_hp_fwd(xp, idx, shape), x)
+    # a larger seeded case against the oracle, odd row width (byte path), uint8 rows (e8m0 scales), many experts
+    rng = np.random.default_rng(5)
+    E, R, align = 96, 3, 32
+    counts_np = rng.integers(0, 40, size=R * E).astype(np.int32)
+    T = int(counts_np.sum())
+    max_len = (T + E * align + align - 1) // align * align
+    want_idx, want_sizes, want_offs = M.generate_permute_indices(counts_np, E, R, max_len, align)
+    idx, sizes, offs = ops.generate_permute_indices(torch.from_numpy(counts_np).to(dev), E, R, max_len, align)
+    assert np.array_equal(idx.cpu().numpy(), want_idx) and np.array_equal(sizes.cpu().numpy(), want_sizes) and np.array_equal(offs.cpu().numpy(), want_offs)
+    for width, dt in ((45, np.uint8), (224, np.uint8), (7168, np.uint16)):
+        x_np = rng.integers(0, np.iinfo(dt).max, size=(T, width)).astype(dt)
+        xt = torch.from_numpy(x_np.view(np.int16 if dt == np.uint16 else np.uint8)).to(dev)
+        got = ops.gather_rows(xt, idx).cpu().numpy().view(dt)
+        assert np.array_equal(got, M.gather_rows(x_np, want_idx))
+        back = ops.scatter_rows(ops.gather_rows(xt, idx), idx, T).cpu().numpy().view(dt)
+        assert np.array_equal(back, x_np)

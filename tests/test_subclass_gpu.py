@@ -211,3 +211,59 @@ def test_dispatcher_ops_and_aten_override():
     _lib.check(lib.ao_prof_collect(buf, 4, ctypes.byref(cnt)))
     assert cnt.value == 3  # mm + unpack + pack all went through ao_amd/_C_mi355.so
     assert torch.equal(y2, y) and torch.equal(q2, qdata)
+
+
+@pytest.mark.gpu
+def test_select_int_on_3d_expert_weights():
+    """aten.select.int (MoE expert selection; reference int4_tile_packed_to_4d_tensor.py:363-385, int8_tensor.py:492-517): a 3-D
+    [experts, N, K] weight quantized per expert, weight[e] == the 2-D tensor quantized from hp[e], bit for bit (the reference's
+    test_select asserts atol = 0, test_int4_tile_packed_to_4d_tensor.py:262-295)."""
+    import torch
+    import torch.nn.functional as F
+    from ao_amd.quantization.int4_tensor import Int4TilePackedTo4dTensor
+    from ao_amd.quantization.int8_tensor import Int8Tensor, QuantizeTensorToInt8Kwargs
+
+    torch.manual_seed(4)
+    E, n, k = 3, 64, 1024
+    w = (torch.randn(E, n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    x = torch.randn(5, k, device="cuda", dtype=torch.bfloat16)
+    w4 = Int4TilePackedTo4dTensor.from_hp(w, [1, 1, 128])
+    assert tuple(w4.shape) == (E, n, k) and w4.qdata.dim() == 5
+    w8 = Int8Tensor.from_hp(w, act_quant_kwargs=QuantizeTensorToInt8Kwargs())
+    assert tuple(w8.qdata.shape) == (E, n, k) and tuple(w8.scale.shape) == (E, n, 1) and w8.block_size == [1, 1, k]
+    for e in range(E):
+        one4 = Int4TilePackedTo4dTensor.from_hp(w[e], [1, 128])
+        sel4 = w4[e]
+        assert type(sel4) is Int4TilePackedTo4dTensor and tuple(sel4.shape) == (n, k) and sel4.block_size == [1, 128]
+        assert torch.equal(sel4.qdata, one4.qdata) and torch.equal(sel4.scale_and_zero, one4.scale_and_zero)
+        assert torch.equal(F.linear(x, sel4), F.linear(x, one4))
+        one8 = Int8Tensor.from_hp(w[e], act_quant_kwargs=QuantizeTensorToInt8Kwargs())
+        sel8 = w8[e]
+        assert type(sel8) is Int8Tensor and sel8.block_size == [1, k]
+        assert torch.equal(sel8.qdata, one8.qdata) and torch.equal(sel8.scale, one8.scale)
+        assert torch.equal(F.linear(x, sel8), F.linear(x, one8))
+    assert torch.equal(w4.dequantize()[1], w4[1].dequantize())
+    with pytest.raises(AssertionError):
+        F.linear(x, w4)
+
+
+@pytest.mark.gpu
+def test_float8_select_int_on_3d_expert_weights():
+    """reference float8_tensor.py:936-955"""
+    import torch
+    import torch.nn.functional as F
+    from ao_amd.quantization.float8_tensor import Float8Tensor, QuantizeTensorToFloat8Kwargs
+    from ao_amd.quantization.granularity import PerRow
+
+    torch.manual_seed(6)
+    E, n, k = 3, 64, 512
+    w = (torch.randn(E, n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    x = torch.randn(4, k, device="cuda", dtype=torch.bfloat16)
+    kw = QuantizeTensorToFloat8Kwargs(granularity=PerRow())
+    w3 = Float8Tensor.from_hp(w, granularity=PerRow(), act_quant_kwargs=kw)
+    for e in range(E):
+        one = Float8Tensor.from_hp(w[e], granularity=PerRow(), act_quant_kwargs=kw)
+        sel = w3[e]
+        assert type(sel) is Float8Tensor and tuple(sel.shape) == (n, k)
+        assert torch.equal(sel.qdata.view(torch.uint8), one.qdata.view(torch.uint8)) and torch.equal(sel.scale, one.scale)
+        assert torch.equal(F.linear(x, sel), F.linear(x, one))
