@@ -68,6 +68,7 @@ _SIGNATURES = {
     "ao_moe_padded_rows": [_I64, _I64, _INT],
     "ao_moe_pad_token_groups": [_P, _P, _P, _P, _P, _I64, _I64, _INT, _I64, _INT, _P],
     "ao_moe_unpad_token_groups": [_P, _P, _P, _P, _I64, _I64, _INT, _I64, _P],
+    "ao_fp8_int4_linear": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_permute_indices": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_gather_rows": [_P, _P, _P, _I64, _I64, _I64, _P],
     "ao_moe_scatter_rows": [_P, _P, _P, _I64, _I64, _I64, _P],

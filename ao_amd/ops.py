@@ -802,6 +802,29 @@ def fused_pad_token_groups(inputs, offsets, alignment_size=32):
     return padded, starts, ends
 
 
+def fp8_int4_linear(xq, x_scale, qdata, scale_and_zero, group_size, bias=None):
+    """mslk.f8i4bf16_rowwise's contract (int4_tensor.py:213-229): e4m3 activations [M, K] with per-row fp32 scales x int4 weights in the
+    tinygemm tile order (offset-8 codes; scale_and_zero bf16 [K/g, N, 2]) -> bf16 [M, N]; the group scale multiplies fp32 group sums."""
+    dev = _require_gpu("fp8_int4_linear", xq, x_scale, qdata, scale_and_zero)
+    xq = _fp8_bytes("fp8_int4_linear", xq)
+    if xq.dim() != 2 or qdata.dim() != 4 or qdata.dtype != torch.int32 or scale_and_zero.dtype != torch.bfloat16:
+        raise RuntimeError("fp8_int4_linear: expected xq [M, K] e4m3, qdata int32 [N/8, K/128, 32, 4], scale_and_zero bf16 [K/g, N, 2]")
+    m, k = xq.shape
+    n = qdata.shape[0] * 8
+    if qdata.shape[1] * 128 != k or tuple(scale_and_zero.shape) != (k // group_size, n, 2):
+        raise RuntimeError(f"fp8_int4_linear: shapes do not agree: xq {tuple(xq.shape)}, qdata {tuple(qdata.shape)}, scale_and_zero {tuple(scale_and_zero.shape)}")
+    xs = x_scale.reshape(-1).to(torch.float32).contiguous()
+    if xs.numel() != m:
+        raise RuntimeError("fp8_int4_linear: one activation scale per row expected")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_fp8_int4_linear(_ptr(xq.contiguous()), _ptr(xs), _ptr(qdata.contiguous()), _ptr(scale_and_zero.contiguous()),
+                                                 _ptr(bias) if bias is not None else None, _ptr(y), m, n, k, group_size, _stream()))
+    return y
+
+
 def generate_permute_indices(tokens_per_expert_group, experts_per_rank, num_ranks, max_len, alignment):
     """torchao.prototype.moe_training.ep.kernels.generate_permute_indices (kernels.py:132-214): expert-major gather indices with every
     expert's group padded to `alignment` rows.  Returns (permuted_indices int32 [max_len] with -1 for padding, m_sizes int32 [E],

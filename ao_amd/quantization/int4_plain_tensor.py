@@ -11,8 +11,9 @@ slice semantics).  The reference needs the un-vendored `mslk` package for both t
   bf16(bf16(q * scale) + zero_point) (zero_point is the value of the middle code in both), so the packed nibbles and the
   scale / zero_point pair are re-laid ONCE into the tile-packed layout (a side buffer next to the checkpoint-format data)
   and `_weight_int4pack_mm` serves it -- same oracle, same kernels, same speed as Int4TilePackedTo4dTensor;
-* activation_dtype = float8_e4m3fn: the activation is cast per row to e4m3 (Float8Tensor's cast), multiplied as those
-  values, and the row scale is applied to the output -- the arithmetic shape of mslk.f8i4bf16_rowwise.
+* activation_dtype = float8_e4m3fn: the activation is cast per row to e4m3 (Float8Tensor's cast) and multiplied with the int4 codes
+  by the fp8 x int4 MFMA kernel (ops.fp8_int4_linear, csrc/fp8_int4_kernels.hip): group scales on fp32 group sums, the row scale on
+  the result -- mslk.f8i4bf16_rowwise's contract.
 """
 from typing import List, Optional
 
@@ -179,10 +180,10 @@ def _(func, types, args, kwargs):
     if x2.shape[0] == 0:
         res = x2.new_zeros((0, n_out))
     elif weight_tensor.activation_dtype == torch.float8_e4m3fn:
-        # dynamic rowwise fp8 activation (mslk.f8i4bf16_rowwise's shape: (xq @ dq(w)) * x_scale); e4m3 values are exact in bf16
+        # dynamic rowwise fp8 activation, then the fp8 x int4 MFMA kernel (mslk.f8i4bf16_rowwise's contract: the e4m3 codes meet the
+        # int4 codes on the matrix pipe, group scales multiply fp32 group sums, the row scale the result)
         xq, x_scale = k.fp8_quantize_rowwise(x2.contiguous())
-        res = k.weight_int4pack_mm(xq.to(torch.bfloat16), qdata_tp, g, sz)
-        res = (res.float() * x_scale).to(torch.bfloat16)
+        res = k.fp8_int4_linear(xq, x_scale, qdata_tp, sz, g, None)
     else:
         res = k.weight_int4pack_mm(x2.contiguous(), qdata_tp, g, sz)
     res = res[:, :n_out].reshape(*orig_act_size[:-1], n_out)

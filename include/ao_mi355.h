@@ -291,6 +291,21 @@ int ao_moe_unpad_token_groups(const void* padded, const int32_t* offsets,
                               int64_t dim, int elem_bytes, int64_t num_groups, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * fp8 activations x int4 weights (Float8DynamicActivationInt4WeightConfig)
+ * ------------------------------------------------------------------------- */
+
+/* Replaces mslk.f8i4bf16_rowwise as called by Int4Tensor's F.linear with activation_dtype = float8_e4m3fn
+ * (torchao/quantization/quantize_/workflows/int4/int4_tensor.py:213-229; quant_api.py:630-699):
+ *   xq e4m3 [M][K], x_scale fp32 [M] (per-row dynamic cast: ao_fp8_quantize_rowwise);
+ *   qdata / scale_and_zero: the int4 weight in the tinygemm tile order with offset-8 codes (what Int4Tensor.tile_packed() builds from
+ *   the PLAIN data; scale_and_zero bf16 [K/group_size][N][2], zero = 0 for the reference's symmetric flavour); bias bf16 [N] or NULL.
+ *   y[m][n] = bf16( x_scale[m] * sum_g ( s[g][n] * sum_{k in g} xq[m][k] (q[n][k] - 8) + z[g][n] * sum_{k in g} xq[m][k] ) + bias[n] )
+ * fp8 MFMA on the codes themselves, the scale applied per group to fp32 sums (no per-weight rounding).  N % 16 == 0, K % 128 == 0. */
+int ao_fp8_int4_linear(const uint8_t* xq, const float* x_scale, const int32_t* qdata,
+                       const uint16_t* scale_and_zero, const uint16_t* bias, uint16_t* y, int64_t M,
+                       int64_t N, int64_t K, int group_size, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Expert-parallel token regrouping (between the all-to-all and the grouped GEMM)
  * ------------------------------------------------------------------------- */
 
