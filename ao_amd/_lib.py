@@ -68,6 +68,9 @@ _SIGNATURES = {
     "ao_moe_padded_rows": [_I64, _I64, _INT],
     "ao_moe_pad_token_groups": [_P, _P, _P, _P, _P, _I64, _I64, _INT, _I64, _INT, _P],
     "ao_moe_unpad_token_groups": [_P, _P, _P, _P, _I64, _I64, _INT, _I64, _P],
+    "ao_allreduce_flag_bytes": [],
+    "ao_allreduce_state_bytes": [],
+    "ao_allreduce_oneshot": [_P, _P, _P, _P, _P, _I64, _INT, _I64, _INT, _INT, _P],
     "ao_fp8_int4_linear": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_permute_indices": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_gather_rows": [_P, _P, _P, _I64, _I64, _I64, _P],
@@ -109,6 +112,8 @@ def lib():
         l.ao_last_error.restype = ctypes.c_char_p
         l.ao_int4_mm_kernel_name.restype = ctypes.c_char_p
         l.ao_moe_padded_rows.restype = _I64
+        l.ao_allreduce_flag_bytes.restype = _I64
+        l.ao_allreduce_state_bytes.restype = _I64
         l.ao_int4_hqq_workspace_bytes.restype = _I64
         _lib = l
     return _lib

@@ -31,40 +31,104 @@ __all__ = ["shard_bounds", "shard_unit", "ColumnParallelLinear", "RowParallelLin
 
 
 class OneShotAllReduce:
-    """SUM all-reduce of SMALL float tensors (decode: a bf16 [1, 8192] partial is 16 KiB) in one hop: every rank publishes its
-    vector in a peer-mapped symmetric buffer, one signal round, every rank reads all peers' buffers over xGMI and adds
-    (`torch.distributed._symmetric_memory` + `symm_mem::one_shot_all_reduce`; SURVEY.md 8(e): "direct / one-shot algorithm for
-    S <= ~1 MiB, never a ring on the fully connected 8-GPU xGMI mesh").  RCCL's all_reduce stays the path for anything larger, for
-    integer / MAX reductions, and whenever symmetric memory cannot be set up (the constructor then leaves `ok` False and the
-    call falls through to RCCL).  PROTOTYPE: exercised here on a world of one GPU only -- no 2-GPU node was available to this build.
+    """SUM all-reduce of SMALL tensors (decode: a bf16 [1, 8192] partial is 16 KiB, the exact protocol's fp32 accumulator 32 KiB) in one
+    hop: every rank stages its vector in a buffer all peers have mapped, raises a flag in every peer, waits for all flags, reads all
+    staged vectors over xGMI and adds them in rank order ("direct / one-shot algorithm for S <= ~1 MiB, never a ring
+    on the fully connected 8-GPU xGMI mesh").
+
+    backend "hip" (default): the hand-written kernel `ao_allreduce_oneshot` (csrc/allreduce_kernels.hip) over buffers exchanged as IPC
+    handles (torch's CUDA-IPC storage sharing; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack) -- fp32 / bf16 / int32, bit-identical
+    on every rank, capturable into a hipGraph (epochs live on the device).  backend "symm_mem": `torch.distributed._symmetric_memory`
+    + `symm_mem::one_shot_all_reduce` (round 2's prototype).  RCCL's all_reduce stays the path for anything larger, for MAX
+    reductions, and whenever the set-up fails (`ok` False, `why` says what happened).  Verified on one GPU with two processes
+    (tests/test_oneshot_allreduce_gpu.py); no multi-GPU node was available to this build.
     """
 
-    def __init__(self, group=None, max_bytes: int = 1 << 20, device=None):
+    _DT = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2}
+
+    def __init__(self, group=None, max_bytes: int = 1 << 20, device=None, backend: str = "hip"):
         self.group = dist.group.WORLD if group is None else group
-        self.max_bytes = max_bytes
+        self.max_bytes = (max_bytes + 15) // 16 * 16
         self.ok = False
         self.why = None
+        self.backend = backend
+        self.calls = 0
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.device = device
         try:
-            import torch.distributed._symmetric_memory as symm_mem
+            if backend == "hip":
+                self._setup_hip(device)
+            else:
+                import torch.distributed._symmetric_memory as symm_mem
 
-            device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-            self.group_name = self.group.group_name
-            if hasattr(symm_mem, "enable_symm_mem_for_group"):
-                symm_mem.enable_symm_mem_for_group(self.group_name)
-            self.buf = symm_mem.empty(max_bytes, dtype=torch.uint8, device=device)
-            self.handle = symm_mem.rendezvous(self.buf, self.group_name)
+                self.group_name = self.group.group_name
+                if hasattr(symm_mem, "enable_symm_mem_for_group"):
+                    symm_mem.enable_symm_mem_for_group(self.group_name)
+                self.buf = symm_mem.empty(self.max_bytes, dtype=torch.uint8, device=device)
+                self.handle = symm_mem.rendezvous(self.buf, self.group_name)
             self.ok = True
         except Exception as e:  # noqa: BLE001 -- any failure means "use RCCL"
             self.why = f"{type(e).__name__}: {e}"
 
+    def _setup_hip(self, device):
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.lib()
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        if world > 8:
+            raise RuntimeError("the one-shot kernel handles at most 8 ranks (one xGMI-connected node)")
+        # own buffers: fresh allocations (zero-filled flags), exported whole
+        self._staging = torch.zeros(2 * self.max_bytes, dtype=torch.uint8, device=device)
+        self._flags = torch.zeros(lib.ao_allreduce_flag_bytes(), dtype=torch.uint8, device=device)
+        self._state = torch.zeros(lib.ao_allreduce_state_bytes() // 4, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        mine = (self._staging.untyped_storage()._share_cuda_(), self._flags.untyped_storage()._share_cuda_())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine, group=self.group)
+        self._peer_tensors = []  # keeps the mapped storages alive
+        data_ptrs, flag_ptrs = [], []
+        for r in range(world):
+            if r == rank:
+                data_ptrs.append(self._staging.data_ptr())
+                flag_ptrs.append(self._flags.data_ptr())
+                continue
+            st_h, fl_h = gathered[r]
+            st = torch.UntypedStorage._new_shared_cuda(*st_h)
+            fl = torch.UntypedStorage._new_shared_cuda(*fl_h)
+            self._peer_tensors.append((st, fl))
+            # _share_cuda_ returns (device, handle, size_bytes, offset_bytes, ...): the storage it rebuilds starts at the tensor's data
+            data_ptrs.append(st.data_ptr())
+            flag_ptrs.append(fl.data_ptr())
+        self._data_arr = (ctypes.c_void_p * world)(*data_ptrs)
+        self._flag_arr = (ctypes.c_void_p * world)(*flag_ptrs)
+        self._lib, self._check = lib, _lib.check
+        self.rank, self.world = rank, world
+        dist.barrier(group=self.group)  # everybody has mapped everybody before the first flag is raised
+
     def fits(self, t: torch.Tensor) -> bool:
-        return (self.ok and t.is_cuda and t.dtype in (torch.bfloat16, torch.float32)
-                and t.numel() * t.element_size() <= self.max_bytes and (t.numel() * t.element_size()) % 16 == 0)
+        if not (self.ok and t.is_cuda and t.is_contiguous()):
+            return False
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0 or nbytes > self.max_bytes or nbytes % 16 != 0 or t.data_ptr() % 16 != 0:
+            return False
+        return t.dtype in (self._DT if self.backend == "hip" else (torch.bfloat16, torch.float32))
+
+    def timed_out(self) -> bool:
+        """True if any call so far gave up waiting for a peer (host-synchronising read of the status word)."""
+        return self.backend == "hip" and self.ok and bool(int(self._state[0].item()))
 
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
         """In-place SUM over the group; returns t."""
         if not self.fits(t):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return t
+        if self.backend == "hip":
+            self.calls += 1
+            self._check(self._lib.ao_allreduce_oneshot(self._data_arr, self._flag_arr, t.data_ptr(), t.data_ptr(), self._state.data_ptr(),
+                                                       t.numel(), self._DT[t.dtype], self.max_bytes, self.rank, self.world,
+                                                       torch.cuda.current_stream(t.device).cuda_stream))
             return t
         nbytes = t.numel() * t.element_size()
         stage = self.buf[:nbytes].view(t.dtype).view(t.shape)

@@ -652,11 +652,20 @@ def config_mx(stream, device, args):
     return out
 
 
+def _dbg(msg):
+    if os.environ.get("AO_BENCH_DEBUG") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def config_fp8_tp(stream, device, args, dist, world):
     """configs[3] for real when N > 1: Llama-3-70B linears sharded TP = N over RCCL (ao_amd/parallel.py)."""
     from ao_amd import parallel
+    _dbg("tp: start")
     from ao_amd.quantization import Float8DynamicActivationFloat8WeightConfig, PerRow, quantize_
-    one_shot = parallel.OneShotAllReduce() if args.tp_one_shot else None
+    # the hand-written one-shot all-reduce (ao_amd/csrc/allreduce_kernels.hip over IPC-mapped buffers): always set up so that the
+    # collectives-only timing below can compare it with the group's all_reduce; the linears use it only with --tp-one-shot
+    one_shot_probe = parallel.OneShotAllReduce()
+    one_shot = one_shot_probe if args.tp_one_shot else None
     gen = torch.Generator(device=device).manual_seed(4)
     layers = 8  # of 80: the same four linears per layer; tokens/s is extrapolated x10 (weights of 8 layers are 2.7 GB per GPU at TP=8)
     mods = []
@@ -669,8 +678,10 @@ def config_fp8_tp(stream, device, args, dist, world):
             mods.append((name, style, parallel.shard_linear_(lin, "colwise" if style == "col" else "rowwise", reduce="exact", one_shot=one_shot)))
             del lin
     torch.cuda.empty_cache()
+    _dbg(f"tp: {len(mods)} sharded linears built; one-shot ok={one_shot_probe.ok} why={one_shot_probe.why}")
     res = {}
     for m in (1, 128, 2048):
+        _dbg(f"tp: M={m}")
         xs = {}
         for name, style, mod in mods:
             kdim = mod.weight.shape[1]
@@ -685,7 +696,10 @@ def config_fp8_tp(stream, device, args, dist, world):
         # decode-size steps are launch-bound in eager mode (six launches + two collectives per row-parallel linear: 27 tok/s eager vs
         # 318 from a graph at M = 1, round 2): every step replays from a hipGraph (RCCL collectives are capturable) unless
         # --no-tp-graph; a failed capture falls back to eager launches on every rank (capture() catches it)
-        run, graphed = (step, False) if args.no_tp_graph else capture(step, stream, use_graph=True)
+        # (gloo collectives cannot be captured, and a failed capture leaves the stream's capture state invalidated for every later launch:
+        # only RCCL runs try)
+        try_graph = not args.no_tp_graph and dist.get_backend() == "nccl"
+        run, graphed = capture(step, stream, use_graph=True) if try_graph else (step, False)
         with torch.cuda.stream(stream):
             t = time_steps(run, stream, device, steps, 2, dist) / steps
             # the collectives alone, same sizes and order: amax MAX [M] + fp32 SUM [M, 8192] per row-parallel linear
@@ -696,13 +710,40 @@ def config_fp8_tp(stream, device, args, dist, world):
                         a, b = bufs[0]
                         dist.all_reduce(a, op=dist.ReduceOp.MAX)
                         dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            _dbg("tp: steps timed; collectives")
             for _ in range(3):
                 comm()
             tc = time_steps(comm, stream, device, steps, 2, dist) / steps
+            _dbg("tp: group all_reduce timed")
+            # the same exchanges with the fp32 SUM through the one-shot kernel (when the vector fits its 1 MiB slot), and the cheaper
+            # protocol's payload for comparison: ONE bf16 [M, 8192] all-reduce per row-parallel linear (reduce="bf16": locally scaled
+            # partials, not bit-faithful to the unsharded linear)
+            tc_one, tc_bf16 = None, None
+            if one_shot_probe.ok and one_shot_probe.fits(bufs[0][1]):
+                def comm_one():
+                    for name, style, mod in mods:
+                        if style == "row":
+                            a, b = bufs[0]
+                            dist.all_reduce(a, op=dist.ReduceOp.MAX)
+                            one_shot_probe(b)
+                for _ in range(3):
+                    comm_one()
+                tc_one = time_steps(comm_one, stream, device, steps, 2, dist) / steps
+            half = torch.zeros(m, 8192, device=device, dtype=torch.bfloat16)
+            def comm_bf16():
+                for name, style, mod in mods:
+                    if style == "row":
+                        dist.all_reduce(half, op=dist.ReduceOp.SUM)
+            for _ in range(3):
+                comm_bf16()
+            tc_bf16 = time_steps(comm_bf16, stream, device, steps, 2, dist) / steps
         flops = sum(2.0 * m * n * k for _, n, k, _ in LLAMA3_70B) * layers / world
         res[f"M{m}"] = {"tokens_per_s": m / (t * 80 / layers), "launch": "hipGraph replay" if graphed else "eager", "ms_per_8_layers": t * 1e3, "allreduce_ms_per_8_layers": tc * 1e3,
                         "allreduce_bytes_per_row_linear": m * 8192 * 4 + m * 4, "per_gpu_TFLOPs": flops / t / 1e12,
-                        "per_gpu_frac_of_fp8_mfma_peak": flops / t / 1e12 / MFMA_8BIT_PEAK_TOPS}
+                        "per_gpu_frac_of_fp8_mfma_peak": flops / t / 1e12 / MFMA_8BIT_PEAK_TOPS,
+                        "allreduce_one_shot_ms_per_8_layers": None if tc_one is None else tc_one * 1e3,
+                        "allreduce_bf16_protocol_ms_per_8_layers": tc_bf16 * 1e3, "allreduce_bf16_protocol_bytes_per_row_linear": m * 8192 * 2,
+                        "one_shot": {"ok": one_shot_probe.ok, "why": one_shot_probe.why, "timed_out": one_shot_probe.timed_out() if one_shot_probe.ok else None}}
     return {"workload": f"Float8 rowwise Llama-3-70B linears, TP={world} over {dist.get_backend()} (nccl = RCCL over xGMI; column-parallel qkv / gate_up, row-parallel o / down with the "
                         "exact protocol: amax all-reduce(MAX) + fp32 accumulator all-reduce(SUM) + one scale epilogue), 8 of 80 layers timed",
             "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (M = 2048, x10 extrapolated to 80 layers)", "by_M": res}
@@ -755,11 +796,14 @@ def main():
     shapes = LLAMA3_8B_MERGED if merged else LLAMA3_8B_UNMERGED
     stream = torch.cuda.Stream(device=device)
     model = Int4Linears(device, args.layers, shapes)
+    _dbg("int4 model built")
     elapsed, graphed = run_int4(model, args.batch, args.steps, args.warmup, stream, device, not args.no_graph, dist if world > 1 else None)
     ms_per_step = elapsed * 1e3 / args.steps
     tokens_per_s = args.batch * world * args.steps / elapsed
 
+    _dbg("headline timed")
     roof = int4_roofline(model, args.batch, stream) if rank == 0 else None
+    _dbg("roofline done")
 
     # the other module layout, for the record (rank 0 of a 1-GPU run only: it doubles resident weights); then both layouts
     # replayed alternately (median / best / worst of 5 rounds), the subclass + F.linear path (a13) and the same-box stack baseline

@@ -291,6 +291,30 @@ int ao_moe_unpad_token_groups(const void* padded, const int32_t* offsets,
                               int64_t dim, int elem_bytes, int64_t num_groups, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * One-shot all-reduce over peer-mapped buffers (TP row-parallel linears at decode sizes)
+ * ------------------------------------------------------------------------- */
+
+/* Bytes of the flag block every rank allocates (zero-filled) and maps into its peers, and of the rank-local state block (zero-filled,
+ * never shared: a status word + one epoch counter per block).  Host-only helpers. */
+int64_t ao_allreduce_flag_bytes(void);
+int64_t ao_allreduce_state_bytes(void);
+
+/* SUM all-reduce of one small vector in ONE launch per rank ("direct / one-shot algorithm for S <= ~1 MiB, never a
+ * ring on the fully connected 8-GPU xGMI mesh"; the caller-issued all-reduce of the reference's TP harness, torchao/testing/utils.py:
+ * 370-467).  Every rank stages its vector in device memory all peers have mapped (IPC), raises a flag in every peer's flag block,
+ * waits (bounded) for all flags, then reads all `world` staged vectors and adds them in rank order (fp32 accumulation for bf16 /
+ * fp32, exact for int32): bit-identical results on every rank.
+ *   peer_data_host / peer_flags_host: HOST arrays of `world` DEVICE pointers, index = rank (own buffers at [rank]); every staging
+ *     buffer is 2 x slot_bytes (double-buffered by epoch parity), every flag block ao_allreduce_flag_bytes() bytes, zero-filled once;
+ *   input / output: count elements of dtype (0 fp32, 1 bf16, 2 int32), count x size a multiple of 16 and <= slot_bytes; may alias;
+ *   local_state: device uint32 [ao_allreduce_state_bytes() / 4]: word 0 is set to 1 if a peer did not arrive within the spin bound
+ *     (~0.5 s) -- check it after synchronising; the rest are the per-block epoch counters the kernel bumps on every call (they live on
+ *     the device so that a launch captured into a hipGraph replays correctly).  Every rank must make the same sequence of calls. */
+int ao_allreduce_oneshot(void* const* peer_data_host, void* const* peer_flags_host, const void* input,
+                         void* output, void* local_state, int64_t count, int dtype, int64_t slot_bytes,
+                         int rank, int world, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * fp8 activations x int4 weights (Float8DynamicActivationInt4WeightConfig)
  * ------------------------------------------------------------------------- */
 
