@@ -165,7 +165,9 @@ struct XRegs {
 // grid.z = S > 1 (round 3 A/B): cross-workgroup split-K -- part ks owns k-blocks [kblocks ks / S, kblocks (ks + 1) / S); the parts'
 //   fp32 tiles meet in the split-K workspace (sc1 stores / loads, one ticket per output tile), the last arriver adds them in part
 //   order and stores the tile.
-template <int G, int MAXM, int DEPTH, int SCHED = 0, int TILES = 1, bool SPLITK = false>
+// STRAIGHT: every wave of the workgroup owns exactly DEPTH blocks per tile (K = 128 DEPTH waves): prologue, one pass of the ring, done --
+//   no steady-state / drain loops, fewer live registers (64 VGPRs: four 8-wave workgroups per CU instead of three)
+template <int G, int MAXM, int DEPTH, int SCHED = 0, int TILES = 1, bool SPLITK = false, bool STRAIGHT = (TILES > 1)>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
     const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets) {
@@ -372,7 +374,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   auto for_slots = [&](auto&& f) {
     [&]<int... D>(std::integer_sequence<int, D...>) { (f(std::integral_constant<int, D>{}), ...); }(std::make_integer_sequence<int, DEPTH>{});
   };
-  if constexpr (TILES > 1) {
+  if constexpr (STRAIGHT) {
     // the host guarantees kb1 - kb0 == DEPTH for every wave: one pass of the ring per tile, refilled with the next tile's blocks
     static_assert(SCHED == 0, "TILES > 1 is built on the word-by-word schedule");
     [&]<int... T>(std::integer_sequence<int, T...>) {
@@ -426,7 +428,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   acc += acc2;
 
   // cross-wave reduction: red[tile][wave][row][col]
-  if constexpr (TILES == 1) {
+  if constexpr (!STRAIGHT) {
     float* r = red + wave * 256 + (kq * 4) * 16 + (lane & 15);
     r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
   }
@@ -1196,7 +1198,7 @@ thread_local int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 95-99
 
 template <int G, int MAXM, int DEPTH = 4, int SCHED = 0, int TILES = 1>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
-              int64_t N, int64_t K, hipStream_t stream, int split = 1) {
+              int64_t N, int64_t K, hipStream_t stream, int split = 1, bool straight = false) {
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;
   constexpr int SLAB = (((SCHED == 2) ? 2 : 1) * MAXM + 1) * ROWSTRIDE;
   const int kblocks = (int)(K >> 7);
@@ -1209,6 +1211,7 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   int wpb = (kpart >= 16) ? 8 : 4;
   if (ntiles * mslabs >= 2048 && wpb > 4 && MAXM > 1) wpb /= 2;
   if (g_tune_wpb >= 4 && g_tune_wpb <= 16) wpb = g_tune_wpb;
+  if (straight && kblocks % DEPTH == 0 && kblocks / DEPTH >= 4 && kblocks / DEPTH <= 16) wpb = kblocks / DEPTH;  // straight-line form
   if (MAXM > 4 && wpb > 8) wpb = 8;  // 16-row variant is built for <= 512 threads
   if (wpb > kpart) wpb = kpart < 4 ? 4 : kpart;
   if (TILES > 1) {
@@ -1230,8 +1233,12 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
                (int)M, (int)N, (int)K, ws, tickets);
     return (int)AO_OK;
   };
-  if constexpr (MAXM == 1 && DEPTH == 4 && SCHED == 0 && TILES == 1) {
+  if constexpr (MAXM == 1 && DEPTH != 4 && (DEPTH == 7 || DEPTH == 14 || DEPTH == 2) && SCHED == 0 && TILES == 1) {
+    AO_REQUIRE(split == 1 && straight && kblocks == wpb * DEPTH && wpb <= 16, "int4_mm: the %d-deep form is straight-line only", DEPTH);
+    if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false, true>)) return rc;
+  } else if constexpr (MAXM == 1 && DEPTH == 4 && SCHED == 0 && TILES == 1) {
     if (split > 1) { if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, true>)) return rc; }
+    else if (straight && kblocks == wpb * DEPTH) { if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false, true>)) return rc; }
     else if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false>)) return rc;
   } else {
     AO_REQUIRE(split == 1, "int4_mm: split-K is built for the single-row kernel only");
@@ -1273,7 +1280,32 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     if (tl == 4) return launch_mm<G, 1, 4, 0, 4>(x, qdata, sz, y, M, N, K, stream);
     return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, sp);
   }
+  if (M == 1 && g_tune_mode == 230) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);  // straight-line form where K = 128 * 4 * waves
+  if (M == 1 && g_tune_mode == 231) {  // ... and K = 128 * 7 * 16 (down_proj): 16 waves, every block of the weight in flight at once
+    if ((K >> 7) == 112) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, 1, true);
+    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);
+  }
+  if (M == 1 && g_tune_mode == 232) {  // down_proj: 8 waves x 14 blocks, all in flight
+    if ((K >> 7) == 112) return launch_mm<G, 1, 14>(x, qdata, sz, y, M, N, K, stream, 1, true);
+    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);
+  }
+  if (M == 1 && g_tune_mode == 233) {  // 231 + narrow K = 4096 weights (o, qkv) as 16 waves x 2 blocks
+    if ((K >> 7) == 112) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, 1, true);
+    if ((K >> 7) == 32 && (N >> 4) < 512) return launch_mm<G, 1, 2>(x, qdata, sz, y, M, N, K, stream, 1, true);
+    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);
+  }
   if (M <= 16 && g_tune_mode < 600 && !(wide && (M > 4 || g_tune_mode == 93))) {
+    if (M == 1 && g_tune_mode != 97) {
+      // round 3: when the weight's K divides into (waves <= 16) x (2 | 4 | 7 | 14 blocks), every block of the tile is requested in the
+      // prologue and the kernel is straight-line code (58 - 64 VGPRs: four 8-wave workgroups per CU, so gate / up's 896 tiles are
+      // resident at once; down_proj as 16 waves x 7 blocks has its whole weight in flight).  Llama-3-8B, same run, five shapes /
+      // merged: 765 -> 818 / 846 -> 906 tok/s (profiles/int4_modes_r03.jsonl); mode 97 = the ring kernel everywhere
+      const int64_t kbl = K >> 7;
+      if (kbl % 4 == 0 && kbl / 4 >= 4 && kbl / 4 <= 16) return launch_mm<G, 1, 4>(x, qdata, sz, y, M, N, K, stream, 1, true);
+      if (kbl % 7 == 0 && kbl / 7 >= 4 && kbl / 7 <= 16) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, 1, true);
+      if (kbl % 14 == 0 && kbl / 14 >= 4 && kbl / 14 <= 16) return launch_mm<G, 1, 14>(x, qdata, sz, y, M, N, K, stream, 1, true);
+      if (kbl % 2 == 0 && kbl / 2 >= 4 && kbl / 2 <= 16) return launch_mm<G, 1, 2>(x, qdata, sz, y, M, N, K, stream, 1, true);
+    }
     if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
     if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
     return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
