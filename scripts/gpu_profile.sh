@@ -28,6 +28,35 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_pmc_fetch 
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_pmc_write -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/prof_pmc_sq -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_sq.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_pmc_sq2 -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_sq2.log 2>&1
+echo "== rocprof pmc + stats, secondary configs (one bench.py process per config; FETCH_SIZE and WRITE_SIZE in separate passes) =="
+CFG_CMD="python $R/bench.py --warmup 1 --steps 2 --no-cpu-baseline --no-second-layout --no-stack-baseline --no-subclass-graph"
+for c in int4_bs128 int8 fp8 mx; do
+  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_cfg_${c}_fetch -o cfg -- $CFG_CMD --configs $c > $O/rocprof_cfg_${c}_fetch.log 2>&1
+  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_cfg_${c}_write -o cfg -- $CFG_CMD --configs $c > $O/rocprof_cfg_${c}_write.log 2>&1
+  python $R/scripts/pmc_summary.py $O/prof_cfg_${c}_fetch $O/prof_cfg_${c}_write -o $O/cfg_${c}_pmc.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --configs $c --steps 2" > /dev/null
+done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg_stats -o cfg -- $CFG_CMD --configs int4_bs128,fp8,mx > $O/rocprof_cfg_stats.log 2>&1
+f=$(find $O/prof_cfg_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/configs_kernel_stats.csv && head -8 "$f" | cut -c1-160
+O=$O python - <<'PY'
+import json, os
+O = os.environ["O"]
+dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8_kernel", "fp8": "gemm8_p8_kernel", "mx": "rb8_kernel"}
+out = {"source": "scripts/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes per config; FETCH x1024 x2 (gfx950), WRITE x1024 (uncalibrated); "
+                 "mean over the dispatches of the config's dominant kernel", "configs": {}}
+for c, k in dom.items():
+    try:
+        d = json.load(open(f"{O}/cfg_{c}_pmc.json"))["kernels"]
+    except Exception as e:  # noqa: BLE001
+        out["configs"][c] = {"error": repr(e)}
+        continue
+    if k in d:
+        e = d[k]
+        out["configs"][c] = {"kernel": k, "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "hbm_read_bytes_per_launch": e.get("hbm_read_bytes_per_launch"),
+                             "hbm_write_bytes_per_launch": e.get("hbm_write_bytes_per_launch"), "dispatches": e.get("dispatches"),
+                             "other_kernels": {kk: vv.get("hbm_bytes_per_launch") for kk, vv in d.items() if kk != k}}
+json.dump(out, open(f"{O}/configs_pmc.json", "w"), indent=1)
+print({c: (round(v.get("hbm_bytes_per_launch") or 0) if isinstance(v, dict) else v) for c, v in out["configs"].items()})
+PY
 echo "== rocprof 8-bit GEMM: stats + MFMA-busy pmc =="
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gemm_stats -o gemm8 -- python $R/tools/bench_8bit.py --which int8,fp8l --m 8192 --iters 5 > $O/rocprof_gemm_stats.log 2>&1
 f=$(find $O/prof_gemm_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/gemm8_kernel_stats.csv; head -5 "$f" | cut -c1-200
@@ -74,4 +103,5 @@ timeout 300 python tools/bench_8bit.py --which mx --m 128 --iters 20 2>/dev/null
 timeout 300 python tools/bench_8bit.py --which mx --m 1024 --iters 20 2>/dev/null | grep "^{" > $O/mx_grouped_128rows.jsonl
 timeout 300 python tools/bench_8bit.py --which quant,fp8 --m 128 --iters 20 2>/dev/null | grep "^{" > $O/bench_8bit_m128.jsonl
 timeout 120 python tools/bench_moe_pad.py 2>/dev/null | grep "^{" > $O/bench_moe_pad.json
+for b in 1 16; do timeout 300 python tools/bench_fp8_int4.py --batch $b 2>/dev/null | grep "^{"; done > $O/fp8_int4.jsonl
 du -sh $O
