@@ -72,18 +72,33 @@ class MXFP8ExpertWeights:
         return torch.Size((e, k, n))
 
 
-_WEIGHT_MEMO = {}  # (data_ptr, version, shape, mode) -> MXFP8ExpertWeights, bounded
+_WEIGHT_MEMO = {}  # (data_ptr, version, shape, stride, mode) -> (weakref to the weight tensor, MXFP8ExpertWeights), bounded
 _WEIGHT_MEMO_MAX = 256
 
 
 def _cached_expert_weights(B_t, mode):
+    """Memo of the one-time MXFP8 cast of an expert weight.  The key alone (address, version counter, shape) is not an identity: a freed
+    weight's address can be handed to a new same-shape tensor (hot-swapped checkpoint, LoRA merge) with an equal version counter, so
+    every entry also holds a WEAK reference to the tensor it was cast from (its base, for the usual `w.transpose(-2, -1)` view that is
+    made anew on every call) -- a hit counts only when that very tensor is alive and is the one asked about; entries of dead tensors
+    are dropped (and no longer pin their casts on the GPU)."""
+    import weakref
+
+    anchor = B_t._base if B_t._base is not None else B_t
     key = (B_t.data_ptr(), B_t._version, tuple(B_t.shape), tuple(B_t.stride()), str(mode))
     hit = _WEIGHT_MEMO.get(key)
-    if hit is None:
-        if len(_WEIGHT_MEMO) >= _WEIGHT_MEMO_MAX:
-            _WEIGHT_MEMO.pop(next(iter(_WEIGHT_MEMO)))
-        hit = _WEIGHT_MEMO[key] = MXFP8ExpertWeights.from_hp(B_t, mode)
-    return hit
+    if hit is not None:
+        ref, cast = hit
+        if ref() is anchor:
+            return cast
+        del _WEIGHT_MEMO[key]  # same address, another (or a dead) tensor: stale
+    for k_ in [k_ for k_, (r, _c) in _WEIGHT_MEMO.items() if r() is None]:
+        del _WEIGHT_MEMO[k_]
+    if len(_WEIGHT_MEMO) >= _WEIGHT_MEMO_MAX:
+        _WEIGHT_MEMO.pop(next(iter(_WEIGHT_MEMO)))
+    cast = MXFP8ExpertWeights.from_hp(B_t, mode)
+    _WEIGHT_MEMO[key] = (weakref.ref(anchor), cast)
+    return cast
 
 
 def _to_mxfp8_then_scaled_grouped_mm(

@@ -115,21 +115,36 @@ def _quantize_by_fqn(model, config, device):
     for fqn, module in modules.items():
         params = [(n, f"{fqn}.{n}" if fqn else n) for n, _ in module.named_parameters(recurse=False)]
         replacement, decided = module, False
-        hits = [(n, _pick_config(pf, table)) for n, pf in params]
-        if any(found for _, (found, _c) in hits):  # parameters named exactly (possibly several of one module)
-            for n, (found, cfg) in hits:
-                if found:
-                    replacement = _apply(replacement, cfg, parameter_name=n)
-            decided = True
+        # 1. parameters named exactly (possibly several of one module); a None config only takes the parameter out of the regex pass
+        regex_params = []
+        for n, pf in params:
+            found, cfg = _pick_config(pf, table)
+            if found:
+                decided = True
+                replacement = _apply(replacement, cfg, parameter_name=n)
+            else:
+                regex_params.append((n, pf))  # (the reference also re-offers exactly-matched, quantized parameters to the regexes; a
+                                              # second quantization of a quantized parameter is never meant, so they stay out here)
+        # 2. the module named exactly -- only when no parameter was
         if not decided:
             found, cfg = _pick_config(fqn, table)
             if found:
                 replacement, decided = _apply(module, cfg), True
-        if not decided:
-            for n, pf in params:
-                found, cfg = _pick_config(pf, table, regex_only=True)
-                if found:
-                    replacement, decided = _apply(replacement, cfg, parameter_name=n), True
+                if device is not None:
+                    replacement = replacement.to(device=device)
+                if replacement is not module and fqn != "":
+                    parent, _, child = fqn.rpartition(".")
+                    setattr(modules[parent], child, replacement)
+                continue
+        # 3. parameter regexes: ALWAYS tried for the parameters step 1 left (reference :1665-1680), every matching pattern in table order
+        #    (a None pattern marks the parameter as handled without quantizing it; a later non-None pattern still applies)
+        import re
+        for n, pf in regex_params:
+            for key, cfg in table.items():
+                if key.startswith("re:") and re.fullmatch(key[3:], pf):
+                    decided = True
+                    replacement = _apply(replacement, cfg, parameter_name=n)
+        # 4. module regexes -- only when nothing above matched: the first full match decides
         if not decided:
             found, cfg = _pick_config(fqn, table, regex_only=True)
             if found:

@@ -143,15 +143,20 @@ def event_profile(lib, check, fn, n_max):
 
 
 def rocprof_avg_us(kernel_substr):
-    """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary (profiles/), or None."""
+    """Average duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary (profiles/), or None.  Every row whose
+    name contains the substring counts (the decode kernel is several template instantiations: 4- and 7-deep straight-line forms)."""
     path = os.path.join(ROOT, "profiles", f"int4_kernel_stats_{ROUND}.csv")
     if not os.path.exists(path):
         return None, None
+    total_ns, calls = 0.0, 0
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if kernel_substr in row.get("Name", ""):
-                return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
-    return None, None
+                total_ns += float(row["TotalDurationNs"])
+                calls += int(row["Calls"])
+    if calls == 0:
+        return None, None
+    return total_ns / calls / 1e3, os.path.relpath(path, ROOT)
 
 
 def pmc_traffic_of(config_key):
