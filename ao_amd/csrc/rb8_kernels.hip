@@ -31,7 +31,11 @@ constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
 // weight ring (per wave), filled kWStages - 1 steps ahead: the HBM stream needs the bytes in flight.  6 stages; 5 for the
 // 8-wave MX form, whose scale rings would otherwise push the workgroup past 160 KiB of LDS
 // (also 5 for the 64-row MX slab, which then fits two workgroups per CU)
-constexpr int w_stages(int waves, int kind, int mt) { return (kind == 2 && (waves == 8 || mt == 4)) ? 5 : 6; }
+constexpr int w_stages(int waves, int kind, int mt, bool slim = false) { return slim ? 3 : (kind == 2 && (waves == 8 || mt == 4)) ? 5 : 6; }
+// SLIM (round 3, MX decode groups: 4 waves, 64-row slabs): 3 weight stages and 64-byte scale slots (only the 16 lanes that carry
+// distinct rows issue the scale DMAs) -> 49.5 KiB of LDS, THREE workgroups per CU instead of two.  With few experts hit the grid is
+// 672 workgroups: two per CU ran them as a full round plus a 31 %-full one at 66 % of the all-experts rate; three per CU keeps
+// every workgroup resident from the start (and the same ~48 KiB of weight bytes in flight per CU: 3 x 4 waves x 2 steps x 2 KiB).
 
 // RB8_FP8_GROUPED: rowwise e4m3 like RB8_FP8, rows grouped by expert like RB8_MX (Float8Tensor's _grouped_mm, float8_tensor.py:1085-1122)
 enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2, RB8_FP8_GROUPED = 3 };
@@ -51,14 +55,16 @@ struct Rb8Args {
   float* ws;
   unsigned* tickets;
   unsigned long long* trace;  // profiling build only
+  int probe;                  // profiling only (mx_stream_kernel): 1 = read each wave's 16 x K weight bytes as contiguous 2 KiB steps, 2 = no activation DMAs, 3 = no weight DMAs, 5 = every activation DMA reads one line (wrong numbers, timing only)
 };
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
 // loop done, meeting done, exit
 // MT = 16-row m-tiles per slab (8, 4, 2): small batches / token groups stage, read and multiply only the rows they can have.
-template <int WAVES, int KIND, int MT = 8, bool TRACE = false>
+template <int WAVES, int KIND, int MT = 8, bool TRACE = false, bool SLIM = false>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
-  unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int SCL = SLIM ? 64 : 256;  // bytes of one scale slot (one dword per row: 16 rows -> 64 B; unmasked DMAs write 256)
+  unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [13] group found, [14] addresses ready
   if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
   constexpr bool INT8 = (KIND == RB8_INT8), MX = (KIND == RB8_MX), GROUPED = (KIND == RB8_MX || KIND == RB8_FP8_GROUPED);
   constexpr int ADMA = 2 * MT / WAVES;  // activation DMAs per wave and stage (8 rows each)
@@ -66,7 +72,8 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   constexpr int kABuf = MT * 2048;      // one activation stage: 16 MT rows x 128 k bytes
   constexpr int BM = 16 * MT;
   constexpr int RPW = BM / WAVES;   // MX: activation-scale rows fetched per wave
-  constexpr int kWStages = w_stages(WAVES, KIND, MT);
+  constexpr int kWStages = w_stages(WAVES, KIND, MT, SLIM);
+  static_assert(!SLIM || (KIND == RB8_MX && BM / WAVES == 16), "SLIM: 16 activation-scale rows per wave");
   // [3][128][128 B] a | [WAVES][6][2 KiB] b | MX: [3][WAVES][256 B] a scales | [WAVES][6][256 B] b scales
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // 64- or 128-row slab reads and multiplies 32 rows (the DMA counts stay static for the hand-counted waits; rows past the
   // group re-read its last row)
   const int mt_have = (min(m_end - m0, BM) + 15) >> 4;
+  if (TRACE) ts[13] = __builtin_amdgcn_s_memtime();
 
   // weight DMA i (0, 1) of a step fetches rows 8 i + (lane >> 3) of the n-tile as FULL 128-byte lines (chunk position lane & 7,
   // same swizzle as the activations); half-line requests -- one lane group per 64 bytes -- ran the stream at 3.7 TB/s
@@ -142,12 +150,14 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const uint32_t bsoff = (uint32_t)nl * kb32;
   const uint8_t* bsrows = MX ? p.b_mx + ((size_t)expert * p.N + (size_t)tile_c * 16) * kb32 : nullptr;
   const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (kWStages * 2048);
-  const uint32_t bs_lds = as_lds + kStages * WAVES * 256 + wave * (kWStages * 256);
+  const uint32_t bs_lds = as_lds + kStages * WAVES * SCL + wave * (kWStages * SCL);
   auto issue_w = [&](int stage, int k) {
     const int kk = k0 + min(k, nk - 1);
     dma_b128_nt_s(brows + (size_t)kk * 128, boff[0], w_lds + stage * 2048);
     dma_b128_nt_s(brows + (size_t)kk * 128, boff[1], w_lds + stage * 2048 + 1024);
-    if constexpr (MX) dma_b32_s(bsrows + (size_t)kk * 4, bsoff, bs_lds + stage * 256);
+    if constexpr (MX) {
+      if (!SLIM || lane < 16) dma_b32_s(bsrows + (size_t)kk * 4, bsoff, bs_lds + stage * SCL);
+    }
   };
 
   f32x4 acc[MT];
@@ -175,8 +185,11 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     const int kk = k0 + min(k, nk - 1);
 #pragma unroll
     for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)kk * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
-    if constexpr (MX) dma_b32_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (stage * WAVES + wave) * 256);
+    if constexpr (MX) {
+      if (!SLIM || lane < 16) dma_b32_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
+    }
   };
+  if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
 #pragma unroll
   for (int i = 0; i < kWStages - 3; ++i) issue_w(i, i);
   issue_a(0, 0); issue_w(kWStages - 3, kWStages - 3);
@@ -184,7 +197,8 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
   int stage = 0, wstage = 0;
   for (int k = 0; k < nk; ++k) {
-    wait_vmcnt<LPSC + 2 + (MX ? 1 : 0)>();
+    // (3 weight stages: w(k) is issued right behind a(k), so only a(k + 1) and w(k + 1) -- one stage -- may still be in flight)
+    if constexpr (kWStages >= 4) wait_vmcnt<LPSC + 2 + (MX ? 1 : 0)>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading step k - 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (TRACE && k < 8) ts[2 + k] = __builtin_amdgcn_s_memtime();
@@ -196,11 +210,11 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(W + (pa ^ 64));
     const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
     // MX: the scale byte of lane group kq is that of 32-k block kq of the step (operand layout probed on gfx950, stream8_kernels.hip)
-    [[maybe_unused]] const char* AS = smem + kStages * kABuf + WAVES * (kWStages * 2048) + stage * WAVES * 256;
+    [[maybe_unused]] const char* AS = smem + kStages * kABuf + WAVES * (kWStages * 2048) + stage * WAVES * SCL;
     int sb = 127;
     if constexpr (MX)
-      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + kStages * WAVES * 256 +
-                                                    (wave * kWStages + wstage) * 256 + nl * 4) >> (8 * kq)) & 0xff;
+      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + kStages * WAVES * SCL +
+                                                    (wave * kWStages + wstage) * SCL + nl * 4) >> (8 * kq)) & 0xff;
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
         int sa = 127;
         if constexpr (MX) {  // row mt * 16 + nl sits in the region of wave row / RPW, slot row % RPW
           const int row = mt * 16 + nl;
-          sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * 256 + (row % RPW) * 4) >> (8 * kq)) & 0xff;
+          sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * SCL + (row % RPW) * 4) >> (8 * kq)) & 0xff;
         }
         acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, sa, 0, sb);
       }
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     if (TRACE && p.trace != nullptr && tid == 0) {
       ts[12] = __builtin_amdgcn_s_memtime();
       unsigned long long* t = p.trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
-      for (int i = 0; i < 13; ++i) t[i] = ts[i];
+      for (int i = 0; i < 16; ++i) t[i] = ts[i];
     }
   };
   if (S > 1 && !split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
@@ -289,9 +303,312 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   dump();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stream-K form of the MX decode kernel (round 3; 4 waves, 64-row slabs, 64-column tiles).
+//
+// rb8_kernel above gives every (non-empty slab, 64-column tile) its own workgroup.  At decode sizes a workgroup then lives
+// for only 32 - 112 k steps, of which (s_memtime traces, profiles/mx_rb_trace_r03.txt) 3 300 - 5 600 cycles go to finding its
+// group, 1 000 - 6 000 to priming the rings, 600 - 1 300 to the first data and ~2 000 to the epilogue; and the grid is whatever the
+// router made it -- 672 workgroups on 512 slots (w1 with three experts hit), 192 on 256 CUs (w2).  In the k loop itself a CU
+// streams 20 - 22 KiB/us (5.2 - 5.6 TB/s over the chip): the launch structure, not the loop, kept config 5 at 0.32 of HBM.
+//
+// Here the grid is the number of resident slots and does not depend on the routing: the (slab, tile, k step) space, G steps,
+// is cut into gridDim.x equal contiguous shares.  A workgroup primes its rings ONCE and walks its share, crossing tile -- and
+// expert -- boundaries with the DMA rings running: three cursors (weight issue, activation issue, compute) step through the
+// same sequence at their own distance and look the next slab up in a group table held in registers (lane e: expert e's rows;
+// E <= 64), so no load result is ever waited for inside the loop.  A tile that lies wholly inside a share is stored from the
+// loop; a tile cut by a share boundary has its pieces parked in the split-K workspace (fp32, written through) when their
+// workgroups finish -- the piece at the head of a share waits in 16 VGPRs until then -- and the last arriver adds the pieces
+// in k order and stores the tile.  At most two pieces per workgroup: <= 2 x 16 KiB against ~300 KiB of weights streamed.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kStreamMinShare = 16;  // k steps: fewer would not pay for priming the rings
+
+template <int WAVES, int SW, bool TRACE>
+__global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
+  constexpr int MT = 4, BM = 64, BN = 16 * WAVES, SCL = 64, kABuf = MT * 2048, NTHR = 64 * WAVES;
+  constexpr int AD = 8 / WAVES;     // activation DMAs per wave and step (8 rows each): the tile is shared by the workgroup's waves
+  constexpr int RPW = BM / WAVES;   // activation-scale rows fetched per wave
+  constexpr int LPSC = AD + 2 + 2;  // DMAs of one stage (activations + their scales, weights + their scales)
+  static_assert(WAVES == 4 || WAVES == 8, "mx_stream_kernel: 4 or 8 waves");
+  unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
+  // [3][64][128 B] a | [WAVES][SW][2 KiB] b | [3][WAVES][64 B] a scales | [WAVES][SW][64 B] b scales
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  const int ksteps = p.K >> 7, NT = (p.N + BN - 1) / BN, n16 = p.N >> 4;
+  const uint32_t kb32 = (uint32_t)(p.K >> 5);
+
+  // group table: lane e holds expert e's rows [lo, hi), its slab count and the running slab count
+  int lo = 0, hi = 0;
+  if (p.offs != nullptr) {
+    if (lane < p.E) {
+      hi = p.offs[lane];
+      lo = (lane > 0) ? p.offs[lane - 1] : 0;
+    }
+  } else if (lane == 0) {
+    hi = p.M;
+  }
+  const int ns = (hi - lo + BM - 1) / BM;
+  int incl = ns;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  const int excl = incl - ns;
+  const int nslabs = __builtin_amdgcn_readlane(incl, 63);
+  const long long G = (long long)nslabs * NT * ksteps;  // < 2^31 (launcher)
+  const long long W = min((long long)gridDim.x, max(1ll, G / kStreamMinShare));
+  const int w = blockIdx.x;
+  if (w >= W) return;  // uniform, before any DMA or barrier
+  const int g0 = (int)(G * w / W), g1 = (int)(G * (w + 1) / W);
+  if (g0 >= g1) return;
+  auto find = [&](int y, int& expert, int& m0, int& m_end) {  // y-th non-empty slab; wave-uniform, registers only
+    const unsigned long long hit = __ballot(incl > y);
+    const int l = __builtin_ctzll(hit);
+    expert = l;
+    m_end = __builtin_amdgcn_readlane(hi, l);
+    m0 = __builtin_amdgcn_readlane(lo, l) + (y - __builtin_amdgcn_readlane(excl, l)) * BM;
+  };
+  if (TRACE) ts[13] = __builtin_amdgcn_s_memtime();
+
+  const uint32_t a_lds = lds_offset(smem);
+  const uint32_t w_lds = a_lds + kStages * kABuf + wave * (SW * 2048);
+  const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (SW * 2048);
+  const uint32_t bs_lds = as_lds + kStages * WAVES * SCL + wave * (SW * SCL);
+  const int tile0 = g0 / ksteps, k00 = g0 - tile0 * ksteps;
+
+  // ---- weight cursor
+  uint32_t boff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * i + (lane >> 3);
+    boff[i] = (uint32_t)row * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
+    if (p.probe == 1) boff[i] = (uint32_t)(i * 1024 + lane * 16);
+  }
+  const int wstep = (p.probe == 1) ? 2048 : 128;
+  const uint32_t bsoff = (uint32_t)nl * kb32;
+  const uint8_t* brows = nullptr;
+  const uint8_t* bsrows = nullptr;
+  int gw = g0, kw = k00, tilew = tile0;
+  auto set_w = [&](int tile) {
+    const int slab = tile / NT, nt = tile - slab * NT;
+    int e, m0, m_end;
+    find(slab, e, m0, m_end);
+    const int t16 = min(nt * WAVES + wave, n16 - 1);  // tiles past N alias the last one; never stored
+    brows = p.b + ((size_t)e * p.N + (size_t)t16 * 16) * p.K;
+    bsrows = p.b_mx + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
+  };
+  auto issue_w = [&](int stage) {  // the cursor's step into `stage`, then on to the next step (the last step repeats past the end)
+    if (p.probe == 3) return;
+    dma_b128_nt_s(brows + (size_t)kw * wstep, boff[0], w_lds + stage * 2048);
+    dma_b128_nt_s(brows + (size_t)kw * wstep, boff[1], w_lds + stage * 2048 + 1024);
+    if (lane < 16) dma_b32_s(bsrows + (size_t)kw * 4, bsoff, bs_lds + stage * SCL);
+    if (gw < g1 - 1) {
+      ++gw;
+      if (++kw == ksteps) { kw = 0; set_w(++tilew); }
+    }
+  };
+  // ---- activation cursor
+  uint32_t aoff[AD], asoff = 0;
+  int ga = g0, ka = k00, tilea = tile0;
+  auto set_a = [&](int tile) {
+    int e, m0, m_end;
+    find(tile / NT, e, m0, m_end);
+#pragma unroll
+    for (int i = 0; i < AD; ++i) {
+      const int row = 8 * (AD * wave + i) + (lane >> 3);  // rows past the group re-read its last row (one line, never used)
+      aoff[i] = (uint32_t)min(m0 + row, m_end - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
+    }
+    asoff = (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32;
+  };
+  auto issue_a = [&](int stage) {
+    if (p.probe == 2) return;
+#pragma unroll
+    for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)ka * 128, (p.probe == 5) ? (uint32_t)((lane & 7) << 4) : aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
+    if (lane < RPW) dma_b32_s(p.a_mx + (size_t)ka * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
+    if (ga < g1 - 1) {
+      ++ga;
+      if (++ka == ksteps) { ka = 0; set_a(++tilea); }
+    }
+  };
+  // ---- compute cursor
+  int kc = k00, kb = k00, tilec = tile0, m0c = 0, m_endc = 0, ntc = 0, mt_have = 0;
+  auto set_c = [&](int tile) {
+    const int slab = tile / NT;
+    int e;
+    find(slab, e, m0c, m_endc);
+    ntc = tile - slab * NT;
+    mt_have = __builtin_amdgcn_readfirstlane((min(m_endc - m0c, BM) + 15) >> 4);
+  };
+  set_w(tile0);
+  set_a(tile0);
+  set_c(tile0);
+
+  uint16_t* __restrict__ y = p.y;
+  auto store_tile = [&](const f32x4 (&v)[MT], int m0, int m_end, int nt) {  // scales were applied by the MFMA: out = bf16(acc)
+    const int t16 = nt * WAVES + wave;
+    if (t16 >= n16) return;
+    const int n = t16 * 16 + nl;  // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mt * 16 + kq * 4 + r;
+        if (m < m_end) y[(size_t)m * p.N + n] = f32_to_bf16_bits(v[mt][r]);
+      }
+  };
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // pieces of cut tiles are parked [slot][m-tile][thread] (slot 2 v: the piece workgroup v's share begins with, 2 v + 1: the piece
+  // it ends with when that is another one); fp32, written through (sc1): the readers sit on other XCDs
+  constexpr int kSc1 = 16;
+  constexpr int kRegBytes = NTHR * 16, kPartBytes = MT * kRegBytes;
+  const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, 0x7fffffff, 0x00020000);
+  auto park = [&](const f32x4 (&v)[MT], int tile, int mth) {  // mth: m-tiles the tile's group has (only those are parked and read)
+    const int mine = (2 * w + (((long long)tile * ksteps > g0) ? 1 : 0)) * kPartBytes;  // same rule as the reader's below
+#pragma unroll
+    for (int r = 0; r < MT; ++r)
+      if (r < mth) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[r]), rws, tid * 16 + r * kRegBytes, mine, kSc1);
+  };
+  bool has_head = false;
+  int head_tile = 0, head_m0 = 0, head_mend = 0, head_nt = 0, head_mth = 0;
+  const int pa = nl * 128 + (((kq ^ (nl >> 1)) & 7) << 4);
+
+  // Issue order (SW >= 4): w(0 .. SW-4) | a(0) w(SW-3) | a(1) w(SW-2), then per step a(i+2) w(i+SW-1): when step i starts the youngest
+  // requests are a(i+1), w(i+SW-2) (one stage: LPSC) and w(i+SW-3) (3 DMAs); everything older has landed.  SW == 3: a(0) w(0) |
+  // a(1) w(1), per step a(i+2) w(i+2): one stage may be in flight.  (The stores of a tile finished inside the loop are younger
+  // than what the next two waits need and VMEM retires in order: those waits only become stricter, never wrong.)
+  if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int i = 0; i < SW - 3; ++i) issue_w(i);
+  issue_a(0); issue_w(SW - 3);
+  issue_a(1); issue_w(SW - 2);
+  if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
+  int stage = 0, wstage = 0;
+  for (int g = g0; g < g1; ++g) {
+    if (p.probe >= 2) wait_vmcnt<3>();  // (timing probes with one of the two streams switched off)
+    else if constexpr (SW >= 4) wait_vmcnt<LPSC + 3>(); else wait_vmcnt<LPSC>();
+    // everyone's share of the activation tile has landed, and everyone has finished reading the step before
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (TRACE && g == g0) ts[2] = __builtin_amdgcn_s_memtime();  // static indices: the stamps stay in SGPRs
+    if (TRACE && g == g0 + 7) ts[9] = __builtin_amdgcn_s_memtime();
+    issue_a((stage == 0) ? 2 : stage - 1);
+    issue_w((wstage == 0) ? SW - 1 : wstage - 1);
+    const char* A = smem + stage * kABuf;
+    const char* Wt = smem + kStages * kABuf + (wave * SW + wstage) * 2048;
+    const u32x4 b0 = *reinterpret_cast<const u32x4*>(Wt + pa);  // the n-tile's 16 rows are laid out like an m-tile
+    const u32x4 b1 = *reinterpret_cast<const u32x4*>(Wt + (pa ^ 64));
+    const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    // the scale byte of lane group kq is that of 32-k block kq of the step (operand layout probed on gfx950, stream8_kernels.hip)
+    const char* AS = smem + kStages * kABuf + WAVES * (SW * 2048) + stage * WAVES * SCL;
+    const int sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (SW * 2048) + kStages * WAVES * SCL +
+                                                            (wave * SW + wstage) * SCL + nl * 4) >> (8 * kq)) & 0xff;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (mt < mt_have) {  // uniform: a 32-row group reads and multiplies two m-tiles
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + (pa ^ 64));
+        const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+        const int row = mt * 16 + nl;  // its scales sit in the slot of wave row / RPW
+        const int sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * SCL + (row % RPW) * 4) >> (8 * kq)) & 0xff;
+        acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, sa, 0, sb);
+      }
+    }
+    stage = (stage == 2) ? 0 : stage + 1;
+    wstage = (wstage == SW - 1) ? 0 : wstage + 1;
+    ++kc;
+    if (kc == ksteps && g + 1 < g1) {  // a tile ends inside the share
+      if (kb == 0) {
+        store_tile(acc, m0c, m_endc, ntc);
+      } else {  // the share began inside this tile: its piece is parked now, its ticket is taken after the loop
+        park(acc, tilec, mt_have);
+        has_head = true; head_tile = tilec; head_m0 = m0c; head_mend = m_endc; head_nt = ntc; head_mth = mt_have;
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      kc = 0; kb = 0;
+      set_c(++tilec);
+    }
+  }
+  wait_vmcnt<0>();  // the repeated fills past the end still write LDS
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (TRACE) ts[10] = __builtin_amdgcn_s_memtime();
+
+  // The pieces of a cut tile meet: every piece parked and written through (the loop's last wait covered the head piece), ONE
+  // ticket round for both of the share's cut tiles (wave 0 takes the tail's, wave 1 the head's), the last arriver of a tile adds
+  // its pieces in k order and stores it.
+  auto owner = [&](long long g) { return (int)(((g + 1) * W - 1) / G); };  // the workgroup whose share holds step g
+  const bool tail_whole = (kb == 0 && kc == ksteps);  // the share's last tile: whole (never cut) or a piece
+  if (tail_whole) store_tile(acc, m0c, m_endc, ntc);
+  else park(acc, tilec, mt_have);
+  if (!has_head && tail_whole) { /* nothing of this share meets */ }
+  else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the tickets are taken
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (lane == 0 && wave < 2) {
+      const bool mine = (wave == 0) ? !tail_whole : has_head;
+      const int tile = (wave == 0) ? tilec : head_tile;
+      int last = 0;
+      if (mine) {
+        const long long t0 = (long long)tile * ksteps;
+        const unsigned S = (unsigned)(owner(t0 + ksteps - 1) - owner(t0) + 1);
+        const unsigned t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == S - 1);
+        if (last) __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      }
+      flag[wave] = last;
+    }
+    __syncthreads();
+    auto gather = [&](f32x4 (&v)[MT], int tile, int mth) {
+      const long long t0 = (long long)tile * ksteps;
+      const int wf = owner(t0), S = owner(t0 + ksteps - 1) - wf + 1;
+#pragma unroll
+      for (int r = 0; r < MT; ++r) v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q0 = 0; q0 < S; q0 += 4) {  // four pieces in flight; indices past S re-read the last piece and are not added
+        f32x4 x[4][MT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int vq = wf + min(q0 + u, S - 1);
+          const long long gv = G * vq / W;  // where workgroup vq's share begins: its piece of this tile begins the share unless the tile starts later
+          const int slot = (2 * vq + ((t0 > gv) ? 1 : 0)) * kPartBytes;
+#pragma unroll
+          for (int r = 0; r < MT; ++r) {
+            x[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < mth) x[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, slot, kSc1));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool keep = q0 + u < S;
+#pragma unroll
+          for (int r = 0; r < MT; ++r) {
+            v[r].x += keep ? x[u][r].x : 0.f; v[r].y += keep ? x[u][r].y : 0.f;
+            v[r].z += keep ? x[u][r].z : 0.f; v[r].w += keep ? x[u][r].w : 0.f;
+          }
+        }
+      }
+    };
+    if (flag[0]) { gather(acc, tilec, mt_have); store_tile(acc, m0c, m_endc, ntc); }
+    if (flag[1]) { gather(acc, head_tile, head_mth); store_tile(acc, head_m0, head_mend, head_nt); }
+  }
+  if (TRACE && p.trace != nullptr && tid == 0) {
+    ts[11] = ts[12] = __builtin_amdgcn_s_memtime();
+    ts[15] = (unsigned long long)(g1 - g0);  // steps of this share
+    unsigned long long* t = p.trace + (size_t)blockIdx.x * 16;
+    for (int i = 0; i < 16; ++i) t[i] = ts[i];
+  }
+}
+
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 
-template <int WAVES, int KIND, int MT = 8>
+template <int WAVES, int KIND, int MT = 8, bool SLIM = false>
 int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   constexpr int BN = WAVES * 16;
   constexpr int BM = 16 * MT;
@@ -301,9 +618,10 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
                       : (p.offs == nullptr) ? (unsigned)p.slabs
                                             : (unsigned)std::min<int64_t>((int64_t)p.slabs * p.E, (p.M + BM - 1) / BM + p.E);
   dim3 grid((unsigned)((p.N + BN - 1) / BN), gy, (unsigned)split), block(64 * WAVES);
-  constexpr int kWStages = w_stages(WAVES, KIND, MT);
+  constexpr int kWStages = w_stages(WAVES, KIND, MT, SLIM);
   constexpr size_t smem = (size_t)kStages * MT * 2048 + (size_t)WAVES * kWStages * 2048 +
-                          ((KIND == RB8_MX) ? (size_t)(kStages + kWStages) * WAVES * 256 : 0);
+                          ((KIND == RB8_MX) ? (size_t)(kStages + kWStages) * WAVES * (SLIM ? 64 : 256) : 0);
+  static_assert(!SLIM || 3 * smem <= 160 * 1024, "SLIM: three workgroups per CU");
   static_assert(smem <= 160 * 1024, "rb8_kernel: LDS");
   if (split > 1) {
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
@@ -312,18 +630,42 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
     if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
   }
   p.trace = g_fp8_rb_trace;
-  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true> : rb8_kernel<WAVES, KIND, MT, false>;
+  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM> : rb8_kernel<WAVES, KIND, MT, false, SLIM>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(rb8_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("rb8_kernel launch");
   return AO_OK;
 }
 
+// Launch of the stream-K form: one workgroup per resident slot of the chip.
+constexpr int kChipCUs = 256;  // MI355X
+thread_local int g_mx_probe = 0;
+template <int WAVES, int SW>
+int launch_mx_stream(Rb8Args p, hipStream_t stream) {
+  constexpr size_t smem = (size_t)kStages * 4 * 2048 + (size_t)WAVES * SW * 2048 + (size_t)(kStages + SW) * WAVES * 64;
+  constexpr int per_cu = (int)((160 * 1024) / smem);
+  static_assert(per_cu >= 2, "mx_stream_kernel: at least two workgroups per CU");
+  const unsigned Wg = (unsigned)(per_cu * kChipCUs);
+  if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)2 * Wg * 64 * 16 * WAVES)) return rc;
+  p.trace = g_fp8_rb_trace;
+  p.probe = g_mx_probe;
+  auto kern = (p.trace != nullptr) ? mx_stream_kernel<WAVES, SW, true> : mx_stream_kernel<WAVES, SW, false>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(mx_stream_kernel)")) return rc;
+  ao::launch(kern, dim3(Wg), dim3(64 * WAVES), smem, stream, p);
+  AO_LAUNCH_CHECK("mx_stream_kernel launch");
+  return AO_OK;
+}
+
+thread_local int g_mx_stream = 1;  // (ao_gemm8_set_variant) 1 product: stream-K (8 waves x 3 weight stages) by shape; 4: always (119); 2: always, 4 waves x 6 (114); 3: always, 4 waves x 3 (118); 0 never (113)
+thread_local bool g_mx_slim_off = false;  // profiling (ao_gemm8_set_variant 112): the two-workgroups-per-CU form of the MX decode kernel
 thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 never, 2 always, 3 always + 64-column tiles, two workgroups per CU
 
 }  // namespace
 
 void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
+void mx_rb_set_slim(bool on) { g_mx_slim_off = !on; }
+void mx_rb_set_stream(int mode) { g_mx_stream = mode; }
+void mx_rb_set_probe(int v) { g_mx_probe = v; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
 bool fp8_rowwise_rb_forced() { return g_fp8_rb_force >= 2; }
 
@@ -388,7 +730,16 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
   // (cutting K into 2 - 4 parts that meet through the split-K workspace -- finer work items for the last round when few experts
   // have tokens -- was measured and dropped: w1 64.6 -> 76.7 us, w2 78 -> 79 us with three experts hit, 105 -> 113 us with all
   // eight: priming a part's rings costs what the shorter tail saves)
-  if (bm == 64) return launch_rb8<4, RB8_MX, 4>(p, 1, stream);
+  // decode-size groups: the stream-K form when its bounds hold (group table in registers: E <= 64; 32-bit step counter; a
+  // ticket per tile) and a slab has few tiles.  Measured with Mixtral's shapes, three experts hit (hipGraph, us): w2 (64 tiles of 64
+  // columns per slab, 192 workgroups per tile) 72.7 -> 63.7; w1 (224 per slab, 672 workgroups) 58.1 -> 61.1 -- with that many
+  // tiles the one-workgroup-per-tile grid already fills the chip and the pieces only add traffic; all eight hit: equal.
+  if (bm == 64 && g_mx_stream != 0 && groups <= 64 && (g_mx_stream != 1 || (N + 63) / 64 <= 128)) {
+    const int64_t tiles = ((M_total + 63) / 64 + groups) * ((N + 63) / 64);  // (64-column tiles: the bound of every form)
+    if (tiles <= kSplitMaxTickets && tiles * (K >> 7) < (1ll << 31))
+      return (g_mx_stream == 2) ? launch_mx_stream<4, 6>(p, stream) : (g_mx_stream == 3) ? launch_mx_stream<4, 3>(p, stream) : launch_mx_stream<8, 3>(p, stream);
+  }
+  if (bm == 64) return (g_mx_slim_off ? launch_rb8<4, RB8_MX, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 4, true>(p, 1, stream));
   return (((N + 127) / 128) * groups * p.slabs < 400) ? launch_rb8<4, RB8_MX, 8>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);
 }
 

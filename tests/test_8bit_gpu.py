@@ -366,6 +366,52 @@ def test_mxfp8_grouped_mm_lds_staged_kernel(sizes, n, k):
     assert _rel(np_from_torch_bf16(y_other), yn) <= 1e-3
 
 
+@pytest.mark.parametrize("variant", [119, 114, 118])
+@pytest.mark.parametrize(
+    "sizes,n,k",
+    [([16, 16, 16, 16], 256, 4096),          # 16 tiles x 32 steps over 32 shares: every tile cut in two
+     ([40, 0, 5, 27], 80, 512),              # 24 steps in all: ONE workgroup walks six tiles of three experts (N not a multiple of 64)
+     ([1, 17, 33, 49, 0, 64, 65, 0], 80, 512),  # every m-tile count, a group of two slabs
+     ([2] * 64, 48, 384),                    # 64 experts (the whole group table), 3-step tiles cut at every offset
+     ([3, 0, 0, 1], 64, 14336),              # 112-step tiles in seven pieces each (more pieces than one batch of the reducer)
+     ([3, 0, 0, 1], 2048, 2048),             # shares that are whole tiles: nothing meets
+     ([32, 0, 0, 0, 32, 64, 0, 0], 1024, 4096)],  # BASELINE config 5's routing
+)
+def test_mxfp8_grouped_mm_stream_k_kernel(sizes, n, k, variant):
+    """mx_stream_kernel (decode-size groups; variant 119 = the product's form, forced for every N: 8 waves / 128-column tiles, 3 weight stages, two workgroups per CU;
+    118: 4 waves / 64 columns, three per CU; 114: 4 waves, 6 stages, two per CU):
+    shares of the (slab, tile, k step) space that cross tile and expert boundaries, pieces of cut tiles meeting through the
+    split-K workspace.  Against the oracle, same bits on repeated launches (the pieces are added in k order), and agreement with the
+    one-workgroup-per-tile kernel (variant 113) up to accumulation order."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    E, M = len(sizes), sum(sizes)
+    assert M <= 48 * E  # the dispatch's decode condition
+    a = _randn_bf16((M, k), 61 + n)
+    w = _randn_bf16((E, n, k), 62 + k, 0.1)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32)
+    a_d, a_s = ops.mxfp8_quantize(a.to(DEV), "rceil")
+    w_d, w_s = ops.mxfp8_quantize(w.to(DEV), "rceil")
+    try:
+        lib.ao_gemm8_set_variant(variant)
+        y = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+        for _ in range(3):  # tickets are left ready for the next launch; the sum does not depend on arrival order
+            assert torch.equal(ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV)), y)
+        lib.ao_gemm8_set_variant(113)
+        y_tile = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs.to(DEV))
+    finally:
+        lib.ao_gemm8_set_variant(0)
+    y_ref, mag = MX.grouped_mm(
+        a_d.view(torch.uint8).cpu().numpy(), a_s.view(torch.uint8).cpu().numpy(),
+        w_d.view(torch.uint8).cpu().numpy(), w_s.view(torch.uint8).cpu().numpy(), offs.numpy(), return_abs=True,
+    )
+    yn = np_from_torch_bf16(y)
+    assert _rel(yn, y_ref) <= 1e-3
+    assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
+    assert _rel(np_from_torch_bf16(y_tile), yn) <= 1e-3
+
+
 @pytest.mark.parametrize("m,n,k,bias", [(128, 1024, 8192, False), (128, 7168, 8192, True), (200, 8192, 1024, True), (2048, 1024, 1024, False),
                                         (96, 48, 256, True), (65, 4096, 3584, False), (1000, 208, 384, True)])
 def test_fp8_weight_streaming_mid_m(m, n, k, bias):

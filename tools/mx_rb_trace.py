@@ -39,6 +39,22 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
+gr, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    ops.mxfp8_grouped_mm(aq, a_s, wq, ws, offs)
+    side.synchronize()
+    with torch.cuda.graph(gr, stream=side):
+        for _ in range(20):
+            ops.mxfp8_grouped_mm(aq, a_s, wq, ws, offs)
+torch.cuda.synchronize()
+gr.replay()
+torch.cuda.synchronize()
+e0.record()
+gr.replay()
+e1.record()
+torch.cuda.synchronize()
+us_graph = e0.elapsed_time(e1) * 50
 trace = torch.zeros(16384 * 16, dtype=torch.int64, device=dev)
 lib.ao_int4_set_trace(ctypes.c_void_p(trace.data_ptr()))
 ops.mxfp8_grouped_mm(aq, a_s, wq, ws, offs)
@@ -50,7 +66,13 @@ act = sum(1 for s in sizes if s)
 d = np.diff(t[:, 2:10], axis=1)
 d = d[(t[:, 2:10] != 0).all(axis=1)]
 steps = k // 128
-print(f"N={n} K={k} sizes={sizes} ({act} active): {us:.1f} us eager back-to-back; {len(t)} workgroups traced; "
-      f"ticks (s_memtime: shader cycles): prime {int((t[:, 1] - t[:, 0]).mean())}, first data {int((t[:, 2] - t[:, 1]).mean())}, "
+if (t[:, 15] != 0).any():  # the stream-K kernel reports the steps of each share
+    steps = float(t[:, 15].mean())
+    sev = (t[:, 9] != 0) & (t[:, 2] != 0)
+    print(f"  stream-K: {steps:.1f} steps per share; first 7 steps {((t[sev, 9] - t[sev, 2]) / 7).mean():.1f} ticks per step; meet + stores {int((t[:, 12] - t[:, 10]).mean())}")
+print(f"N={n} K={k} sizes={sizes} ({act} active): {us:.1f} us eager back-to-back, {us_graph:.1f} us in a hipGraph; {len(t)} workgroups traced; "
+      f"ticks (s_memtime: shader cycles): prime {int((t[:, 1] - t[:, 0]).mean())} (group found at {int((t[:, 13] - t[:, 0]).mean())}, addresses at {int((t[:, 14] - t[:, 0]).mean())}), first data {int((t[:, 2] - t[:, 1]).mean())}, "
       f"per step {d.mean():.1f} (first 7 steps), whole loop {int((t[:, 10] - t[:, 2]).mean())} = {(t[:, 10] - t[:, 2]).mean() / steps:.1f} per step, "
-      f"tail {int((t[:, 12] - t[:, 10]).mean())}; launch span {int(t[:, 12].max() - t[:, 0].min())}")
+      f"tail {int((t[:, 12] - t[:, 10]).mean())}; launch span {int(t[:, 12].max() - t[:, 0].min())}; "
+      f"entry spread p50 {int(np.percentile(t[:, 0] - t[:, 0].min(), 50))} p90 {int(np.percentile(t[:, 0] - t[:, 0].min(), 90))} max {int((t[:, 0] - t[:, 0].min()).max())}; "
+      f"exit p10 {int(np.percentile(t[:, 12] - t[:, 0].min(), 10))} p50 {int(np.percentile(t[:, 12] - t[:, 0].min(), 50))} max {int((t[:, 12] - t[:, 0].min()).max())}")
