@@ -24,8 +24,7 @@ void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
 extern thread_local int g_mx_variant;  // stream8_kernels.hip
 void mx_rb_set_slim(bool on);          // rb8_kernels.hip
-void mx_rb_set_stream(int mode);
-void mx_rb_set_probe(int v);
+void mx_rb_set_stream(int mode, bool quad);
 int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                    int64_t M, int64_t N, int64_t K, hipStream_t stream);
 int int8_scaled_rb(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
@@ -430,13 +429,14 @@ int check_gemm_shape(const char* fn, int64_t M, int64_t N, int64_t K) {
 using namespace ao;
 
 extern "C" int ao_gemm8_set_variant(int variant) {
-  mx_rb_set_probe(variant / 1000);  // timing probes of the MX stream kernel ride in the thousands (wrong numbers; profiling only)
-  variant %= 1000;
   g_gemm8_force_regstage = (variant == 1);
   g_gemm8_tiled_only = (variant == 100);
   g_mx_variant = (variant == 110) ? 1 : (variant == 111) ? 2 : 0;
   mx_rb_set_slim(variant != 112);
-  mx_rb_set_stream((variant == 112 || variant == 113) ? 0 : (variant == 114) ? 2 : (variant == 118) ? 3 : (variant == 119) ? 4 : 1);
+  // MX decode groups: 113 one workgroup per tile; stream-K forms 119 (the product's, forced), 118 (4 waves x 3 stages), 114 (4 x 6); 129 / 128 = 119 / 118 with
+  // the scales fetched per step instead of per 4 steps
+  mx_rb_set_stream((variant == 112 || variant == 113) ? 0 : (variant == 114) ? 2 : (variant == 118 || variant == 128) ? 3 : (variant == 119 || variant == 129) ? 4 : 1,
+                   variant != 128 && variant != 129);
   g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16 || variant == 32) ? variant : 0;
   // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
   fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : (variant != 0 && variant < 110) ? 1 : 0);

@@ -55,7 +55,6 @@ struct Rb8Args {
   float* ws;
   unsigned* tickets;
   unsigned long long* trace;  // profiling build only
-  int probe;                  // profiling only (mx_stream_kernel): 1 = read each wave's 16 x K weight bytes as contiguous 2 KiB steps, 2 = no activation DMAs, 3 = no weight DMAs, 5 = every activation DMA reads one line (wrong numbers, timing only)
 };
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
@@ -323,16 +322,23 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kStreamMinShare = 16;  // k steps: fewer would not pay for priming the rings
 
-template <int WAVES, int SW, bool TRACE>
+// QS = k steps per scale fetch.  1: one 4-byte DMA per row, step and operand (16 lanes of a wave).  4: one 16-byte DMA per row and FOUR
+// steps (K % 512 == 0, 3 weight stages).  The dword DMAs moved 1 % of the bytes and cost a quarter of the kernel: with them switched
+// off (timing probe, profiles/mx_rb_trace_r03.txt session F) w1 went 65.9 -> 49.3 us and w2 64.7 -> 44.9 -- the LDS-DMA path is
+// bound by instructions, not bytes (fetching the activation tile through ONE line per DMA instead of eight: -4 %).
+template <int WAVES, int SW, int QS, bool TRACE>
 __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
+  static_assert(QS == 1 || (QS == 4 && SW == 3), "mx_stream_kernel: scale fetches per step, or per 4 steps with 3 weight stages");
   constexpr int MT = 4, BM = 64, BN = 16 * WAVES, SCL = 64, kABuf = MT * 2048, NTHR = 64 * WAVES;
   constexpr int AD = 8 / WAVES;     // activation DMAs per wave and step (8 rows each): the tile is shared by the workgroup's waves
   constexpr int RPW = BM / WAVES;   // activation-scale rows fetched per wave
-  constexpr int LPSC = AD + 2 + 2;  // DMAs of one stage (activations + their scales, weights + their scales)
+  constexpr int LPSC = AD + 2 + (QS == 1 ? 2 : 0);  // DMAs of one stage (activations, weights; QS == 1: + the scales of both)
+  constexpr int ASB = (QS == 1) ? SCL : RPW * 16, BSB = (QS == 1) ? SCL : 256;  // bytes of one scale slot (activations per wave, weights per wave)
+  constexpr int ASN = (QS == 1) ? kStages : 2, BSN = (QS == 1) ? SW : 2;          // slots per wave
   static_assert(WAVES == 4 || WAVES == 8, "mx_stream_kernel: 4 or 8 waves");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
-  // [3][64][128 B] a | [WAVES][SW][2 KiB] b | [3][WAVES][64 B] a scales | [WAVES][SW][64 B] b scales
+  // [3][64][128 B] a | [WAVES][SW][2 KiB] b | a scales [ASN][WAVES][ASB] | b scales [WAVES][BSN][BSB]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -361,10 +367,11 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   const int excl = incl - ns;
   const int nslabs = __builtin_amdgcn_readlane(incl, 63);
   const long long G = (long long)nslabs * NT * ksteps;  // < 2^31 (launcher)
+  const long long GQ = G / QS;                           // shares are cut at multiples of QS steps (ksteps % QS == 0: launcher)
   const long long W = min((long long)gridDim.x, max(1ll, G / kStreamMinShare));
   const int w = blockIdx.x;
   if (w >= W) return;  // uniform, before any DMA or barrier
-  const int g0 = (int)(G * w / W), g1 = (int)(G * (w + 1) / W);
+  const int g0 = (int)(GQ * w / W) * QS, g1 = (int)(GQ * (w + 1) / W) * QS;
   if (g0 >= g1) return;
   auto find = [&](int y, int& expert, int& m0, int& m_end) {  // y-th non-empty slab; wave-uniform, registers only
     const unsigned long long hit = __ballot(incl > y);
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   const uint32_t a_lds = lds_offset(smem);
   const uint32_t w_lds = a_lds + kStages * kABuf + wave * (SW * 2048);
   const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (SW * 2048);
-  const uint32_t bs_lds = as_lds + kStages * WAVES * SCL + wave * (SW * SCL);
+  const uint32_t bs_lds = as_lds + ASN * WAVES * ASB + wave * (BSN * BSB);
   const int tile0 = g0 / ksteps, k00 = g0 - tile0 * ksteps;
 
   // ---- weight cursor
@@ -387,9 +394,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   for (int i = 0; i < 2; ++i) {
     const int row = 8 * i + (lane >> 3);
     boff[i] = (uint32_t)row * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
-    if (p.probe == 1) boff[i] = (uint32_t)(i * 1024 + lane * 16);
   }
-  const int wstep = (p.probe == 1) ? 2048 : 128;
   const uint32_t bsoff = (uint32_t)nl * kb32;
   const uint8_t* brows = nullptr;
   const uint8_t* bsrows = nullptr;
@@ -403,10 +408,11 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     bsrows = p.b_mx + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
   };
   auto issue_w = [&](int stage) {  // the cursor's step into `stage`, then on to the next step (the last step repeats past the end)
-    if (p.probe == 3) return;
-    dma_b128_nt_s(brows + (size_t)kw * wstep, boff[0], w_lds + stage * 2048);
-    dma_b128_nt_s(brows + (size_t)kw * wstep, boff[1], w_lds + stage * 2048 + 1024);
-    if (lane < 16) dma_b32_s(bsrows + (size_t)kw * 4, bsoff, bs_lds + stage * SCL);
+    dma_b128_nt_s(brows + (size_t)kw * 128, boff[0], w_lds + stage * 2048);
+    dma_b128_nt_s(brows + (size_t)kw * 128, boff[1], w_lds + stage * 2048 + 1024);
+    if constexpr (QS == 1) {
+      if (lane < 16) dma_b32_s(bsrows + (size_t)kw * 4, bsoff, bs_lds + stage * SCL);
+    }
     if (gw < g1 - 1) {
       ++gw;
       if (++kw == ksteps) { kw = 0; set_w(++tilew); }
@@ -426,13 +432,34 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     asoff = (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32;
   };
   auto issue_a = [&](int stage) {
-    if (p.probe == 2) return;
 #pragma unroll
-    for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)ka * 128, (p.probe == 5) ? (uint32_t)((lane & 7) << 4) : aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
-    if (lane < RPW) dma_b32_s(p.a_mx + (size_t)ka * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
+    for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)ka * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
+    if constexpr (QS == 1) {
+      if (lane < RPW) dma_b32_s(p.a_mx + (size_t)ka * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
+    }
     if (ga < g1 - 1) {
       ++ga;
       if (++ka == ksteps) { ka = 0; set_a(++tilea); }
+    }
+  };
+  // ---- scale cursor (QS == 4): the 16 scale bytes of 4 steps per row, two slots per wave and operand
+  uint32_t asoff4 = 0;
+  const uint8_t* bsrows4 = nullptr;
+  int gs = g0, ks4 = k00, tiles4 = tile0;
+  auto set_s = [&](int tile) {
+    const int slab = tile / NT, nt = tile - slab * NT;
+    int e, m0, m_end;
+    find(slab, e, m0, m_end);
+    const int t16 = min(nt * WAVES + wave, n16 - 1);
+    bsrows4 = p.b_mx + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
+    asoff4 = (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32;
+  };
+  auto issue_s = [&](int slot) {  // (the last block repeats past the end, like the tiles)
+    if (lane < RPW) dma_b128_s(p.a_mx + (size_t)ks4 * 4, asoff4, as_lds + (slot * WAVES + wave) * ASB);
+    if (lane < 16) dma_b128_s(bsrows4 + (size_t)ks4 * 4, bsoff, bs_lds + slot * BSB);
+    if (gs + 4 < g1) {
+      gs += 4;
+      if ((ks4 += 4) == ksteps) { ks4 = 0; set_s(++tiles4); }
     }
   };
   // ---- compute cursor
@@ -447,6 +474,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   set_w(tile0);
   set_a(tile0);
   set_c(tile0);
+  if constexpr (QS == 4) set_s(tile0);
 
   uint16_t* __restrict__ y = p.y;
   auto store_tile = [&](const f32x4 (&v)[MT], int m0, int m_end, int nt) {  // scales were applied by the MFMA: out = bf16(acc)
@@ -485,6 +513,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   // a(1) w(1), per step a(i+2) w(i+2): one stage may be in flight.  (The stores of a tile finished inside the loop are younger
   // than what the next two waits need and VMEM retires in order: those waits only become stricter, never wrong.)
   if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
+  if constexpr (QS == 4) issue_s(0);  // QS == 4: scales of steps 0..3 first; of steps 4 j + 4 .. + 7 at the head of step 4 j + 1 (below)
 #pragma unroll
   for (int i = 0; i < SW - 3; ++i) issue_w(i);
   issue_a(0); issue_w(SW - 3);
@@ -492,12 +521,18 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
   int stage = 0, wstage = 0;
   for (int g = g0; g < g1; ++g) {
-    if (p.probe >= 2) wait_vmcnt<3>();  // (timing probes with one of the two streams switched off)
+    if constexpr (QS == 4) { if (((g - g0) & 3) == 2) wait_vmcnt<LPSC + 2>(); else wait_vmcnt<LPSC>(); }
     else if constexpr (SW >= 4) wait_vmcnt<LPSC + 3>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading the step before
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (TRACE && g == g0) ts[2] = __builtin_amdgcn_s_memtime();  // static indices: the stamps stay in SGPRs
     if (TRACE && g == g0 + 7) ts[9] = __builtin_amdgcn_s_memtime();
+    if constexpr (QS == 4) {
+      // step i of the share (i = g - g0; shares and tiles begin at multiples of 4): the next block's scales go out at i % 4 == 1 into
+      // the slot the block before this one used (last read at step i - 2); they are older than a(i + 2), w(i + 2), whose wait at
+      // step i + 2 therefore covers them, and at that wait -- only there -- two more requests are younger than what it needs
+      if (((g - g0) & 3) == 1) issue_s((((g - g0) >> 2) + 1) & 1);
+    }
     issue_a((stage == 0) ? 2 : stage - 1);
     issue_w((wstage == 0) ? SW - 1 : wstage - 1);
     const char* A = smem + stage * kABuf;
@@ -506,9 +541,10 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(Wt + (pa ^ 64));
     const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
     // the scale byte of lane group kq is that of 32-k block kq of the step (operand layout probed on gfx950, stream8_kernels.hip)
-    const char* AS = smem + kStages * kABuf + WAVES * (SW * 2048) + stage * WAVES * SCL;
-    const int sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (SW * 2048) + kStages * WAVES * SCL +
-                                                            (wave * SW + wstage) * SCL + nl * 4) >> (8 * kq)) & 0xff;
+    const int blk = ((g - g0) >> 2) & 1, ph = (g - g0) & 3;  // QS == 4: slot and position of this step's scale dword
+    const char* AS = smem + kStages * kABuf + WAVES * (SW * 2048) + ((QS == 1) ? stage : blk) * WAVES * ASB + ((QS == 1) ? 0 : ph * 4);
+    const char* BS = smem + kStages * kABuf + WAVES * (SW * 2048) + ASN * WAVES * ASB + (wave * BSN + ((QS == 1) ? wstage : blk)) * BSB;
+    const int sb = (int)(*reinterpret_cast<const uint32_t*>(BS + ((QS == 1) ? nl * 4 : nl * 16 + ph * 4)) >> (8 * kq)) & 0xff;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (mt < mt_have) {  // uniform: a 32-row group reads and multiplies two m-tiles
@@ -516,7 +552,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
         const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + (pa ^ 64));
         const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
         const int row = mt * 16 + nl;  // its scales sit in the slot of wave row / RPW
-        const int sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * SCL + (row % RPW) * 4) >> (8 * kq)) & 0xff;
+        const int sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * ASB + (row % RPW) * ((QS == 1) ? 4 : 16)) >> (8 * kq)) & 0xff;
         acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, sa, 0, sb);
       }
     }
@@ -543,7 +579,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   // The pieces of a cut tile meet: every piece parked and written through (the loop's last wait covered the head piece), ONE
   // ticket round for both of the share's cut tiles (wave 0 takes the tail's, wave 1 the head's), the last arriver of a tile adds
   // its pieces in k order and stores it.
-  auto owner = [&](long long g) { return (int)(((g + 1) * W - 1) / G); };  // the workgroup whose share holds step g
+  auto owner = [&](long long g) { return (int)(((g / QS + 1) * W - 1) / GQ); };  // the workgroup whose share holds step g
   const bool tail_whole = (kb == 0 && kc == ksteps);  // the share's last tile: whole (never cut) or a piece
   if (tail_whole) store_tile(acc, m0c, m_endc, ntc);
   else park(acc, tilec, mt_have);
@@ -576,7 +612,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int vq = wf + min(q0 + u, S - 1);
-          const long long gv = G * vq / W;  // where workgroup vq's share begins: its piece of this tile begins the share unless the tile starts later
+          const long long gv = GQ * vq / W * QS;  // where workgroup vq's share begins: its piece of this tile begins the share unless the tile starts later
           const int slot = (2 * vq + ((t0 > gv) ? 1 : 0)) * kPartBytes;
 #pragma unroll
           for (int r = 0; r < MT; ++r) {
@@ -639,23 +675,23 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
 
 // Launch of the stream-K form: one workgroup per resident slot of the chip.
 constexpr int kChipCUs = 256;  // MI355X
-thread_local int g_mx_probe = 0;
-template <int WAVES, int SW>
+template <int WAVES, int SW, int QS>
 int launch_mx_stream(Rb8Args p, hipStream_t stream) {
-  constexpr size_t smem = (size_t)kStages * 4 * 2048 + (size_t)WAVES * SW * 2048 + (size_t)(kStages + SW) * WAVES * 64;
+  constexpr size_t scales = (QS == 1) ? (size_t)(kStages + SW) * WAVES * 64 : (size_t)2 * WAVES * (64 / WAVES) * 16 + (size_t)WAVES * 2 * 256;
+  constexpr size_t smem = (size_t)kStages * 4 * 2048 + (size_t)WAVES * SW * 2048 + scales;
   constexpr int per_cu = (int)((160 * 1024) / smem);
   static_assert(per_cu >= 2, "mx_stream_kernel: at least two workgroups per CU");
   const unsigned Wg = (unsigned)(per_cu * kChipCUs);
   if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)2 * Wg * 64 * 16 * WAVES)) return rc;
   p.trace = g_fp8_rb_trace;
-  p.probe = g_mx_probe;
-  auto kern = (p.trace != nullptr) ? mx_stream_kernel<WAVES, SW, true> : mx_stream_kernel<WAVES, SW, false>;
+  auto kern = (p.trace != nullptr) ? mx_stream_kernel<WAVES, SW, QS, true> : mx_stream_kernel<WAVES, SW, QS, false>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(mx_stream_kernel)")) return rc;
   ao::launch(kern, dim3(Wg), dim3(64 * WAVES), smem, stream, p);
   AO_LAUNCH_CHECK("mx_stream_kernel launch");
   return AO_OK;
 }
 
+thread_local bool g_mx_quad = true;  // (ao_gemm8_set_variant 12x: off) scales per 4 steps
 thread_local int g_mx_stream = 1;  // (ao_gemm8_set_variant) 1 product: stream-K (8 waves x 3 weight stages) by shape; 4: always (119); 2: always, 4 waves x 6 (114); 3: always, 4 waves x 3 (118); 0 never (113)
 thread_local bool g_mx_slim_off = false;  // profiling (ao_gemm8_set_variant 112): the two-workgroups-per-CU form of the MX decode kernel
 thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 never, 2 always, 3 always + 64-column tiles, two workgroups per CU
@@ -664,8 +700,7 @@ thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 
 
 void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
 void mx_rb_set_slim(bool on) { g_mx_slim_off = !on; }
-void mx_rb_set_stream(int mode) { g_mx_stream = mode; }
-void mx_rb_set_probe(int v) { g_mx_probe = v; }
+void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = quad; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
 bool fp8_rowwise_rb_forced() { return g_fp8_rb_force >= 2; }
 
@@ -731,13 +766,18 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
   // have tokens -- was measured and dropped: w1 64.6 -> 76.7 us, w2 78 -> 79 us with three experts hit, 105 -> 113 us with all
   // eight: priming a part's rings costs what the shorter tail saves)
   // decode-size groups: the stream-K form when its bounds hold (group table in registers: E <= 64; 32-bit step counter; a
-  // ticket per tile) and a slab has few tiles.  Measured with Mixtral's shapes, three experts hit (hipGraph, us): w2 (64 tiles of 64
-  // columns per slab, 192 workgroups per tile) 72.7 -> 63.7; w1 (224 per slab, 672 workgroups) 58.1 -> 61.1 -- with that many
-  // tiles the one-workgroup-per-tile grid already fills the chip and the pieces only add traffic; all eight hit: equal.
-  if (bm == 64 && g_mx_stream != 0 && groups <= 64 && (g_mx_stream != 1 || (N + 63) / 64 <= 128)) {
+  // ticket per tile).  Mixtral's shapes, hipGraph, us (w1 / w2; profiles/mx_rb_trace_r03.txt session G): three experts hit 58.0 / 71.3
+  // with one workgroup per tile -> 56.1 / 52.2; all eight 111 / 110 -> 101 / 91.
+  if (bm == 64 && g_mx_stream != 0 && groups <= 64) {
     const int64_t tiles = ((M_total + 63) / 64 + groups) * ((N + 63) / 64);  // (64-column tiles: the bound of every form)
     if (tiles <= kSplitMaxTickets && tiles * (K >> 7) < (1ll << 31))
-      return (g_mx_stream == 2) ? launch_mx_stream<4, 6>(p, stream) : (g_mx_stream == 3) ? launch_mx_stream<4, 3>(p, stream) : launch_mx_stream<8, 3>(p, stream);
+    {
+      // scales fetched per 4 steps when K allows (16-byte pieces of 16-byte-aligned scale rows), else per step
+      const bool quad = g_mx_quad && K % 512 == 0 && ((uintptr_t)a_scale % 16 == 0) && ((uintptr_t)b_scale % 16 == 0);
+      if (g_mx_stream == 2) return launch_mx_stream<4, 6, 1>(p, stream);
+      if (g_mx_stream == 3) return quad ? launch_mx_stream<4, 3, 4>(p, stream) : launch_mx_stream<4, 3, 1>(p, stream);
+      return quad ? launch_mx_stream<8, 3, 4>(p, stream) : launch_mx_stream<8, 3, 1>(p, stream);
+    }
   }
   if (bm == 64) return (g_mx_slim_off ? launch_rb8<4, RB8_MX, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 4, true>(p, 1, stream));
   return (((N + 127) / 128) * groups * p.slabs < 400) ? launch_rb8<4, RB8_MX, 8>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);

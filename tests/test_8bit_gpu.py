@@ -366,7 +366,7 @@ def test_mxfp8_grouped_mm_lds_staged_kernel(sizes, n, k):
     assert _rel(np_from_torch_bf16(y_other), yn) <= 1e-3
 
 
-@pytest.mark.parametrize("variant", [119, 114, 118])
+@pytest.mark.parametrize("variant", [119, 118, 129, 128, 114])
 @pytest.mark.parametrize(
     "sizes,n,k",
     [([16, 16, 16, 16], 256, 4096),          # 16 tiles x 32 steps over 32 shares: every tile cut in two
@@ -379,7 +379,8 @@ def test_mxfp8_grouped_mm_lds_staged_kernel(sizes, n, k):
 )
 def test_mxfp8_grouped_mm_stream_k_kernel(sizes, n, k, variant):
     """mx_stream_kernel (decode-size groups; variant 119 = the product's form, forced for every N: 8 waves / 128-column tiles, 3 weight stages, two workgroups per CU;
-    118: 4 waves / 64 columns, three per CU; 114: 4 waves, 6 stages, two per CU):
+    118: 4 waves / 64 columns, three per CU; both fetch the block scales per 4 k steps when K % 512 == 0 (129 / 128: per step, as every K % 512 != 0
+    does); 114: 4 waves, 6 stages, two per CU):
     shares of the (slab, tile, k step) space that cross tile and expert boundaries, pieces of cut tiles meeting through the
     split-K workspace.  Against the oracle, same bits on repeated launches (the pieces are added in k order), and agreement with the
     one-workgroup-per-tile kernel (variant 113) up to accumulation order."""
