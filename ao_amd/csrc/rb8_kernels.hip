@@ -60,9 +60,12 @@ struct Rb8Args {
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
 // loop done, meeting done, exit
 // MT = 16-row m-tiles per slab (8, 4, 2): small batches / token groups stage, read and multiply only the rows they can have.
-template <int WAVES, int KIND, int MT = 8, bool TRACE = false, bool SLIM = false>
+// QS (MX): k steps per scale fetch -- 1: a dword DMA per row, step and operand; 4: one 16-byte DMA per row and FOUR steps, two slots
+// per wave and operand (K % 512 == 0, no K split).  The dword DMAs cost a quarter of the decode kernel (mx_stream_kernel below).
+template <int WAVES, int KIND, int MT = 8, bool TRACE = false, bool SLIM = false, int QS = 1>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   constexpr int SCL = SLIM ? 64 : 256;  // bytes of one scale slot (one dword per row: 16 rows -> 64 B; unmasked DMAs write 256)
+  static_assert(QS == 1 || (QS == 4 && KIND == RB8_MX && !SLIM), "rb8_kernel: 4-step scale fetches are an MX form");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [13] group found, [14] addresses ready
   if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
   constexpr bool INT8 = (KIND == RB8_INT8), MX = (KIND == RB8_MX), GROUPED = (KIND == RB8_MX || KIND == RB8_FP8_GROUPED);
@@ -149,12 +152,18 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const uint32_t bsoff = (uint32_t)nl * kb32;
   const uint8_t* bsrows = MX ? p.b_mx + ((size_t)expert * p.N + (size_t)tile_c * 16) * kb32 : nullptr;
   const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (kWStages * 2048);
-  const uint32_t bs_lds = as_lds + kStages * WAVES * SCL + wave * (kWStages * SCL);
+  constexpr int ASB = (QS == 1) ? SCL : RPW * 16, BSB = 256;  // QS == 4: slot bytes (activation rows of a wave, its 16 weight rows: 16 B each)
+  const uint32_t bs_lds = (QS == 1) ? as_lds + kStages * WAVES * SCL + wave * (kWStages * SCL) : as_lds + 2 * WAVES * ASB + wave * (2 * BSB);
+  auto issue_s = [&](int slot, int k) {  // QS == 4: the scales of steps k .. k + 3 (k % 4 == 0); past the end: the last block again
+    const int kk = k0 + min(k, nk - 4);
+    if (lane < RPW) dma_b128_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (slot * WAVES + wave) * ASB);
+    if (lane < 16) dma_b128_s(bsrows + (size_t)kk * 4, bsoff, bs_lds + slot * BSB);
+  };
   auto issue_w = [&](int stage, int k) {
     const int kk = k0 + min(k, nk - 1);
     dma_b128_nt_s(brows + (size_t)kk * 128, boff[0], w_lds + stage * 2048);
     dma_b128_nt_s(brows + (size_t)kk * 128, boff[1], w_lds + stage * 2048 + 1024);
-    if constexpr (MX) {
+    if constexpr (MX && QS == 1) {
       if (!SLIM || lane < 16) dma_b32_s(bsrows + (size_t)kk * 4, bsoff, bs_lds + stage * SCL);
     }
   };
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // the last waves re-fetch the group's last row into rows nobody reads): a 32-row group in a 64-row slab costs the workgroup
   // 4 activation DMAs per step, not 8 -- the activation tile is half of what a CU's texture path moves per step
   constexpr int AD = (2 * MTC >= WAVES) ? 2 * MTC / WAVES : 1;
-  constexpr int LPSC = AD + 2 + (MX ? 2 : 0);
+  constexpr int LPSC = AD + 2 + ((MX && QS == 1) ? 2 : 0);
   uint32_t aoff[AD];
 #pragma unroll
   for (int i = 0; i < AD; ++i) {
@@ -184,11 +193,12 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     const int kk = k0 + min(k, nk - 1);
 #pragma unroll
     for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)kk * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
-    if constexpr (MX) {
+    if constexpr (MX && QS == 1) {
       if (!SLIM || lane < 16) dma_b32_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
     }
   };
   if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
+  if constexpr (QS == 4) issue_s(0, 0);  // then the block of steps 4 j + 4 .. at the head of step 4 j + 1 (older than a(4 j + 3): landed by then)
 #pragma unroll
   for (int i = 0; i < kWStages - 3; ++i) issue_w(i, i);
   issue_a(0, 0); issue_w(kWStages - 3, kWStages - 3);
@@ -197,10 +207,15 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   int stage = 0, wstage = 0;
   for (int k = 0; k < nk; ++k) {
     // (3 weight stages: w(k) is issued right behind a(k), so only a(k + 1) and w(k + 1) -- one stage -- may still be in flight)
-    if constexpr (kWStages >= 4) wait_vmcnt<LPSC + 2 + (MX ? 1 : 0)>(); else wait_vmcnt<LPSC>();
+    // (QS == 4: at k % 4 == 2 the two scale requests of step k - 1 are younger than a(k) too)
+    if constexpr (QS == 4) { if ((k & 3) == 2) wait_vmcnt<LPSC + 2 + 2>(); else wait_vmcnt<LPSC + 2>(); }
+    else if constexpr (kWStages >= 4) wait_vmcnt<LPSC + 2 + (MX ? 1 : 0)>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading step k - 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (TRACE && k < 8) ts[2 + k] = __builtin_amdgcn_s_memtime();
+    if constexpr (QS == 4) {
+      if ((k & 3) == 1) issue_s(((k >> 2) + 1) & 1, (k & ~3) + 4);
+    }
     issue_a((stage == 0) ? 2 : stage - 1, k + 2);
     issue_w((wstage == 0) ? kWStages - 1 : wstage - 1, k + kWStages - 1);
     const char* A = smem + stage * kABuf;
@@ -209,11 +224,15 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(W + (pa ^ 64));
     const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
     // MX: the scale byte of lane group kq is that of 32-k block kq of the step (operand layout probed on gfx950, stream8_kernels.hip)
-    [[maybe_unused]] const char* AS = smem + kStages * kABuf + WAVES * (kWStages * 2048) + stage * WAVES * SCL;
+    [[maybe_unused]] const char* AS = smem + kStages * kABuf + WAVES * (kWStages * 2048) +
+                                      ((QS == 1) ? stage * WAVES * SCL : ((k >> 2) & 1) * WAVES * ASB + (k & 3) * 4);
     int sb = 127;
-    if constexpr (MX)
+    if constexpr (MX && QS == 1)
       sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + kStages * WAVES * SCL +
                                                     (wave * kWStages + wstage) * SCL + nl * 4) >> (8 * kq)) & 0xff;
+    if constexpr (MX && QS == 4)
+      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + 2 * WAVES * ASB +
+                                                    (wave * 2 + ((k >> 2) & 1)) * BSB + nl * 16 + (k & 3) * 4) >> (8 * kq)) & 0xff;
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
         int sa = 127;
         if constexpr (MX) {  // row mt * 16 + nl sits in the region of wave row / RPW, slot row % RPW
           const int row = mt * 16 + nl;
-          sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * SCL + (row % RPW) * 4) >> (8 * kq)) & 0xff;
+          sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * ((QS == 1) ? SCL : ASB) + (row % RPW) * ((QS == 1) ? 4 : 16)) >> (8 * kq)) & 0xff;
         }
         acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, sa, 0, sb);
       }
@@ -644,7 +663,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 
-template <int WAVES, int KIND, int MT = 8, bool SLIM = false>
+template <int WAVES, int KIND, int MT = 8, bool SLIM = false, int QS = 1>
 int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   constexpr int BN = WAVES * 16;
   constexpr int BM = 16 * MT;
@@ -656,7 +675,8 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   dim3 grid((unsigned)((p.N + BN - 1) / BN), gy, (unsigned)split), block(64 * WAVES);
   constexpr int kWStages = w_stages(WAVES, KIND, MT, SLIM);
   constexpr size_t smem = (size_t)kStages * MT * 2048 + (size_t)WAVES * kWStages * 2048 +
-                          ((KIND == RB8_MX) ? (size_t)(kStages + kWStages) * WAVES * (SLIM ? 64 : 256) : 0);
+                          ((KIND != RB8_MX) ? 0 : (QS == 4) ? (size_t)2 * 16 * MT * 16 + (size_t)WAVES * 2 * 256
+                                                            : (size_t)(kStages + kWStages) * WAVES * (SLIM ? 64 : 256));
   static_assert(!SLIM || 3 * smem <= 160 * 1024, "SLIM: three workgroups per CU");
   static_assert(smem <= 160 * 1024, "rb8_kernel: LDS");
   if (split > 1) {
@@ -666,7 +686,7 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
     if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
   }
   p.trace = g_fp8_rb_trace;
-  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM> : rb8_kernel<WAVES, KIND, MT, false, SLIM>;
+  auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(rb8_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("rb8_kernel launch");
@@ -779,8 +799,14 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
       return quad ? launch_mx_stream<8, 3, 4>(p, stream) : launch_mx_stream<8, 3, 1>(p, stream);
     }
   }
-  if (bm == 64) return (g_mx_slim_off ? launch_rb8<4, RB8_MX, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 4, true>(p, 1, stream));
-  return (((N + 127) / 128) * groups * p.slabs < 400) ? launch_rb8<4, RB8_MX, 8>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);
+  // larger groups (and more than 64 experts): one workgroup per (slab, tile); scales per 4 steps when K allows
+  const bool quad = g_mx_quad && K % 512 == 0 && ((uintptr_t)a_scale % 16 == 0) && ((uintptr_t)b_scale % 16 == 0);
+  if (bm == 64) {
+    if (g_mx_slim_off) return launch_rb8<4, RB8_MX, 4>(p, 1, stream);  // (112: the round-2 form)
+    return quad ? launch_rb8<4, RB8_MX, 4, false, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 4, true>(p, 1, stream);
+  }
+  if (((N + 127) / 128) * groups * p.slabs < 400) return quad ? launch_rb8<4, RB8_MX, 8, false, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 8>(p, 1, stream);
+  return quad ? launch_rb8<8, RB8_MX, 8, false, 4>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);
 }
 
 // Float8Tensor's _grouped_mm, rowwise (float8_tensor.py:1085-1122 -> scaled_grouped_mm with RowWise scales):

@@ -410,7 +410,9 @@ def test_mxfp8_grouped_mm_stream_k_kernel(sizes, n, k, variant):
     yn = np_from_torch_bf16(y)
     assert _rel(yn, y_ref) <= 1e-3
     assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
-    assert _rel(np_from_torch_bf16(y_tile), yn) <= 1e-3
+    yt = np_from_torch_bf16(y_tile)  # the one-workgroup-per-tile kernel (scales per 4 steps when K % 512 == 0) against the oracle too
+    assert _rel(yt, yn) <= 1e-3
+    assert np.all(np.abs(yt - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
 
 
 @pytest.mark.parametrize("m,n,k,bias", [(128, 1024, 8192, False), (128, 7168, 8192, True), (200, 8192, 1024, True), (2048, 1024, 1024, False),
