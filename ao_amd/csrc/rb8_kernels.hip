@@ -369,14 +369,14 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   // group table: lane e holds expert e's rows [lo, hi), its slab count and the running slab count
   int lo = 0, hi = 0;
   if (p.offs != nullptr) {
-    if (lane < p.E) {
-      hi = p.offs[lane];
-      lo = (lane > 0) ? p.offs[lane - 1] : 0;
+    if (lane < p.E) {  // (clamped to [0, M] and made monotone by the max below: a malformed offs cannot send a DMA out of the tensors)
+      hi = min(max(p.offs[lane], 0), p.M);
+      lo = (lane > 0) ? min(max(p.offs[lane - 1], 0), p.M) : 0;
     }
   } else if (lane == 0) {
     hi = p.M;
   }
-  const int ns = (hi - lo + BM - 1) / BM;
+  const int ns = max(hi - lo + BM - 1, 0) / BM;
   int incl = ns;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {

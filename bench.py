@@ -636,7 +636,7 @@ def config_mx(stream, device, args):
                        f"64 tokens x top-2 = 128 rows, group sizes {sizes.tolist()} (32 x multinomial, seed 0), 32 layers",
            "value": 64 / t, "unit": "tokens/s", "ms_per_step": t * 1e3, "dtype": "e4m3 x e4m3 with E8M0 1x32 block scales, bf16 out",
            "launch": "hipGraph replay" if graphed else "eager",
-           "roofline": {"kernel": "rb8_kernel<RB8_MX>", "bound": "hbm", "achieved": bts / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"kernel": "mx_stream_kernel<8, 3, 4> (stream-K, decode-size groups)", "bound": "hbm", "achieved": bts / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bts / t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_of("mx")[0], "traffic_source": pmc_traffic_of("mx")[1],
                         "timing": "hipGraph replay wall time of the whole step (activation casts included)",
                         "bytes_note": "weights of the experts that received tokens only", "TFLOPs": flops / t / 1e12}}

@@ -30,7 +30,8 @@ timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA 
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_pmc_sq2 -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_sq2.log 2>&1
 echo "== rocprof pmc + stats, secondary configs (one bench.py process per config; FETCH_SIZE and WRITE_SIZE in separate passes) =="
 CFG_CMD="python $R/bench.py --warmup 1 --steps 2 --no-cpu-baseline --no-second-layout --no-stack-baseline --no-subclass-graph"
-for c in int4_bs128 int8 fp8 mx; do
+# (fp8: its FETCH_SIZE pass did not finish in 900 s under counter collection in this round's first profile run -- not repeated; `traffic` stays null for it)
+for c in int4_bs128 int8 mx; do
   timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_cfg_${c}_fetch -o cfg -- $CFG_CMD --configs $c > $O/rocprof_cfg_${c}_fetch.log 2>&1
   timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_cfg_${c}_write -o cfg -- $CFG_CMD --configs $c > $O/rocprof_cfg_${c}_write.log 2>&1
   python $R/scripts/pmc_summary.py $O/prof_cfg_${c}_fetch $O/prof_cfg_${c}_write -o $O/cfg_${c}_pmc.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --configs $c --steps 2" > /dev/null
@@ -40,7 +41,7 @@ f=$(find $O/prof_cfg_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && 
 O=$O python - <<'PY'
 import json, os
 O = os.environ["O"]
-dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8_kernel", "fp8": "gemm8_p8_kernel", "mx": "rb8_kernel"}
+dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8_kernel", "mx": "mx_stream_kernel"}
 out = {"source": "scripts/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes per config; FETCH x1024 x2 (gfx950), WRITE x1024 (uncalibrated); "
                  "mean over the dispatches of the config's dominant kernel", "configs": {}}
 for c, k in dom.items():
@@ -54,6 +55,8 @@ for c, k in dom.items():
         out["configs"][c] = {"kernel": k, "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "hbm_read_bytes_per_launch": e.get("hbm_read_bytes_per_launch"),
                              "hbm_write_bytes_per_launch": e.get("hbm_write_bytes_per_launch"), "dispatches": e.get("dispatches"),
                              "other_kernels": {kk: vv.get("hbm_bytes_per_launch") for kk, vv in d.items() if kk != k}}
+out["configs"]["fp8"] = {"kernel": "gemm8_p8_kernel", "hbm_bytes_per_launch": None,
+                         "note": "FETCH_SIZE pass of this config exceeded 900 s under counter collection (first round-3 profile run); not collected"}
 json.dump(out, open(f"{O}/configs_pmc.json", "w"), indent=1)
 print({c: (round(v.get("hbm_bytes_per_launch") or 0) if isinstance(v, dict) else v) for c, v in out["configs"].items()})
 PY
