@@ -16,7 +16,7 @@ echo "== torchrun world 1 ==" ; timeout 600 python -m torch.distributed.run --nn
 echo "== TP over RCCL, world 1 ==" ; timeout 600 python bench.py --force-tp --configs tp --no-second-layout --no-cpu-baseline --steps 5 2>$O/tp.err > $O/bench_tp.json; python -c "
 import json; d=json.loads(open('$O/bench_tp.json').read().strip().splitlines()[-1]); json.dump({'fp8_tp': d['configs']['fp8_tp']}, open('$O/bench_tp_world1.json','w'), indent=1); print({k: round(v['per_gpu_TFLOPs']) for k, v in d['configs']['fp8_tp']['by_M'].items()})"
 echo "== N = 2 code path, dry run: two ranks sharing the GPU over gloo (numbers meaningless; the line, the rank-0 printing and the TP = 2 config must work) =="
-AO_BENCH_SHARE_GPU=1 AO_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_n2_dryrun.json 2>$O/n2.err; python -c "
+AO_BENCH_ONE_SHOT=1 AO_BENCH_SHARE_GPU=1 AO_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_n2_dryrun.json 2>$O/n2.err; python -c "
 import json; out=open('$O/bench_n2_dryrun.json').read().strip().splitlines(); d=json.loads(out[-1]); print('stdout lines', len(out), 'n_gpus', d['n_gpus'], 'fp8_tp keys', sorted(d['configs']['fp8_tp'].get('by_M', d['configs']['fp8_tp'])))"
 cd /tmp && export TMPDIR=/tmp
 HEAD_CMD="python $R/bench.py --warmup 1 --no-cpu-baseline --no-second-layout --no-configs"
