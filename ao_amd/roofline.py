@@ -28,6 +28,13 @@ gpu_name_to_specs = {
         # measured on this hardware (MI355X_MICROARCH.md): bf16 32x32x16 micro-benchmark 2495 TF of 2500; float4 copy 6.29 of 8.0 TB/s
         "pct_achievable_gemm_tops": 0.95,
         "pct_achievable_mem_bw": 0.79,
+        # measured in round 3 on the pool's boxes (tools/mfma_rate.hip -> profiles/mfma_rate_r03.txt: every SIMD issuing independent MFMAs back
+        # to back; the chip holds ~2.07 - 2.3 GHz under that load, not 2.4): what "100 % of the matrix pipe" is in practice
+        "bf16_measured_mfma_tops": 2.39e15,   # 16x16x32, 16 cycles
+        "fp8_measured_mfma_tops": 4.52e15,    # f8f6f4 16x16x128 / 32x32x64 with e4m3 operands, 32 / 64 cycles
+        "int8_measured_mfma_tops": 4.22e15,   # i32_16x16x64_i8, 16 cycles
+        # streaming reads of 60 - 500 MB launches top out here in every kernel of this repo
+        "measured_read_bw_bytes_sec": 4.5e12,
         # xGMI: 7 links x ~153 GB/s per GPU, fully connected 8-GPU node
         "xgmi_links": 7,
         "xgmi_link_bytes_sec": 153e9,

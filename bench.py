@@ -289,6 +289,7 @@ def int4_roofline(model, batch, stream):
         "peak": MFMA_BF16_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
         "unit": "TFLOP/s" if mfma_bound else "GB/s",
         "avg_kernel_us": kd["avg_kernel_us"],
+        "measured_ceiling": (_SPECS["bf16_measured_mfma_tops"] / 1e12) if mfma_bound else (_SPECS["measured_read_bw_bytes_sec"] / 1e9),
         "timing": "HIP extension events on the launch stream, one eager step, mean of 3",
         "launches_per_step": len(model.weights),
         "sum_kernel_ms_per_step": float(prof.sum()),
@@ -525,6 +526,7 @@ def config_int8(stream, device, args):
            "launch": "hipGraph replay" if graphed else "eager", "launches_per_layer": 2 * nchunk * len(ws),
            "roofline": {"kernel": "gemm8_p8_kernel<int8> (256x256 phase-interleaved; gemm8_dma_kernel below 160 tiles)", "bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_8BIT_PEAK_TOPS,
                         "unit": "TOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_8BIT_PEAK_TOPS, "traffic": pmc_traffic_of("int8")[0], "traffic_source": pmc_traffic_of("int8")[1],
+                        "measured_mfma_ceiling": _SPECS["int8_measured_mfma_tops"] / 1e12, "frac_of_measured_ceiling": flops / (gemm_ms * 1e-3) / _SPECS["int8_measured_mfma_tops"],
                         "timing": "HIP extension events, one eager layer", "gemm_ms_per_layer": gemm_ms, "act_cast_ms_per_layer": cast_ms,
                         "end_to_end_TOPs": flops / t / 1e12}}
     if not args.no_cpu_baseline:
@@ -586,6 +588,7 @@ def config_fp8_shards(stream, device, args):
            "by_M": res,
            "roofline": {"kernel": "gemm8_p8_kernel<fp8> / gemm8_dma_kernel / rb8_kernel by shard shape", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": res["M2048"]["frac"], "traffic": pmc_traffic_of("fp8")[0], "traffic_source": pmc_traffic_of("fp8")[1],
+                        "measured_mfma_ceiling": _SPECS["fp8_measured_mfma_tops"] / 1e12, "frac_of_measured_ceiling": res["M2048"]["TFLOPs"] * 1e12 / _SPECS["fp8_measured_mfma_tops"],
                         "timing": "hipGraph replay wall time of the whole step (casts included)"}}
     if not args.no_cpu_baseline:
         from oracle import c_ref
