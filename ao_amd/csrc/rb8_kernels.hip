@@ -438,7 +438,11 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     }
   };
   // ---- activation cursor
+  // QS == 4: a wave only requests the 8-row pieces (and the scale rows) its group HAS -- a 32-row group costs 4 of the tile's 8
+  // DMA instructions, and on this path instructions are what costs.  The hand-counted waits then follow what was really
+  // issued (a_prev / s_prev below); rows nobody fetched keep stale bytes that only the m-tiles past the group would read.
   uint32_t aoff[AD], asoff = 0;
+  int a_cnt = AD;  // pieces of the cursor's slab this wave fetches
   int ga = g0, ka = k00, tilea = tile0;
   auto set_a = [&](int tile) {
     int e, m0, m_end;
@@ -449,10 +453,13 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
       aoff[i] = (uint32_t)min(m0 + row, m_end - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
     }
     asoff = (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32;
+    if constexpr (QS == 4) a_cnt = __builtin_amdgcn_readfirstlane(max(0, min(AD, (min(m_end - m0, BM) - 8 * AD * wave + 7) >> 3)));
   };
-  auto issue_a = [&](int stage) {
+  auto issue_a = [&](int stage) -> int {  // returns the DMAs issued
+    const int cnt = a_cnt;
 #pragma unroll
-    for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)ka * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
+    for (int i = 0; i < AD; ++i)
+      if (QS == 1 || i < cnt) dma_b128_s(p.a + (size_t)ka * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
     if constexpr (QS == 1) {
       if (lane < RPW) dma_b32_s(p.a_mx + (size_t)ka * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
     }
@@ -460,9 +467,11 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
       ++ga;
       if (++ka == ksteps) { ka = 0; set_a(++tilea); }
     }
+    return cnt;
   };
   // ---- scale cursor (QS == 4): the 16 scale bytes of 4 steps per row, two slots per wave and operand
   uint32_t asoff4 = 0;
+  bool as_have = true;  // this wave's activation-scale rows exist in the cursor's slab
   const uint8_t* bsrows4 = nullptr;
   int gs = g0, ks4 = k00, tiles4 = tile0;
   auto set_s = [&](int tile) {
@@ -472,13 +481,27 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     const int t16 = min(nt * WAVES + wave, n16 - 1);
     bsrows4 = p.b_mx + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
     asoff4 = (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32;
+    as_have = RPW * wave < m_end - m0;
   };
-  auto issue_s = [&](int slot) {  // (the last block repeats past the end, like the tiles)
-    if (lane < RPW) dma_b128_s(p.a_mx + (size_t)ks4 * 4, asoff4, as_lds + (slot * WAVES + wave) * ASB);
+  auto issue_s = [&](int slot) -> int {  // (the last block repeats past the end, like the tiles); returns the DMAs issued
+    const int cnt = as_have ? 2 : 1;
+    if (as_have) {
+      if (lane < RPW) dma_b128_s(p.a_mx + (size_t)ks4 * 4, asoff4, as_lds + (slot * WAVES + wave) * ASB);
+    }
     if (lane < 16) dma_b128_s(bsrows4 + (size_t)ks4 * 4, bsoff, bs_lds + slot * BSB);
     if (gs + 4 < g1) {
       gs += 4;
       if ((ks4 += 4) == ksteps) { ks4 = 0; set_s(++tiles4); }
+    }
+    return cnt;
+  };
+  auto wait_upto = [&](int n) {  // s_waitcnt vmcnt(n) for a wave-uniform n in [2, AD + 4] (the immediate has to be a constant)
+    switch (n) {
+      case 2: wait_vmcnt<2>(); break;
+      case 3: wait_vmcnt<3>(); break;
+      case 4: wait_vmcnt<4>(); break;
+      case 5: wait_vmcnt<5>(); break;
+      default: wait_vmcnt<6>(); break;
     }
   };
   // ---- compute cursor
@@ -536,11 +559,12 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 #pragma unroll
   for (int i = 0; i < SW - 3; ++i) issue_w(i);
   issue_a(0); issue_w(SW - 3);
-  issue_a(1); issue_w(SW - 2);
+  int a_prev = issue_a(1), s_prev = 0;  // QS == 4: what the step before issued besides its two weight DMAs (= all that may be in flight)
+  issue_w(SW - 2);
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
   int stage = 0, wstage = 0;
   for (int g = g0; g < g1; ++g) {
-    if constexpr (QS == 4) { if (((g - g0) & 3) == 2) wait_vmcnt<LPSC + 2>(); else wait_vmcnt<LPSC>(); }
+    if constexpr (QS == 4) wait_upto(a_prev + 2 + s_prev);
     else if constexpr (SW >= 4) wait_vmcnt<LPSC + 3>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading the step before
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -550,9 +574,9 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
       // step i of the share (i = g - g0; shares and tiles begin at multiples of 4): the next block's scales go out at i % 4 == 1 into
       // the slot the block before this one used (last read at step i - 2); they are older than a(i + 2), w(i + 2), whose wait at
       // step i + 2 therefore covers them, and at that wait -- only there -- two more requests are younger than what it needs
-      if (((g - g0) & 3) == 1) issue_s((((g - g0) >> 2) + 1) & 1);
+      s_prev = (((g - g0) & 3) == 1) ? issue_s((((g - g0) >> 2) + 1) & 1) : 0;
     }
-    issue_a((stage == 0) ? 2 : stage - 1);
+    a_prev = issue_a((stage == 0) ? 2 : stage - 1);
     issue_w((wstage == 0) ? SW - 1 : wstage - 1);
     const char* A = smem + stage * kABuf;
     const char* Wt = smem + kStages * kABuf + (wave * SW + wstage) * 2048;
