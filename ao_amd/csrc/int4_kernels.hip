@@ -508,7 +508,7 @@ constexpr int rb_wstages(int waves, int mt, int wst) {
   return room >= kRbWeightStages ? kRbWeightStages : (room < 3 ? 3 : room);
 }
 
-// ABL (profiling builds only): 1 no 16x16x32 MFMAs, 2 no dequant, 3 no A reads, 4 no DMAs, 5 product + s_memtime stamps of wave 0
+// ABL (profiling builds only): 1 no 16x16x32 MFMAs, 2 no dequant, 3 no A reads, 4 no DMAs, 6 no scale / zero DMAs, 5 product + s_memtime stamps of wave 0
 // (16 u64 per workgroup: entry, ring primed, barrier of k-blocks 0..7 passed, loop done, meeting done, exit)
 // MT = 16-row m-tiles per slab (8, 4, 2, 1): batches below 128 rows stage, read and multiply only the rows they have.
 // PROD: WAVES more waves that do nothing but issue the ring's DMAs (producer wave WAVES + w feeds consumer wave w: its weight ring and
@@ -526,10 +526,11 @@ __global__ __launch_bounds__(64 * WAVES * (PROD ? 2 : 1), (WAVES == 4 && !PROD) 
   constexpr int ADMA = 4 * MT / WAVES;    // x DMAs per wave and stage (4 rows each)
   static_assert(ADMA >= 1, "every wave issues the same number of DMAs per stage");
   constexpr int ABUF = MT * 4096;         // one x stage: 16 MT rows x 256 B
-  constexpr int LPS = ADMA + NT * (1 + NG);  // DMAs per wave and stage
+  constexpr int NGD = (ABL == 6) ? 0 : NG;    // scale / zero DMAs per n-tile and k-block (ABL 6: none, timing only)
+  constexpr int LPS = ADMA + NT * (1 + NGD);  // DMAs per wave and stage
   constexpr int SLOTS = 16 * NT;          // schedule slots per k-block (MT / 4 MFMAs each)
   constexpr int KW = rb_wstages(WAVES, MT, WST);  // weight ring stages
-  constexpr int WDMAS = NT * (1 + NG);    // weight DMAs per wave and stage
+  constexpr int WDMAS = NT * (1 + NGD);   // weight DMAs per wave and stage
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][128 rows][256 B] x | [WAVES][KW][WST]
 
   const int tid = threadIdx.x;
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(64 * WAVES * (PROD ? 2 : 1), (WAVES == 4 && !PROD) 
       dma_b128_s(x + (size_t)k * 128, aoff[idx], a_lds + stage * ABUF + (ADMA * wave + idx) * 1024);
     } else {
       const int k = kb0 + min(kbw, nkb - 1);
-      constexpr int t = (idx - ADMA) / (1 + NG), part = (idx - ADMA) % (1 + NG);
+      constexpr int t = (idx - ADMA) / (1 + NGD), part = (idx - ADMA) % (1 + NGD);
       const int tile = min(tile0 + t, ntiles - 1);  // tiles past N alias the last one; their columns are never stored
       const uint32_t dst = w_lds + wstage * WST + t * WBLK;
       if constexpr (part == 0) {
@@ -1340,6 +1341,11 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     const int sp = (g_tune_mode == 900) ? (int)std::max<int64_t>(1, std::min<int64_t>({256 / base9, fit9, 8, kblocks / 8}))
                                         : (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode - 900), kblocks, fit9}));
     return launch_mm_rb<G, 4, 1, 8, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
+  } else if (g_tune_mode == 910 && M > 64) {
+    // profiling: the same without the scale / zero DMAs (wrong numbers): what the dword LDS-DMAs cost
+    const int64_t base9 = ((N + 63) / 64) * ((M + 127) / 128);
+    const int64_t fit9 = (int64_t)kSplitMaxTiles * 128 * 128 / (base9 * 64 * 128);
+    return launch_mm_rb<G, 4, 1, 8, 6, true>(x, qdata, sz, y, M, N, K, (int)std::max<int64_t>(1, std::min<int64_t>({256 / base9, fit9, 8, kblocks / 8})), stream);
   } else if (g_tune_mode >= 800 && g_tune_mode < 840 && M > 16) {
     // profiling (round 3): two n-tiles per wave -- every A fragment read from LDS feeds two MFMAs.  80S / 81S: 64-row slabs x 128
     // columns (4 waves, fused / with DMA-producer waves), 82S / 83S: 128-row slabs x 128 columns; S = K parts (0: fill ~256 workgroups)
