@@ -90,8 +90,13 @@ def parse_args():
 # ----------------------------------------------------------------------------------------------------------------------
 # timing helpers
 # ----------------------------------------------------------------------------------------------------------------------
-def capture(fn, stream, use_graph=True):
-    """Run fn once eagerly (first touch, lazy workspaces), then capture it into a hipGraph.  Returns a replay callable."""
+def capture(fn, stream, use_graph=True, collectives=False):
+    """Run fn once eagerly (first touch, lazy workspaces), then capture it into a hipGraph.  Returns a replay callable.
+    collectives: fn issues RCCL collectives.  ProcessGroupNCCL's watchdog thread polls the events of every collective issued so far
+    (hipEventQuery, every ~100 ms); in the default "global" capture mode such a call from ANOTHER thread while this one captures
+    invalidates the capture, and the works issued during the broken capture then take the process down from the watchdog
+    (hipErrorCapturedEvent -> std::terminate; seen once in six runs of the world-1 TP leg, profiles/tp_capture_abort_r03.txt).  So:
+    let the watchdog reap everything that is outstanding before the capture starts, and capture in thread-local mode."""
     with torch.cuda.stream(stream):
         fn()
         stream.synchronize()
@@ -99,7 +104,10 @@ def capture(fn, stream, use_graph=True):
             return fn, False
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream):
+            if collectives:
+                torch.cuda.synchronize()
+                time.sleep(0.5)
+            with torch.cuda.graph(g, stream=stream, **({"capture_error_mode": "thread_local"} if collectives else {})):
                 fn()
             return g.replay, True
         except Exception as e:  # noqa: BLE001
@@ -715,7 +723,7 @@ def config_fp8_tp(stream, device, args, dist, world):
         # (gloo collectives cannot be captured, and a failed capture leaves the stream's capture state invalidated for every later launch:
         # only RCCL runs try)
         try_graph = not args.no_tp_graph and dist.get_backend() == "nccl"
-        run, graphed = capture(step, stream, use_graph=True) if try_graph else (step, False)
+        run, graphed = capture(step, stream, use_graph=True, collectives=True) if try_graph else (step, False)
         with torch.cuda.stream(stream):
             t = time_steps(run, stream, device, steps, 2, dist) / steps
             # the collectives alone, same sizes and order: amax MAX [M] + fp32 SUM [M, 8192] per row-parallel linear
