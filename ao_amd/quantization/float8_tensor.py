@@ -189,7 +189,11 @@ def _(func, types, args, kwargs):
     ws = mat_b.scale.transpose(-2, -1)  # [E, N, 1]
     if mat_b.act_quant_kwargs is None:
         raise NotImplementedError("weight-only Float8Tensor _grouped_mm is not on the MI355X hot path: use dynamic activation quantization")
-    _check(mat_b.act_quant_kwargs.granularity, mat_b.act_quant_kwargs.float8_dtype)  # PerRow only, like the reference
+    _check(mat_b.act_quant_kwargs.granularity, mat_b.act_quant_kwargs.float8_dtype)
+    # PerRow only, like the reference (float8_tensor.py:1098-1101 asserts rowwise scales on both operands)
+    if not isinstance(mat_b.act_quant_kwargs.granularity, PerRow) or ws.shape[-2] != wq.shape[-2]:
+        raise NotImplementedError("Float8Tensor _grouped_mm implements PerRow activations and PerRow weight scales only "
+                                  f"(got activations {mat_b.act_quant_kwargs.granularity}, weight scale {tuple(mat_b.scale.shape)})")
     aq, a_s = ops.fp8_quantize_rowwise(mat_a.to(torch.bfloat16).contiguous())
     return ops.fp8_grouped_mm(aq, a_s, wq, ws, offs.to(torch.int32)).to(output_dtype)
 

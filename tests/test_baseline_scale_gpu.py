@@ -232,6 +232,21 @@ def test_fp8_grouped_mm_vs_oracle(sizes, n, k):
     assert np.all(np.abs(yn - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -14)
 
 
+def test_fp8_grouped_mm_rejects_per_tensor_activations():
+    """Float8Tensor _grouped_mm is PerRow x PerRow like the reference (float8_tensor.py:1098-1101): PerTensor activation kwargs fail with a
+    message that names the reason instead of surfacing later in the kernel's scale-shape check."""
+    from ao_amd.quantization import Float8Tensor
+    from ao_amd.quantization.float8_tensor import QuantizeTensorToFloat8Kwargs
+    from ao_amd.quantization.granularity import PerTensor
+
+    w = _randn_bf16((2, 64, 256), 53, 0.05).to(DEV)
+    wt = Float8Tensor.from_hp(w, act_quant_kwargs=QuantizeTensorToFloat8Kwargs(granularity=PerTensor()))
+    a = _randn_bf16((32, 256), 54).to(DEV)
+    offs = torch.tensor([16, 32], dtype=torch.int32, device=DEV)
+    with pytest.raises(NotImplementedError, match="PerRow"):
+        torch._grouped_mm(a, wt.transpose(-2, -1), offs=offs)
+
+
 def test_mxfp8_moe_forward_with_cached_expert_weights():
     """_to_mxfp8_then_scaled_grouped_mm: casting the expert weights once (MXFP8ExpertWeights / cache_weights=True) gives the bits of
     casting them in every call (the reference's forward), and an in-place weight update invalidates the memo."""
