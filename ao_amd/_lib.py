@@ -71,6 +71,9 @@ _SIGNATURES = {
     "ao_allreduce_flag_bytes": [],
     "ao_allreduce_state_bytes": [],
     "ao_allreduce_oneshot": [_P, _P, _P, _P, _P, _I64, _INT, _I64, _INT, _INT, _P],
+    "ao_moe_a2a_flag_bytes": [],
+    "ao_moe_a2a_state_bytes": [],
+    "ao_moe_a2a_v": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P],
     "ao_fp8_int4_linear": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_permute_indices": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_gather_rows": [_P, _P, _P, _I64, _I64, _I64, _P],
@@ -114,6 +117,8 @@ def lib():
         l.ao_moe_padded_rows.restype = _I64
         l.ao_allreduce_flag_bytes.restype = _I64
         l.ao_allreduce_state_bytes.restype = _I64
+        l.ao_moe_a2a_flag_bytes.restype = _I64
+        l.ao_moe_a2a_state_bytes.restype = _I64
         l.ao_int4_hqq_workspace_bytes.restype = _I64
         _lib = l
     return _lib

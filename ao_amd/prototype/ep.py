@@ -14,6 +14,10 @@ like the reference's MXTensor input (mxfp8_grouped_mm.py:173-178, 482-486).
   * permute.py / unpermute.py / kernels.py -- regrouping the received tokens from rank-major to expert-major order with aligned
     groups (`generate_permute_indices`, `permute_and_pad`, `permute_mxfp8_fwd`) and back (`unpermute_hp_fwd`): HIP index + row
     kernels (csrc/moe_permute_kernels.hip) instead of Triton.
+  * kernels/mxfp8/comms.py:25-400 -- the ON-DEVICE all-to-all-v (`OnDeviceAllToAllV`, `mxfp8_on_device_all_to_all_v`): split sizes stay
+    on the device, every rank pulls its rows from peer-mapped staging buffers with one HIP kernel (csrc/a2a_kernels.hip) instead of
+    the reference's Triton kernel over symmetric memory.  Opt-in (verified with two ranks on one GPU); RCCL's all_to_all_single is
+    the default exchange.
 Backward passes are training-only (outside SURVEY.md section 8).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -24,7 +28,7 @@ import torch.distributed as dist
 from .mx import BLOCK, ScaleCalculationMode
 
 __all__ = ["MXFP8Tokens", "a2a_dispatch_mxfp8_fwd", "a2a_combine_hp_fwd", "exchange_split_sizes", "generate_permute_indices",
-           "permute_and_pad", "permute_mxfp8_fwd", "unpermute_hp_fwd"]
+           "permute_and_pad", "permute_mxfp8_fwd", "unpermute_hp_fwd", "OnDeviceAllToAllV", "mxfp8_on_device_all_to_all_v"]
 
 
 def _round_up(x: int, y: int) -> int:
@@ -140,3 +144,105 @@ def exchange_split_sizes(num_tokens_per_expert: torch.Tensor, group=None) -> Tup
     input_splits = counts.view(world, -1).sum(dim=1).tolist()
     output_splits = recv.view(world, -1).sum(dim=1).tolist()
     return input_splits, output_splits, recv
+
+
+class OnDeviceAllToAllV:
+    """All-to-all-v of MXFP8 token rows with the split sizes ON THE DEVICE (reference MXFP8OnDeviceAllToAllV / _mxfp8_on_device_all_to_all_v,
+    kernels/mxfp8/comms.py:25-167, 271-316).  One instance per (group, D, max rows): it owns this rank's staging buffers -- e4m3 rows,
+    E8M0 scale rows, the int64 split vector -- and a flag block, all exported to the peers as IPC handles once (torch's CUDA-IPC storage
+    sharing over the process group; HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack), like the reference's symmetric-memory buffers.
+    `__call__` stages the inputs and launches `ao_moe_a2a_v`: no host synchronisation, capturable into a hipGraph.
+    `ok` False / `why`: the set-up failed (callers fall back to `a2a_dispatch_mxfp8_fwd` over RCCL)."""
+
+    def __init__(self, max_rows: int, dim: int, group=None, device=None):
+        import ctypes
+
+        from .. import _lib
+
+        self.group = dist.group.WORLD if group is None else group
+        self.max_rows, self.dim = int(max_rows), int(dim)
+        self.ok, self.why = False, None
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.device = device
+        try:
+            assert dim % BLOCK == 0 and dim % 16 == 0, f"D = {dim} must be a multiple of {BLOCK}"
+            lib = _lib.lib()
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+            if world > 8:
+                raise RuntimeError("the on-device all-to-all handles at most 8 ranks (one xGMI-connected node)")
+            self._data = torch.zeros((self.max_rows, dim), dtype=torch.uint8, device=device)
+            self._scales = torch.zeros((self.max_rows, dim // BLOCK), dtype=torch.uint8, device=device)
+            self._splits = torch.zeros(world, dtype=torch.int64, device=device)
+            self._flags = torch.zeros(lib.ao_moe_a2a_flag_bytes(), dtype=torch.uint8, device=device)
+            self._state = torch.zeros(lib.ao_moe_a2a_state_bytes() // 4, dtype=torch.int32, device=device)
+            torch.cuda.synchronize(device)
+            own = (self._data, self._scales, self._splits, self._flags)
+            mine = tuple(t.untyped_storage()._share_cuda_() for t in own)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine, group=self.group)
+            self._keep = []  # the mapped peer storages
+            ptrs = [[], [], [], []]
+            for r in range(world):
+                if r == rank:
+                    for i, t in enumerate(own):
+                        ptrs[i].append(t.data_ptr())
+                    continue
+                for i, h in enumerate(gathered[r]):
+                    st = torch.UntypedStorage._new_shared_cuda(*h)
+                    self._keep.append(st)
+                    ptrs[i].append(st.data_ptr())
+            self._arrs = [(ctypes.c_void_p * world)(*p) for p in ptrs]
+            self._lib, self._check = lib, _lib.check
+            self.rank, self.world = rank, world
+            dist.barrier(group=self.group)  # everybody has mapped everybody before the first flag is raised
+            self.ok = True
+        except Exception as e:  # noqa: BLE001 -- any failure means "use the RCCL exchange"
+            self.why = f"{type(e).__name__}: {e}"
+
+    def status(self) -> int:
+        """bit 0: a peer did not arrive within the spin bound; bit 1: more rows arrived than max_rows (host-synchronising read)."""
+        return int(self._state[0].item())
+
+    def __call__(self, data: torch.Tensor, scales: torch.Tensor, input_splits: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """data e4m3 / uint8 [T, D] ordered by destination rank, scales e8m0 / uint8 [T, D / 32], input_splits int64 [world] ON THE DEVICE
+        -> (out_data uint8 [max_rows, D], out_scales uint8 [max_rows, D / 32], output_splits int64 [world]); rows past
+        output_splits.sum() are undefined, like the reference's."""
+        assert self.ok, f"on-device all-to-all is not set up: {self.why}"
+        t = data.shape[0]
+        assert data.dim() == 2 and data.shape[1] == self.dim and t <= self.max_rows and scales.shape == (t, self.dim // BLOCK)
+        assert input_splits.dtype == torch.int64 and input_splits.numel() == self.world and input_splits.is_cuda
+        self._data[:t].copy_(data.view(torch.uint8))
+        self._scales[:t].copy_(scales.view(torch.uint8))
+        self._splits.copy_(input_splits)
+        out = torch.empty((self.max_rows, self.dim), dtype=torch.uint8, device=self.device)
+        out_s = torch.empty((self.max_rows, self.dim // BLOCK), dtype=torch.uint8, device=self.device)
+        out_splits = torch.empty(self.world, dtype=torch.int64, device=self.device)
+        self._check(self._lib.ao_moe_a2a_v(*self._arrs, out.data_ptr(), out_s.data_ptr(), out_splits.data_ptr(), self._state.data_ptr(),
+                                          self.dim, self.dim // BLOCK, self.max_rows, self.rank, self.world,
+                                          torch.cuda.current_stream(self.device).cuda_stream))
+        return out, out_s, out_splits
+
+
+_ON_DEVICE_A2A = {}  # (group id, D, max rows) -> OnDeviceAllToAllV: the reference keeps its symmetric buffers as class attributes
+
+
+def mxfp8_on_device_all_to_all_v(input: torch.Tensor, input_splits: torch.Tensor, max_output_rows_per_rank: int, group=None,
+                                 cast: Optional[Callable] = None):
+    """reference MXFP8OnDeviceAllToAllV.forward (comms.py:52-167): cast the tokens to MXFP8 (to_mx defaults: FLOOR, 1 x 32), exchange
+    data and scales on the device as `input_splits` (an int64 DEVICE tensor, rows for every rank) says, dequantize what arrived.
+    Returns (tokens in input.dtype [sum(output_splits), D], output_splits int64 [world] on the device).  The only host sync is the
+    final slice by output_splits.sum(), as in the reference (:164-166)."""
+    assert input.dtype in (torch.float32, torch.bfloat16) and input.dim() == 2
+    group = dist.group.WORLD if group is None else group
+    key = (id(group), input.shape[1], int(max_output_rows_per_rank))
+    ex = _ON_DEVICE_A2A.get(key)
+    if ex is None:
+        ex = _ON_DEVICE_A2A[key] = OnDeviceAllToAllV(max_output_rows_per_rank, input.shape[1], group, input.device)
+    if not ex.ok:
+        raise RuntimeError(f"on-device all-to-all unavailable ({ex.why}); use a2a_dispatch_mxfp8_fwd")
+    data, scale = (cast or _gpu_cast)(input.to(torch.bfloat16).contiguous(), ScaleCalculationMode.FLOOR)
+    out, out_s, output_splits = ex(data, scale, input_splits)
+    from .mx import mx_dequantize
+
+    hp = mx_dequantize(out_s.view(torch.float8_e8m0fnu), out.view(torch.float8_e4m3fn), input.dtype)
+    return hp[: int(output_splits.sum().item())], output_splits

@@ -318,6 +318,24 @@ int ao_allreduce_oneshot(void* const* peer_data_host, void* const* peer_flags_ho
                          void* output, void* local_state, int64_t count, int dtype, int64_t slot_bytes,
                          int rank, int world, void* stream);
 
+/* On-device all-to-all-v of MXFP8 token rows (expert-parallel dispatch without a host round trip for the split sizes).  Replaces the
+ * Triton kernel torchao/prototype/moe_training/kernels/mxfp8/comms.py:318-460 (_mxfp8_all_to_all_v_kernel, _exchange_row_offsets) that
+ * MXFP8OnDeviceAllToAllV.forward (:52-167) launches over symmetric memory.  Every rank has staged its e4m3 rows (ordered by destination
+ * rank), its E8M0 scale rows and its int64 split vector (rows it sends to rank r) in buffers all peers have mapped; this rank pulls the
+ * rows addressed to it: from rank q, rows [sum_{r < rank} splits_q[r], + splits_q[rank]) land at local rows [sum_{p < q} splits_p[rank], ..),
+ * and out_splits[q] = splits_q[rank].  Barriers before (inputs staged everywhere) and after (staging may be overwritten) are inside
+ * the launch; epochs live on the device (hipGraph-replayable); a peer that never arrives sets bit 0 of local_state[0] after ~0.5 s,
+ * more rows than max_out_rows sets bit 1 (the rows past the end are not written).
+ *   peer_*_host: HOST arrays of `world` DEVICE pointers, index = rank (own buffers at [rank]); data / scale staging 16-byte aligned,
+ *     flag blocks ao_moe_a2a_flag_bytes() bytes, zero-filled once; local_state: ao_moe_a2a_state_bytes() bytes, zero-filled once;
+ *   row_bytes = D (e4m3), a multiple of 16; scale_row_bytes = D / 32.  Every rank must make the same sequence of calls. */
+int64_t ao_moe_a2a_flag_bytes(void);
+int64_t ao_moe_a2a_state_bytes(void);
+int ao_moe_a2a_v(void* const* peer_data_host, void* const* peer_scales_host, void* const* peer_splits_host,
+                 void* const* peer_flags_host, void* out_data, void* out_scales, int64_t* out_splits,
+                 void* local_state, int64_t row_bytes, int64_t scale_row_bytes, int64_t max_out_rows,
+                 int rank, int world, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * fp8 activations x int4 weights (Float8DynamicActivationInt4WeightConfig)
  * ------------------------------------------------------------------------- */

@@ -75,3 +75,18 @@ def scatter_rows(y, idx, num_rows):
     out = np.zeros((num_rows + 1,) + y.shape[1:], y.dtype)
     out[np.asarray(idx, dtype=np.int64)] = y
     return out[:-1]
+
+
+def a2a_v(rows_per_rank, splits_per_rank, rank):
+    """What rank `rank` holds after the all-to-all-v of the reference's _mxfp8_all_to_all_v_kernel / _exchange_row_offsets
+    (torchao/prototype/moe_training/kernels/mxfp8/comms.py:318-460): rows_per_rank[q] = rank q's rows ordered by destination,
+    splits_per_rank[q][r] = how many of them go to rank r.  Returns (rows received, ordered by source rank; output_splits)."""
+    import numpy as np
+
+    got, out_splits = [], []
+    for q, (rows, splits) in enumerate(zip(rows_per_rank, splits_per_rank)):
+        in_off = int(sum(splits[:rank]))
+        n = int(splits[rank])
+        got.append(rows[in_off:in_off + n])
+        out_splits.append(n)
+    return np.concatenate(got, axis=0), np.asarray(out_splits, dtype=np.int64)
