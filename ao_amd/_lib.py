@@ -10,7 +10,7 @@ import re
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_C_mi355.so")
+LIB_PATH = os.environ.get("AO_MI355_LIB") or os.path.join(_HERE, "_C_mi355.so")  # (AO_MI355_LIB: profiling builds under tools/bin/)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ao_mi355.h")
 
 AO_OK = 0

@@ -125,9 +125,14 @@ __device__ __forceinline__ void dequant_stage(DequantPipe& d, uint32_t p, float 
     d.tp0 = pack_bf16x2(t0.x, t1.x); d.tp1 = pack_bf16x2(t2.x, t3.x);  // rounding #1
     d.tp2 = pack_bf16x2(t0.y, t1.y); d.tp3 = pack_bf16x2(t2.y, t3.y);
   } else if constexpr (STAGE == 2) {
+#ifdef AO_DEQUANT_VALU  // profiling build (tools/bin/_C_mi355_valu.so): the t + z add on the VALU instead of the matrix pipe -- 12 VALU for 2 MFMAs per word
+    d.w0 = f32x4{bf16_lo_to_f32(d.tp0) + z, bf16_hi_to_f32(d.tp0) + z, bf16_lo_to_f32(d.tp1) + z, bf16_hi_to_f32(d.tp1) + z};
+    d.w1 = f32x4{bf16_lo_to_f32(d.tp2) + z, bf16_hi_to_f32(d.tp2) + z, bf16_lo_to_f32(d.tp3) + z, bf16_hi_to_f32(d.tp3) + z};
+#else
     const f32x4 zz = {z, z, z, z};
     d.w0 = widen_add(ident, d.tp0, d.tp1, zz);
     d.w1 = widen_add(ident, d.tp2, d.tp3, zz);
+#endif
   } else {
     d.out[0] = pack_bf16x2(d.w0.x, d.w0.y); d.out[1] = pack_bf16x2(d.w0.z, d.w0.w);  // rounding #2
     d.out[2] = pack_bf16x2(d.w1.x, d.w1.y); d.out[3] = pack_bf16x2(d.w1.z, d.w1.w);
