@@ -125,6 +125,7 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
       bf[nt][1] = *reinterpret_cast<const u32x4*>(buf + (off ^ 64));
     }
   };
+  const int unit_scale = 127;  // E8M0 1.0
   auto multiply = [&](int mi, int nj) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -141,7 +142,12 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
                             (int)af[mt][1].x, (int)af[mt][1].y, (int)af[mt][1].z, (int)af[mt][1].w};
           const i32x8 bv = {(int)bf[nt][0].x, (int)bf[nt][0].y, (int)bf[nt][0].z, (int)bf[nt][0].w,
                             (int)bf[nt][1].x, (int)bf[nt][1].y, (int)bf[nt][1].z, (int)bf[nt][1].w};
-          c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, 127, 0, 127);
+          // As inline asm, not the builtin: a builtin MFMA is a pure value computation and the instruction selector is free to place
+          // it anywhere in the loop body -- it put all 32 at the END of the K tile (round 3 disassembly: "rrrr DD | | DD | | rrrr DD |
+          // | DD MMMM...M |"), so both wave rows multiplied at the same time and loaded at the same time, and the fp8 GEMM ran 21 %
+          // behind its int8 twin.  Volatile asm keeps its place between the seams.  (Unit E8M0 scales in a VGPR; cbsz = blgp = 0: e4m3.
+          // The accumulator's next reader is the asm MFMA one K tile later or the epilogue: no hazard the compiler has to see.)
+          asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(av), "v"(bv), "v"(unit_scale));
         }
       }
     if constexpr (IS_INT) {
