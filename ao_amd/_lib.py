@@ -107,7 +107,10 @@ def lib():
                 "(the MI355X backend has no CPU/eager fallback)"
             )
         l = ctypes.CDLL(LIB_PATH)
+        older_profiling_build = bool(os.environ.get("AO_MI355_LIB"))  # a library of an earlier commit may lack the newest entry points
         for name, argtypes in _SIGNATURES.items():
+            if older_profiling_build and not hasattr(l, name):
+                continue
             fn = getattr(l, name)  # AttributeError if the .so is stale
             fn.argtypes = argtypes
             fn.restype = _INT
@@ -117,8 +120,9 @@ def lib():
         l.ao_moe_padded_rows.restype = _I64
         l.ao_allreduce_flag_bytes.restype = _I64
         l.ao_allreduce_state_bytes.restype = _I64
-        l.ao_moe_a2a_flag_bytes.restype = _I64
-        l.ao_moe_a2a_state_bytes.restype = _I64
+        if hasattr(l, "ao_moe_a2a_flag_bytes"):
+            l.ao_moe_a2a_flag_bytes.restype = _I64
+            l.ao_moe_a2a_state_bytes.restype = _I64
         l.ao_int4_hqq_workspace_bytes.restype = _I64
         _lib = l
     return _lib

@@ -545,6 +545,9 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 #pragma unroll
     for (int r = 0; r < MT; ++r)
       if (r < mth) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[r]), rws, tid * 16 + r * kRegBytes, mine, kSc1);
+    // the data registers stay live (and untouched) for 16 more cycles: the caller zeroes them next, and a buffer_store_dwordx4 with an
+    // SGPR soffset whose data register is overwritten by the next instruction can store the new value on gfx950 (splitk.h)
+    asm volatile("s_nop 7\n\ts_nop 7" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
   };
   bool has_head = false;
   int head_tile = 0, head_m0 = 0, head_mend = 0, head_nt = 0, head_mth = 0;

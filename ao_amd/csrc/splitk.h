@@ -41,6 +41,13 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kSc1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
+  // The accumulators stay LIVE until the stores have completed.  Round 3: hipcc re-used a data register of a just-issued
+  // `buffer_store_dwordx4 v[6:9], v32, s[8:11], s1 offen sc1` for the next store's address in the very next instruction
+  // (`v_or_b32 v8, 0x2000, v32`); LLVM knows that hazard only for stores WITHOUT an SGPR soffset, gfx950 showed it with one: now and
+  // then the parked tile carried the address bits instead of component z of its first register (rows 4 kq + 2 of m-tile 0 off by one
+  // part's contribution; the fp8 kernel at (33, 4096, 4096), cold launches; tools/stress_fp8_splitk.py).
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(acc[r]));
   __syncthreads();
   if (tid == 0) {
     const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
