@@ -4,8 +4,12 @@
 # full parity suite + smoke, the full bench line, the torchrun (world 1) and TP-over-RCCL (world 1) paths, rocprofv3
 # --kernel-trace --stats of the headline command, PMC passes (FETCH_SIZE / WRITE_SIZE / SQ_* in separate runs, as the gfx950 guide
 # prescribes: never together with a trace domain), the 8-bit GEMM's MFMA-busy counters, and the secondary micro-benchmarks.
+# (Round 3 lesson: a box whose first GPU access faults -- "Memory access fault by GPU node-2" 0.3 s after HSA init, before any kernel of
+# this repository had been launched -- left a rocprofv3-wrapped python hanging until its timeout and cost 15 GPU-minutes.  Every
+# rocprofv3 step below therefore runs under its own short timeout, and the script starts with a 60-second canary.)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
+timeout 60 python -c "import torch; torch.zeros(1, device='cuda').add_(1).item(); print('canary ok')" || { echo "GPU canary failed: not profiling on this box"; exit 3; }
 O=$R/gpurun_out/${1:-prof}
 mkdir -p $O
 cd $R

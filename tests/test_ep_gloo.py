@@ -76,3 +76,47 @@ def test_ep_dispatch_and_combine_world2():
         assert back_ok, f"rank {rank}: combine did not return the rows to their source"
     # rank 0 hosts experts 0, 1: it receives [10, 0] from itself and [17, 25] from rank 1 (and rank 1: [30, 24], [21, 1])
     assert res[0][4] == [10, 0, 17, 25] and res[1][4] == [30, 24, 21, 1]
+
+
+def _a2a_oracle_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import moe_ref
+
+        ok = True
+        for call in range(4):
+            # every rank can regenerate every rank's rows and split vector (what the GPU test of the on-device kernel relies on)
+            gens = [np.random.default_rng(1000 * call + r) for r in range(world)]
+            splits = [g.integers(0, 9, size=world).astype(np.int64) for g in gens]
+            if call == 2:
+                splits[0][1] = 0
+            rows = [g.integers(0, 256, size=(int(s.sum()), 48), dtype=np.uint8) for g, s in zip(gens, splits)]
+            want, want_splits = moe_ref.a2a_v(rows, splits, rank)
+            # the collective the reference's own test checks its on-device kernel against (test_comms.py: all_to_all_single with the
+            # split sizes on the host)
+            out_splits = torch.empty(world, dtype=torch.int64)
+            dist.all_to_all_single(out_splits, torch.from_numpy(splits[rank]))
+            got = torch.empty((int(out_splits.sum()), 48), dtype=torch.uint8)
+            dist.all_to_all_single(got, torch.from_numpy(rows[rank]), out_splits.tolist(), splits[rank].tolist())
+            ok = ok and np.array_equal(out_splits.numpy(), want_splits) and np.array_equal(got.numpy(), want)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a2a_v_oracle_equals_all_to_all_single_world2():
+    """oracle/moe_ref.py::a2a_v -- the checker of the on-device all-to-all-v kernel (tests/test_ondevice_a2a_gpu.py) -- pinned against
+    torch.distributed.all_to_all_single with host-side splits: the equivalence the reference's kernel is defined by
+    (torchao/prototype/moe_training/kernels/mxfp8/comms.py:25-60, 405-460)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_a2a_oracle_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get() for _ in range(world)) == [(0, True), (1, True)]
