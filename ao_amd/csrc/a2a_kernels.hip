@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "peer_sync.h"
 
 namespace ao {
 namespace {
@@ -20,7 +21,6 @@ namespace {
 constexpr int kA2AMaxWorld = 8;
 constexpr int kA2ABlocksPerRank = 16;                         // reference: BLOCKS_PER_REMOTE_RANK = 32 of 16 Ki elements
 constexpr int kA2AMaxBlocks = kA2AMaxWorld * kA2ABlocksPerRank;
-constexpr unsigned kA2ASpinLimit = 1u << 22;                  // ~0.5 s
 
 struct A2AArgs {
   const char* data[kA2AMaxWorld];        // every rank's staged rows      [max_rows][row_bytes]
@@ -30,29 +30,16 @@ struct A2AArgs {
   char* out_data;
   char* out_scales;
   long long* out_splits;                 // [world]: rows received from rank r
-  unsigned* state;                       // local: [0] status (1 = a wait timed out, 2 = more rows than the output holds), [1 + b] epoch
-  long long row_bytes, scale_row_bytes, max_out_rows;
+  unsigned* state;                       // local: [0] status bits (1 a wait timed out, 2 more rows than the output holds, 4 a peer's splits
+                                         //        reach past its staged rows), [1 + b] epoch
+  long long row_bytes, scale_row_bytes, max_out_rows, max_in_rows;
+  unsigned long long timeout_ticks;
   int rank, world;
 };
 
-__device__ __forceinline__ u32x4 ld_sys16(const char* p) {
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ uint32_t ld_sys4(const char* p) {
-  uint32_t v;
-  asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ uint32_t ld_sys1(const char* p) {
-  uint32_t v;
-  asm volatile("global_load_ubyte %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
 __global__ __launch_bounds__(256) void moe_a2a_v_kernel(A2AArgs a) {
   __shared__ long long s_remote[kA2AMaxWorld], s_to_me[kA2AMaxWorld];
+  __shared__ int s_late;
   const int tid = threadIdx.x, b = blockIdx.x;
   const int remote = b / kA2ABlocksPerRank, part = b % kA2ABlocksPerRank;
   const unsigned epoch = a.state[1 + b] + 1u;
@@ -63,15 +50,20 @@ __global__ __launch_bounds__(256) void moe_a2a_v_kernel(A2AArgs a) {
       unsigned* f = a.flags[tid] + ((size_t)phase * kA2AMaxBlocks + b) * kA2AMaxWorld + a.rank;
       __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       const unsigned* w = a.flags[a.rank] + ((size_t)phase * kA2AMaxBlocks + b) * kA2AMaxWorld + tid;
-      unsigned spins = 0;
-      while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > kA2ASpinLimit) { atomicOr(a.state, 1u); break; }
-      }
+      if (!wait_flag(w, epoch, a.timeout_ticks)) { atomicOr(a.state, 1u); s_late = 1; }
     }
     __syncthreads();
   };
+  if (tid == 0) s_late = 0;
   barrier(0);
+  if (s_late) {
+    // a peer never staged its inputs (status bit 0): nothing of its memory is read; this block reports zero rows from `remote`
+    // and still takes part in the closing barrier so that the epochs stay in step
+    if (part == 0 && tid == 0) a.out_splits[remote] = 0;
+    barrier(1);
+    if (tid == 0) a.state[1 + b] = epoch;
+    return;
+  }
   // offsets from the peers' split vectors (_exchange_row_offsets): remote's whole vector, and what every rank sends to this one
   if (tid < a.world) {
     const char* p = reinterpret_cast<const char*>(a.splits[remote] + tid);
@@ -85,6 +77,11 @@ __global__ __launch_bounds__(256) void moe_a2a_v_kernel(A2AArgs a) {
   for (int q = 0; q < remote; ++q) out_off += s_to_me[q];
   long long n = s_remote[a.rank];
   if (n < 0) n = 0;
+  if (in_off < 0 || in_off + n > a.max_in_rows) {  // a split vector whose prefix leaves the peer's staged rows: never read past them
+    if (tid == 0) atomicOr(a.state, 4u);
+    in_off = std::min<long long>(std::max<long long>(in_off, 0), a.max_in_rows);
+    n = std::max<long long>(0, std::min<long long>(n, a.max_in_rows - in_off));
+  }
   if (out_off + n > a.max_out_rows) {  // never write past the output: report it instead
     if (tid == 0) atomicOr(a.state, 2u);
     n = std::max<long long>(0, a.max_out_rows - out_off);
@@ -128,7 +125,7 @@ extern "C" int64_t ao_moe_a2a_state_bytes(void) { return (int64_t)(1 + kA2AMaxBl
 
 extern "C" int ao_moe_a2a_v(void* const* peer_data_host, void* const* peer_scales_host, void* const* peer_splits_host, void* const* peer_flags_host,
                             void* out_data, void* out_scales, int64_t* out_splits, void* local_state, int64_t row_bytes, int64_t scale_row_bytes,
-                            int64_t max_out_rows, int rank, int world, void* stream) {
+                            int64_t max_in_rows, int64_t max_out_rows, int rank, int world, void* stream) {
   AO_REQUIRE_PTR(peer_data_host);
   AO_REQUIRE_PTR(peer_scales_host);
   AO_REQUIRE_PTR(peer_splits_host);
@@ -140,8 +137,8 @@ extern "C" int ao_moe_a2a_v(void* const* peer_data_host, void* const* peer_scale
   AO_REQUIRE(world >= 1 && world <= kA2AMaxWorld && rank >= 0 && rank < world, "ao_moe_a2a_v: bad rank %d / world %d (at most %d ranks)", rank, world,
              kA2AMaxWorld);
   AO_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0, "ao_moe_a2a_v: rows must be a multiple of 16 bytes, got %lld", (long long)row_bytes);
-  AO_REQUIRE(scale_row_bytes > 0 && max_out_rows >= 0, "ao_moe_a2a_v: bad scale row size %lld / output rows %lld", (long long)scale_row_bytes,
-             (long long)max_out_rows);
+  AO_REQUIRE(scale_row_bytes > 0 && max_out_rows >= 0 && max_in_rows >= 0, "ao_moe_a2a_v: bad scale row size %lld / staged rows %lld / output rows %lld",
+             (long long)scale_row_bytes, (long long)max_in_rows, (long long)max_out_rows);
   AO_REQUIRE((uintptr_t)out_data % 16 == 0 && (uintptr_t)out_scales % 16 == 0, "ao_moe_a2a_v: 16-byte aligned outputs expected");
   A2AArgs a{};
   for (int r = 0; r < world; ++r) {
@@ -155,7 +152,8 @@ extern "C" int ao_moe_a2a_v(void* const* peer_data_host, void* const* peer_scale
   }
   a.out_data = static_cast<char*>(out_data); a.out_scales = static_cast<char*>(out_scales); a.out_splits = reinterpret_cast<long long*>(out_splits);
   a.state = static_cast<unsigned*>(local_state);
-  a.row_bytes = row_bytes; a.scale_row_bytes = scale_row_bytes; a.max_out_rows = max_out_rows; a.rank = rank; a.world = world;
+  a.row_bytes = row_bytes; a.scale_row_bytes = scale_row_bytes; a.max_out_rows = max_out_rows; a.max_in_rows = max_in_rows;
+  a.timeout_ticks = collective_timeout_ticks(); a.rank = rank; a.world = world;
   ao::launch(moe_a2a_v_kernel, dim3((unsigned)(world * kA2ABlocksPerRank)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   AO_LAUNCH_CHECK("moe_a2a_v_kernel launch");
   return AO_OK;

@@ -15,13 +15,13 @@
 #include <algorithm>
 
 #include "common.h"
+#include "peer_sync.h"
 
 namespace ao {
 namespace {
 
 constexpr int kMaxWorld = 8;
 constexpr int kArBlocks = 16;            // EVERY call launches this many blocks (slices and epochs line up across calls of any size)
-constexpr unsigned kSpinLimit = 1u << 22;  // polls (~100 ns each with s_sleep) before giving up: ~0.5 s
 
 struct ArArgs {
   char* data[kMaxWorld];      // staging of every rank (index = rank), 2 x slot_bytes each (parity-major)
@@ -31,18 +31,14 @@ struct ArArgs {
   unsigned* state;            // local, never shared: [0] status (1 = a wait timed out), [1 + b] epoch of block b's last call
   long long count;            // elements
   long long slot_bytes;
+  unsigned long long timeout_ticks;  // 100 MHz ticks a wait may take
   int rank, world;
 };
 
-__device__ __forceinline__ u32x4 load_sys(const char* p) {  // system-scope (sc0 sc1) 16-byte load: never served from a stale cache
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
-// DT: 0 fp32, 1 bf16, 2 int32
-template <int DT>
+// DT: 0 fp32, 1 bf16, 2 int32;  MAX: elementwise maximum instead of the sum (the amax exchange of the exact row-parallel protocol)
+template <int DT, bool MAX>
 __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(ArArgs a) {
+  __shared__ int s_late;
   const int tid = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
   // the epoch lives on the device (one counter per block, bumped by every call; every call launches all kArBlocks blocks, so the
   // counters move in lockstep = a call counter): a launch captured into a hipGraph replays with fresh epochs and alternating parity.
@@ -59,31 +55,46 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(ArArgs a) {
   __threadfence_system();  // the slice is in memory, visible to every agent, before any flag says so
   __syncthreads();
   // 2. signal every rank (own block included), 3. wait for every rank
+  if (tid == 0) s_late = 0;
+  __syncthreads();
   if (tid < a.world) {
     unsigned* f = a.flags[tid] + ((size_t)par * kArBlocks + b) * kMaxWorld + a.rank;
     __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned* w = a.flags[a.rank] + ((size_t)par * kArBlocks + b) * kMaxWorld + tid;
-    unsigned spins = 0;
-    while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > kSpinLimit) { atomicExch(a.state, 1u); break; }
-    }
+    if (!wait_flag(w, epoch, a.timeout_ticks)) { atomicExch(a.state, 1u); s_late = 1; }
   }
   __syncthreads();
   if (tid == 0) a.state[1 + b] = epoch;  // (every thread read the old value before the barriers above)
+  if (s_late) {
+    // a peer did not arrive in time: its staging holds an older call's bytes.  Poison this slice (NaN / INT_MIN) instead of returning a
+    // plausible wrong sum; state[0] = 1 says why (OneShotAllReduce.check() raises on it).
+    const u32x4 bad = (DT == 0) ? u32x4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u}
+                                : (DT == 1) ? u32x4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u} : u32x4{0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
+    for (long long i = v0 + tid; i < v1; i += 256) *reinterpret_cast<u32x4*>(static_cast<char*>(a.out) + i * 16) = bad;
+    return;
+  }
   // 4. reduce in rank order
+  auto comb = [](f32x4 x, f32x4 y) {
+    if constexpr (MAX) return f32x4{fmaxf(x.x, y.x), fmaxf(x.y, y.y), fmaxf(x.z, y.z), fmaxf(x.w, y.w)};
+    else return x + y;
+  };
   for (long long i = v0 + tid; i < v1; i += 256) {
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    i32x4 si = {0, 0, 0, 0};
+    f32x4 s0, s1;
+    i32x4 si;
     for (int r = 0; r < a.world; ++r) {
-      const u32x4 v = load_sys(a.data[r] + (long long)par * a.slot_bytes + i * 16);
+      const u32x4 v = ld_sys16(a.data[r] + (long long)par * a.slot_bytes + i * 16);
       if constexpr (DT == 0) {
-        s0 += __builtin_bit_cast(f32x4, v);
+        const f32x4 t = __builtin_bit_cast(f32x4, v);
+        s0 = (r == 0) ? t : comb(s0, t);
       } else if constexpr (DT == 1) {
-        s0 += f32x4{bf16_lo_to_f32(v.x), bf16_hi_to_f32(v.x), bf16_lo_to_f32(v.y), bf16_hi_to_f32(v.y)};
-        s1 += f32x4{bf16_lo_to_f32(v.z), bf16_hi_to_f32(v.z), bf16_lo_to_f32(v.w), bf16_hi_to_f32(v.w)};
+        const f32x4 t0 = {bf16_lo_to_f32(v.x), bf16_hi_to_f32(v.x), bf16_lo_to_f32(v.y), bf16_hi_to_f32(v.y)};
+        const f32x4 t1 = {bf16_lo_to_f32(v.z), bf16_hi_to_f32(v.z), bf16_lo_to_f32(v.w), bf16_hi_to_f32(v.w)};
+        s0 = (r == 0) ? t0 : comb(s0, t0);
+        s1 = (r == 0) ? t1 : comb(s1, t1);
       } else {
-        si += __builtin_bit_cast(i32x4, v);
+        const i32x4 t = __builtin_bit_cast(i32x4, v);
+        if constexpr (MAX) si = (r == 0) ? t : i32x4{max(si.x, t.x), max(si.y, t.y), max(si.z, t.z), max(si.w, t.w)};
+        else si = (r == 0) ? t : si + t;
       }
     }
     u32x4 o;
@@ -102,14 +113,15 @@ using namespace ao;
 extern "C" int64_t ao_allreduce_flag_bytes(void) { return (int64_t)2 * kArBlocks * kMaxWorld * sizeof(unsigned); }
 extern "C" int64_t ao_allreduce_state_bytes(void) { return (int64_t)(1 + kArBlocks) * sizeof(unsigned); }
 
-extern "C" int ao_allreduce_oneshot(void* const* peer_data_host, void* const* peer_flags_host, const void* input, void* output, void* local_state,
-                                    int64_t count, int dtype, int64_t slot_bytes, int rank, int world, void* stream) {
+extern "C" int ao_allreduce_oneshot_op(void* const* peer_data_host, void* const* peer_flags_host, const void* input, void* output, void* local_state,
+                                       int64_t count, int dtype, int op, int64_t slot_bytes, int rank, int world, void* stream) {
   AO_REQUIRE_PTR(peer_data_host);
   AO_REQUIRE_PTR(peer_flags_host);
   AO_REQUIRE_PTR(local_state);
   AO_REQUIRE(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, "ao_allreduce_oneshot: bad rank %d / world %d (at most %d ranks)", rank, world,
              kMaxWorld);
   AO_REQUIRE(dtype >= 0 && dtype <= 2, "ao_allreduce_oneshot: dtype must be 0 (fp32), 1 (bf16) or 2 (int32), got %d", dtype);
+  AO_REQUIRE(op == 0 || op == 1, "ao_allreduce_oneshot: op must be 0 (SUM) or 1 (MAX), got %d", op);
   const int64_t bytes = count * (dtype == 1 ? 2 : 4);
   AO_REQUIRE(count >= 0 && ((bytes + 15) / 16) * 16 <= slot_bytes, "ao_allreduce_oneshot: %lld bytes do not fit the %lld-byte staging slot", (long long)bytes,
              (long long)slot_bytes);
@@ -126,13 +138,22 @@ extern "C" int ao_allreduce_oneshot(void* const* peer_data_host, void* const* pe
   }
   a.in = input; a.out = output; a.state = static_cast<unsigned*>(local_state);
   a.count = count; a.slot_bytes = slot_bytes; a.rank = rank; a.world = world;
-  const int64_t nvec = (bytes + 15) / 16;
-  (void)nvec;
-  const int blocks = kArBlocks;
+  a.timeout_ticks = collective_timeout_ticks();
+  const dim3 grid(kArBlocks), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == 0) ao::launch(allreduce_oneshot_kernel<0>, dim3(blocks), dim3(256), 0, st, a);
-  else if (dtype == 1) ao::launch(allreduce_oneshot_kernel<1>, dim3(blocks), dim3(256), 0, st, a);
-  else ao::launch(allreduce_oneshot_kernel<2>, dim3(blocks), dim3(256), 0, st, a);
+  switch (dtype * 2 + op) {
+    case 0: ao::launch(allreduce_oneshot_kernel<0, false>, grid, block, 0, st, a); break;
+    case 1: ao::launch(allreduce_oneshot_kernel<0, true>, grid, block, 0, st, a); break;
+    case 2: ao::launch(allreduce_oneshot_kernel<1, false>, grid, block, 0, st, a); break;
+    case 3: ao::launch(allreduce_oneshot_kernel<1, true>, grid, block, 0, st, a); break;
+    case 4: ao::launch(allreduce_oneshot_kernel<2, false>, grid, block, 0, st, a); break;
+    default: ao::launch(allreduce_oneshot_kernel<2, true>, grid, block, 0, st, a); break;
+  }
   AO_LAUNCH_CHECK("allreduce_oneshot_kernel launch");
   return AO_OK;
+}
+
+extern "C" int ao_allreduce_oneshot(void* const* peer_data_host, void* const* peer_flags_host, const void* input, void* output, void* local_state,
+                                    int64_t count, int dtype, int64_t slot_bytes, int rank, int world, void* stream) {
+  return ao_allreduce_oneshot_op(peer_data_host, peer_flags_host, input, output, local_state, count, dtype, 0, slot_bytes, rank, world, stream);
 }

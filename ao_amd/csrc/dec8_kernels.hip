@@ -1,0 +1,366 @@
+// 8-bit decode linears (M <= 16) on gfx950, round 4: the weight stream as FULL 128-byte lines in a register ring.
+//
+//   int8:  y = bf16(bf16(i32(xq . wq^T) * sx[m]) * sw[n] + bias[n])     Int8Tensor F.linear, int8_tensor.py:305-359 (+ :176-248 cast)
+//   fp8 :  y = bf16((xq . wq^T) * sx[m] * sw[n] + bias[n])              Float8Tensor rowwise, float8/inference.py:104-123
+//          (+ float8_tensor.py:167-253 cast)
+//
+// Bound: HBM -- 1 byte per weight, read once.  What the round-3 kernels (stream8_kernel / dyn8_kernel) left on the table, found by the
+// disassembly scan at the end of that round: their k loop loaded ONE 2 KiB step, waited vmcnt(0), multiplied, looped; and every weight
+// load instruction touched 16 different 128-byte lines for 16 bytes each (lane = (row n, 16-byte piece kq): the MFMA operand layout),
+// so a 2 KiB step cost the texture path 128 line look-ups for 32 lines of data.
+//
+// Here: one workgroup per 16-row n-tile, its waves split K in contiguous runs of DEPTH steps (K = 128 * DEPTH * waves: straight-line
+// code, no loop), and
+//   * every wave requests its whole run in the prologue -- 2 x global_load_dwordx4 per step in which 8 consecutive lanes cover one
+//     full line (lane l: row 8 i + (l >> 3), 16-byte chunk l & 7) -- DEPTH x 2 KiB per wave in flight in a static register ring,
+//     the compiler counts the vmcnt(N) waits;
+//   * the activation is cast (DYN: amax -> scale -> codes with quant_math.h's arithmetic, one row held in registers; its loads are
+//     issued BEFORE the ring's so that they are not queued behind 128 KiB of weights) or copied ONCE per workgroup into LDS while the
+//     weights are in flight;
+//   * a step is turned into the MFMA's operand layout through a wave-private 2.25 KiB LDS slab (rows 144 bytes apart: the
+//     ds_read_b128 of 16 rows hit 64 distinct banks): 2 ds_write_b128 + 2 ds_read_b128, no barrier (DS ops of a wave run in order);
+//   * operands keep stream8_kernel's k assignment (lane group kq: k = 16 kq .. +15 and 64 + 16 kq .. +15), so a wave's accumulator
+//     sees the same products in the same MFMA as before; rows >= M of the A operand alias row 0 (their outputs are never stored);
+//   * one barrier for the cross-wave reduction (wave order: reproducible), the reference's epilogues in fp32, bf16 out.
+#include "common.h"
+#include "quant_math.h"
+
+#include <type_traits>
+
+namespace ao {
+thread_local int g_dec8_mode = 0;  // ao_gemm8_set_variant 200 + d: force ring depth d; 290: half-line loads (no LDS transposition); 299: never this kernel
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+struct Dec8Args {
+  const void* x;           // DYN: bf16 [M][K];  else codes [M][K]
+  const float* row_scale;  // !DYN: fp32 [M]
+  const uint8_t* b;        // [N][K] int8 / e4m3
+  const float* col_scale;  // [N]
+  const uint16_t* bias;    // [N] bf16 or null
+  uint16_t* out;           // [M][N] bf16
+  int M, N, K;
+};
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope release fence, which on gfx9 means
+// s_waitcnt vmcnt(0) -- it would drain the weight ring that is in flight across every barrier of this kernel
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// max over the 64 lanes without LDS traffic: DPP within rows of 16, then the four row results through SGPRs
+__device__ __forceinline__ float wave_max(float m) {
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x140>{}));  // row_mirror
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+constexpr int kSlabStride = 144;            // bytes between the 16 rows of a wave's transposition slab
+constexpr int kSlab = 16 * kSlabStride;     // 2304 B
+constexpr int kXV = 4;                      // 16-byte activation vectors a thread may hold while the ring is in flight
+
+// XFAST: a wave holds the activation slice of its own k-run in registers (DYN: M == 1; pre-quantized: M x DEPTH <= 32) -- those loads
+// go out first, the ring behind them, cast / copy run under the weights' flight and stay wave-private.  Otherwise the workgroup-wide
+// cast / copy loops run first and the ring is requested after them.
+template <bool INT8, bool DYN, int DEPTH, bool XFAST, bool HALF>
+__global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+  const int stride = p.K + 16;  // bytes between rows of codes: (K + 16) / 4 = 4 (mod 64) banks for K % 256 == 0
+  char* xq = smem;                                                              // [M][K + 16]
+  char* slab = smem + ((p.M * stride + 15) & ~15) + wave * kSlab;               // [nwaves][16][144]
+  float* red = reinterpret_cast<float*>(smem + ((p.M * stride + 15) & ~15) + nwaves * kSlab);  // [nwaves][256]
+  float* wmax = red + nwaves * 256;                                             // [nwaves][16]
+  float* rs = wmax + nwaves * 16;                                               // [16]
+
+  const int ntile = blockIdx.x;
+  const int ks0 = wave * DEPTH;  // this wave's first 128-k step
+  const int kq = lane >> 4, nl = lane & 15;
+
+  struct Stage {
+    u32x4 b0, b1;
+  };
+  Stage st[DEPTH];
+  auto issue_ring = [&]() {
+    if constexpr (HALF) {
+      const uint8_t* brow = p.b + ((size_t)ntile * 16 + nl) * p.K + kq * 16 + (size_t)ks0 * 128;
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        st[d].b0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + d * 128));
+        st[d].b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + d * 128 + 64));
+        __builtin_amdgcn_sched_barrier(0);  // request order = consumption order (VMEM returns in order)
+      }
+    } else {
+      // lane l: row (l >> 3) of the tile's rows 0..7 (b0) / 8..15 (b1), chunk l & 7 of the step's 128 bytes
+      const uint8_t* brow = p.b + ((size_t)ntile * 16 + (lane >> 3)) * p.K + (lane & 7) * 16 + (size_t)ks0 * 128;
+      const size_t half = (size_t)8 * p.K;
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        st[d].b0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + d * 128));
+        st[d].b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + half + d * 128));
+        __builtin_amdgcn_sched_barrier(0);  // request order = consumption order (VMEM returns in order)
+      }
+    }
+    // nothing that waits for an earlier load (the activation's) may be scheduled above the ring's requests
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- 1. activation -> codes in LDS (once per workgroup), weights requested as early as the VMEM queue order allows
+  if constexpr (DYN && XFAST) {
+    // M == 1.  A wave multiplies only its own k-run, so it casts only that: DEPTH x 128 bf16 = DEPTH x 16 vectors of 8, held in
+    // registers between amax and cast and written to the wave's own part of the code row -- the one cross-wave dependency left is the
+    // row's amax (ONE LDS-only barrier; the codes need none: DS operations of a wave execute in order).
+    constexpr int XW = (DEPTH * 16 + 63) / 64;  // vectors per lane
+    const u32x4* xr = reinterpret_cast<const u32x4*>(p.x) + (size_t)ks0 * 16;
+    u32x4 xv[XW];
+#pragma unroll
+    for (int i = 0; i < XW; ++i) xv[i] = xr[min(lane + i * 64, DEPTH * 16 - 1)];  // clamped, unconditional: straight-line vmcnt
+    __builtin_amdgcn_sched_barrier(0);
+    issue_ring();
+    float m = 0.f;
+    bool has_nan = false;
+#pragma unroll
+    for (int i = 0; i < XW; ++i) m = fmaxf(m, amax8(xv[i], has_nan));
+    if (has_nan) m = INFINITY;  // (NaN rows are outside the contract, as in the stand-alone cast)
+    m = wave_max(m);
+    if (lane == 0) wmax[wave * 16] = m;
+    lds_barrier();
+    float mm = 0.f;
+    for (int w = 0; w < nwaves; ++w) mm = fmaxf(mm, wmax[w * 16]);
+    const float s = INT8 ? int8_row_scale(mm) : fp8_row_scale(mm);
+    const float inv = 1.0f / s;
+    if (tid == 0) rs[0] = s;
+#pragma unroll
+    for (int i = 0; i < XW; ++i) {
+      const int idx = lane + i * 64;
+      if (idx < DEPTH * 16) *reinterpret_cast<u32x2*>(xq + ks0 * 128 + idx * 8) = INT8 ? int8_quant8(xv[i], inv) : fp8_quant8(xv[i], s);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private codes: no barrier)
+  } else if constexpr (DYN) {
+    // dyn8_kernel's two passes over the L2-resident activation, then the ring
+    const int nvec = p.K >> 3;
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(p.x);
+    for (int r = 0; r < p.M; ++r) {
+      const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)r * p.K);
+      float m = 0.f;
+      bool has_nan = false;
+      for (int i = tid; i < nvec; i += nthreads) m = fmaxf(m, amax8(xr[i], has_nan));
+      if (has_nan) m = INFINITY;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if (lane == 0) wmax[wave * 16 + r] = m;
+    }
+    lds_barrier();
+    if (tid < p.M) {
+      float m = 0.f;
+      for (int w = 0; w < nwaves; ++w) m = fmaxf(m, wmax[w * 16 + tid]);
+      rs[tid] = INT8 ? int8_row_scale(m) : fp8_row_scale(m);
+    }
+    lds_barrier();
+    for (int r = 0; r < p.M; ++r) {
+      const u32x4* xr = reinterpret_cast<const u32x4*>(x + (size_t)r * p.K);
+      const float s = rs[r];
+      const float inv = 1.0f / s;
+      for (int i = tid; i < nvec; i += nthreads)
+        *reinterpret_cast<u32x2*>(xq + r * stride + i * 8) = INT8 ? int8_quant8(xr[i], inv) : fp8_quant8(xr[i], s);
+    }
+    issue_ring();
+  } else if constexpr (XFAST) {
+    // codes [M][K]: a wave copies the part of every row that ITS k-run multiplies (M x DEPTH x 8 vectors of 16 bytes, at most kXV
+    // per lane) -- wave-private, so no barrier stands between the copy and the first MFMA
+    const int nvec = p.M * DEPTH * 8;
+    u32x4 xv[kXV];
+    int off[kXV];
+#pragma unroll
+    for (int i = 0; i < kXV; ++i) {
+      const int v = min(lane + i * 64, nvec - 1);
+      const int r = v / (DEPTH * 8), c = v - r * (DEPTH * 8);
+      off[i] = r * stride + ks0 * 128 + c * 16;
+      xv[i] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.x) + (size_t)r * p.K + ks0 * 128 + c * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue_ring();
+#pragma unroll
+    for (int i = 0; i < kXV; ++i)
+      if (lane + i * 64 < nvec) *reinterpret_cast<u32x4*>(xq + off[i]) = xv[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+    const int vpr = p.K >> 4, nvec = p.M * vpr;
+    const u32x4* xr = reinterpret_cast<const u32x4*>(p.x);
+    for (int idx = tid; idx < nvec; idx += nthreads) {
+      const int r = idx / vpr, c = idx - r * vpr;
+      *reinterpret_cast<u32x4*>(xq + r * stride + c * 16) = xr[idx];
+    }
+    issue_ring();
+  }
+  if constexpr (!XFAST) lds_barrier();  // (XFAST: every wave wrote the codes it reads itself)
+
+  // ---- 2. one pass of the ring: transpose a step through the slab, multiply
+  // rows >= M of the A operand alias row 0: they only reach output rows that are never stored
+  const char* arow = xq + (nl < p.M ? nl : 0) * stride + kq * 16 + ks0 * 128;
+  char* wr0 = slab + (lane >> 3) * kSlabStride + (lane & 7) * 16;  // this lane's piece of rows 0..7; rows 8..15: + 8 rows
+  const char* rd = slab + nl * kSlabStride + kq * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};  // int8: int32 bit patterns
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    u32x4 b0, b1;
+    if constexpr (HALF) {
+      b0 = st[d].b0; b1 = st[d].b1;
+    } else {
+      *reinterpret_cast<u32x4*>(wr0) = st[d].b0;
+      *reinterpret_cast<u32x4*>(wr0 + 8 * kSlabStride) = st[d].b1;
+      b0 = *reinterpret_cast<const u32x4*>(rd);
+      b1 = *reinterpret_cast<const u32x4*>(rd + 64);
+    }
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(arow + d * 128);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(arow + d * 128 + 64);
+    if constexpr (INT8) {
+      i32x4 c = __builtin_bit_cast(i32x4, acc);
+      c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, b0), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, b1), c, 0, 0, 0);
+      acc = __builtin_bit_cast(f32x4, c);
+    } else {
+      const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+      const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+      acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc, 0, 0, 0, 127, 0, 127);
+    }
+  }
+
+  // ---- 3. split-K reduction across waves (wave order: reproducible), scales, store
+  {
+    float* r = red + (size_t)wave * 256 + (kq * 4) * 16 + nl;  // [row 16][col 16]
+    r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
+  }
+  lds_barrier();
+  for (int idx = tid; idx < p.M * 16; idx += nthreads) {  // (workgroups of 1 .. 3 waves have fewer threads than outputs)
+    const int row = idx >> 4, col = idx & 15;
+    const int gn = ntile * 16 + col;
+    const float sx = DYN ? rs[row] : p.row_scale[row];
+    float v;
+    if constexpr (INT8) {
+      int isum = 0;
+      for (int w = 0; w < nwaves; ++w) isum += __float_as_int(red[(size_t)w * 256 + idx]);
+      // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+      v = round_bf16((float)isum * sx) * p.col_scale[gn];
+    } else {
+      float sum = 0.f;
+      for (int w = 0; w < nwaves; ++w) sum += red[(size_t)w * 256 + idx];
+      v = sum * sx * p.col_scale[gn];
+    }
+    if (p.bias != nullptr) v += bf16_lo_to_f32(p.bias[gn]);
+    p.out[(size_t)row * p.N + gn] = f32_to_bf16_bits(v);
+  }
+}
+
+struct Dec8Shape {
+  int waves, depth;
+};
+
+// K = 128 * depth * waves: the deepest ring of {8, 7, 4, 2, 1} that leaves at most 16 waves.  (Measured on the 70B / TP8 fp8 shards and the
+// Llama-3-8B int8 shapes, profiles/dec8_forms_r04.txt: the deeper ring wins at every K, down to ONE wave x 8 steps for K = 1024 --
+// fewer waves mean fewer partials to reduce and more workgroups per CU.)
+bool dec8_shape(int64_t K, int forced_depth, Dec8Shape* out) {
+  if (K % 128 != 0) return false;
+  const int ksteps = (int)(K / 128);
+  static const int depths[] = {8, 7, 4, 2, 1};
+  for (int d : depths) {
+    if (forced_depth != 0 && d != forced_depth) continue;
+    if (ksteps % d != 0) continue;
+    const int w = ksteps / d;
+    if (w >= 1 && w <= 16) {
+      *out = Dec8Shape{w, d};
+      return true;
+    }
+  }
+  return false;
+}
+
+size_t dec8_lds(int64_t M, int64_t K, int waves) {
+  return (size_t)((M * (K + 16) + 15) & ~(int64_t)15) + (size_t)waves * kSlab + (size_t)(waves * 256 + waves * 16 + 16) * sizeof(float);
+}
+
+template <bool INT8, bool DYN, int DEPTH, bool XFAST>
+int launch_dec8_h(const Dec8Args& p, int waves, bool half, hipStream_t stream) {
+  const size_t smem = dec8_lds(p.M, p.K, waves);
+  const void* kern = half ? reinterpret_cast<const void*>(dec8_kernel<INT8, DYN, DEPTH, XFAST, true>)
+                          : reinterpret_cast<const void*>(dec8_kernel<INT8, DYN, DEPTH, XFAST, false>);
+  if (int rc = ensure_dynamic_lds(kern, smem, "hipFuncSetAttribute(dec8_kernel)")) return rc;
+  if (half) ao::launch(dec8_kernel<INT8, DYN, DEPTH, XFAST, true>, dim3((unsigned)(p.N / 16)), dim3(waves * 64), smem, stream, p);
+  else ao::launch(dec8_kernel<INT8, DYN, DEPTH, XFAST, false>, dim3((unsigned)(p.N / 16)), dim3(waves * 64), smem, stream, p);
+  AO_LAUNCH_CHECK("dec8_kernel launch");
+  return AO_OK;
+}
+
+template <bool INT8, bool DYN>
+int launch_dec8(const Dec8Args& p, const Dec8Shape& s, hipStream_t stream) {
+  const bool xfast = DYN ? (p.M == 1) : (p.M * s.depth * 8 <= kXV * 64);
+  const bool half = g_dec8_mode == 290;
+#define AO_DEC8_CASE(D)                                                                      \
+  case D:                                                                                    \
+    return xfast ? launch_dec8_h<INT8, DYN, D, true>(p, s.waves, half, stream) : launch_dec8_h<INT8, DYN, D, false>(p, s.waves, half, stream);
+  switch (s.depth) {
+    AO_DEC8_CASE(8)
+    AO_DEC8_CASE(7)
+    AO_DEC8_CASE(4)
+    AO_DEC8_CASE(2)
+    AO_DEC8_CASE(1)
+  }
+#undef AO_DEC8_CASE
+  set_error("dec8: no instantiation for ring depth %d", s.depth);
+  return AO_ERR_INVALID_ARGUMENT;
+}
+
+// Whether the straight-line decode kernel takes this problem: M <= 16, the codes of the activation within 64 KiB of LDS,
+// K = 128 x depth x waves.  A function of the shape only, so that the fused (cast inside) and the two-launch forms of one linear pick
+// the same wave split and give the same bits.
+bool dec8_takes_shape(int64_t M, int64_t N, int64_t K, Dec8Shape* shape) {
+  if (g_dec8_mode == 299) return false;
+  if (M < 1 || M > 16 || N % 16 != 0 || K % 128 != 0 || N >= (1ll << 31) || K >= (1ll << 24)) return false;
+  Dec8Shape s;
+  const int forced = (g_dec8_mode > 200 && g_dec8_mode <= 208) ? g_dec8_mode - 200 : 0;
+  if (!dec8_shape(K, forced, &s)) return false;
+  if (dec8_lds(M, K, s.waves) > 64 * 1024 + 24 * 1024) return false;  // x codes <= 64 KiB (the old fused kernel's bound) + slabs
+  if (M * (K + 16) > 64 * 1024) return false;
+  if (shape != nullptr) *shape = s;
+  return true;
+}
+
+}  // namespace
+
+bool dec8_takes(int64_t M, int64_t N, int64_t K) { return dec8_takes_shape(M, N, K, nullptr); }
+
+// xq . wq^T with the scale epilogue, activation already cast (aten::_int_mm + scales / aten::_scaled_mm rowwise at decode sizes)
+int dec8_scaled(bool int8, const void* xq, const float* x_scale, const void* wq, const float* w_scale, const uint16_t* bias, uint16_t* y,
+                int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+  Dec8Shape s;
+  if (!dec8_takes_shape(M, N, K, &s)) {
+    set_error("dec8_scaled: shape M=%lld N=%lld K=%lld not covered", (long long)M, (long long)N, (long long)K);
+    return AO_ERR_INVALID_ARGUMENT;
+  }
+  Dec8Args p{xq, x_scale, reinterpret_cast<const uint8_t*>(wq), w_scale, bias, y, (int)M, (int)N, (int)K};
+  return int8 ? launch_dec8<true, false>(p, s, stream) : launch_dec8<false, false>(p, s, stream);
+}
+
+// the dynamic-activation linear with the cast fused in
+int dec8_dynamic(bool int8, const uint16_t* x, const void* wq, const float* w_scale, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N,
+                 int64_t K, hipStream_t stream) {
+  Dec8Shape s;
+  if (!dec8_takes_shape(M, N, K, &s)) {
+    set_error("dec8_dynamic: shape M=%lld N=%lld K=%lld not covered", (long long)M, (long long)N, (long long)K);
+    return AO_ERR_INVALID_ARGUMENT;
+  }
+  Dec8Args p{x, nullptr, reinterpret_cast<const uint8_t*>(wq), w_scale, bias, y, (int)M, (int)N, (int)K};
+  return int8 ? launch_dec8<true, true>(p, s, stream) : launch_dec8<false, true>(p, s, stream);
+}
+
+}  // namespace ao

@@ -17,6 +17,10 @@
 #include <algorithm>
 
 namespace ao {
+// dec8_kernels.hip (round 4): the same linear with the weights as full lines in a register ring and the cast under their flight
+bool dec8_takes(int64_t M, int64_t N, int64_t K);
+int dec8_dynamic(bool int8, const uint16_t* x, const void* wq, const float* w_scale, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N,
+                 int64_t K, hipStream_t stream);
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -168,6 +172,7 @@ extern "C" int ao_int8_dynamic_linear(const uint16_t* x, const int8_t* wq, const
   AO_REQUIRE_PTR(wq);
   AO_REQUIRE_PTR(w_scale);
   AO_REQUIRE_PTR(y);
+  if (dec8_takes(M, N, K)) return dec8_dynamic(true, x, wq, w_scale, bias, y, M, N, K, (hipStream_t)stream);
   Dyn8Args p{x, reinterpret_cast<const uint8_t*>(wq), w_scale, bias, y, (int)M, (int)N, (int)K};
   return launch_dyn8<true>(p, (hipStream_t)stream);
 }
@@ -180,6 +185,7 @@ extern "C" int ao_fp8_dynamic_linear(const uint16_t* x, const uint8_t* wq, const
   AO_REQUIRE_PTR(wq);
   AO_REQUIRE_PTR(w_scale);
   AO_REQUIRE_PTR(y);
+  if (dec8_takes(M, N, K)) return dec8_dynamic(false, x, wq, w_scale, bias, y, M, N, K, (hipStream_t)stream);
   Dyn8Args p{x, wq, w_scale, bias, y, (int)M, (int)N, (int)K};
   return launch_dyn8<false>(p, (hipStream_t)stream);
 }

@@ -5,7 +5,9 @@
 #include "common.h"
 #include "splitk.h"
 
+#include <atomic>
 #include <mutex>
+#include <string.h>
 #include <vector>
 
 namespace ao {
@@ -148,7 +150,74 @@ int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_
   return AO_OK;
 }
 
+// ---- collectives: wait bound shared by the one-shot all-reduce and the all-to-all-v (peer_sync.h) --------------------------------
+namespace {
+std::atomic<int> g_collective_timeout_ms{5000};
+}
+unsigned long long collective_timeout_ticks() { return (unsigned long long)g_collective_timeout_ms.load() * 100000ull; }  // 100 MHz
+
 }  // namespace ao
+
+extern "C" int ao_collective_set_timeout_ms(int ms) {
+  using namespace ao;
+  AO_REQUIRE(ms >= 1 && ms <= 600000, "ao_collective_set_timeout_ms: %d ms outside [1, 600000]", ms);
+  g_collective_timeout_ms.store(ms);
+  return AO_OK;
+}
+extern "C" int ao_collective_timeout_ms(void) { return ao::g_collective_timeout_ms.load(); }
+
+// ---- peer-visible device memory (flags / staging of the hand-written collectives) -------------------------------------------------
+extern "C" int ao_peer_alloc(void** ptr_out_host, int64_t bytes, int kind) {
+  using namespace ao;
+  AO_REQUIRE_PTR(ptr_out_host);
+  AO_REQUIRE(bytes > 0 && bytes < (1ll << 40), "ao_peer_alloc: bad size %lld", (long long)bytes);
+  AO_REQUIRE(kind == 0 || kind == 1, "ao_peer_alloc: kind must be 0 (uncached: flags) or 1 (fine-grained: staging), got %d", kind);
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, kind == 0 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+  if (e != hipSuccess) return hip_failed(e, kind == 0 ? "hipExtMallocWithFlags(hipDeviceMallocUncached)" : "hipExtMallocWithFlags(hipDeviceMallocFinegrained)");
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(peer buffer)"); }
+  *ptr_out_host = p;
+  return AO_OK;
+}
+extern "C" int ao_peer_free(void* ptr) {
+  using namespace ao;
+  if (ptr == nullptr) return AO_OK;
+  hipError_t e = hipFree(ptr);
+  if (e != hipSuccess) return hip_failed(e, "hipFree(peer buffer)");
+  return AO_OK;
+}
+extern "C" int ao_peer_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+extern "C" int ao_peer_export(void* ptr, void* handle_out_host) {
+  using namespace ao;
+  AO_REQUIRE_PTR(ptr);
+  AO_REQUIRE_PTR(handle_out_host);
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, ptr);
+  if (e != hipSuccess) return hip_failed(e, "hipIpcGetMemHandle (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on dmabuf-only hosts)");
+  memcpy(handle_out_host, &h, sizeof(h));
+  return AO_OK;
+}
+extern "C" int ao_peer_import(const void* handle_host, void** ptr_out_host) {
+  using namespace ao;
+  AO_REQUIRE_PTR(handle_host);
+  AO_REQUIRE_PTR(ptr_out_host);
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle_host, sizeof(h));
+  void* p = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return hip_failed(e, "hipIpcOpenMemHandle");
+  *ptr_out_host = p;
+  return AO_OK;
+}
+extern "C" int ao_peer_close(void* imported_ptr) {
+  using namespace ao;
+  if (imported_ptr == nullptr) return AO_OK;
+  hipError_t e = hipIpcCloseMemHandle(imported_ptr);
+  if (e != hipSuccess) return hip_failed(e, "hipIpcCloseMemHandle");
+  return AO_OK;
+}
 
 extern "C" int ao_abi_version(void) { return AO_MI355_ABI_VERSION; }
 extern "C" const char* ao_last_error(void) { return ao::g_err; }

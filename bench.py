@@ -421,27 +421,43 @@ def stack_baseline(model, stream, device, args):
     return out
 
 
+def _reference_root():
+    """Where the REAL reference can be imported from: the checkout (build container) or its staged Python under oracle/_ref (built by
+    `make -C oracle ref`; travels to the GPU box with the snapshot).  Only the cpu_baseline leg uses it."""
+    for ref in ("/root/reference", os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref")):
+        if os.path.isdir(os.path.join(ref, "torchao")):
+            return ref
+    return None
+
+
 def reference_cpu_baseline_int4():
     """BASELINE.md section 3 by the letter, when the reference checkout is reachable (the build container; never the GPU box):
     torchao's own groupwise_affine_dequantize_tensor_from_qparams + bf16 F.linear on ONE layer's five linears at M = 1."""
-    ref = "/root/reference"
-    if not os.path.isdir(os.path.join(ref, "torchao")):
+    ref = _reference_root()
+    if ref is None:
         return None
     try:
         sys.path.insert(0, ref)
+        os.environ.setdefault("TORCHAO_FORCE_SKIP_LOADING_SO_FILES", "1")  # a checkout's CUDA .so files are not for this box
         from torchao.quantization.utils import groupwise_affine_dequantize_tensor_from_qparams, groupwise_affine_quantize_tensor_from_qparams, get_groupwise_affine_qparams  # noqa: E501
-        tt = 0.0
+        ops = []
         for _, n, k in LLAMA3_8B_UNMERGED:
             w = torch.randn(n, k, dtype=torch.bfloat16) * 0.02
             sc, zp = get_groupwise_affine_qparams(w, 4, GROUP, torch.bfloat16)
             q = groupwise_affine_quantize_tensor_from_qparams(w, sc, zp, 4, GROUP)
-            x = torch.randn(1, k, dtype=torch.bfloat16)
-            t0 = time.perf_counter()
-            wd = groupwise_affine_dequantize_tensor_from_qparams(q, sc, zp, 4, GROUP)
-            torch.nn.functional.linear(x, wd)
-            tt += time.perf_counter() - t0
-        return {"value": 1.0 / (tt * N_LAYERS), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "reference",
-                "sample": "1 of 32 layers (5 linears) at M = 1 through torchao's groupwise_affine_dequantize_tensor_from_qparams + bf16 F.linear, x32"}
+            ops.append((q, sc, zp, torch.randn(1, k, dtype=torch.bfloat16)))
+        tt, reps, t_begin = 0.0, 0, time.perf_counter()
+        while reps < 1 or (time.perf_counter() - t_begin < 8.0 and reps < 20):  # bounded: ~10 s of host time
+            for q, sc, zp, x in ops:
+                t0 = time.perf_counter()
+                wd = groupwise_affine_dequantize_tensor_from_qparams(q, sc, zp, 4, GROUP)
+                torch.nn.functional.linear(x, wd)
+                tt += time.perf_counter() - t0
+            reps += 1
+        tt /= reps
+        return {"value": 1.0 / (tt * N_LAYERS), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "reference", "ms_per_layer": tt * 1e3,
+                "sample": f"1 of 32 layers (5 linears) at M = 1 through torchao's groupwise_affine_dequantize_tensor_from_qparams + bf16 F.linear "
+                          f"(torch CPU, {torch.get_num_threads()} threads, host has {os.cpu_count()} cpus), mean of {reps} reps, x32 extrapolated"}
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)}
     finally:
@@ -912,11 +928,18 @@ def main():
         if stack is not None:
             out["stack_baseline"] = stack
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_int4(args.batch)
-            out["cpu_baseline"]["reference_checkout_reachable"] = os.path.isdir("/root/reference/torchao")
+            port = cpu_baseline_int4(args.batch)
             ref = reference_cpu_baseline_int4() if args.batch == 1 else None
-            if ref is not None:  # the build container only: the GPU box has no /root/reference (kind stays "port" there)
-                out["cpu_baseline_reference"] = ref
+            if ref is not None and "value" in ref:
+                # the REAL reference's CPU dequant -> bf16 matmul path, imported from the checkout (build container) or from its
+                # staged Python under oracle/_ref (the GPU box): BASELINE.md section 3 by the letter.  The C port rides along.
+                ref["reference_root"] = _reference_root()
+                out["cpu_baseline"], out["cpu_baseline_port"] = ref, port
+            else:
+                out["cpu_baseline"] = port
+                out["cpu_baseline"]["reference_reachable"] = False
+                if ref is not None:
+                    out["cpu_baseline"]["reference_error"] = ref.get("error")
         if configs:
             out["configs"] = configs
         # the driver's parser keeps top-level scalars only: every config's value / fraction again as flat keys

@@ -44,7 +44,7 @@ extern "C" {
 #define AO_ERR_NULL_POINTER (-2)
 #define AO_ERR_HIP (-3) /* a HIP runtime call failed; message has hipGetErrorString */
 
-#define AO_MI355_ABI_VERSION 1
+#define AO_MI355_ABI_VERSION 2 /* 2: ao_moe_a2a_v takes max_in_rows; peer memory + MAX all-reduce entry points */
 
 /* Library / ABI version and last error of the calling thread. */
 int ao_abi_version(void);
@@ -298,25 +298,49 @@ int ao_moe_unpad_token_groups(const void* padded, const int32_t* offsets,
  * One-shot all-reduce over peer-mapped buffers (TP row-parallel linears at decode sizes)
  * ------------------------------------------------------------------------- */
 
+/* Peer-visible device memory for the flag blocks and staging buffers below, and its IPC handles.  The caching allocator's memory is
+ * coarse-grained: a flag a REMOTE GPU writes may be served to the spinning owner from its local L2 for ever (two processes on ONE GPU
+ * share that L2 and cannot show it).  kind 0 = hipDeviceMallocUncached (flag blocks), kind 1 = hipDeviceMallocFinegrained (staging);
+ * zero-filled.  ao_peer_export writes ao_peer_handle_bytes() (64) opaque bytes any process of the node can ao_peer_import (maps the
+ * peer's allocation, enabling peer access lazily); ao_peer_close unmaps an imported pointer, ao_peer_free releases an own one.  All
+ * HOST-side, synchronous, not capturable. */
+int ao_peer_alloc(void** ptr_out_host, int64_t bytes, int kind);
+int ao_peer_free(void* ptr);
+int ao_peer_handle_bytes(void);
+int ao_peer_export(void* ptr, void* handle_out_host);
+int ao_peer_import(const void* handle_host, void** ptr_out_host);
+int ao_peer_close(void* imported_ptr);
+/* How long a collective kernel waits for a peer before it gives up (1 ms .. 10 min, default 5000 ms; measured with the 100 MHz
+ * constant clock on the device).  A launch that gives up sets bit 0 of its local_state[0] AND poisons its output (NaN / INT_MIN for the
+ * all-reduce, zero rows for the all-to-all): a late rank never yields a plausible wrong result.  Process-wide. */
+int ao_collective_set_timeout_ms(int ms);
+int ao_collective_timeout_ms(void);
+
 /* Bytes of the flag block every rank allocates (zero-filled) and maps into its peers, and of the rank-local state block (zero-filled,
  * never shared: a status word + one epoch counter per block).  Host-only helpers. */
 int64_t ao_allreduce_flag_bytes(void);
 int64_t ao_allreduce_state_bytes(void);
 
-/* SUM all-reduce of one small vector in ONE launch per rank ("direct / one-shot algorithm for S <= ~1 MiB, never a
- * ring on the fully connected 8-GPU xGMI mesh"; the caller-issued all-reduce of the reference's TP harness, torchao/testing/utils.py:
- * 370-467).  Every rank stages its vector in device memory all peers have mapped (IPC), raises a flag in every peer's flag block,
- * waits (bounded) for all flags, then reads all `world` staged vectors and adds them in rank order (fp32 accumulation for bf16 /
- * fp32, exact for int32): bit-identical results on every rank.
+/* SUM (or, _op with op = 1, elementwise MAX) all-reduce of one small vector in ONE launch per rank ("direct / one-shot
+ * algorithm for S <= ~1 MiB, never a ring on the fully connected 8-GPU xGMI mesh"; the caller-issued all-reduce of the reference's TP
+ * harness, torchao/testing/utils.py:370-467; MAX is the row-amax exchange of the exact row-parallel protocol).  Every rank stages its
+ * vector in device memory all peers have mapped (IPC), raises a flag in every peer's flag block, waits (bounded) for all flags, then
+ * reads all `world` staged vectors and combines them in rank order (fp32 accumulation for bf16 / fp32, exact for int32):
+ * bit-identical results on every rank.
  *   peer_data_host / peer_flags_host: HOST arrays of `world` DEVICE pointers, index = rank (own buffers at [rank]); every staging
- *     buffer is 2 x slot_bytes (double-buffered by epoch parity), every flag block ao_allreduce_flag_bytes() bytes, zero-filled once;
+ *     buffer is 2 x slot_bytes (double-buffered by epoch parity), every flag block ao_allreduce_flag_bytes() bytes, zero-filled once
+ *     (ao_peer_alloc kinds 1 and 0);
  *   input / output: count elements of dtype (0 fp32, 1 bf16, 2 int32), count x size a multiple of 16 and <= slot_bytes; may alias;
- *   local_state: device uint32 [ao_allreduce_state_bytes() / 4]: word 0 is set to 1 if a peer did not arrive within the spin bound
- *     (~0.5 s) -- check it after synchronising; the rest are the per-block epoch counters the kernel bumps on every call (they live on
- *     the device so that a launch captured into a hipGraph replays correctly).  Every rank must make the same sequence of calls. */
+ *   local_state: device uint32 [ao_allreduce_state_bytes() / 4]: word 0 is set to 1 if a peer did not arrive within the timeout
+ *     (the output is then NaN / INT_MIN) -- check it wherever the host synchronises anyway; the rest are the per-block epoch counters
+ *     the kernel bumps on every call (they live on the device so that a launch captured into a hipGraph replays correctly).  Every
+ *     rank must make the same sequence of calls. */
 int ao_allreduce_oneshot(void* const* peer_data_host, void* const* peer_flags_host, const void* input,
                          void* output, void* local_state, int64_t count, int dtype, int64_t slot_bytes,
                          int rank, int world, void* stream);
+int ao_allreduce_oneshot_op(void* const* peer_data_host, void* const* peer_flags_host, const void* input,
+                            void* output, void* local_state, int64_t count, int dtype, int op,
+                            int64_t slot_bytes, int rank, int world, void* stream);
 
 /* On-device all-to-all-v of MXFP8 token rows (expert-parallel dispatch without a host round trip for the split sizes).  Replaces the
  * Triton kernel torchao/prototype/moe_training/kernels/mxfp8/comms.py:318-460 (_mxfp8_all_to_all_v_kernel, _exchange_row_offsets) that
@@ -324,8 +348,9 @@ int ao_allreduce_oneshot(void* const* peer_data_host, void* const* peer_flags_ho
  * rank), its E8M0 scale rows and its int64 split vector (rows it sends to rank r) in buffers all peers have mapped; this rank pulls the
  * rows addressed to it: from rank q, rows [sum_{r < rank} splits_q[r], + splits_q[rank]) land at local rows [sum_{p < q} splits_p[rank], ..),
  * and out_splits[q] = splits_q[rank].  Barriers before (inputs staged everywhere) and after (staging may be overwritten) are inside
- * the launch; epochs live on the device (hipGraph-replayable); a peer that never arrives sets bit 0 of local_state[0] after ~0.5 s,
- * more rows than max_out_rows sets bit 1 (the rows past the end are not written).
+ * the launch; epochs live on the device (hipGraph-replayable); a peer that never arrives sets bit 0 of local_state[0] after the
+ * collective timeout (nothing is read from it: out_splits of that peer = 0), more rows than max_out_rows sets bit 1 (the rows past the
+ * end are not written), a peer's split prefix that reaches past its max_in_rows staged rows sets bit 2 (the read is clamped to them).
  *   peer_*_host: HOST arrays of `world` DEVICE pointers, index = rank (own buffers at [rank]); data / scale staging 16-byte aligned,
  *     flag blocks ao_moe_a2a_flag_bytes() bytes, zero-filled once; local_state: ao_moe_a2a_state_bytes() bytes, zero-filled once;
  *   row_bytes = D (e4m3), a multiple of 16; scale_row_bytes = D / 32.  Every rank must make the same sequence of calls. */
@@ -333,8 +358,8 @@ int64_t ao_moe_a2a_flag_bytes(void);
 int64_t ao_moe_a2a_state_bytes(void);
 int ao_moe_a2a_v(void* const* peer_data_host, void* const* peer_scales_host, void* const* peer_splits_host,
                  void* const* peer_flags_host, void* out_data, void* out_scales, int64_t* out_splits,
-                 void* local_state, int64_t row_bytes, int64_t scale_row_bytes, int64_t max_out_rows,
-                 int rank, int world, void* stream);
+                 void* local_state, int64_t row_bytes, int64_t scale_row_bytes, int64_t max_in_rows,
+                 int64_t max_out_rows, int rank, int world, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * fp8 activations x int4 weights (Float8DynamicActivationInt4WeightConfig)

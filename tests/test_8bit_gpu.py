@@ -138,6 +138,51 @@ def test_fused_dynamic_linear_equals_cast_plus_matmul(kind, m, n, k, bias):
     assert torch.equal(one, two)
 
 
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+@pytest.mark.parametrize("m,n,k,bias", [(1, 1280, 8192, False), (1, 512, 1024, True), (1, 256, 3584, False), (2, 64, 4096, True), (5, 48, 896, True),
+                                        (16, 32, 2048, False), (3, 64, 14336, False), (1, 16, 128, True), (16, 16, 3968, True), (7, 80, 256, False)])
+def test_decode_kernel_every_form(kind, m, n, k, bias):
+    """Round 4: the straight-line decode kernel (dec8_kernels.hip: weights as full lines in a register ring, transposed through a
+    wave-private LDS slab) in every ring depth it is built with, with half-line loads, and against the round-3 kernels: int8 bit-exact
+    against the oracle in every form; fp8 within 1e-3 of the oracle, the fused and the two-launch call of one form bit-identical."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    x = _randn_bf16((m, k), 31 * m + k)
+    w = _randn_bf16((n, k), 37 * n + k, 0.05)
+    b = _randn_bf16((n,), 5) if bias else None
+    bd = None if b is None else b.to(DEV)
+    xd = x.to(DEV)
+    bn = None if b is None else b.float().numpy()
+    if kind == "int8":
+        wq, ws = ops.int8_quantize_rowwise(w.to(DEV))
+        xq, xs = ops.int8_quantize_rowwise(xd)
+        y_ref = I.linear(x.float().numpy(), w.float().numpy(), bn)
+    else:
+        wq, ws = ops.fp8_quantize_rowwise(w.to(DEV))
+        xq, xs = ops.fp8_quantize_rowwise(xd)
+        y_ref = F.linear(x.float().numpy(), w.float().numpy(), bn)
+    ran = 0
+    for variant in (0, 299, 290, 201, 202, 204, 207, 208):
+        lib.ao_gemm8_set_variant(variant)
+        try:
+            if kind == "int8":
+                two = ops.int8_scaled_mm(xq, xs, wq, ws, bd)
+                one = ops.int8_dynamic_linear(xd, wq, ws, bd) if ops.dynamic_linear_fits(m, n, k) else two
+            else:
+                two = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), bd)
+                one = ops.fp8_dynamic_linear(xd, wq, ws, bd) if ops.dynamic_linear_fits(m, n, k) else two
+        finally:
+            lib.ao_gemm8_set_variant(0)
+        ran += 1
+        assert torch.equal(one, two), (variant, "fused != two-launch")
+        if kind == "int8":
+            assert np.array_equal(np_from_torch_bf16(two), y_ref), variant
+        else:
+            assert _rel(two.float().cpu().numpy(), np.asarray(y_ref, dtype=np.float32)) <= 1e-3, variant
+    assert ran == 8
+
+
 def test_fused_dynamic_linear_shape_limits():
     assert ops.dynamic_linear_fits(16, 64, 2048) and not ops.dynamic_linear_fits(17, 64, 2048)
     assert not ops.dynamic_linear_fits(8, 64, 14336) and not ops.dynamic_linear_fits(1, 40, 4096) and not ops.dynamic_linear_fits(1, 64, 4000)

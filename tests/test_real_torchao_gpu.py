@@ -1,9 +1,10 @@
 """End to end with the REAL torchao: an unmodified `torchao.quantize_` + the reference's own tensor
 subclasses reach the MI355X kernels through the aten:: overrides of `_C_mi355_ops.so`, and produce the bits the mirror produces.
 
-Needs a GPU AND an importable torchao (a checkout on PYTHONPATH: `TORCHAO_PATH=/path/to/ao pytest tests/test_real_torchao_gpu.py -m gpu`,
-or torchao installed).  The image of the GPU pool ships no torchao and the reference checkout does not travel to it (only this
-repository does), so at round end these tests SKIP there -- the op-by-op override tests (tests/test_dispatcher_gpu.py) are what runs.
+Needs a GPU AND an importable torchao.  The image of the GPU pool ships none, so `make -C oracle ref` (run by
+`__graft_entry__.build()` whenever the read-only reference checkout is present) stages the reference's Python package into the
+git-ignored `oracle/_ref/`, which travels to the GPU box with the repository snapshot; `TORCHAO_PATH=/path/to/ao` overrides it, an
+installed torchao is the last resort.  Without any of the three the tests skip.
 Each case runs in a fresh process: AO_MI355_OVERRIDE_ATEN=1 has to be in the environment when `_C_mi355_ops.so` is loaded.
 """
 import importlib.util
@@ -16,7 +17,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TORCHAO_PATH = os.environ.get("TORCHAO_PATH", "")
+_STAGED = os.path.join(ROOT, "oracle", "_ref")
+TORCHAO_PATH = os.environ.get("TORCHAO_PATH", "") or (_STAGED if os.path.isdir(os.path.join(_STAGED, "torchao")) else "")
 
 
 def _torchao_importable():

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""8-bit decode linears (M <= 16) per shape, COLD: every call of a replay reads a different copy of the weight, enough copies to
+exceed the 256 MiB Infinity Cache.  A/B over the kernel forms of ao_gemm8_set_variant (0 product, 299 the round-3 kernels,
+290 half-line loads, 201..208 forced ring depth).  Measurement aid; output goes to profiles/.
+
+    python tools/bench_dec8.py [--ms 1,4,16] [--variants 0,299,290,204,208] [--kinds fp8,int8]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ao_amd import _lib, ops  # noqa: E402
+
+SHAPES = {
+    "fp8": [("qkv70b/8", 1280, 8192), ("o70b/8", 8192, 1024), ("gate_up70b/8", 7168, 8192), ("down70b/8", 8192, 3584)],
+    "int8": [("qkv8b", 6144, 4096), ("o8b", 4096, 4096), ("gate8b", 14336, 4096), ("down8b", 4096, 14336)],
+}
+
+
+def graph_time(calls, reps=5):
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        calls[0]()
+        side.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            for c in calls:
+                c()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e-3 / len(calls))
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ms", default="1,4,16")
+    ap.add_argument("--variants", default="0,299,290,201,202,204,207,208")
+    ap.add_argument("--kinds", default="fp8,int8")
+    args = ap.parse_args()
+    lib = _lib.lib()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    for kind in args.kinds.split(","):
+        quant = ops.fp8_quantize_rowwise if kind == "fp8" else ops.int8_quantize_rowwise
+        for name, n, k in SHAPES[kind]:
+            copies = max(2, -(-(300 << 20) // (n * k)))
+            ws = []
+            for _ in range(copies):
+                w = torch.randn(n, k, device=dev, dtype=torch.bfloat16) * 0.02
+                ws.append(quant(w))
+                del w
+            for m in [int(v) for v in args.ms.split(",")]:
+                x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
+                xq, xs = quant(x)
+                for v in [int(v) for v in args.variants.split(",")]:
+                    lib.ao_gemm8_set_variant(v)
+                    try:
+                        if kind == "fp8":
+                            two = [lambda wq=wq, wsc=wsc: ops.fp8_scaled_mm(xq, wq.t(), xs, wsc.t()) for wq, wsc in ws]
+                            one = [lambda wq=wq, wsc=wsc: ops.fp8_dynamic_linear(x, wq, wsc) for wq, wsc in ws]
+                        else:
+                            two = [lambda wq=wq, wsc=wsc: ops.int8_scaled_mm(xq, xs, wq, wsc) for wq, wsc in ws]
+                            one = [lambda wq=wq, wsc=wsc: ops.int8_dynamic_linear(x, wq, wsc) for wq, wsc in ws]
+                        rec = {"kind": kind, "shape": name, "N": n, "K": k, "M": m, "variant": v, "copies": copies}
+                        t = graph_time(two)
+                        rec["mm_us"] = round(t * 1e6, 2)
+                        rec["mm_TBps"] = round(n * k / t / 1e12, 3)
+                        if ops.dynamic_linear_fits(m, n, k):
+                            t = graph_time(one)
+                            rec["fused_us"] = round(t * 1e6, 2)
+                            rec["fused_TBps"] = round(n * k / t / 1e12, 3)
+                    except Exception as e:  # noqa: BLE001
+                        rec["error"] = repr(e)[:200]
+                    finally:
+                        lib.ao_gemm8_set_variant(0)
+                    print(json.dumps(rec), flush=True)
+            del ws
+
+
+if __name__ == "__main__":
+    main()
