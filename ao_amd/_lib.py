@@ -73,7 +73,16 @@ _SIGNATURES = {
     "ao_allreduce_oneshot": [_P, _P, _P, _P, _P, _I64, _INT, _I64, _INT, _INT, _P],
     "ao_moe_a2a_flag_bytes": [],
     "ao_moe_a2a_state_bytes": [],
-    "ao_moe_a2a_v": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _INT, _P],
+    "ao_moe_a2a_v": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _P],
+    "ao_allreduce_oneshot_op": [_P, _P, _P, _P, _P, _I64, _INT, _INT, _I64, _INT, _INT, _P],
+    "ao_peer_alloc": [_P, _I64, _INT],
+    "ao_peer_free": [_P],
+    "ao_peer_handle_bytes": [],
+    "ao_peer_export": [_P, _P],
+    "ao_peer_import": [_P, _P],
+    "ao_peer_close": [_P],
+    "ao_collective_set_timeout_ms": [_INT],
+    "ao_collective_timeout_ms": [],
     "ao_fp8_int4_linear": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_permute_indices": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_gather_rows": [_P, _P, _P, _I64, _I64, _I64, _P],

@@ -76,8 +76,12 @@ def _prune_objects(bdir, keep):
             os.remove(p)
 
 
-def build(force=False, verbose=False):
-    """Compile every .hip under ao_amd/csrc into one shared library, then the dispatcher binding."""
+def build(force=False, verbose=False, lab=False):
+    """Compile every .hip under ao_amd/csrc into one shared library, then the dispatcher binding.  lab=True: the laboratory
+    library instead (tools/bin/_C_mi355_lab.so, -DAO_LAB: the product plus the wrong-result ablation builds of the profiling
+    tools; select it with AO_MI355_LIB=tools/bin/_C_mi355_lab.so) -- never what ao_amd loads by default."""
+    if lab:
+        return _build_lab(verbose)
     if not force and not _stale():
         build_ops(force=False, verbose=verbose)
         return LIB
@@ -105,5 +109,28 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def _build_lab(verbose=False):
+    out = os.path.join(os.path.dirname(HERE), "tools", "bin", "_C_mi355_lab.so")
+    bdir = os.path.join(HERE, "build", "lab")
+    os.makedirs(bdir, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    objs, procs = [], []
+    for src in sources():
+        obj = os.path.join(bdir, os.path.basename(src) + ".o")
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-DAO_LAB=1", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        o, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{o.decode()}")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout.decode()}")
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))

@@ -24,6 +24,10 @@ void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
 extern thread_local int g_mx_variant;  // stream8_kernels.hip
 extern thread_local int g_dec8_mode;   // dec8_kernels.hip
+extern thread_local int g_mid8_mode;   // mid8_kernels.hip
+bool mid8_takes(int64_t M, int64_t N, int64_t K);
+int mid8_scaled(bool int8, const void* a, const float* scale_a, const void* b, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M,
+                int64_t N, int64_t K, hipStream_t stream);
 bool dec8_takes(int64_t M, int64_t N, int64_t K);
 int dec8_scaled(bool int8, const void* xq, const float* x_scale, const void* wq, const float* w_scale, const uint16_t* bias, uint16_t* y,
                 int64_t M, int64_t N, int64_t K, hipStream_t stream);
@@ -443,6 +447,8 @@ extern "C" int ao_gemm8_set_variant(int variant) {
                    variant != 128 && variant != 129);
   // the straight-line decode kernel (dec8_kernels.hip): 201 / 202 / 204 / 207 / 208 force its ring depth, 290 half-line loads, 299 never
   g_dec8_mode = (variant >= 200 && variant <= 299) ? variant : 0;
+  // the register-ring mid-M kernel (mid8_kernels.hip): 300 never, 301 wherever the shape allows, 310 + S: S K-parts forced
+  g_mid8_mode = (variant >= 300 && variant <= 329) ? variant : 0;
   g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16 || variant == 32) ? variant : 0;
   // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
   fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : (variant != 0 && variant < 110) ? 1 : 0);
@@ -463,6 +469,8 @@ extern "C" int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const i
   // through the tiled GEMM
   if (M <= 16 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only && dec8_takes(M, N, K))
     return dec8_scaled(true, xq, x_scale, wq, w_scale, bias, y, M, N, K, (hipStream_t)stream);  // round 4: full-line register ring
+  if (M > 16 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only && g_gemm8_tm == 0 && !g_gemm8_force_regstage && mid8_takes(M, N, K))
+    return mid8_scaled(true, xq, x_scale, wq, w_scale, bias, y, M, N, K, (hipStream_t)stream);  // round 4: 16 < M <= 256, few output tiles
   if (N % 16 == 0 && K % 128 == 0 && M <= 32 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only)
     return int8_scaled_stream(xq, wq, x_scale, w_scale, bias, y, M, N, K, (hipStream_t)stream);
   if (N % 16 == 0 && fp8_rowwise_rb_preferred(M, N, K)) return int8_scaled_rb(xq, wq, x_scale, w_scale, bias, y, M, N, K, (hipStream_t)stream);
@@ -515,6 +523,8 @@ extern "C" int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float*
   // (at 32 < M <= 64 it only wins once K is long enough to amortise its start-up and split-K meeting: o_proj shard 8192x1024 8.5 vs 10.9 us)
   if (M <= 16 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only && dec8_takes(M, N, K))
     return dec8_scaled(false, a, scale_a, b, scale_b, bias, y, M, N, K, (hipStream_t)stream);  // round 4: full-line register ring
+  if (M > 16 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only && g_gemm8_tm == 0 && !g_gemm8_force_regstage && mid8_takes(M, N, K))
+    return mid8_scaled(false, a, scale_a, b, scale_b, bias, y, M, N, K, (hipStream_t)stream);  // round 4: 16 < M <= 256, few output tiles
   const bool rb = fp8_rowwise_rb_preferred(M, N, K) && (M > 64 || K >= 4096 || fp8_rowwise_rb_forced());
   if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb)) && !(fp8_rowwise_rb_forced() && rb) && !g_gemm8_tiled_only)
     return fp8_rowwise_stream(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);

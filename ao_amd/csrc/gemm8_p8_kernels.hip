@@ -202,6 +202,13 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
     seam();
   }
   if (wr == 0) asm volatile("s_barrier" ::: "memory");  // wave row 0 catches up: from here on the LDS is free for every wave
+  if constexpr (!IS_INT) {
+    // the fp8 MFMAs are opaque volatile asm, so the compiler's hazard recognizer does not know that the accumulators are
+    // matrix-pipe results still in flight: gfx9 wants up to 19 wait states (16-pass XDL op) between an MFMA's issue and a VALU / VMEM
+    // read of its destination, and nothing but luck (the barrier above on one wave row, the epilogue's scale loads) stood between the
+    // last multiply() and the epilogue.  20 wait states, explicitly; tests/test_isa_structure.py checks they survive.
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------

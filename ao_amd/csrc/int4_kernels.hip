@@ -1267,7 +1267,9 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   // Modes 94-99: A/B builds for profiling (94 never / 93 always the batched kernel on wide weights at M <= 16, 95 / 96 ring depth
   // 6 / 8, 98 the 4-row build at M = 1, 99 the 16-row build at any M).
   const bool wide = (N >> 4) >= 1024 && g_tune_mode != 94;
+#ifdef AO_LAB  // wrong-result ablation builds exist only in the laboratory library (python -m ao_amd.build --lab -> tools/bin/_C_mi355_lab.so)
   if (M == 1 && g_tune_mode == 90) return launch_mm<G, 1, 4, 3>(x, qdata, sz, y, M, N, K, stream);
+#endif
   if (M == 1 && g_tune_mode == 91) return launch_mm<G, 1, 4, 1>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 92) return launch_mm<G, 1, 4, 2>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 89) return launch_mm<G, 1, 6, 2>(x, qdata, sz, y, M, N, K, stream);
@@ -1332,10 +1334,12 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     if constexpr (G == 128) {
       const int64_t base = ((N + 127) / 128) * ((M + 127) / 128);
       const int sp = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)forced_split, kblocks, kSplitMaxTiles / std::max<int64_t>(base, 1)}));
+#ifdef AO_LAB  // 1 - 4: parts of the k-block removed (wrong results): laboratory library only
       if (abl == 1) return launch_mm_rb<G, 8, 1, 8, 1>(x, qdata, sz, y, M, N, K, sp, stream);
       if (abl == 2) return launch_mm_rb<G, 8, 1, 8, 2>(x, qdata, sz, y, M, N, K, sp, stream);
       if (abl == 3) return launch_mm_rb<G, 8, 1, 8, 3>(x, qdata, sz, y, M, N, K, sp, stream);
       if (abl == 4) return launch_mm_rb<G, 8, 1, 8, 4>(x, qdata, sz, y, M, N, K, sp, stream);
+#endif
       if (abl == 5) return launch_mm_rb<G, 8, 1, 8, 5>(x, qdata, sz, y, M, N, K, sp, stream);
       if (abl == 6) return launch_mm_rb<G, 4, 2>(x, qdata, sz, y, M, N, K, sp, stream);
     }
@@ -1346,11 +1350,13 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     const int sp = (g_tune_mode == 900) ? (int)std::max<int64_t>(1, std::min<int64_t>({256 / base9, fit9, 8, kblocks / 8}))
                                         : (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)(g_tune_mode - 900), kblocks, fit9}));
     return launch_mm_rb<G, 4, 1, 8, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
+#ifdef AO_LAB
   } else if (g_tune_mode == 910 && M > 64) {
     // profiling: the same without the scale / zero DMAs (wrong numbers): what the dword LDS-DMAs cost
     const int64_t base9 = ((N + 63) / 64) * ((M + 127) / 128);
     const int64_t fit9 = (int64_t)kSplitMaxTiles * 128 * 128 / (base9 * 64 * 128);
     return launch_mm_rb<G, 4, 1, 8, 6, true>(x, qdata, sz, y, M, N, K, (int)std::max<int64_t>(1, std::min<int64_t>({256 / base9, fit9, 8, kblocks / 8})), stream);
+#endif
   } else if (g_tune_mode >= 800 && g_tune_mode < 840 && M > 16) {
     // profiling (round 3): two n-tiles per wave -- every A fragment read from LDS feeds two MFMAs.  80S / 81S: 64-row slabs x 128
     // columns (4 waves, fused / with DMA-producer waves), 82S / 83S: 128-row slabs x 128 columns; S = K parts (0: fill ~256 workgroups)
@@ -1376,7 +1382,11 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     const int64_t fit8 = (int64_t)kSplitMaxTiles * 128 * 128 / (base8 * 64 * 128);
     const int sp = (int)std::max<int64_t>(1, std::min<int64_t>({256 / base8, fit8, 8, kblocks / 8}));
     if (g_tune_mode < 870) return launch_mm_kh<G, 8, 1>(x, qdata, sz, y, M, N, K, sp, stream);
+#ifdef AO_LAB  // no DMAs at all (wrong results)
     return launch_mm_kh<G, 8, 6>(x, qdata, sz, y, M, N, K, sp, stream);
+#else
+    return launch_mm_kh<G, 8, 1>(x, qdata, sz, y, M, N, K, sp, stream);
+#endif
   } else if (g_tune_mode >= 700 && g_tune_mode < 800) {
     mt = 1 << std::min(3, (g_tune_mode - 700) / 10);
     waves = (g_tune_wpb == 8 && mt >= 2) ? 8 : 4;

@@ -1,0 +1,343 @@
+// 8-bit linears at 16 < M <= 256 with few output tiles (round 4): the TP-shard / batched-decode sizes of BASELINE config 4, where the
+// op is bound by reading the weights once and by the fixed costs of a short launch.
+//
+//   fp8 :  y[M,N] = bf16((a . b^T) * scale_a[m] * scale_b[n] + bias[n])     aten::_scaled_mm rowwise, float8/inference.py:104-123
+//   int8:  y[M,N] = bf16(bf16(i32(a . b^T) * sx[m]) * sw[n] + bias[n])      _int_mm + scales, int8_tensor.py:305-359
+//   fused: a, scale_a = per-row cast of x (bf16) inside the same launch     float8_tensor.py:347-355, int8_tensor.py:287-294
+//
+// rb8_kernel (round 1-3) stages BOTH operands through LDS-DMA rings: 144 KiB of LDS, ONE workgroup per CU, so ring priming (2-3 us),
+// the split-K meeting and the epilogue of a 10-20 us launch overlap with nothing.  Here the weights take dec8_kernel's path instead --
+// full 128-byte lines straight into a static REGISTER ring (G steps = G x 2 KiB per wave in flight, compiler-counted waits), turned
+// into the MFMA operand layout through a wave-private 2.25 KiB slab -- and only the activation tile goes through a shared,
+// double-buffered LDS tile (rows 144 bytes apart: conflict-free fragment reads): 54 KiB per workgroup, TWO workgroups per CU; one's
+// fixed costs hide behind the other's k loop, and twice the weight bytes are in flight per CU.
+//   * a workgroup = 8 waves = 8 n-tiles (128 columns) x MT m-tiles (32 / 64 / 128 rows) x one K part of nk steps (nk % G == 0);
+//   * per step and wave: 2 weight loads + NA activation loads (issued G resp. PA steps ahead), 2 + NA ds_write_b128, 2 + 2 MT
+//     ds_read_b128, MT (fp8) or 2 MT (int8) MFMAs, ONE LDS-only barrier;
+//   * K parts meet through the two-level meeting of splitk.h (groups of four parts: two dependent round trips instead of S / 4);
+//   * FUSED: before its k loop every workgroup takes rows of x from a ticket counter -- amax -> scale -> codes with quant_math.h's
+//     arithmetic, written through (sc1) to a scratch copy in the stream's workspace -- until none are left, then waits for the
+//     `done` counter.  The wait only ever depends on rows a RUNNING workgroup has taken, so no co-residency is assumed; the weight
+//     ring is requested first, so the cast runs under the weights' flight.  One launch per linear instead of two.
+#include "common.h"
+#include "quant_math.h"
+#include "splitk.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace ao {
+thread_local int g_mid8_mode = 0;  // ao_gemm8_set_variant 300: never this kernel; 301: always (where the shape allows); 31S: force S K-parts
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+struct Mid8Args {
+  const uint8_t* a;        // [M][K] codes (FUSED: the scratch copy the prologue writes)
+  const uint16_t* x;       // FUSED: bf16 [M][K]
+  const uint8_t* b;        // [N][K]
+  const float* scale_a;    // [M] (FUSED: scratch)
+  const float* scale_b;    // [N]
+  const uint16_t* bias;    // [N] bf16 or null
+  uint16_t* y;             // [M][N] bf16
+  int M, N, K;
+  float* ws;               // split-K parts
+  unsigned* tickets;
+  uint8_t* xq;             // FUSED scratch: codes [M][K]
+  float* xs;               // FUSED scratch: scales [M]
+  unsigned* sync;          // FUSED: [0] next row, [1] rows done, [2] workgroups past the wait (the last one re-zeroes all three)
+};
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kRow = 144;          // LDS bytes per 128-byte row (weights slab and activation tile): 16 rows hit 64 distinct banks
+constexpr int kSlab = 16 * kRow;   // 2304 B per wave
+constexpr int kPA = 2;             // activation steps requested ahead (L2 hits)
+
+
+template <bool INT8, int MT, int G, bool FUSED>
+__global__ __launch_bounds__(512, 4) void mid8_kernel(Mid8Args p) {
+  constexpr int BM = 16 * MT;
+  constexpr int AROWS = (BM < 64) ? 64 : BM;  // rows of the LDS activation tile (512 threads fetch 64 rows per pass)
+  constexpr int NA = AROWS / 64;              // activation loads per thread and step
+  static_assert(G % kPA == 0 && G % 2 == 0, "ring slots and LDS buffers are compile-time indices of the unrolled group");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [2][AROWS][144] activation tile | [8][16][144] weight slabs
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nl = lane & 15, kq = lane >> 4;
+  char* abuf = smem;
+  char* slab = smem + 2 * AROWS * kRow + wave * kSlab;
+
+  const int ntiles = p.N >> 4;
+  const int tile = blockIdx.x * 8 + wave;
+  const int tile_c = min(tile, ntiles - 1);  // tiles past N alias the last one; never stored
+  const int m0 = blockIdx.y * BM;
+  const int ksteps = p.K >> 7;
+  const int S = gridDim.z, ks = blockIdx.z;
+  const int nk = ksteps / S;  // host: ksteps % (S * G) == 0
+  const int k0 = ks * nk;
+
+  // ---- weight ring: lane l fetches row (l >> 3) of the tile's rows 0..7 / 8..15, chunk l & 7 of the step's 128 bytes (full lines).
+  // Buffer addressing (SGPR descriptor + one 32-bit VGPR offset + an SGPR offset per step): no 64-bit pointers in VGPRs.
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.b), 0, (int)((size_t)p.N * p.K), 0x00020000);
+  const uint32_t woff = ((uint32_t)tile_c * 16 + (lane >> 3)) * (uint32_t)p.K + (lane & 7) * 16;
+  const uint32_t whalf = 8u * (uint32_t)p.K;
+  struct WStage {
+    u32x4 b0, b1;
+  };
+  WStage wr[G];
+  auto issue_w = [&](WStage& s, int k) {
+    const uint32_t so = (uint32_t)(k0 + min(k, nk - 1)) * 128u;  // past the end: the last step again, unused
+    s.b0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)woff, (int)so, 2 /* nt: streamed once */));
+    s.b1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)woff, (int)(so + whalf), 2));
+  };
+#pragma unroll
+  for (int g = 0; g < G; ++g) issue_w(wr[g], g);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- FUSED: the per-row cast, shared out by a ticket counter (see the header)
+  if constexpr (FUSED) {
+    __shared__ float s_part[8];
+    __shared__ int s_row;
+    const int nvec = p.K >> 3;  // 8 bf16 per 16 B
+    for (;;) {
+      if (tid == 0) s_row = (int)__hip_atomic_fetch_add(&p.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lds_barrier();
+      const int r = s_row;
+      if (r >= p.M) break;  // uniform
+      const u32x4* xr = reinterpret_cast<const u32x4*>(p.x + (size_t)r * p.K);
+      float m = 0.f;
+      bool has_nan = false;
+      for (int i = tid; i < nvec; i += 512) m = fmaxf(m, amax8(xr[i], has_nan));
+      if (has_nan) m = INFINITY;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if (lane == 0) s_part[wave] = m;
+      lds_barrier();
+      float mm = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) mm = fmaxf(mm, s_part[w]);
+      const float s = INT8 ? int8_row_scale(mm) : fp8_row_scale(mm);
+      const float inv = 1.0f / s;
+      for (int i = tid; i < nvec; i += 512) {
+        const u32x2 q = INT8 ? int8_quant8(xr[i], inv) : fp8_quant8(xr[i], s);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.xq + (size_t)r * p.K + (size_t)i * 8),
+                           ((unsigned long long)q.y << 32) | q.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: written through
+      }
+      if (tid == 0) __hip_atomic_store(p.xs + r, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (drains this wave's part of the weight ring too: it has long landed by now)
+      lds_barrier();                                      // every wave's stores are out before the row counts as done
+      if (tid == 0) __hip_atomic_fetch_add(&p.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(&p.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.M) __builtin_amdgcn_s_sleep(2);
+      // the last workgroup past the wait leaves the counters at zero for the next launch on this stream
+      const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+      if (__hip_atomic_fetch_add(&p.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+        __hip_atomic_store(&p.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p.sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    lds_barrier();
+  }
+
+  // ---- activation tile: thread t fetches chunk t & 7 of rows (t >> 3) + 64 i (clamped into the matrix: rows past M are never stored)
+  // (FUSED: the scratch codes were written through by other workgroups -- the agent-scope (sc1) cache policy on these loads)
+  uint32_t aoff[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) aoff[i] = (uint32_t)min(m0 + (tid >> 3) + 64 * i, p.M - 1) * (uint32_t)p.K + (tid & 7) * 16;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.a), 0, (int)((size_t)p.M * p.K), 0x00020000);
+  char* awr = abuf + (tid >> 3) * kRow + (tid & 7) * 16;  // + 64 i rows, + buffer
+  u32x4 ar[kPA][NA];
+  auto load_a = [&](u32x4 (&dst)[NA], int k) {
+    const uint32_t so = (uint32_t)(k0 + min(k, nk - 1)) * 128u;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)aoff[i], (int)so, FUSED ? 16 /* sc1 */ : 0));
+  };
+  auto store_a = [&](const u32x4 (&src)[NA], int buf) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(awr + (buf * AROWS + 64 * i) * kRow) = src[i];
+  };
+  {
+    u32x4 first[NA];
+    load_a(first, 0);
+#pragma unroll
+    for (int s = 1; s <= kPA; ++s) load_a(ar[s % kPA], s);
+    store_a(first, 0);
+  }
+  lds_barrier();
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  char* wwr = slab + (lane >> 3) * kRow + (lane & 7) * 16;  // this lane's piece of slab rows 0..7; rows 8..15: + 8 rows
+  const char* wrd = slab + nl * kRow + kq * 16;
+  const char* ard = abuf + nl * kRow + kq * 16;
+
+  for (int kb = 0; kb < nk; kb += G) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k = kb + g;
+      // A(k + 1) -> the other LDS buffer (its readers finished at the previous barrier), its registers refilled with A(k + 1 + PA)
+      store_a(ar[(g + 1) % kPA], (g + 1) & 1);
+      load_a(ar[(g + 1) % kPA], k + 1 + kPA);
+      // W(k): registers -> slab -> operand layout; the slot refilled with W(k + G)
+      *reinterpret_cast<u32x4*>(wwr) = wr[g].b0;
+      *reinterpret_cast<u32x4*>(wwr + 8 * kRow) = wr[g].b1;
+      issue_w(wr[g], k + G);
+      const u32x4 b0 = *reinterpret_cast<const u32x4*>(wrd);
+      const u32x4 b1 = *reinterpret_cast<const u32x4*>(wrd + 64);
+      const char* A = ard + (g & 1) * AROWS * kRow;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 16 * kRow);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + mt * 16 * kRow + 64);
+        if constexpr (INT8) {  // acc holds int32 bit patterns
+          i32x4 c = __builtin_bit_cast(i32x4, acc[mt]);
+          c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, b0), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, b1), c, 0, 0, 0);
+          acc[mt] = __builtin_bit_cast(f32x4, c);
+        } else {
+          const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+          const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+          acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, 127, 0, 127);
+        }
+      }
+      // (the fence keeps a step's MFMAs inside the step: left alone the scheduler carries accumulators across the barrier in renamed
+      // registers, and the fused MT = 8 forms spilled their weight ring at the 128-VGPR budget of four waves per SIMD)
+      __builtin_amdgcn_sched_barrier(0);
+      lds_barrier();  // A(k + 1) is in LDS for everyone; everyone is done reading A(k)
+    }
+  }
+
+  // ---- K parts meet (two-level, part order: reproducible); the last arriver of a tile goes on to the epilogue
+  if (S > 1 && !split_k_meet2<MT, 512, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) return;
+  if (tile >= ntiles) return;
+
+  // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
+  const int n = tile * 16 + nl;
+  uint16_t* __restrict__ y = p.y;
+  const float* __restrict__ scale_a = FUSED ? p.xs : p.scale_a;
+  const float sb = p.scale_b[n];
+  const float bias = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
+  float sa[4 * MT];  // all row scales first: the stores below must not sit between dependent loads
+#pragma unroll
+  for (int i = 0; i < 4 * MT; ++i) {
+    const int m = min(m0 + (i >> 2) * 16 + kq * 4 + (i & 3), p.M - 1);
+    if constexpr (FUSED) sa[i] = __hip_atomic_load(scale_a + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else sa[i] = scale_a[m];
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + mt * 16 + kq * 4 + r;
+      if (m < p.M) {
+        float v;
+        if constexpr (INT8) {
+          // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+          v = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt])[r] * sa[mt * 4 + r]) * sb;
+        } else {
+          v = acc[mt][r] * sa[mt * 4 + r] * sb;
+        }
+        if (p.bias != nullptr) v += bias;
+        y[(size_t)m * p.N + n] = f32_to_bf16_bits(v);
+      }
+    }
+}
+
+constexpr int kG = 4;  // ring depth of the k loop (G x 2 KiB per wave in flight; 16 waves per CU)
+
+struct Mid8Plan {
+  int mt, split;
+};
+
+// Rows: 32 / 64 / 128-row slabs.  K parts: enough workgroups for ~two per CU, parts of >= kG steps that divide the K steps evenly.
+bool mid8_plan(int64_t M, int64_t N, int64_t K, Mid8Plan* out) {
+  if (g_mid8_mode == 300) return false;
+  if (M <= 16 || M > 256 || N % 16 != 0 || K % (128 * kG) != 0 || M * K >= (1ll << 31) || N * K >= (1ll << 31)) return false;
+  const int mt = (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
+  const int64_t slabs = (M + 16 * mt - 1) / (16 * mt), cols = (N + 127) / 128, groups = K / (128 * kG);
+  const int64_t base = cols * slabs;
+  if (g_mid8_mode != 301 && !(g_mid8_mode >= 310 && g_mid8_mode < 330) && base >= 400) return false;  // enough tiles for the tiled GEMMs
+  int64_t want = std::max<int64_t>(1, 512 / base);
+  if (g_mid8_mode >= 310 && g_mid8_mode < 330) want = g_mid8_mode - 310;
+  int split = 1;
+  for (int64_t s = 1; s <= std::min<int64_t>(groups, 16); ++s)
+    if (groups % s == 0 && s <= want) split = (int)s;
+  // the meeting's workspace: (S + ceil(S / 4)) parked tiles per output tile
+  if (split > 1 && base * (split + (split + 3) / 4) * 128 * 16 * mt > (int64_t)kSplitMaxTiles * 128 * 128) return false;
+  if (split > 1 && base * (1 + (split + 3) / 4) > kSplitMaxTickets - 8) return false;
+  *out = Mid8Plan{mt, split};
+  return true;
+}
+
+template <bool INT8, int MT, bool FUSED>
+int launch_mid8(Mid8Args p, int split, hipStream_t stream) {
+  constexpr int BM = 16 * MT, AROWS = (BM < 64) ? 64 : BM;
+  constexpr size_t smem = (size_t)2 * AROWS * kRow + 8 * kSlab;
+  const dim3 grid((unsigned)((p.N + 127) / 128), (unsigned)((p.M + BM - 1) / BM), (unsigned)split), block(512);
+  const size_t tiles = (size_t)grid.x * grid.y;
+  const size_t part_floats = (split > 1) ? tiles * (split + (split + 3) / 4) * 128 * BM : 0;
+  const size_t scratch_floats = FUSED ? ((size_t)p.M * p.K + 15) / 16 * 4 + (size_t)((p.M + 3) / 4 * 4) : 0;
+  if (split > 1 || FUSED) {
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, part_floats + scratch_floats)) return rc;
+    if constexpr (FUSED) {
+      p.xq = reinterpret_cast<uint8_t*>(p.ws + part_floats);
+      p.xs = p.ws + part_floats + ((size_t)p.M * p.K + 15) / 16 * 4;
+      p.sync = p.tickets + kSplitMaxTickets - 4;  // the last tickets of the stream's workspace: zero between launches
+      p.a = p.xq;
+    }
+  }
+  auto kern = mid8_kernel<INT8, MT, kG, FUSED>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(mid8_kernel)")) return rc;
+  ao::launch(kern, grid, block, smem, stream, p);
+  AO_LAUNCH_CHECK("mid8_kernel launch");
+  return AO_OK;
+}
+
+template <bool INT8, bool FUSED>
+int run_mid8(const Mid8Args& p, const Mid8Plan& plan, hipStream_t stream) {
+  switch (plan.mt) {
+    case 2: return launch_mid8<INT8, 2, FUSED>(p, plan.split, stream);
+    case 4: return launch_mid8<INT8, 4, FUSED>(p, plan.split, stream);
+    default: return launch_mid8<INT8, 8, FUSED>(p, plan.split, stream);
+  }
+}
+
+}  // namespace
+
+bool mid8_takes(int64_t M, int64_t N, int64_t K) {
+  Mid8Plan plan;
+  return mid8_plan(M, N, K, &plan);
+}
+
+int mid8_scaled(bool int8, const void* a, const float* scale_a, const void* b, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M,
+                int64_t N, int64_t K, hipStream_t stream) {
+  Mid8Plan plan;
+  if (!mid8_plan(M, N, K, &plan)) {
+    set_error("mid8_scaled: shape M=%lld N=%lld K=%lld not covered", (long long)M, (long long)N, (long long)K);
+    return AO_ERR_INVALID_ARGUMENT;
+  }
+  Mid8Args p{};
+  p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.y = y;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  return int8 ? run_mid8<true, false>(p, plan, stream) : run_mid8<false, false>(p, plan, stream);
+}
+
+int mid8_dynamic(bool int8, const uint16_t* x, const void* b, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
+                 hipStream_t stream) {
+  Mid8Plan plan;
+  if (!mid8_plan(M, N, K, &plan)) {
+    set_error("mid8_dynamic: shape M=%lld N=%lld K=%lld not covered", (long long)M, (long long)N, (long long)K);
+    return AO_ERR_INVALID_ARGUMENT;
+  }
+  Mid8Args p{};
+  p.x = x; p.b = static_cast<const uint8_t*>(b); p.scale_b = scale_b; p.bias = bias; p.y = y;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  return int8 ? run_mid8<true, true>(p, plan, stream) : run_mid8<false, true>(p, plan, stream);
+}
+
+}  // namespace ao

@@ -90,5 +90,85 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// Two-level meeting (round 4).  With S parts the meeting above makes the last arriver read S - 1 parked tiles through ONE CU's
+// memory path in S / 4 dependent round trips (fp8 qkv shard at M = 128: 15 x 64 KiB, ~8 us of an 18 us launch).  Here the parts of a
+// tile form groups of four: the last arriver of a GROUP adds its (<= 4) parts in part order and parks the group sum, takes a
+// second-level ticket, and the last group adds the (<= 4, S <= 16) group sums in group order: two round trips on the critical
+// path, the first level spread over S / 4 workgroups.  The sum is ((p0 + p1 + p2 + p3) + (p4 + ..) + ..) whatever the arrival
+// order: reproducible.  Workspace per tile: S + ceil(S / 4) parked parts; tickets per tile: 1 + ceil(S / 4).
+// ---------------------------------------------------------------------------
+template <int NREG, int NTHR, bool INT = false>
+__device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
+  constexpr int kSc1 = 16;
+  constexpr int kRegBytes = NTHR * 16;
+  constexpr int kPartBytes = NREG * kRegBytes;
+  const int NG = (S + 3) >> 2;          // groups
+  const int slots = S + NG;             // parked tiles per output tile: parts, then group sums
+  const __amdgpu_buffer_rsrc_t rws =
+      __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * slots * (kPartBytes / 4), 0, slots * kPartBytes, 0x00020000);
+  unsigned* tk = tickets + (size_t)tile * (1 + NG);  // [0] second level, [1 + g] group g
+  auto park = [&](int slot) {
+#pragma unroll
+    for (int r = 0; r < NREG; ++r)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, slot * kPartBytes, kSc1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(acc[r]));  // the data registers stay untouched until the stores are out
+    __syncthreads();
+  };
+  auto last_of = [&](unsigned* t, int n) {
+    if (tid == 0) {
+      const unsigned v = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (v == (unsigned)n - 1);
+      if (v == (unsigned)n - 1) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();  // (flag is re-used by the second level)
+    return last;
+  };
+  // acc = slot[first] + .. + slot[first + n - 1], n <= 4, in slot order.  U parts per round trip: 4, or 2 when the tile has 8 registers
+  // per thread (4 x 8 x 16 B would not fit the 128 VGPRs of a kernel that runs four waves per SIMD).  acc is dead here: the own part
+  // is re-read from its slot like the others.
+  auto gather = [&](int first, int n) {
+    constexpr int U = (NREG >= 8) ? 2 : 4;
+#pragma unroll
+    for (int u0 = 0; u0 < 4; u0 += U) {
+      if (u0 > 0 && u0 >= n) break;  // uniform
+      f32x4 v[U][NREG];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r)
+          v[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, (first + min(u0 + u, n - 1)) * kPartBytes, kSc1));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool keep = u0 + u < n;
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          if (u0 + u == 0) {
+            acc[r] = v[0][r];
+          } else if constexpr (INT) {
+            const i32x4 a = __builtin_bit_cast(i32x4, acc[r]), b = __builtin_bit_cast(i32x4, v[u][r]);
+            acc[r] = __builtin_bit_cast(f32x4, i32x4{a.x + (keep ? b.x : 0), a.y + (keep ? b.y : 0), a.z + (keep ? b.z : 0), a.w + (keep ? b.w : 0)});
+          } else {
+            acc[r].x += keep ? v[u][r].x : 0.f; acc[r].y += keep ? v[u][r].y : 0.f;
+            acc[r].z += keep ? v[u][r].z : 0.f; acc[r].w += keep ? v[u][r].w : 0.f;
+          }
+        }
+      }
+    }
+  };
+  const int g = ks >> 2, gn = min(4, S - 4 * g);
+  park(ks);
+  if (!last_of(tk + 1 + g, gn)) return false;
+  gather(4 * g, gn);
+  if (NG == 1) return true;
+  park(S + g);
+  if (!last_of(tk, NG)) return false;
+  gather(S, NG);  // NG <= 4 (S <= 16)
+  return true;
+}
 
 }  // namespace ao

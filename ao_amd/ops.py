@@ -900,7 +900,8 @@ def fused_unpad_token_groups(inputs, offsets, padded_group_start_offsets, num_to
 
 
 def dynamic_linear_fits(m: int, n: int, k: int) -> bool:
-    """Whether the fused cast + matmul kernels take this shape (decode sizes: the cast activation must fit LDS)."""
+    """Whether the fused cast + matmul kernels take this shape (M <= 16: the cast activation must fit LDS; 16 < M <= 256: weights with
+    few output tiles and K % 512 == 0)."""
     return bool(_lib.lib().ao_dyn_linear_fits(m, n, k))
 
 
@@ -908,8 +909,9 @@ def dynamic_linear_preferred(m: int, n: int, k: int) -> bool:
     """Whether the fused kernel beats cast + matmul: every workgroup (one per 16 output columns) casts the whole activation
     itself, so the redundant work must stay small.  Measured on Llama-3-8B int8 (us, cast + matmul vs fused): M = 1 qkv 10.3 vs
     8.2, o 8.9 vs 6.9, down 21.5 vs 17.4, gate_up 26.5 vs 26.5; M = 2 qkv 10.6 vs 8.9 but gate_up 27.0 vs 28.5; M = 4 gate_up
-    28.5 vs 35.1."""
-    return dynamic_linear_fits(m, n, k) and m * (n // 16) <= 1024
+    28.5 vs 35.1.  16 < M <= 256 on few output tiles (round 4, mid8_kernels.hip): the rows of the cast are shared out among the
+    workgroups of the launch, nothing is cast twice -- always one launch."""
+    return dynamic_linear_fits(m, n, k) and (m > 16 or m * (n // 16) <= 1024)
 
 
 def int8_linear(x2: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias=None) -> torch.Tensor:

@@ -16,7 +16,9 @@ Row-parallel 8-bit linears reproduce the UNSHARDED oracle: the 
 is the full-K one (a slice of a tensor quantized before sharding keeps it), the per-row ACTIVATION
 scale is made the full-K one by an all_reduce(MAX) of the rows' amax ([M] fp32) before the cast, the
 raw accumulators (int32 / fp32 [M, N]) are all-reduced, and the scale epilogue runs once on the sum --
-int8 bit-exact, fp8 within fp32 summation order of the unsharded linear.  `reduce="bf16"` is the
+int8 bit-exact, fp8 within fp32 summation order of the unsharded linear.  From M = 128 rows on the all-reduce
+is split around the epilogue: reduce-scatter (fp32 / int32) -> epilogue on M / world rows -> all-gather (bf16),
+25 % fewer bytes over xGMI and a world-times smaller epilogue, the same bits for int8.  `reduce="bf16"` is the
 cheaper protocol a caller of F.linear(x_shard, w_shard) + all_reduce gets from the reference
 subclasses (locally scaled activation shards, bf16 partials; half the exchange bytes, ~1e-2 rel).
 """
@@ -36,9 +38,11 @@ class OneShotAllReduce:
     staged vectors over xGMI and adds them in rank order ("direct / one-shot algorithm for S <= ~1 MiB, never a ring
     on the fully connected 8-GPU xGMI mesh").
 
-    backend "hip" (default): the hand-written kernel `ao_allreduce_oneshot` (csrc/allreduce_kernels.hip) over buffers exchanged as IPC
-    handles (torch's CUDA-IPC storage sharing; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack) -- fp32 / bf16 / int32, bit-identical
-    on every rank, capturable into a hipGraph (epochs live on the device).  backend "symm_mem": `torch.distributed._symmetric_memory`
+    backend "hip" (default): the hand-written kernel `ao_allreduce_oneshot_op` (csrc/allreduce_kernels.hip), SUM or MAX, over buffers
+    allocated through the C ABI as fine-grained (staging) / uncached (flags) device memory and exchanged as raw IPC handles
+    (ao_amd/peer_mem.py; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack; `memory` names what was really allocated) -- fp32 / bf16 /
+    int32, bit-identical on every rank, capturable into a hipGraph (epochs live on the device).  A rank that waits longer than
+    `ao_collective_set_timeout_ms` for a peer poisons its output with NaN / INT_MIN and `check()` raises.  backend "symm_mem": `torch.distributed._symmetric_memory`
     + `symm_mem::one_shot_all_reduce` (round 2's prototype).  RCCL's all_reduce stays the path for anything larger, for MAX
     reductions, and whenever the set-up fails (`ok` False, `why` says what happened).  Verified on one GPU with two processes
     (tests/test_oneshot_allreduce_gpu.py); no multi-GPU node was available to this build.
@@ -46,8 +50,10 @@ class OneShotAllReduce:
 
     _DT = {torch.float32: 0, torch.bfloat16: 1, torch.int32: 2}
 
-    def __init__(self, group=None, max_bytes: int = 1 << 20, device=None, backend: str = "hip"):
+    def __init__(self, group=None, max_bytes: int = 1 << 20, device=None, backend: str = "hip", force_coarse_grained: bool = False):
         self.group = dist.group.WORLD if group is None else group
+        self._force_coarse = force_coarse_grained  # tests: the round-3 allocation path (torch allocator + storage sharing)
+        self.memory = None
         self.max_bytes = (max_bytes + 15) // 16 * 16
         self.ok = False
         self.why = None
@@ -73,51 +79,69 @@ class OneShotAllReduce:
     def _setup_hip(self, device):
         import ctypes
 
-        from . import _lib
+        from . import _lib, peer_mem
 
         lib = _lib.lib()
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         if world > 8:
             raise RuntimeError("the one-shot kernel handles at most 8 ranks (one xGMI-connected node)")
-        # own buffers: fresh allocations (zero-filled flags), exported whole
-        self._staging = torch.zeros(2 * self.max_bytes, dtype=torch.uint8, device=device)
-        self._flags = torch.zeros(lib.ao_allreduce_flag_bytes(), dtype=torch.uint8, device=device)
+        # own buffers: staging fine-grained, flags uncached (peer_mem.py says why), zero-filled, exported as raw IPC handles
+        own, ptrs, self._keep, self.memory = peer_mem.exchange(
+            [(2 * self.max_bytes, peer_mem.FINEGRAINED), (lib.ao_allreduce_flag_bytes(), peer_mem.UNCACHED)], self.group, device,
+            force_fallback=self._force_coarse)
+        self._staging, self._flags = own
         self._state = torch.zeros(lib.ao_allreduce_state_bytes() // 4, dtype=torch.int32, device=device)
+        self._scratch = torch.empty(self.max_bytes, dtype=torch.uint8, device=device)  # contiguous, 16-byte aligned stand-in
         torch.cuda.synchronize(device)
-        mine = (self._staging.untyped_storage()._share_cuda_(), self._flags.untyped_storage()._share_cuda_())
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine, group=self.group)
-        self._peer_tensors = []  # keeps the mapped storages alive
-        data_ptrs, flag_ptrs = [], []
-        for r in range(world):
-            if r == rank:
-                data_ptrs.append(self._staging.data_ptr())
-                flag_ptrs.append(self._flags.data_ptr())
-                continue
-            st_h, fl_h = gathered[r]
-            st = torch.UntypedStorage._new_shared_cuda(*st_h)
-            fl = torch.UntypedStorage._new_shared_cuda(*fl_h)
-            self._peer_tensors.append((st, fl))
-            # _share_cuda_ returns (device, handle, size_bytes, offset_bytes, ...): the storage it rebuilds starts at the tensor's data
-            data_ptrs.append(st.data_ptr())
-            flag_ptrs.append(fl.data_ptr())
-        self._data_arr = (ctypes.c_void_p * world)(*data_ptrs)
-        self._flag_arr = (ctypes.c_void_p * world)(*flag_ptrs)
+        self._data_arr = (ctypes.c_void_p * world)(*ptrs[0])
+        self._flag_arr = (ctypes.c_void_p * world)(*ptrs[1])
         self._lib, self._check = lib, _lib.check
         self.rank, self.world = rank, world
         dist.barrier(group=self.group)  # everybody has mapped everybody before the first flag is raised
 
     def fits(self, t: torch.Tensor) -> bool:
-        if not (self.ok and t.is_cuda and t.is_contiguous()):
+        """Whether `t` goes through the one-shot kernel.  Decided from RANK-INVARIANT properties only (dtype, element count): a
+        layout or alignment that differs between ranks must never send one rank to RCCL while the others spin in the kernel --
+        non-contiguous or misaligned tensors are copied through a scratch buffer instead."""
+        if not (self.ok and t.is_cuda):
             return False
         nbytes = t.numel() * t.element_size()
-        if nbytes == 0 or nbytes > self.max_bytes or nbytes % 16 != 0 or t.data_ptr() % 16 != 0:
+        if nbytes == 0 or nbytes > self.max_bytes:
             return False
-        return t.dtype in (self._DT if self.backend == "hip" else (torch.bfloat16, torch.float32))
+        if self.backend == "hip":
+            return t.dtype in self._DT  # (any size: the last 16-byte unit is padded in the scratch buffer)
+        return nbytes % 16 == 0 and t.is_contiguous() and t.dtype in (torch.bfloat16, torch.float32)
 
     def timed_out(self) -> bool:
         """True if any call so far gave up waiting for a peer (host-synchronising read of the status word)."""
         return self.backend == "hip" and self.ok and bool(int(self._state[0].item()))
+
+    def check(self):
+        """Raise if a call gave up waiting for a peer -- its output was poisoned (NaN / INT_MIN), not summed.  Host-synchronising:
+        call it where the host waits for the device anyway (end of a step, before results leave the GPU)."""
+        if self.timed_out():
+            raise RuntimeError(f"one-shot all-reduce: a peer of rank {self.rank} did not arrive within {self._lib.ao_collective_timeout_ms()} ms "
+                               "(ao_collective_set_timeout_ms); the affected outputs were filled with NaN / INT_MIN")
+
+    def _run(self, t: torch.Tensor, op: int) -> torch.Tensor:
+        self.calls += 1
+        nbytes = t.numel() * t.element_size()
+        direct = t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes % 16 == 0
+        if direct:
+            buf, count = t, t.numel()
+        else:  # pad to 16 bytes with zeros (SUM: neutral; MAX: the padding is never copied back)
+            padded = (nbytes + 15) // 16 * 16
+            raw = self._scratch[:padded]
+            raw[nbytes:].zero_()
+            buf = raw[:nbytes].view(t.dtype)
+            buf.copy_(t.reshape(-1))
+            count = padded // t.element_size()
+        self._check(self._lib.ao_allreduce_oneshot_op(self._data_arr, self._flag_arr, buf.data_ptr(), buf.data_ptr(), self._state.data_ptr(),
+                                                      count, self._DT[t.dtype], op, self.max_bytes, self.rank, self.world,
+                                                      torch.cuda.current_stream(t.device).cuda_stream))
+        if not direct:
+            t.copy_(buf.view(t.shape) if t.is_contiguous() else buf.reshape(t.shape))
+        return t
 
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
         """In-place SUM over the group; returns t."""
@@ -125,15 +149,18 @@ class OneShotAllReduce:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             return t
         if self.backend == "hip":
-            self.calls += 1
-            self._check(self._lib.ao_allreduce_oneshot(self._data_arr, self._flag_arr, t.data_ptr(), t.data_ptr(), self._state.data_ptr(),
-                                                       t.numel(), self._DT[t.dtype], self.max_bytes, self.rank, self.world,
-                                                       torch.cuda.current_stream(t.device).cuda_stream))
-            return t
+            return self._run(t, 0)
         nbytes = t.numel() * t.element_size()
         stage = self.buf[:nbytes].view(t.dtype).view(t.shape)
         stage.copy_(t)
         t.copy_(torch.ops.symm_mem.one_shot_all_reduce(stage, "sum", self.group_name))
+        return t
+
+    def max_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place elementwise MAX over the group (the row-amax exchange of the exact row-parallel protocol: [M] fp32)."""
+        if self.backend == "hip" and self.fits(t):
+            return self._run(t, 1)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
 
@@ -230,8 +257,11 @@ class RowParallelLinear(nn.Module):
     tensors) all-reduces the bf16 partial of F.linear."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], group=None, input_is_parallel: bool = True,
-                 reduce: str = "exact", blocks=None, one_shot: Optional["OneShotAllReduce"] = None):
+                 reduce: str = "exact", blocks=None, one_shot: Optional["OneShotAllReduce"] = None, scatter_min_rows: int = 128):
         super().__init__()
+        # exact protocol at M >= scatter_min_rows (and M % world == 0): reduce-scatter -> epilogue on M / world rows -> all-gather
+        self.scatter_min_rows = scatter_min_rows
+        self._native_rs = dist.get_backend(group) != "gloo"
         if reduce not in ("exact", "bf16"):
             raise ValueError(f"reduce must be 'exact' or 'bf16', got {reduce!r}")
         self.group = group
@@ -276,16 +306,51 @@ class RowParallelLinear(nn.Module):
             x2 = (x2 * pre).to(torch.bfloat16)
         if self.input_is_parallel:
             amax = self.blocks.amax(x2)                       # over this rank's K shard
-            dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)  # [M] fp32: the full-K amax
+            if self.one_shot is not None:                     # [M] fp32: the full-K amax, one launch over the peers' buffers
+                self.one_shot.max_(amax)
+            else:
+                dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.group)
             x_sh = x2
         else:
             amax = self.blocks.amax(x2)                       # x is replicated: the full-K amax is local
             x_sh = x2[:, k0:k1]
         xq, xs = self.blocks.quantize(self.kind, x_sh, amax)  # the shard of the unsharded qdata, the unsharded scale
         acc = self.blocks.partial_mm(self.kind, xq, w)        # int32 / fp32 [M, N], unscaled
-        self._sum(acc)
-        y = self.blocks.epilogue(self.kind, acc, xs, w, self.bias)
+        world = dist.get_world_size(self.group)
+        m = acc.shape[0]
+        if world > 1 and m >= self.scatter_min_rows and m % world == 0:
+            # large M: reduce-scatter the accumulator (each rank ends with the summed rows [r M / W, (r + 1) M / W)), run the scale
+            # epilogue on that 1 / W of the rows only, all-gather the bf16 result.  Against all-reduce + full epilogue: the exchange
+            # moves (W - 1) / W x M x N x (4 + 2) bytes per rank instead of (W - 1) / W x M x N x 8 (-25 %), the epilogue pass is W times
+            # smaller, and the sums are the same sums (int32 exact; fp32 in whatever order the collective adds, as before).
+            rows = m // world
+            r0 = dist.get_rank(self.group) * rows
+            part = self._reduce_scatter(acc, rows, r0)
+            y_part = self.blocks.epilogue(self.kind, part, xs[r0 : r0 + rows], w, self.bias)
+            y = self._all_gather(y_part.contiguous(), m)
+        else:
+            self._sum(acc)
+            y = self.blocks.epilogue(self.kind, acc, xs, w, self.bias)
         return y.reshape(*x.shape[:-1], y.shape[-1]).to(out_dtype)
+
+    def _reduce_scatter(self, acc, rows, r0):
+        """SUM over the group of `acc` [M, N], this rank's row block [r0, r0 + rows) returned.  RCCL: reduce_scatter_tensor (two-shot
+        over all xGMI links for large buffers); gloo has no reduce-scatter: all-reduce + slice (CPU tests)."""
+        acc = acc.contiguous()
+        if self._native_rs:
+            part = torch.empty((rows, acc.shape[1]), dtype=acc.dtype, device=acc.device)
+            dist.reduce_scatter_tensor(part, acc, op=dist.ReduceOp.SUM, group=self.group)
+            return part
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+        return acc[r0 : r0 + rows]
+
+    def _all_gather(self, y_part, m):
+        y = torch.empty((m, y_part.shape[1]), dtype=y_part.dtype, device=y_part.device)
+        if not self._native_rs:  # gloo knows neither bf16 nor 16-bit integers: move the bytes
+            dist.all_gather_into_tensor(y.view(torch.uint8), y_part.view(torch.uint8), group=self.group)
+        else:
+            dist.all_gather_into_tensor(y, y_part, group=self.group)
+        return y
 
     def forward(self, x):
         if self.exact:

@@ -149,8 +149,9 @@ def exchange_split_sizes(num_tokens_per_expert: torch.Tensor, group=None) -> Tup
 class OnDeviceAllToAllV:
     """All-to-all-v of MXFP8 token rows with the split sizes ON THE DEVICE (reference MXFP8OnDeviceAllToAllV / _mxfp8_on_device_all_to_all_v,
     kernels/mxfp8/comms.py:25-167, 271-316).  One instance per (group, D, max rows): it owns this rank's staging buffers -- e4m3 rows,
-    E8M0 scale rows, the int64 split vector -- and a flag block, all exported to the peers as IPC handles once (torch's CUDA-IPC storage
-    sharing over the process group; HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack), like the reference's symmetric-memory buffers.
+    E8M0 scale rows, the int64 split vector -- and a flag block, allocated through the C ABI as fine-grained / uncached device memory and
+    exported to the peers as raw IPC handles once (ao_amd/peer_mem.py; HSA_ENABLE_IPC_MODE_LEGACY=0 on this stack), like the reference's
+    symmetric-memory buffers.
     `__call__` stages the inputs and launches `ao_moe_a2a_v`: no host synchronisation, capturable into a hipGraph.
     `ok` False / `why`: the set-up failed (callers fall back to `a2a_dispatch_mxfp8_fwd` over RCCL)."""
 
@@ -170,27 +171,18 @@ class OnDeviceAllToAllV:
             world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
             if world > 8:
                 raise RuntimeError("the on-device all-to-all handles at most 8 ranks (one xGMI-connected node)")
-            self._data = torch.zeros((self.max_rows, dim), dtype=torch.uint8, device=device)
-            self._scales = torch.zeros((self.max_rows, dim // BLOCK), dtype=torch.uint8, device=device)
-            self._splits = torch.zeros(world, dtype=torch.int64, device=device)
-            self._flags = torch.zeros(lib.ao_moe_a2a_flag_bytes(), dtype=torch.uint8, device=device)
+            from .. import peer_mem
+
+            # staging (rows, scale rows, the split vector: read by the peers) fine-grained, the flag block uncached -- peer_mem.py
+            own, ptrs, self._keep, self.memory = peer_mem.exchange(
+                [(self.max_rows * dim, peer_mem.FINEGRAINED), (self.max_rows * (dim // BLOCK), peer_mem.FINEGRAINED),
+                 (8 * world, peer_mem.FINEGRAINED), (lib.ao_moe_a2a_flag_bytes(), peer_mem.UNCACHED)], self.group, device)
+            self._data = own[0].view(self.max_rows, dim)
+            self._scales = own[1].view(self.max_rows, dim // BLOCK)
+            self._splits = own[2].view(torch.int64)
+            self._flags = own[3]
             self._state = torch.zeros(lib.ao_moe_a2a_state_bytes() // 4, dtype=torch.int32, device=device)
             torch.cuda.synchronize(device)
-            own = (self._data, self._scales, self._splits, self._flags)
-            mine = tuple(t.untyped_storage()._share_cuda_() for t in own)
-            gathered = [None] * world
-            dist.all_gather_object(gathered, mine, group=self.group)
-            self._keep = []  # the mapped peer storages
-            ptrs = [[], [], [], []]
-            for r in range(world):
-                if r == rank:
-                    for i, t in enumerate(own):
-                        ptrs[i].append(t.data_ptr())
-                    continue
-                for i, h in enumerate(gathered[r]):
-                    st = torch.UntypedStorage._new_shared_cuda(*h)
-                    self._keep.append(st)
-                    ptrs[i].append(st.data_ptr())
             self._arrs = [(ctypes.c_void_p * world)(*p) for p in ptrs]
             self._lib, self._check = lib, _lib.check
             self.rank, self.world = rank, world
@@ -200,8 +192,17 @@ class OnDeviceAllToAllV:
             self.why = f"{type(e).__name__}: {e}"
 
     def status(self) -> int:
-        """bit 0: a peer did not arrive within the spin bound; bit 1: more rows arrived than max_rows (host-synchronising read)."""
+        """bit 0: a peer did not arrive within the collective timeout (its rows were not read); bit 1: more rows arrived than max_rows;
+        bit 2: a peer's split vector reached past its staged rows (host-synchronising read)."""
         return int(self._state[0].item())
+
+    def check(self):
+        """Raise on any status bit -- call it where the host synchronises anyway."""
+        st = self.status()
+        if st:
+            why = [m for b, m in ((1, "a peer did not arrive within the collective timeout"), (2, f"more than max_rows = {self.max_rows} rows arrived"),
+                                  (4, "a peer's input_splits reach past its staged rows")) if st & b]
+            raise RuntimeError("on-device all-to-all-v: " + "; ".join(why))
 
     def __call__(self, data: torch.Tensor, scales: torch.Tensor, input_splits: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """data e4m3 / uint8 [T, D] ordered by destination rank, scales e8m0 / uint8 [T, D / 32], input_splits int64 [world] ON THE DEVICE
@@ -218,7 +219,7 @@ class OnDeviceAllToAllV:
         out_s = torch.empty((self.max_rows, self.dim // BLOCK), dtype=torch.uint8, device=self.device)
         out_splits = torch.empty(self.world, dtype=torch.int64, device=self.device)
         self._check(self._lib.ao_moe_a2a_v(*self._arrs, out.data_ptr(), out_s.data_ptr(), out_splits.data_ptr(), self._state.data_ptr(),
-                                          self.dim, self.dim // BLOCK, self.max_rows, self.rank, self.world,
+                                          self.dim, self.dim // BLOCK, self.max_rows, self.max_rows, self.rank, self.world,
                                           torch.cuda.current_stream(self.device).cuda_stream))
         return out, out_s, out_splits
 
@@ -245,4 +246,6 @@ def mxfp8_on_device_all_to_all_v(input: torch.Tensor, input_splits: torch.Tensor
     from .mx import mx_dequantize
 
     hp = mx_dequantize(out_s.view(torch.float8_e8m0fnu), out.view(torch.float8_e4m3fn), input.dtype)
-    return hp[: int(output_splits.sum().item())], output_splits
+    rows = int(output_splits.sum().item())  # the reference's one host sync (:164-166); the status word is read behind it
+    ex.check()
+    return hp[:rows], output_splits

@@ -137,10 +137,14 @@ class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
 
 @dataclass
 class Float8DynamicActivationInt4WeightConfig(AOBaseConfig):
-    """float8 e4m3 rowwise dynamic activation x int4 groupwise (symmetric) weight, PLAIN packing (reference
-    quant_api.py:630-699: group_size 128, Int4Tensor with activation_dtype float8_e4m3fn)."""
+    """float8 e4m3 rowwise dynamic activation x int4 groupwise (symmetric) weight (reference quant_api.py:630-699: group_size 128).
 
-    int4_packing_format: Int4PackingFormat = Int4PackingFormat.PLAIN
+    `int4_packing_format`: "preshuffled" (the reference's default, :646) or "plain".  The reference's preshuffled tensor is the same
+    quantization in a layout pre-arranged for its H100 kernel; the MI355X counterpart of that is the PLAIN `Int4Tensor` carrying its
+    gfx950 compute layout (tile-packed codes + stacked scale / zero, built once at from_hp) -- both values produce it, so the
+    reference's default config runs unchanged.  The checkpoint-format nibbles stay available (`release_plain_()` drops them)."""
+
+    int4_packing_format: Int4PackingFormat = Int4PackingFormat.PRESHUFFLED
     group_size: int = 128
 
     def __post_init__(self):

@@ -19,6 +19,15 @@ from .granularity import Granularity, PerRow, PerTensor
 __all__ = ["Float8Tensor", "QuantizeTensorToFloat8Kwargs"]
 
 
+def _require_bf16_activation(x, what):
+    """The reference quantizes the activation in ITS dtype (fp16 scales are upcast on purpose, int8_tensor.py:311-317); the MI355X
+    casts take bfloat16 only, and a silent .to(bfloat16) would round fp16 / fp32 activations before the scale is taken -- not the
+    reference's arithmetic.  Refuse instead of approximating."""
+    if x.dtype != torch.bfloat16:
+        raise NotImplementedError(f"{what} on MI355X takes bfloat16 activations, got {x.dtype}: cast the activation explicitly "
+                                  "(x.to(torch.bfloat16)) if that rounding is acceptable")
+
+
 @dataclass
 class QuantizeTensorToFloat8Kwargs:
     """reference float8_tensor.py:50-81 (PerRow / PerTensor, e4m3fn)"""
@@ -102,10 +111,74 @@ implements_torch_function = Float8Tensor.implements_torch_function
 @implements(aten.linear.default)
 @implements_torch_function(F.linear)
 def _(func, types, args, kwargs):
+    return _float8_linear(args[0], args[1], args[2] if len(args) > 2 else kwargs.get("bias", None))
+
+
+def _as_weight(w_t):
+    """mm / matmul / addmm_ receive the weight as the reference's callers pass it: the TRANSPOSED view [K, N] of a Float8Tensor
+    quantized along K (`weight.t()`); the kernels want [N, K] K-contiguous, which is that view transposed back (no copy)."""
+    assert isinstance(w_t, Float8Tensor) and w_t.qdata.dim() == 2, "expected a 2-D Float8Tensor operand"
+    assert w_t.qdata.stride(0) == 1 or w_t.qdata.shape[0] == 1 or w_t.qdata.shape[1] == 1, (
+        "Float8Tensor mm on MI355X takes the transposed view of an [N, K] weight (K-contiguous), as _float8_addmm_impl's callers pass it")
+    return w_t.transpose(0, 1)
+
+
+@implements(aten.t.default)
+def _(func, types, args, kwargs):
+    """reference :863-885 (aten.t): transpose(0, 1) of a 2-D tensor"""
+    self = args[0]
+    assert self.qdata.dim() == 2
+    bs = list(self.block_size)
+    return Float8Tensor(self.qdata.t(), self.scale.t(), [bs[1], bs[0]], self.dtype_, self.act_quant_kwargs, self.act_pre_scale)
+
+
+@implements(aten.mm.default)
+@implements_torch_function(torch.mm)
+def _(func, types, args, kwargs):
+    """reference :296-300: _float8_addmm_impl(input, weight_t)"""
+    return _float8_linear(args[0], _as_weight(args[1]), None)
+
+
+@implements(aten.matmul.default)
+@implements_torch_function(torch.matmul)
+def _(func, types, args, kwargs):
+    """reference :289-293"""
+    return _float8_linear(args[0], _as_weight(args[1]), None)
+
+
+@implements(aten.addmm_.default)
+def _(func, types, args, kwargs):
+    """reference :303-314: bias.add_(input @ weight_t), alpha = beta = 1 only"""
+    bias_tensor, x, w_t = args[0], args[1], args[2]
+    assert kwargs.get("alpha", 1) == 1, "only alpha=1 is supported"
+    assert kwargs.get("beta", 1) == 1, "only beta=1 is supported"
+    return bias_tensor.add_(_float8_linear(x, _as_weight(w_t), None))
+
+
+@implements(aten.cat.default)
+def _(func, types, args, kwargs):
+    """reference :790-846 (merged-weight loaders: q / k / v or gate / up quantized separately, concatenated along N): along a
+    dimension whose block size is 1 the scales are concatenated too, along a blocked dimension they must be equal."""
+    tensors = args[0]
+    dim = (args[1] if len(args) > 1 else kwargs.get("dim", 0)) % tensors[0].dim()
+    t0 = tensors[0]
+    for t in tensors[1:]:
+        assert t0.qdata.dim() == t.qdata.dim() and t0.scale.dim() == t.scale.dim()
+        assert list(t0.block_size) == list(t.block_size) and t0.act_quant_kwargs == t.act_quant_kwargs
+    qdata = torch.cat([t.qdata for t in tensors], dim=dim)
+    if t0.block_size[dim] == 1:
+        scale = torch.cat([t.scale for t in tensors], dim=dim)
+    else:
+        for t in tensors[1:]:
+            assert torch.equal(t0.scale, t.scale)
+        scale = t0.scale
+    block_size = [qdata.shape[i] // scale.shape[i] for i in range(qdata.dim())]
+    return Float8Tensor(qdata, scale, block_size, t0.dtype_, t0.act_quant_kwargs, t0.act_pre_scale)
+
+
+def _float8_linear(x, w, bias):
     """reference :278-469 -> preprocess_data / preprocess_scale -> _scaled_mm(A row-major,
     B = W.t() column-major, scale_a [M,1], scale_b [1,N], bias, out_dtype, use_fast_accum)."""
-    x, w = args[0], args[1]
-    bias = args[2] if len(args) > 2 else kwargs.get("bias", None)
     assert isinstance(w, Float8Tensor), f"Expected weight to be Float8Tensor, got {type(w)}"
     out_dtype = x.dtype
     if w.act_pre_scale is not None:
@@ -116,7 +189,8 @@ def _(func, types, args, kwargs):
             "use Float8DynamicActivationFloat8WeightConfig"
         )
     _check(w.act_quant_kwargs.granularity, w.act_quant_kwargs.float8_dtype)
-    x2 = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
+    _require_bf16_activation(x, "Float8Tensor dynamic-activation linear")
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
     n = w.qdata.shape[0]
     w_tensorwise = w.scale.numel() == 1
     if isinstance(w.act_quant_kwargs.granularity, PerTensor) != w_tensorwise:
@@ -194,7 +268,8 @@ def _(func, types, args, kwargs):
     if not isinstance(mat_b.act_quant_kwargs.granularity, PerRow) or ws.shape[-2] != wq.shape[-2]:
         raise NotImplementedError("Float8Tensor _grouped_mm implements PerRow activations and PerRow weight scales only "
                                   f"(got activations {mat_b.act_quant_kwargs.granularity}, weight scale {tuple(mat_b.scale.shape)})")
-    aq, a_s = ops.fp8_quantize_rowwise(mat_a.to(torch.bfloat16).contiguous())
+    _require_bf16_activation(mat_a, "Float8Tensor _grouped_mm")
+    aq, a_s = ops.fp8_quantize_rowwise(mat_a.contiguous())
     return ops.fp8_grouped_mm(aq, a_s, wq, ws, offs.to(torch.int32)).to(output_dtype)
 
 

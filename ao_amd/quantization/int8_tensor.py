@@ -20,6 +20,15 @@ from .quant_primitives import MappingType
 __all__ = ["Int8Tensor", "QuantizeTensorToInt8Kwargs"]
 
 
+def _require_bf16_activation(x, what):
+    """The reference quantizes the activation in ITS dtype (fp16 scales are upcast on purpose, int8_tensor.py:311-317); the MI355X
+    casts take bfloat16 only, and a silent .to(bfloat16) would round fp16 / fp32 activations before the scale is taken -- not the
+    reference's arithmetic.  Refuse instead of approximating."""
+    if x.dtype != torch.bfloat16:
+        raise NotImplementedError(f"{what} on MI355X takes bfloat16 activations, got {x.dtype}: cast the activation explicitly "
+                                  "(x.to(torch.bfloat16)) if that rounding is acceptable")
+
+
 @dataclass
 class QuantizeTensorToInt8Kwargs:
     """reference int8_tensor.py:41-56"""
@@ -161,7 +170,8 @@ def _(func, types, args, kwargs):
     if w.zero_point is not None:
         raise NotImplementedError("Int8Tensor linear on MI355X takes symmetric weights (asymmetric is an ACTIVATION option in the reference)")
     assert w.qdata.dim() == 2, "F.linear takes a 2-D weight: select an expert of a 3-D weight first (weight[e])"
-    x2 = x.reshape(-1, x.shape[-1]).to(torch.bfloat16).contiguous()
+    _require_bf16_activation(x, "Int8Tensor dynamic-activation linear")
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
     n = w.qdata.shape[0]
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))

@@ -203,16 +203,18 @@ def _int4_weight_only_transform(module, config, *, parameter_name="weight"):
 
 @register_quantize_module_handler(Float8DynamicActivationInt4WeightConfig)
 def _float8_dynamic_activation_int4_weight_transform(module, config, *, parameter_name="weight"):
-    """reference quant_api.py:660-699: Int4Tensor (PLAIN) with activation_dtype float8_e4m3fn; shapes whose K is not a multiple
-    of the group size are left unquantized."""
+    """reference quant_api.py:660-699: Int4Tensor with activation_dtype float8_e4m3fn; shapes whose K is not a multiple of the
+    group size are left unquantized.  "preshuffled" (the reference's default) and "plain" both give the Int4Tensor that carries its
+    gfx950 compute layout -- the MI355X counterpart of the reference's H100-preshuffled tensor (config.py)."""
     from .int4_plain_tensor import Int4Tensor
 
     assert hasattr(module, parameter_name), (
         f"applying float8 dynamic activation int4 weight quant requires module to have {parameter_name} attribute"
     )
     weight = getattr(module, parameter_name)
-    assert config.int4_packing_format == Int4PackingFormat.PLAIN, (
-        f"only the plain packing format is implemented on MI355X for this config, got {config.int4_packing_format}"
+    # reference :660-669: "only preshuffled and plain int4_packing_format supported right now"
+    assert config.int4_packing_format in (Int4PackingFormat.PRESHUFFLED, Int4PackingFormat.PLAIN), (
+        f"only preshuffled and plain int4_packing_format supported right now, got: {config.int4_packing_format}"
     )
     if weight.shape[-1] % config.group_size != 0:
         logger.info(f"Skipping quantizing weight of shape {weight.shape}: not compatible with group_size {config.group_size}")

@@ -654,10 +654,25 @@ def config_mx(stream, device, args):
         for name, n, k, wq, wsc in wts:
             aq, asc = ops.mxfp8_quantize(xs[k], "rceil")  # activations: dynamic cast every forward
             ops.mxfp8_grouped_mm(aq, asc, wq, wsc, offs)
+    # SURVEY 8(d)'s second workload: 16 tokens on EVERY expert, each group padded to the 32-row alignment of the grouped GEMM
+    # (fused_pad_token_groups semantics: 8 x 32 = 256 rows, half of them zero padding) -- all 8 experts' weights are read: 484 MB per w1
+    rows_u = 32 * E
+    offs_u = torch.arange(1, E + 1, device=device, dtype=torch.int32) * 32
+    xs_u = {}
+    for k in (4096, 14336):
+        t = torch.zeros(rows_u, k, device=device, dtype=torch.bfloat16)
+        t.view(E, 32, k)[:, :16] = torch.randn(E, 16, k, device=device, dtype=torch.bfloat16, generator=gen)
+        xs_u[k] = t
+    def step_u():
+        for name, n, k, wq, wsc in wts:
+            aq, asc = ops.mxfp8_quantize(xs_u[k], "rceil")
+            ops.mxfp8_grouped_mm(aq, asc, wq, wsc, offs_u)
     with torch.cuda.stream(stream):
         t, graphed = _graph_time(step, stream, device, steps=5)
+        tu, _ = _graph_time(step_u, stream, device, steps=5)
     used = int((sizes > 0).sum())
     bts = sum(used * n * k * (1 + 1 / 32) + rows * k * 2 + rows * k * (1 + 1 / 32) + rows * n * 2 for _, n, k, _, _ in wts)
+    bts_u = sum(E * n * k * (1 + 1 / 32) + rows_u * k * 2 + rows_u * k * (1 + 1 / 32) + rows_u * n * 2 for _, n, k, _, _ in wts)
     flops = sum(2.0 * rows * n * k for _, n, k, _, _ in wts)
     out = {"workload": f"MXFP8 grouped GEMM (to_mx RCEIL + scaled grouped mm), Mixtral-8x7B expert shapes E=8 (w1, w3 14336x4096; w2 4096x14336), "
                        f"64 tokens x top-2 = 128 rows, group sizes {sizes.tolist()} (32 x multinomial, seed 0), 32 layers",
@@ -666,7 +681,12 @@ def config_mx(stream, device, args):
            "roofline": {"kernel": "mx_stream_kernel<8, 3, 4> (stream-K, decode-size groups)", "bound": "hbm", "achieved": bts / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bts / t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_of("mx")[0], "traffic_source": pmc_traffic_of("mx")[1],
                         "timing": "hipGraph replay wall time of the whole step (activation casts included)",
-                        "bytes_note": "weights of the experts that received tokens only", "TFLOPs": flops / t / 1e12}}
+                        "bytes_note": "weights of the experts that received tokens only", "TFLOPs": flops / t / 1e12},
+           "uniform16": {"workload": "the same 96 grouped GEMMs with 16 tokens on each of the 8 experts, groups padded to 32 rows (256 rows, offs = 32, 64, .. 256): "
+                                     "every expert's weights are read (SURVEY.md 8(d): 484.4 MB per w1)",
+                         "value": 64 / tu, "unit": "tokens/s", "ms_per_step": tu * 1e3,
+                         "roofline": {"bound": "hbm", "achieved": bts_u / tu / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bts_u / tu / 1e9 / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_step": bts_u, "timing": "hipGraph replay wall time of the whole step (activation casts included)"}}}
     if not args.no_cpu_baseline:
         from oracle import c_ref
         rng = np.random.default_rng(3)
@@ -850,7 +870,7 @@ def main():
 
     # the other module layout, for the record (rank 0 of a 1-GPU run only: it doubles resident weights); then both layouts
     # replayed alternately (median / best / worst of 5 rounds), the subclass + F.linear path (a13) and the same-box stack baseline
-    other_tok_s, stats, subclass, stack = None, None, None, None
+    other_tok_s, stats, subclass, stack, merged_cfg = None, None, None, None, None
     if rank == 0 and world == 1 and not args.no_second_layout:
         m2 = Int4Linears(device, args.layers, LLAMA3_8B_UNMERGED if merged else LLAMA3_8B_MERGED)
         steps2 = min(args.steps, 20)
@@ -859,6 +879,19 @@ def main():
         if not args.no_graph:
             names = ("merged", "five") if merged else ("five", "merged")
             stats = replay_stats({names[0]: model, names[1]: m2}, args.batch, stream, device)
+        if not merged and args.batch == 1:
+            # the vLLM module layout (gate and up as ONE 28672 x 4096 linear: 128 launches per token) as a config of its own, with its own
+            # roofline -- the in-contract way to spend fewer launches on the same weights
+            try:
+                roof2 = int4_roofline(m2, args.batch, stream)
+                b2 = m2.bytes_per_step(args.batch)
+                merged_cfg = {"workload": "Int4WeightOnlyConfig(group_size=128) Llama-3-8B linears in the vLLM module layout (qkv_proj 6144x4096, o_proj, "
+                                          "gate_up_proj 28672x4096, down_proj), bs=1 seq=1, 32 layers, 128 launches per token",
+                              "value": other_tok_s, "unit": "tokens/s", "ms_per_step": 1e3 / other_tok_s, "dtype": "bf16 x int4 (dequant bf16, fp32 accumulate)",
+                              "launch": "hipGraph replay" if not args.no_graph else "eager", "bytes_per_token": b2,
+                              "frac_of_hbm_roofline_end_to_end": other_tok_s * b2 / (HBM_PEAK_GBS * 1e9), "roofline": roof2}
+            except Exception as e:  # noqa: BLE001
+                merged_cfg = {"error": repr(e)}
         del m2
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.batch == 1 and not args.no_graph:
@@ -871,6 +904,8 @@ def main():
             stack = stack_baseline(model, stream, device, args)
 
     configs = {}
+    if merged_cfg is not None:
+        configs["int4_bs1_merged"] = merged_cfg
     want = set() if args.no_configs else set(args.configs.split(","))
     if rank == 0 and world == 1 and args.batch == 1:
         for key, fn in (("int4_bs128", lambda: config_int4_bs128(model, stream, device, args)),
@@ -940,6 +975,10 @@ def main():
                 out["cpu_baseline"]["reference_reachable"] = False
                 if ref is not None:
                     out["cpu_baseline"]["reference_error"] = ref.get("error")
+        if "int4_bs1_merged" in configs and "cpu_baseline" in out and "value" in configs["int4_bs1_merged"]:
+            cb = dict(out["cpu_baseline"])
+            cb["sample"] = "the headline's CPU measurement (the same 218.1M weights per layer; only the module boundaries differ): " + str(cb.get("sample"))
+            configs["int4_bs1_merged"]["cpu_baseline"] = cb
         if configs:
             out["configs"] = configs
         # the driver's parser keeps top-level scalars only: every config's value / fraction again as flat keys
@@ -952,6 +991,8 @@ def main():
         if stack and "int4_bs1" in stack:
             flat["stack_int4_bs1_tokens_per_s"] = stack["int4_bs1"].get("tokens_per_s")
         c = configs
+        if "int4_bs1_merged" in c and "value" in c["int4_bs1_merged"]:
+            flat["int4_bs1_merged_frac_of_hbm_roofline"] = c["int4_bs1_merged"]["frac_of_hbm_roofline_end_to_end"]
         if "int4_bs128" in c and "value" in c["int4_bs128"]:
             flat["int4_bs128_tokens_per_s"] = c["int4_bs128"]["value"]
             flat["int4_bs128_frac_of_bf16_mfma_peak"] = c["int4_bs128"]["roofline"]["frac"]
@@ -966,6 +1007,9 @@ def main():
         if "mxfp8_mixtral_bs64" in c and "value" in c["mxfp8_mixtral_bs64"]:
             flat["mxfp8_mixtral_tokens_per_s"] = c["mxfp8_mixtral_bs64"]["value"]
             flat["mxfp8_mixtral_frac_of_hbm_peak"] = c["mxfp8_mixtral_bs64"]["roofline"]["frac"]
+            if "uniform16" in c["mxfp8_mixtral_bs64"]:
+                flat["mxfp8_mixtral_uniform16_tokens_per_s"] = c["mxfp8_mixtral_bs64"]["uniform16"]["value"]
+                flat["mxfp8_mixtral_uniform16_frac_of_hbm_peak"] = c["mxfp8_mixtral_bs64"]["uniform16"]["roofline"]["frac"]
         if "fp8_tp" in c and "by_M" in c["fp8_tp"]:
             for mk, r in c["fp8_tp"]["by_M"].items():
                 flat[f"fp8_tp_{mk}_tokens_per_s"] = r["tokens_per_s"]

@@ -112,8 +112,10 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
                               int group_size, void* stream);
 
 /* Launch-shape override for tuning sweeps (bench/tools only): waves per
- * workgroup (0 = heuristic) and a profiling mode (0 = product kernel; 1/2 =
- * ablation builds, 12/18 = prefetch depth 2/8) of the int4 mm. */
+ * workgroup (0 = heuristic) and an A/B mode of the int4 mm (0 = product dispatch).  Every mode this library honours computes the
+ * SAME result as the product (other ring depths, tile shapes, K splits, trace stamps); the ablation builds that drop parts of the
+ * kernel -- and so return wrong numbers -- exist only in the laboratory build (`python -m ao_amd.build --lab` ->
+ * tools/bin/_C_mi355_lab.so, compiled with -DAO_LAB; tools select it through AO_MI355_LIB).  Thread-local. */
 int ao_int4_set_tuning(int waves_per_block, int mode);
 /* Profiling only: 0 = product dispatch of the 8-bit GEMMs (LDS-DMA staged kernel when K % 128 == 0),
  * 1 = force the register-staged kernel, 2 / 4 / 8 = force the LDS-DMA kernel with 128x128, 256x128 (4 waves), 256x256 (8 waves) tiles,

@@ -183,8 +183,61 @@ def test_decode_kernel_every_form(kind, m, n, k, bias):
     assert ran == 8
 
 
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+@pytest.mark.parametrize("m,n,k,bias", [(128, 1280, 8192, False), (128, 8192, 1024, True), (17, 64, 512, True), (33, 200 * 16, 2048, False), (64, 7168, 4096, True),
+                                        (100, 48, 3584, True), (256, 512, 1536, False), (129, 4096, 3584, False), (32, 16, 8192, True)])
+def test_mid_m_register_ring_kernel(kind, m, n, k, bias):
+    """Round 4: mid8_kernel (16 < M <= 256, few output tiles: weights through a register ring, two workgroups per CU, two-level K
+    meeting) -- the product dispatch, every forced number of K parts that divides the shape, and the round-3 kernels give the oracle's
+    result (int8: bit for bit, also between all forms; fp8 within 1e-3), and the FUSED form (the cast shared out among the workgroups of
+    the same launch) gives the bits of cast + matmul on the same kernel form."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    x = _randn_bf16((m, k), 41 * m + k)
+    x[0, :7] = torch.tensor([0.0, -0.0, 1e-30, 3.0e38, -3.0e38, 448.0, -57344.0]).to(torch.bfloat16)
+    w = _randn_bf16((n, k), 43 * n + k, 0.05)
+    b = _randn_bf16((n,), 5) if bias else None
+    bd = None if b is None else b.to(DEV)
+    xd = x.to(DEV)
+    bn = None if b is None else b.float().numpy()
+    if kind == "int8":
+        wq, ws = ops.int8_quantize_rowwise(w.to(DEV))
+        xq, xs = ops.int8_quantize_rowwise(xd)
+        y_ref = I.linear(x.float().numpy(), w.float().numpy(), bn)
+    else:
+        wq, ws = ops.fp8_quantize_rowwise(w.to(DEV))
+        xq, xs = ops.fp8_quantize_rowwise(xd)
+        y_ref = F.linear(x.float().numpy(), w.float().numpy(), bn)
+    groups = k // 512
+    variants = [0, 300, 301] + [310 + s for s in (1, 2, 4, 7, 8, 16) if groups % s == 0]
+    for variant in variants:
+        lib.ao_gemm8_set_variant(variant)
+        try:
+            fits = ops.dynamic_linear_fits(m, n, k)
+            if kind == "int8":
+                two = ops.int8_scaled_mm(xq, xs, wq, ws, bd)
+                one = ops.int8_dynamic_linear(xd, wq, ws, bd) if fits else two
+                again = ops.int8_dynamic_linear(xd, wq, ws, bd) if fits else two  # the ticket counters are back at zero
+            else:
+                two = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), bd)
+                one = ops.fp8_dynamic_linear(xd, wq, ws, bd) if fits else two
+                again = ops.fp8_dynamic_linear(xd, wq, ws, bd) if fits else two
+        finally:
+            lib.ao_gemm8_set_variant(0)
+        assert variant == 300 or fits, (variant, "mid8 should take this shape")
+        assert torch.equal(one, two) and torch.equal(again, two), (variant, "fused != two-launch")
+        if kind == "int8":
+            assert np.array_equal(np_from_torch_bf16(two), y_ref), variant
+        else:
+            got, want = two.float().cpu().numpy(), np.asarray(y_ref, dtype=np.float32)
+            ok = np.isfinite(want)
+            assert np.array_equal(np.isfinite(got), ok) and _rel(got[ok], want[ok]) <= 1e-3, variant
+
+
 def test_fused_dynamic_linear_shape_limits():
-    assert ops.dynamic_linear_fits(16, 64, 2048) and not ops.dynamic_linear_fits(17, 64, 2048)
+    assert ops.dynamic_linear_fits(16, 64, 2048) and ops.dynamic_linear_fits(17, 64, 2048) and not ops.dynamic_linear_fits(17, 64, 2176)
+    assert not ops.dynamic_linear_fits(257, 64, 2048)
     assert not ops.dynamic_linear_fits(8, 64, 14336) and not ops.dynamic_linear_fits(1, 40, 4096) and not ops.dynamic_linear_fits(1, 64, 4000)
     x = torch.zeros(8, 14336, dtype=torch.bfloat16, device=DEV)
     wq = torch.zeros(64, 14336, dtype=torch.int8, device=DEV)

@@ -14,7 +14,7 @@ def test_library_loads_and_exports_declared_symbols():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ao_mi355.h but not exported"
     assert set(_lib._SIGNATURES) | {"ao_last_error"} == set(names)
-    assert lib.ao_abi_version() == 1
+    assert lib.ao_abi_version() == 2
 
 
 def test_null_pointer_is_reported():

@@ -57,6 +57,11 @@ def test_hqq_only_with_tile_packed_and_plain_checks():
         Int4Tensor.from_hp(w, [1, 1])  # per-channel codes are not groupwise
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         quantize_(m, Float8DynamicActivationInt4WeightConfig())
+    # the reference's default packing for this config is "preshuffled" (quant_api.py:646); both accepted values reach the kernels,
+    # anything else fails with the reference's wording (:660-669)
+    assert Float8DynamicActivationInt4WeightConfig().int4_packing_format == "preshuffled"
+    with pytest.raises(AssertionError, match="only preshuffled and plain int4_packing_format supported right now"):
+        quantize_(m, Float8DynamicActivationInt4WeightConfig(int4_packing_format="tile_packed_to_4d"))
 
 
 def test_incompatible_group_size_is_skipped_silently():

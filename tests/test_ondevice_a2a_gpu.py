@@ -100,7 +100,8 @@ def _worker(rank, world, port, q):
         dim, tokens = 128, 40
         gens = [torch.Generator().manual_seed(500 + r) for r in range(world)]
         xs = [torch.randn(tokens, dim, generator=gg).to(torch.bfloat16) for gg in gens]
-        sps = [torch.tensor([tokens - 10 * (r + 1), 10 * (r + 1)], dtype=torch.int64) for r in range(world)]
+        sps = [torch.tensor([3 + ((r + j) % 4) for j in range(world)], dtype=torch.int64) for r in range(world)]
+        xs = [x[: int(sp.sum())] for x, sp in zip(xs, sps)]
         got, got_splits = ep.mxfp8_on_device_all_to_all_v(xs[rank].cuda(), sps[rank].cuda(), 256)
         from ao_amd import ops
         from ao_amd.prototype.mx import ScaleCalculationMode, mx_dequantize
@@ -111,6 +112,21 @@ def _worker(rank, world, port, q):
             deq.append(mx_dequantize(qs, qd, torch.bfloat16).float().cpu().numpy())
         want, want_splits = moe_ref.a2a_v(deq, [s.numpy() for s in sps], rank)
         out["api"] = bool(np.array_equal(got.float().cpu().numpy(), want) and np.array_equal(got_splits.cpu().numpy(), want_splits))
+        # a split vector whose prefix reaches past the sender's staged rows must be clamped and reported, never read
+        ex = ep.OnDeviceAllToAllV(64, 128)
+        assert ex.ok, ex.why
+        rows_d = torch.zeros((8, 128), dtype=torch.uint8, device="cuda")
+        sc_d = torch.zeros((8, 4), dtype=torch.uint8, device="cuda")
+        lie = torch.full((world,), 40, dtype=torch.int64, device="cuda")  # 40 rows "for every rank" out of 8 staged (capacity 64)
+        _, _, osp = ex(rows_d, sc_d, lie)
+        torch.cuda.synchronize()
+        st = ex.status()
+        out["overreach"] = (st, osp.cpu().tolist())
+        try:
+            ex.check()
+            out["overreach_raised"] = False
+        except RuntimeError:
+            out["overreach_raised"] = True
     except Exception as e:  # noqa: BLE001
         import traceback
 
@@ -120,18 +136,24 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_on_device_all_to_all_v_two_processes_one_gpu():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_on_device_all_to_all_v_processes_share_one_gpu(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = [q.get(timeout=300) for _ in range(world)]
+    outs = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
-        p.join(60)
+        p.join(120)
     for o in outs:
         assert "error" not in o, o
         assert all(ok for ok, _ in o["ok"]), f"set-up failed: {o['ok']}"
         assert all(s == 0 for s in o["status"]), f"a wait timed out or rows overflowed: {o['status']}"
         assert o["bad"] == [] and o["graph_bad"] == [] and o["api"], o
+        # the rows "for rank r" start at row 40 r of every sender: ranks >= 1 would read past the 64 staged rows -> bit 2 (value 4);
+        # 40 rows from each of `world` peers overflow the 64-row output from the second peer on -> bit 1 (value 2)
+        st, osp = o["overreach"]
+        assert (st & 4 if o["rank"] >= 1 else st & 2) and o["overreach_raised"], o["overreach"]
+        assert all(0 <= v <= 40 for v in osp) and sum(osp) <= 64, o["overreach"]

@@ -110,26 +110,29 @@ def _worker_8bit(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(11)
-        n, k, m = 32, 512, 5
+        n, k = 32, 512
         w = bf16.bf16_round((rng.standard_normal((n, k)) * 0.05).astype(np.float32))
-        x = bf16.bf16_round(rng.standard_normal((m, k)).astype(np.float32))
-        x[:, 300] *= 32.0  # the full-K amax sits in one rank's shard only (power of two: stays bf16)
         bias = bf16.bf16_round(rng.standard_normal(n).astype(np.float32))
-        xt, bt = torch.from_numpy(x).to(torch.bfloat16), torch.from_numpy(bias).to(torch.bfloat16)
+        bt = torch.from_numpy(bias).to(torch.bfloat16)
         out = []
-        for kind, ref, cls, kw in (("int8", int8_ref, Int8Tensor, QuantizeTensorToInt8Kwargs()),
-                                   ("fp8", fp8_ref, Float8Tensor, QuantizeTensorToFloat8Kwargs())):
-            wq, ws = ref.quantize_rowwise(w)
-            wt = cls(torch.from_numpy(wq), torch.from_numpy(np.ascontiguousarray(ws)).reshape(-1, 1), [1, k], torch.bfloat16,
-                     act_quant_kwargs=kw)
-            want = ref.linear(x, w, bias)
-            for parallel_in in (False, True):
-                row = RowParallelLinear(wt, bt, input_is_parallel=parallel_in, blocks=_OracleBlocks)
-                k0, k1 = row.cols
-                y = row(xt[:, k0:k1] if parallel_in else xt).float().numpy()
-                exact = bool(np.array_equal(y, want))
-                rel = float(np.linalg.norm(y - want) / np.linalg.norm(want))
-                out.append((kind, parallel_in, exact, rel))
+        # m = 5: all-reduce + one epilogue;  m = 6 with scatter_min_rows = 4: reduce-scatter -> epilogue on m / world rows -> all-gather
+        for m, scatter_min in ((5, 128), (6, 4)):
+            x = bf16.bf16_round(rng.standard_normal((m, k)).astype(np.float32))
+            x[:, 300] *= 32.0  # the full-K amax sits in one rank's shard only (power of two: stays bf16)
+            xt = torch.from_numpy(x).to(torch.bfloat16)
+            for kind, ref, cls, kw in (("int8", int8_ref, Int8Tensor, QuantizeTensorToInt8Kwargs()),
+                                       ("fp8", fp8_ref, Float8Tensor, QuantizeTensorToFloat8Kwargs())):
+                wq, ws = ref.quantize_rowwise(w)
+                wt = cls(torch.from_numpy(wq), torch.from_numpy(np.ascontiguousarray(ws)).reshape(-1, 1), [1, k], torch.bfloat16,
+                         act_quant_kwargs=kw)
+                want = ref.linear(x, w, bias)
+                for parallel_in in (False, True):
+                    row = RowParallelLinear(wt, bt, input_is_parallel=parallel_in, blocks=_OracleBlocks, scatter_min_rows=scatter_min)
+                    k0, k1 = row.cols
+                    y = row(xt[:, k0:k1] if parallel_in else xt).float().numpy()
+                    exact = bool(np.array_equal(y, want))
+                    rel = float(np.linalg.norm(y - want) / np.linalg.norm(want))
+                    out.append((kind, parallel_in, exact, rel))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
