@@ -84,6 +84,8 @@ _SIGNATURES = {
     "ao_collective_set_timeout_ms": [_INT],
     "ao_collective_timeout_ms": [],
     "ao_fp8_int4_linear": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
+    "ao_fp8_int4_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
+    "ao_fp8_int4_dynamic_fits": [_I64, _I64, _I64],
     "ao_moe_permute_indices": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_moe_gather_rows": [_P, _P, _P, _I64, _I64, _I64, _P],
     "ao_moe_scatter_rows": [_P, _P, _P, _I64, _I64, _I64, _P],

@@ -4,6 +4,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/ao_mi355.h"
 
 namespace ao {
@@ -89,6 +91,22 @@ __device__ __forceinline__ float round_bf16(float f) {
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(uint16_t, b);
+}
+
+// max over the 64 lanes without LDS traffic: DPP within rows of 16, then the four row results through SGPRs
+__device__ __forceinline__ float wave_max(float m) {
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x141>{}));  // row_half_mirror
+  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x140>{}));  // row_mirror
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
 }  // namespace ao

@@ -47,22 +47,6 @@ struct Dec8Args {
 // s_waitcnt vmcnt(0) -- it would drain the weight ring that is in flight across every barrier of this kernel
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// max over the 64 lanes without LDS traffic: DPP within rows of 16, then the four row results through SGPRs
-__device__ __forceinline__ float wave_max(float m) {
-  auto dpp = [](float v, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
-  };
-  m = fmaxf(m, dpp(m, std::integral_constant<int, 0xB1>{}));   // quad_perm [1,0,3,2]
-  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x4E>{}));   // quad_perm [2,3,0,1]
-  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x141>{}));  // row_half_mirror
-  m = fmaxf(m, dpp(m, std::integral_constant<int, 0x140>{}));  // row_mirror
-  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 0));
-  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 16));
-  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 32));
-  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 48));
-  return fmaxf(fmaxf(a, b), fmaxf(c, d));
-}
-
 constexpr int kSlabStride = 144;            // bytes between the 16 rows of a wave's transposition slab
 constexpr int kSlab = 16 * kSlabStride;     // 2304 B
 constexpr int kXV = 4;                      // 16-byte activation vectors a thread may hold while the ring is in flight

@@ -22,7 +22,7 @@ bool dec8_takes(int64_t M, int64_t N, int64_t K);
 int dec8_dynamic(bool int8, const uint16_t* x, const void* wq, const float* w_scale, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N,
                  int64_t K, hipStream_t stream);
 // mid8_kernels.hip (round 4): 16 < M <= 256 with few output tiles -- the per-row cast shared out among the workgroups of the same launch
-bool mid8_takes(int64_t M, int64_t N, int64_t K);
+bool mid8_takes_fused(int64_t M, int64_t N, int64_t K);
 int mid8_dynamic(bool int8, const uint16_t* x, const void* b, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
                  hipStream_t stream);
 namespace {
@@ -152,7 +152,7 @@ int launch_dyn8(const Dyn8Args& p, hipStream_t stream) {
 int check_dyn(const char* fn, int64_t M, int64_t N, int64_t K) {
   AO_REQUIRE(M >= 0 && N > 0 && K > 0, "%s: bad shape M=%lld N=%lld K=%lld", fn, (long long)M, (long long)N, (long long)K);
   AO_REQUIRE(N % 16 == 0 && K % 128 == 0, "%s: N=%lld must be a multiple of 16 and K=%lld of 128", fn, (long long)N, (long long)K);
-  AO_REQUIRE((M <= kMaxRows && M * (K + 16) <= 64 * 1024) || (M > kMaxRows && mid8_takes(M, N, K)),
+  AO_REQUIRE((M <= kMaxRows && M * (K + 16) <= 64 * 1024) || (M > kMaxRows && mid8_takes_fused(M, N, K)),
              "%s: the fused form holds the cast activation in LDS: M <= 16 and M * (K + 16) <= 65536 (or 16 < M <= 256 on a weight with "
              "few output tiles and K %% 512 == 0), got M=%lld K=%lld (use the cast + matmul entry points)", fn, (long long)M, (long long)K);
   AO_REQUIRE(N < (1ll << 31) && K < (1ll << 31), "%s: dimension too large", fn);
@@ -165,7 +165,7 @@ int check_dyn(const char* fn, int64_t M, int64_t N, int64_t K) {
 using namespace ao;
 
 extern "C" int ao_dyn_linear_fits(int64_t M, int64_t N, int64_t K) {
-  if (M > kMaxRows) return mid8_takes(M, N, K) ? 1 : 0;
+  if (M > kMaxRows) return mid8_takes_fused(M, N, K) ? 1 : 0;
   return (M > 0 && M <= kMaxRows && M * (K + 16) <= 64 * 1024 && N % 16 == 0 && K % 128 == 0) ? 1 : 0;
 }
 

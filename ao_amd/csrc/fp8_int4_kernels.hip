@@ -20,13 +20,21 @@
 #include <utility>
 
 #include "common.h"
+#include "quant_math.h"
 
 namespace ao {
 namespace {
 
 typedef long i64_t;
 
-template <int G, int DEPTH>
+// FUSE (round 4, SURVEY 8 f1 for this path): the per-row e4m3 cast of the activation inside the launch -- x arrives as bf16 [M][K]
+// (M <= 16, M (K + 16) <= 64 KiB), is cast ONCE per workgroup into an LDS copy of the codes with quant_math.h's arithmetic (the bits of
+// ao_fp8_quantize_rowwise), and the waves take their blocks' x slices from there instead of from global memory.
+//   1: M == 1 -- a wave casts only the k-run it multiplies itself, held in registers between amax and cast; its loads go out before the
+//      ring's, the one workgroup barrier is the amax exchange;
+//   2: 2 <= M <= 16 -- the workgroup casts the whole activation (two passes over the L2-resident rows), then the ring is requested.
+// Without it the stand-alone cast cost this path 28 % (818 -> 587 tok/s on the Llama-3-8B linears, profiles/fp8_int4_r03.jsonl).
+template <int G, int DEPTH, int FUSE = 0>
 __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restrict__ xq, const float* __restrict__ x_scale,
                                                           const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz,
                                                           const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int M, int N, int K) {
@@ -46,6 +54,11 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   const int kb1 = (kblocks * (wave + 1)) / nwaves;
   char* slab = smem + wave * SLAB;
   float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
+  // FUSE: [M][K + 16] codes | [nwaves][16] row maxima | [16] row scales, behind the reduction area
+  const int cstride = K + 16;
+  char* codes = smem + nwaves * (SLAB + 1024);
+  float* wmax = reinterpret_cast<float*>(codes + ((M * cstride + 15) & ~15));
+  float* rs = wmax + nwaves * 16;
 
   const int n = ntile * 16 + (lane & 15);
   const int kq = lane >> 4;
@@ -67,16 +80,23 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
     const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
 #pragma unroll
     for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
-    const u32x4* xs = reinterpret_cast<const u32x4*>(xp + (size_t)kb * 128);
-    s.x0 = xs[0];
-    s.x1 = xs[1];
+    if constexpr (FUSE == 0) {
+      const u32x4* xs = reinterpret_cast<const u32x4*>(xp + (size_t)kb * 128);
+      s.x0 = xs[0];
+      s.x1 = xs[1];
+    }
   };
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const i64_t ones = 0x3838383838383838L;  // eight e4m3 1.0
-  auto consume = [&](const Stage& s) {
+  // FUSE: lane (r, j)'s 32 bytes of the block come from the LDS copy of the codes (rows past M: the last row)
+  const char* cp = codes + min(lane >> 2, rows - 1) * cstride + (lane & 3) * 32;
+  auto consume = [&](const Stage& s, int kb) {
     // stage x: d0..d3 = tile 2j (kq 0..3), d4..d7 = tile 2j + 1
-    const uint32_t d[8] = {s.x0.x, s.x0.y, s.x0.z, s.x0.w, s.x1.x, s.x1.y, s.x1.z, s.x1.w};
+    u32x4 x0, x1;
+    if constexpr (FUSE == 0) { x0 = s.x0; x1 = s.x1; }
+    else { x0 = *reinterpret_cast<const u32x4*>(cp + kb * 128); x1 = *reinterpret_cast<const u32x4*>(cp + kb * 128 + 16); }
+    const uint32_t d[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(st_base + q * 32) = u32x2{d[q], d[4 + q]};
     const u32x4 xa = *reinterpret_cast<const u32x4*>(a_base);       // (A0, B0, A1, B1)
@@ -106,8 +126,69 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   };
 
   const int kb_last = max(kb1 - 1, kb0);
+  auto prime = [&] {
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
+    for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
+    __builtin_amdgcn_sched_barrier(0);  // nothing that waits for an earlier load may move above the ring's requests
+  };
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };  // LDS-only: must not drain the ring
+  if constexpr (FUSE == 1) {
+    // M == 1: this wave's k-run is blocks [kb0, kb1): (kb1 - kb0) x 16 vectors of 8 bf16, at most XW per lane (host: <= 16 blocks per wave)
+    constexpr int XW = 4;
+    const int nv = (kb1 - kb0) * 16;
+    const u32x4* xr = reinterpret_cast<const u32x4*>(xq) + (size_t)kb0 * 16;  // (xq: the bf16 activation)
+    u32x4 xv[XW];
+#pragma unroll
+    for (int i = 0; i < XW; ++i) xv[i] = xr[max(min(lane + i * 64, nv - 1), 0)];
+    __builtin_amdgcn_sched_barrier(0);
+    prime();
+    float m = 0.f;
+    bool has_nan = false;
+#pragma unroll
+    for (int i = 0; i < XW; ++i) m = fmaxf(m, amax8(xv[i], has_nan));
+    if (has_nan) m = INFINITY;
+    m = wave_max(m);
+    wmax[wave * 16] = m;
+    lds_barrier();
+    float mm = 0.f;
+    for (int w = 0; w < nwaves; ++w) mm = fmaxf(mm, wmax[w * 16]);
+    const float sc = fp8_row_scale(mm);
+    rs[0] = sc;  // (every thread: same value)
+#pragma unroll
+    for (int i = 0; i < XW; ++i) {
+      const int idx = lane + i * 64;
+      if (idx < nv) *reinterpret_cast<u32x2*>(codes + kb0 * 128 + idx * 8) = fp8_quant8(xv[i], sc);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private codes: no barrier
+  } else if constexpr (FUSE == 2) {
+    const int nvec = K >> 3, nthreads = blockDim.x, tid = threadIdx.x;
+    const uint16_t* xb = reinterpret_cast<const uint16_t*>(xq) + (size_t)m0 * K;
+    for (int r = 0; r < rows; ++r) {
+      const u32x4* xr = reinterpret_cast<const u32x4*>(xb + (size_t)r * K);
+      float m = 0.f;
+      bool has_nan = false;
+      for (int i = tid; i < nvec; i += nthreads) m = fmaxf(m, amax8(xr[i], has_nan));
+      if (has_nan) m = INFINITY;
+      m = wave_max(m);
+      wmax[wave * 16 + r] = m;
+    }
+    lds_barrier();
+    if (tid < rows) {
+      float m = 0.f;
+      for (int w = 0; w < nwaves; ++w) m = fmaxf(m, wmax[w * 16 + tid]);
+      rs[tid] = fp8_row_scale(m);
+    }
+    lds_barrier();
+    for (int r = 0; r < rows; ++r) {
+      const u32x4* xr = reinterpret_cast<const u32x4*>(xb + (size_t)r * K);
+      const float sc = rs[r];
+      for (int i = tid; i < nvec; i += nthreads) *reinterpret_cast<u32x2*>(codes + r * cstride + i * 8) = fp8_quant8(xr[i], sc);
+    }
+    prime();
+    lds_barrier();
+  } else {
+    prime();
+  }
   auto for_slots = [&](auto&& f) {
     [&]<int... D>(std::integer_sequence<int, D...>) { (f(std::integral_constant<int, D>{}), ...); }(std::make_integer_sequence<int, DEPTH>{});
   };
@@ -115,21 +196,21 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
     for_slots([&](auto dc) {
       constexpr int d = decltype(dc)::value;
-      consume(st[d]);
+      consume(st[d], kb + d);
       issue(st[d], kb + d + DEPTH);
     });
   }
   for_slots([&](auto dc) {
     constexpr int d = decltype(dc)::value;
     if (kb + d < kb1) {
-      consume(st[d]);
+      consume(st[d], kb + d);
       if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
     }
   });
   kb += DEPTH;
   for_slots([&](auto dc) {
     constexpr int d = decltype(dc)::value;
-    if (kb + d < kb1) consume(st[d]);
+    if (kb + d < kb1) consume(st[d], kb + d);
   });
 
   // cross-wave reduction: red[wave][row][col]; D layout: lane (col = lane & 15, group kq) holds rows 4 kq + {0..3}
@@ -144,7 +225,7 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
     if (row < rows) {
       float sum = 0.f;
       for (int w = 0; w < nwaves; ++w) sum += red[w * 256 + tid];
-      float v = sum * x_scale[m0 + row];
+      float v = sum * (FUSE != 0 ? rs[row] : x_scale[m0 + row]);
       if (bias != nullptr) v += bf16_lo_to_f32(bias[ntile * 16 + col]);
       y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(v);
     }
@@ -153,15 +234,45 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
 
 template <int G>
 int launch_fp8_int4(const uint8_t* xq, const float* x_scale, const int32_t* qdata, const uint16_t* sz, const uint16_t* bias, uint16_t* y,
-                    int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+                    int64_t M, int64_t N, int64_t K, hipStream_t stream, bool fused) {
   const int kblocks = (int)(K >> 7);
   int wpb = (kblocks >= 16) ? 8 : 4;
   if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
-  const size_t smem = (size_t)wpb * (16 * (128 + 16) + 1024);
+  size_t smem = (size_t)wpb * (16 * (128 + 16) + 1024);
   dim3 grid((unsigned)(N >> 4), (unsigned)((M + 15) / 16)), block(wpb * 64);
-  ao::launch(fp8_int4_mm_kernel<G, 4>, grid, block, smem, stream, xq, x_scale, reinterpret_cast<const u32x4*>(qdata),
-             reinterpret_cast<const uint32_t*>(sz), bias, y, (int)M, (int)N, (int)K);
+  const u32x4* qd = reinterpret_cast<const u32x4*>(qdata);
+  const uint32_t* szw = reinterpret_cast<const uint32_t*>(sz);
+  if (!fused) {
+    ao::launch(fp8_int4_mm_kernel<G, 4, 0>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+  } else {
+    smem += (size_t)((M * (K + 16) + 15) & ~(int64_t)15) + (size_t)(wpb * 16 + 16) * sizeof(float);
+    // M == 1 with at most 16 blocks per wave: the wave-private form; else the workgroup-wide cast
+    const bool priv = M == 1 && (kblocks + wpb - 1) / wpb <= 16;
+    const void* kern = priv ? reinterpret_cast<const void*>(fp8_int4_mm_kernel<G, 4, 1>) : reinterpret_cast<const void*>(fp8_int4_mm_kernel<G, 4, 2>);
+    if (int rc = ensure_dynamic_lds(kern, smem, "hipFuncSetAttribute(fp8_int4_mm_kernel)")) return rc;
+    if (priv) ao::launch(fp8_int4_mm_kernel<G, 4, 1>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+    else ao::launch(fp8_int4_mm_kernel<G, 4, 2>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+  }
   AO_LAUNCH_CHECK("fp8_int4_mm_kernel launch");
+  return AO_OK;
+}
+
+int fp8_int4_dispatch(const uint8_t* xq, const float* x_scale, const int32_t* qdata, const uint16_t* sz, const uint16_t* bias, uint16_t* y, int64_t M,
+                      int64_t N, int64_t K, int group_size, hipStream_t s, bool fused) {
+  switch (group_size) {
+    case 32: return launch_fp8_int4<32>(xq, x_scale, qdata, sz, bias, y, M, N, K, s, fused);
+    case 64: return launch_fp8_int4<64>(xq, x_scale, qdata, sz, bias, y, M, N, K, s, fused);
+    case 128: return launch_fp8_int4<128>(xq, x_scale, qdata, sz, bias, y, M, N, K, s, fused);
+    default: return launch_fp8_int4<256>(xq, x_scale, qdata, sz, bias, y, M, N, K, s, fused);
+  }
+}
+
+int fp8_int4_check(const char* fn, int64_t M, int64_t N, int64_t K, int group_size) {
+  AO_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0, "%s: N=%lld must be a multiple of 16 and K=%lld of 128", fn, (long long)N, (long long)K);
+  AO_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256, "%s: group_size must be 32, 64, 128 or 256, got %d", fn,
+             group_size);
+  AO_REQUIRE(K % group_size == 0, "%s: K=%lld not divisible by group_size=%d", fn, (long long)K, group_size);
+  AO_REQUIRE(M >= 0 && M < (1ll << 20) && N < (1ll << 31) && K < (1ll << 31), "%s: bad M=%lld", fn, (long long)M);
   return AO_OK;
 }
 
@@ -174,21 +285,27 @@ extern "C" int ao_fp8_int4_linear(const uint8_t* xq, const float* x_scale, const
                                   const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K, int group_size, void* stream) {
   AO_REQUIRE_PTR(qdata);
   AO_REQUIRE_PTR(scale_and_zero);
-  AO_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0, "ao_fp8_int4_linear: N=%lld must be a multiple of 16 and K=%lld of 128", (long long)N,
-             (long long)K);
-  AO_REQUIRE(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256, "ao_fp8_int4_linear: group_size must be 32, 64, 128 or 256, got %d",
-             group_size);
-  AO_REQUIRE(K % group_size == 0, "ao_fp8_int4_linear: K=%lld not divisible by group_size=%d", (long long)K, group_size);
-  AO_REQUIRE(M >= 0 && M < (1ll << 20) && N < (1ll << 31) && K < (1ll << 31), "ao_fp8_int4_linear: bad M=%lld", (long long)M);
+  if (int rc = fp8_int4_check(__func__, M, N, K, group_size)) return rc;
   if (M == 0) return AO_OK;
   AO_REQUIRE_PTR(xq);
   AO_REQUIRE_PTR(x_scale);
   AO_REQUIRE_PTR(y);
-  hipStream_t s = (hipStream_t)stream;
-  switch (group_size) {
-    case 32: return launch_fp8_int4<32>(xq, x_scale, qdata, scale_and_zero, bias, y, M, N, K, s);
-    case 64: return launch_fp8_int4<64>(xq, x_scale, qdata, scale_and_zero, bias, y, M, N, K, s);
-    case 128: return launch_fp8_int4<128>(xq, x_scale, qdata, scale_and_zero, bias, y, M, N, K, s);
-    default: return launch_fp8_int4<256>(xq, x_scale, qdata, scale_and_zero, bias, y, M, N, K, s);
-  }
+  return fp8_int4_dispatch(xq, x_scale, qdata, scale_and_zero, bias, y, M, N, K, group_size, (hipStream_t)stream, false);
+}
+
+extern "C" int ao_fp8_int4_dynamic_fits(int64_t M, int64_t N, int64_t K) {
+  return (M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && M * (K + 16) <= 64 * 1024) ? 1 : 0;
+}
+
+extern "C" int ao_fp8_int4_dynamic_linear(const uint16_t* x, const int32_t* qdata, const uint16_t* scale_and_zero, const uint16_t* bias, uint16_t* y,
+                                          int64_t M, int64_t N, int64_t K, int group_size, void* stream) {
+  AO_REQUIRE_PTR(qdata);
+  AO_REQUIRE_PTR(scale_and_zero);
+  if (int rc = fp8_int4_check(__func__, M, N, K, group_size)) return rc;
+  if (M == 0) return AO_OK;
+  AO_REQUIRE(ao_fp8_int4_dynamic_fits(M, N, K), "%s: the fused form holds the cast activation in LDS: M <= 16 and M * (K + 16) <= 65536, got M=%lld K=%lld "
+             "(use ao_fp8_quantize_rowwise + ao_fp8_int4_linear)", __func__, (long long)M, (long long)K);
+  AO_REQUIRE_PTR(x);
+  AO_REQUIRE_PTR(y);
+  return fp8_int4_dispatch(reinterpret_cast<const uint8_t*>(x), nullptr, qdata, scale_and_zero, bias, y, M, N, K, group_size, (hipStream_t)stream, true);
 }

@@ -96,42 +96,65 @@ __global__ __launch_bounds__(512, 4) void mid8_kernel(Mid8Args p) {
   for (int g = 0; g < G; ++g) issue_w(wr[g], g);
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- FUSED: the per-row cast, shared out by a ticket counter (see the header)
+  // ---- FUSED: the per-row cast, shared out by a ticket counter (see the header).  A workgroup takes one row per ticket and casts
+  // it with all 512 threads: the row (K <= 16384: at most 4 vectors of 8 bf16 per thread) stays in registers between amax and cast.
+  // Control flow around the s_barriers must be UNIFORM in the compiler's eyes (inline-asm barriers, a ticket loop): the first version
+  // took the ticket under `if (tid == 0)` and read it back from LDS as a plain value -- the loop counted as divergent, the
+  // structurizer rotated the lane-0 blocks around the back edge and sent the other lanes of wave 0 into the next iteration's
+  // s_barrier ahead of lane 0: the workgroup hung.  Now: a scalar branch on the wave index, all 64 lanes of wave 0 add 1 (the compiler
+  // folds that into ONE atomic add of 64 by the first lane, so the counters advance in units of 64) and readfirstlane hands the
+  // ticket to the scalar unit; every lane stores the same ticket / scale to the same address instead of branching on the lane.
   if constexpr (FUSED) {
     __shared__ float s_part[8];
     __shared__ int s_row;
-    const int nvec = p.K >> 3;  // 8 bf16 per 16 B
+    constexpr int XV = 4;
+    const int nvec = p.K >> 3;  // 8 bf16 per 16 B; <= XV * 512 (host)
     for (;;) {
-      if (tid == 0) s_row = (int)__hip_atomic_fetch_add(&p.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wave == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&p.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_row = __builtin_amdgcn_readfirstlane((int)old) >> 6;
+      }
       lds_barrier();
-      const int r = s_row;
-      if (r >= p.M) break;  // uniform
+      const int r = __builtin_amdgcn_readfirstlane(s_row);
+      if (r >= p.M) break;
       const u32x4* xr = reinterpret_cast<const u32x4*>(p.x + (size_t)r * p.K);
+      u32x4 xv[XV];
+#pragma unroll
+      for (int i = 0; i < XV; ++i) xv[i] = xr[min(tid + i * 512, nvec - 1)];  // clamped, unconditional
       float m = 0.f;
       bool has_nan = false;
-      for (int i = tid; i < nvec; i += 512) m = fmaxf(m, amax8(xr[i], has_nan));
-      if (has_nan) m = INFINITY;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-      if (lane == 0) s_part[wave] = m;
+      for (int i = 0; i < XV; ++i) m = fmaxf(m, amax8(xv[i], has_nan));
+      if (has_nan) m = INFINITY;
+      m = wave_max(m);
+      s_part[wave] = m;  // (every lane: same value, same address)
       lds_barrier();
       float mm = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) mm = fmaxf(mm, s_part[w]);
       const float s = INT8 ? int8_row_scale(mm) : fp8_row_scale(mm);
       const float inv = 1.0f / s;
-      for (int i = tid; i < nvec; i += 512) {
-        const u32x2 q = INT8 ? int8_quant8(xr[i], inv) : fp8_quant8(xr[i], s);
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.xq + (size_t)r * p.K + (size_t)i * 8),
-                           ((unsigned long long)q.y << 32) | q.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: written through
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.xq + (size_t)r * p.K);
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int idx = tid + i * 512;
+        if (idx < nvec) {
+          const u32x2 q = INT8 ? int8_quant8(xv[i], inv) : fp8_quant8(xv[i], s);
+          __hip_atomic_store(dst + idx, ((unsigned long long)q.y << 32) | q.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: written through
+        }
       }
-      if (tid == 0) __hip_atomic_store(p.xs + r, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.xs + r, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (drains this wave's part of the weight ring too: it has long landed by now)
       lds_barrier();                                      // every wave's stores are out before the row counts as done
-      if (tid == 0) __hip_atomic_fetch_add(&p.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wave == 0) __hip_atomic_fetch_add(&p.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tid == 0) {
-      while (__hip_atomic_load(&p.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.M) __builtin_amdgcn_s_sleep(2);
+      // (bounded: a bug here must not hang the device -- after 2 s of the 100 MHz clock the wait gives up and marks sync[3])
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(&p.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 64u * (unsigned)p.M) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(&p.sync[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
       // the last workgroup past the wait leaves the counters at zero for the next launch on this stream
       const unsigned total = gridDim.x * gridDim.y * gridDim.z;
       if (__hip_atomic_fetch_add(&p.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(512, 4) void mid8_kernel(Mid8Args p) {
   }
 
   // ---- K parts meet (two-level, part order: reproducible); the last arriver of a tile goes on to the epilogue
-  if (S > 1 && !split_k_meet2<MT, 512, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) return;
+  if (S > 1 && !split_k_meet2<MT, 512, INT8, (MT >= 8 ? 2 : 4)>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) return;
   if (tile >= ntiles) return;
 
   // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
@@ -254,15 +277,22 @@ struct Mid8Plan {
   int mt, split;
 };
 
-// Rows: 32 / 64 / 128-row slabs.  K parts: enough workgroups for ~two per CU, parts of >= kG steps that divide the K steps evenly.
+// Rows: 32 / 64 / 128-row slabs.  K parts: ~one workgroup per CU, parts that divide the K steps evenly.
+// Product dispatch (cold weights, 70B / TP8 fp8 shards, profiles/mid8_sweep_r04.txt): the kernel beats the round-3 paths at
+// 17 .. 32 rows on long K (qkv 1280 x 8192 at M = 32: 11.1 us against 15.1; gate_up 7168 x 8192: 17.2 against 27.8) and loses
+// everywhere else (M = 128: qkv 21 us against rb8_kernel's 16, gate_up 28 against 26.5, down 27 against 19 -- its k loop waits on
+// activation / weight requests only 2 / 4 steps old and on every A-fragment read, at the 128 VGPRs of four waves per SIMD), so that
+// is all it takes by itself; 301 / 31S force it anywhere for A/B runs and the parity tests.
 bool mid8_plan(int64_t M, int64_t N, int64_t K, Mid8Plan* out) {
   if (g_mid8_mode == 300) return false;
   if (M <= 16 || M > 256 || N % 16 != 0 || K % (128 * kG) != 0 || M * K >= (1ll << 31) || N * K >= (1ll << 31)) return false;
+  const bool forced = g_mid8_mode == 301 || (g_mid8_mode >= 310 && g_mid8_mode < 330);
+  if (!forced && !(M <= 32 && K >= 4096)) return false;
   const int mt = (M <= 32) ? 2 : (M <= 64) ? 4 : 8;
   const int64_t slabs = (M + 16 * mt - 1) / (16 * mt), cols = (N + 127) / 128, groups = K / (128 * kG);
   const int64_t base = cols * slabs;
-  if (g_mid8_mode != 301 && !(g_mid8_mode >= 310 && g_mid8_mode < 330) && base >= 400) return false;  // enough tiles for the tiled GEMMs
-  int64_t want = std::max<int64_t>(1, 512 / base);
+  if (!forced && base >= 400) return false;  // enough tiles for the tiled GEMMs
+  int64_t want = std::max<int64_t>(1, 256 / base);
   if (g_mid8_mode >= 310 && g_mid8_mode < 330) want = g_mid8_mode - 310;
   int split = 1;
   for (int64_t s = 1; s <= std::min<int64_t>(groups, 16); ++s)
@@ -313,6 +343,7 @@ bool mid8_takes(int64_t M, int64_t N, int64_t K) {
   Mid8Plan plan;
   return mid8_plan(M, N, K, &plan);
 }
+bool mid8_takes_fused(int64_t M, int64_t N, int64_t K) { return K <= 16384 && mid8_takes(M, N, K); }
 
 int mid8_scaled(bool int8, const void* a, const float* scale_a, const void* b, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M,
                 int64_t N, int64_t K, hipStream_t stream) {
@@ -330,7 +361,7 @@ int mid8_scaled(bool int8, const void* a, const float* scale_a, const void* b, c
 int mid8_dynamic(bool int8, const uint16_t* x, const void* b, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
                  hipStream_t stream) {
   Mid8Plan plan;
-  if (!mid8_plan(M, N, K, &plan)) {
+  if (K > 16384 || !mid8_plan(M, N, K, &plan)) {  // (the fused cast holds a row in 4 x 512 vectors of 8)
     set_error("mid8_dynamic: shape M=%lld N=%lld K=%lld not covered", (long long)M, (long long)N, (long long)K);
     return AO_ERR_INVALID_ARGUMENT;
   }

@@ -275,7 +275,15 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       for (int i = 0; i < 16; ++i) t[i] = ts[i];
     }
   };
-  if (S > 1 && !split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
+  // more than four K parts (rowwise kinds): the two-level meeting of splitk.h (round 4) -- groups of four parts, so the last arriver
+  // reads 3 + 3 parked tiles in two round trips instead of S - 1 in S / 4 (the 70B / TP8 qkv shard at M = 128 cuts K 16 ways: 15 x 64 KiB
+  // through one CU's memory path)
+  bool go_on = true;
+  if (S > 1) {
+    if (!GROUPED && S > 4) go_on = split_k_meet2<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem));
+    else go_on = split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem));
+  }
+  if (!go_on) {
     dump();
     return;
   }
@@ -707,10 +715,13 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   static_assert(!SLIM || 3 * smem <= 160 * 1024, "SLIM: three workgroups per CU");
   static_assert(smem <= 160 * 1024, "rb8_kernel: LDS");
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
+    // (two-level meeting for > 4 parts of the rowwise kinds: S + ceil(S / 4) parked tiles and 1 + ceil(S / 4) tickets per output tile)
+    const bool two_level = !kGrouped && split > 4;
+    const int64_t slots = two_level ? split + (split + 3) / 4 : split, tks = two_level ? 1 + (split + 3) / 4 : 1;
+    AO_REQUIRE((int64_t)grid.x * grid.y * slots * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
-    AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "rb8: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
+    AO_REQUIRE((int64_t)grid.x * grid.y * tks <= kSplitMaxTickets - 8, "rb8: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * slots * BN * BM)) return rc;
   }
   p.trace = g_fp8_rb_trace;
   auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS>;
@@ -775,7 +786,7 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   const bool narrow = !wide || g_fp8_rb_force == 3;
   const int bn = narrow ? 64 : 128;
   const int64_t base = ((N + bn - 1) / bn) * slabs;
-  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * bm);
+  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * bm) * 4 / 5;  // (x 4 / 5: the two-level meeting parks S + S / 4 tiles)
   const int64_t target = (g_fp8_rb_force == 3) ? 512 : 256;
   const int split = (int)std::max<int64_t>(1, std::min<int64_t>({target / base, fit, 16, ksteps / 4}));
   if (bm == 64) return narrow ? launch_rb8<4, KIND, 4>(p, split, stream) : launch_rb8<8, KIND, 4>(p, split, stream);

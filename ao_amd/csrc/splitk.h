@@ -98,7 +98,8 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
 // path, the first level spread over S / 4 workgroups.  The sum is ((p0 + p1 + p2 + p3) + (p4 + ..) + ..) whatever the arrival
 // order: reproducible.  Workspace per tile: S + ceil(S / 4) parked parts; tickets per tile: 1 + ceil(S / 4).
 // ---------------------------------------------------------------------------
-template <int NREG, int NTHR, bool INT = false>
+// UMAX: parts gathered per round trip (4 x NREG x 4 VGPRs: callers that run four waves per SIMD pass 2 for 8-register tiles)
+template <int NREG, int NTHR, bool INT = false, int UMAX = 4>
 __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
   constexpr int kSc1 = 16;
   constexpr int kRegBytes = NTHR * 16;
@@ -128,11 +129,10 @@ __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, uns
     __syncthreads();  // (flag is re-used by the second level)
     return last;
   };
-  // acc = slot[first] + .. + slot[first + n - 1], n <= 4, in slot order.  U parts per round trip: 4, or 2 when the tile has 8 registers
-  // per thread (4 x 8 x 16 B would not fit the 128 VGPRs of a kernel that runs four waves per SIMD).  acc is dead here: the own part
+  // acc = slot[first] + .. + slot[first + n - 1], n <= 4, in slot order, UMAX parts per round trip.  acc is dead here: the own part
   // is re-read from its slot like the others.
   auto gather = [&](int first, int n) {
-    constexpr int U = (NREG >= 8) ? 2 : 4;
+    constexpr int U = UMAX;
 #pragma unroll
     for (int u0 = 0; u0 < 4; u0 += U) {
       if (u0 > 0 && u0 >= n) break;  // uniform

@@ -825,6 +825,35 @@ def fp8_int4_linear(xq, x_scale, qdata, scale_and_zero, group_size, bias=None):
     return y
 
 
+def fp8_int4_dynamic_fits(m: int, n: int, k: int) -> bool:
+    """Whether the fp8-activation x int4 kernel with the activation cast fused in takes this shape (M <= 16, codes within 64 KiB of LDS)."""
+    return bool(_lib.lib().ao_fp8_int4_dynamic_fits(m, n, k))
+
+
+def fp8_int4_act_linear(x, qdata, scale_and_zero, group_size, bias=None):
+    """Float8DynamicActivationInt4WeightConfig's F.linear on a 2-D bf16 activation (int4_tensor.py:205-235): per-row e4m3 cast of x, then
+    mslk.f8i4bf16_rowwise's contract.  Decode sizes run cast + matmul in ONE launch (round 4: the stand-alone cast cost this path 28 %);
+    everything else ao_fp8_quantize_rowwise + ao_fp8_int4_linear.  Same bits either way."""
+    dev = _require_gpu("fp8_int4_act_linear", x, qdata, scale_and_zero)
+    if x.dim() != 2 or x.dtype != torch.bfloat16:
+        raise RuntimeError(f"fp8_int4_act_linear: x must be a 2-D bfloat16 tensor, got {tuple(x.shape)} {x.dtype}")
+    m, k = x.shape
+    n = qdata.shape[0] * 8
+    if not fp8_int4_dynamic_fits(m, n, k):
+        xq, xs = fp8_quantize_rowwise(x.contiguous())
+        return fp8_int4_linear(xq, xs, qdata, scale_and_zero, group_size, bias)
+    if qdata.dim() != 4 or qdata.dtype != torch.int32 or scale_and_zero.dtype != torch.bfloat16 or qdata.shape[1] * 128 != k \
+            or tuple(scale_and_zero.shape) != (k // group_size, n, 2):
+        raise RuntimeError(f"fp8_int4_act_linear: shapes do not agree: x {tuple(x.shape)}, qdata {tuple(qdata.shape)}, scale_and_zero {tuple(scale_and_zero.shape)}")
+    if bias is not None:
+        bias = bias.to(torch.bfloat16).contiguous()
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_fp8_int4_dynamic_linear(_ptr(x.contiguous()), _ptr(qdata.contiguous()), _ptr(scale_and_zero.contiguous()),
+                                                         _ptr(bias) if bias is not None else None, _ptr(y), m, n, k, group_size, _stream()))
+    return y
+
+
 def generate_permute_indices(tokens_per_expert_group, experts_per_rank, num_ranks, max_len, alignment):
     """torchao.prototype.moe_training.ep.kernels.generate_permute_indices (kernels.py:132-214): expert-major gather indices with every
     expert's group padded to `alignment` rows.  Returns (permuted_indices int32 [max_len] with -1 for padding, m_sizes int32 [E],
@@ -909,9 +938,11 @@ def dynamic_linear_preferred(m: int, n: int, k: int) -> bool:
     """Whether the fused kernel beats cast + matmul: every workgroup (one per 16 output columns) casts the whole activation
     itself, so the redundant work must stay small.  Measured on Llama-3-8B int8 (us, cast + matmul vs fused): M = 1 qkv 10.3 vs
     8.2, o 8.9 vs 6.9, down 21.5 vs 17.4, gate_up 26.5 vs 26.5; M = 2 qkv 10.6 vs 8.9 but gate_up 27.0 vs 28.5; M = 4 gate_up
-    28.5 vs 35.1.  16 < M <= 256 on few output tiles (round 4, mid8_kernels.hip): the rows of the cast are shared out among the
-    workgroups of the launch, nothing is cast twice -- always one launch."""
-    return dynamic_linear_fits(m, n, k) and (m > 16 or m * (n // 16) <= 1024)
+    28.5 vs 35.1.  16 < M <= 256 (round 4, mid8_kernels.hip: the rows of the cast are shared out among the workgroups of the
+    launch through a ticket counter) is reachable but NOT preferred: three dependent memory round trips (ticket, the row, written
+    through and counted) sit in front of every workgroup's k loop -- measured + 15 .. 20 us per linear against + 4 .. 5 for the
+    stand-alone cast (profiles/mid8_sweep_r04.txt)."""
+    return m <= 16 and dynamic_linear_fits(m, n, k) and m * (n // 16) <= 1024
 
 
 def int8_linear(x2: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias=None) -> torch.Tensor:

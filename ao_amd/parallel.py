@@ -346,10 +346,17 @@ class RowParallelLinear(nn.Module):
 
     def _all_gather(self, y_part, m):
         y = torch.empty((m, y_part.shape[1]), dtype=y_part.dtype, device=y_part.device)
-        if not self._native_rs:  # gloo knows neither bf16 nor 16-bit integers: move the bytes
-            dist.all_gather_into_tensor(y.view(torch.uint8), y_part.view(torch.uint8), group=self.group)
-        else:
+        if self._native_rs:
             dist.all_gather_into_tensor(y, y_part, group=self.group)
+            return y
+        # gloo (CPU tests, the one-GPU dry run of bench.py --gpus 2) knows neither bf16 nor 16-bit integers: move the bytes
+        yb, pb = y.view(torch.uint8), y_part.view(torch.uint8)
+        try:
+            dist.all_gather_into_tensor(yb, pb, group=self.group)
+        except RuntimeError:  # a gloo build without the flat variant for this device
+            parts = [torch.empty_like(pb) for _ in range(dist.get_world_size(self.group))]
+            dist.all_gather(parts, pb, group=self.group)
+            yb.copy_(torch.cat(parts, dim=0))
         return y
 
     def forward(self, x):

@@ -182,8 +182,8 @@ def _(func, types, args, kwargs):
     elif weight_tensor.activation_dtype == torch.float8_e4m3fn:
         # dynamic rowwise fp8 activation, then the fp8 x int4 MFMA kernel (mslk.f8i4bf16_rowwise's contract: the e4m3 codes meet the
         # int4 codes on the matrix pipe, group scales multiply fp32 group sums, the row scale the result)
-        xq, x_scale = k.fp8_quantize_rowwise(x2.contiguous())
-        res = k.fp8_int4_linear(xq, x_scale, qdata_tp, sz, g, None)
+        # (one op: decode sizes run the cast inside the matmul launch, ops.fp8_int4_act_linear)
+        res = k.fp8_int4_act_linear(x2.contiguous(), qdata_tp, sz, g, None)
     else:
         res = k.weight_int4pack_mm(x2.contiguous(), qdata_tp, g, sz)
     res = res[:, :n_out].reshape(*orig_act_size[:-1], n_out)

@@ -60,6 +60,7 @@ _lib_def.define("fp8_linear_tensorwise(Tensor x, Tensor wq, Tensor w_scale, Tens
 _lib_def.define("fp8_linear_clamped(Tensor x, Tensor wq, Tensor w_scale, Tensor? bias, float lb, float ub, bool tensorwise) -> Tensor")
 _lib_def.define("int8_linear_static(Tensor x, Tensor wq, Tensor w_scale, Tensor act_scale, Tensor? act_zero_point, Tensor? w_row_sums, Tensor? bias) -> Tensor")
 _lib_def.define("fp8_int4_linear(Tensor xq, Tensor x_scale, Tensor qdata, Tensor scale_and_zero, int group_size, Tensor? bias) -> Tensor")
+_lib_def.define("fp8_int4_act_linear(Tensor x, Tensor qdata, Tensor scale_and_zero, int group_size, Tensor? bias) -> Tensor")
 _lib_def.define("int8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("fp8_quantize_rowwise(Tensor x) -> (Tensor, Tensor)")
 _lib_def.define("mxfp8_quantize(Tensor x, str scaling_mode) -> (Tensor, Tensor)")
@@ -85,6 +86,7 @@ _lib_impl.impl("fp8_linear_tensorwise", ops.fp8_linear_tensorwise)
 _lib_impl.impl("fp8_linear_clamped", ops.fp8_linear_clamped)
 _lib_impl.impl("int8_linear_static", ops.int8_linear_static)
 _lib_impl.impl("fp8_int4_linear", ops.fp8_int4_linear)
+_lib_impl.impl("fp8_int4_act_linear", ops.fp8_int4_act_linear)
 _lib_impl.impl("int8_quantize_rowwise", ops.int8_quantize_rowwise)
 _lib_impl.impl("fp8_quantize_rowwise", ops.fp8_quantize_rowwise)
 _lib_impl.impl("mxfp8_quantize", lambda x, mode: ops.mxfp8_quantize(x, mode))
@@ -164,6 +166,11 @@ def _(xq, x_scale, qdata, scale_and_zero, group_size, bias):
     return xq.new_empty((xq.shape[0], qdata.shape[0] * 8), dtype=torch.bfloat16)
 
 
+@torch.library.register_fake("ao_mi355::fp8_int4_act_linear")
+def _(x, qdata, scale_and_zero, group_size, bias):
+    return x.new_empty((x.shape[0], qdata.shape[0] * 8), dtype=torch.bfloat16)
+
+
 @torch.library.register_fake("ao_mi355::int8_quantize_rowwise")
 def _(x):
     return x.new_empty(x.shape, dtype=torch.int8), x.new_empty((x.shape[0], 1), dtype=torch.float32)
@@ -206,7 +213,7 @@ def _(inputs, offsets, padded_group_start_offsets, num_tokens, alignment_size):
 _lib_autograd = torch.library.Library("ao_mi355", "IMPL", "Autograd")
 for _name in ("weight_int4pack_mm", "convert_weight_to_int4pack", "int8_scaled_mm", "fp8_scaled_mm", "int8_dynamic_linear", "fp8_dynamic_linear",
               "int8_linear", "fp8_linear", "int8_linear_asym", "int8_linear_tensorwise", "fp8_linear_tensorwise", "fp8_linear_clamped",
-              "int8_linear_static", "fp8_int4_linear", "int8_quantize_rowwise", "fp8_quantize_rowwise", "mxfp8_quantize", "mxfp8_grouped_mm",
+              "int8_linear_static", "fp8_int4_linear", "fp8_int4_act_linear", "int8_quantize_rowwise", "fp8_quantize_rowwise", "mxfp8_quantize", "mxfp8_grouped_mm",
               "fused_pad_token_groups", "fused_unpad_token_groups"):
     _lib_autograd.impl(_name, torch.library.fallthrough_kernel)
 

@@ -377,6 +377,13 @@ int ao_moe_a2a_v(void* const* peer_data_host, void* const* peer_scales_host, voi
 int ao_fp8_int4_linear(const uint8_t* xq, const float* x_scale, const int32_t* qdata,
                        const uint16_t* scale_and_zero, const uint16_t* bias, uint16_t* y, int64_t M,
                        int64_t N, int64_t K, int group_size, void* stream);
+/* The same linear on the bf16 activation, its per-row e4m3 cast (ao_fp8_quantize_rowwise's arithmetic: float8_tensor.py:167-253 as
+ * Int4Tensor's F.linear applies it, int4_tensor.py:205-212) fused into the launch -- SURVEY.md 8 f1 for this path.  Shapes:
+ * ao_fp8_int4_dynamic_fits (M <= 16, M * (K + 16) <= 65536).  Same bits as cast + ao_fp8_int4_linear. */
+int ao_fp8_int4_dynamic_fits(int64_t M, int64_t N, int64_t K);
+int ao_fp8_int4_dynamic_linear(const uint16_t* x, const int32_t* qdata, const uint16_t* scale_and_zero,
+                               const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
+                               int group_size, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Expert-parallel token regrouping (between the all-to-all and the grouped GEMM)

@@ -225,19 +225,23 @@ def test_mid_m_register_ring_kernel(kind, m, n, k, bias):
                 again = ops.fp8_dynamic_linear(xd, wq, ws, bd) if fits else two
         finally:
             lib.ao_gemm8_set_variant(0)
-        assert variant == 300 or fits, (variant, "mid8 should take this shape")
+        assert fits == (variant != 300 and (variant != 0 or (m <= 32 and k >= 4096)) and k <= 16384), (variant, fits, "which shapes the fused mid-M form takes")
         assert torch.equal(one, two) and torch.equal(again, two), (variant, "fused != two-launch")
         if kind == "int8":
             assert np.array_equal(np_from_torch_bf16(two), y_ref), variant
         else:
-            got, want = two.float().cpu().numpy(), np.asarray(y_ref, dtype=np.float32)
-            ok = np.isfinite(want)
-            assert np.array_equal(np.isfinite(got), ok) and _rel(got[ok], want[ok]) <= 1e-3, variant
+            # (row 0 carries +-3e38 / 1e-30 for the fused == two-launch check above: acc * sx overflows fp32 there, in every kernel of
+            # the library and in _scaled_mm alike, while the float64 oracle does not -- the oracle comparison takes the other rows)
+            got, want = two.float().cpu().numpy()[1:], np.asarray(y_ref, dtype=np.float32)[1:]
+            assert np.isfinite(got).all() and _rel(got, want) <= 1e-3, variant
 
 
 def test_fused_dynamic_linear_shape_limits():
-    assert ops.dynamic_linear_fits(16, 64, 2048) and ops.dynamic_linear_fits(17, 64, 2048) and not ops.dynamic_linear_fits(17, 64, 2176)
-    assert not ops.dynamic_linear_fits(257, 64, 2048)
+    # 16 < M <= 256: the form with the cast shared out inside the launch (mid8_kernels.hip) -- by itself only where it is the faster
+    # kernel (M <= 32, K >= 4096, K % 512 == 0, K <= 16384), anywhere the shape allows when forced (ao_gemm8_set_variant 301)
+    assert ops.dynamic_linear_fits(16, 64, 2048) and not ops.dynamic_linear_fits(17, 64, 2048)
+    assert ops.dynamic_linear_fits(17, 64, 4096) and ops.dynamic_linear_fits(32, 1280, 8192) and not ops.dynamic_linear_fits(33, 1280, 8192)
+    assert not ops.dynamic_linear_fits(17, 64, 4096 + 128) and not ops.dynamic_linear_fits(32, 64, 32768)
     assert not ops.dynamic_linear_fits(8, 64, 14336) and not ops.dynamic_linear_fits(1, 40, 4096) and not ops.dynamic_linear_fits(1, 64, 4000)
     x = torch.zeros(8, 14336, dtype=torch.bfloat16, device=DEV)
     wq = torch.zeros(64, 14336, dtype=torch.int8, device=DEV)

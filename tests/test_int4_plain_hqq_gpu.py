@@ -132,6 +132,33 @@ def test_fp8_int4_kernel_matches_oracle(m, g):
         want = P.fp8_int4_linear(F8.e4m3_to_f32(xq), xs, wt.qdata.cpu().numpy(), np_from_torch_bf16(wt.scale), np_from_torch_bf16(wt.zero_point), g, bias)
         rel = _rel(y, want)
         assert rel <= 1e-3 and np.mean(y == want) > 0.9, (symmetric, rel, float(np.mean(y == want)))
+        # round 4: the one-op form on the bf16 activation (cast fused into the launch at M <= 16: the wave-private form at M = 1, the
+        # workgroup-wide cast up to 16 rows; two launches beyond) gives the bits of cast + ao_fp8_int4_linear
+        x_t = torch_bf16_from_f32(x).to(DEV)
+        one = ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g, torch_bf16_from_f32(bias).to(DEV))
+        assert ops.fp8_int4_dynamic_fits(m, n, k) == (m <= 16)
+        assert np.array_equal(np_from_torch_bf16(one), y), (symmetric, m, g, "fused cast != cast + matmul")
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 256, 4096), (1, 64, 14336), (1, 48, 128), (3, 64, 8192), (16, 32, 3968), (1, 4096, 4096)])
+def test_fp8_int4_fused_cast_at_llama_sizes(m, n, k):
+    """The fused-cast forms at the K of the Llama-3-8B linears (8 waves x 4 .. 14 blocks per wave at M = 1; ragged block counts per wave;
+    the 64 KiB LDS bound at 16 rows): same bits as the two-launch path, <= 1e-3 of the oracle."""
+    g = 128
+    rng = np.random.default_rng(7 * m + k)
+    w = bf16.bf16_round((rng.standard_normal((n, k)) * 0.05).astype(np.float32))
+    x = bf16.bf16_round(rng.standard_normal((m, k)).astype(np.float32))
+    wt = Int4Tensor.from_hp(torch_bf16_from_f32(w).to(DEV), [1, g], activation_dtype=torch.float8_e4m3fn)
+    qdata_tp, sz = wt.tile_packed()
+    x_t = torch_bf16_from_f32(x).to(DEV)
+    xq_t, xs_t = ops.fp8_quantize_rowwise(x_t)
+    two = ops.fp8_int4_linear(xq_t, xs_t, qdata_tp, sz, g)
+    assert ops.fp8_int4_dynamic_fits(m, n, k)
+    one = ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g)
+    assert torch.equal(one, two)
+    xq, xs = F8.quantize_rowwise(x)
+    want = P.fp8_int4_linear(F8.e4m3_to_f32(xq), xs, wt.qdata.cpu().numpy(), np_from_torch_bf16(wt.scale), np_from_torch_bf16(wt.zero_point), g)
+    assert _rel(np_from_torch_bf16(one), want) <= 1e-3
 
 
 def test_hqq_golden_and_oracle():

@@ -39,11 +39,15 @@ def main():
             xq, xsc = ops.fp8_quantize_rowwise(xs_bf16[k])
             ops.fp8_int4_linear(xq, xsc, qdata, sz, bench.GROUP)
     xs_bf16 = {k: torch.randn(B, k, device=dev, dtype=torch.bfloat16) for k in xs}
+    def step_fp8_fused():  # round 4: cast inside the matmul launch at decode sizes (ops.fp8_int4_act_linear)
+        for qdata, sz, n, k, _ in model.weights:
+            ops.fp8_int4_act_linear(xs_bf16[k], qdata, sz, bench.GROUP)
     out = {"batch": B, "layout": "five", "bytes_per_step": model.bytes_per_step(B)}
     with torch.cuda.stream(stream):
         t_bf16, _ = bench.run_int4(model, B, args.steps, 3, stream, dev, True)
         out["bf16_x_int4_tokens_per_s"] = B * args.steps / t_bf16
-        for name, fn in (("fp8_x_int4_gemm_only", step_fp8), ("fp8_x_int4_with_activation_cast", step_fp8_with_cast)):
+        for name, fn in (("fp8_x_int4_gemm_only", step_fp8), ("fp8_x_int4_with_activation_cast", step_fp8_with_cast),
+                         ("fp8_x_int4_act_linear_one_op", step_fp8_fused)):
             run, graphed = bench.capture(fn, stream)
             t = bench.time_steps(run, stream, dev, args.steps, 3) / args.steps
             out[name + "_tokens_per_s"] = B / t
