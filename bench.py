@@ -46,7 +46,7 @@ _SPECS = _roofline.get_specs("AMD Instinct MI355X")
 HBM_PEAK_GBS = _SPECS["peak_mem_bw_bytes_sec"] / 1e9   # 8000: MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = _SPECS["bf16_peak_tops"] / 1e12  # 2500: dense bf16 MFMA
 MFMA_8BIT_PEAK_TOPS = _SPECS["fp8_peak_tops"] / 1e12     # 5000: dense fp8 / int8 MFMA (fp8 ~5 PF dense, int8 ~2x the bf16 rate)
-ROUND = "r03"                    # names of the committed rocprofv3 summaries under profiles/
+ROUND = "r04"                    # names of the committed rocprofv3 summaries under profiles/
 
 LLAMA3_8B_MERGED = [("qkv_proj", 6144, 4096), ("o_proj", 4096, 4096), ("gate_up_proj", 28672, 4096), ("down_proj", 4096, 14336)]
 LLAMA3_8B_UNMERGED = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate", 14336, 4096), ("up", 14336, 4096), ("down", 4096, 14336)]
@@ -81,6 +81,7 @@ def parse_args():
     ap.add_argument("--gemm-variant", type=int, default=0, help="tuning: ao_gemm8_set_variant for the 8-bit configs (profiling only)")
     ap.add_argument("--tp-graph", action="store_true", help=argparse.SUPPRESS)  # round 2's opt-in; graph replay is the default now
     ap.add_argument("--no-tp-graph", action="store_true", help="TP config: launch eagerly (default: each step -- kernels + RCCL collectives -- replays from a hipGraph, eager if the capture fails)")
+    ap.add_argument("--fp8-layers", type=int, default=80, help="fp8 shard config: layers (80 = Llama-3-70B; counter-collection passes use fewer)")
     ap.add_argument("--no-stack-baseline", action="store_true", help="skip the PyTorch-core (what torchao-on-ROCm runs today) timing")
     ap.add_argument("--no-subclass-graph", action="store_true", help="skip the quantize_()-subclass + F.linear graph timing (a13)")
     ap.add_argument("--tp-one-shot", action="store_true", help="TP config: accumulator all-reduces of <= 1 MiB through the symmetric-memory one-shot path (prototype; default RCCL)")
@@ -553,6 +554,31 @@ def config_int8(stream, device, args):
                         "measured_mfma_ceiling": _SPECS["int8_measured_mfma_tops"] / 1e12, "frac_of_measured_ceiling": flops / (gemm_ms * 1e-3) / _SPECS["int8_measured_mfma_tops"],
                         "timing": "HIP extension events, one eager layer", "gemm_ms_per_layer": gemm_ms, "act_cast_ms_per_layer": cast_ms,
                         "end_to_end_TOPs": flops / t / 1e12}}
+    # the same config at decode size (M = 1, all 32 layers' int8 weights distinct and resident: 6.98 GB): what the round-4 decode kernel
+    # (dec8_kernels.hip: cast fused in, full-line register ring) does for the int8 format -- HBM-bound, priced against 8 TB/s
+    try:
+        del xs
+        torch.cuda.empty_cache()
+        dws = []
+        for _ in range(N_LAYERS):
+            for name, n, k in LLAMA3_8B_UNMERGED:
+                w = torch.randn(n, k, device=device, dtype=torch.bfloat16, generator=gen) * 0.02
+                dws.append((n, k) + ops.int8_quantize_rowwise(w))
+                del w
+        x1 = {k: torch.randn(1, k, device=device, dtype=torch.bfloat16, generator=gen) for k in {w[1] for w in dws}}
+        def decode():
+            for n, k, wq, wsc in dws:
+                ops.int8_linear(x1[k], wq, wsc)
+        with torch.cuda.stream(stream):
+            td, _ = _graph_time(decode, stream, device, steps=10)
+        dbytes = sum(n * k + 4 * n + 2 * k + 2 * n for n, k, _, _ in dws)
+        out["decode_M1"] = {"workload": "the same linears at M = 1 (cast + matmul in one launch per linear), 32 layers, 160 launches per token",
+                            "tokens_per_s": 1.0 / td, "ms_per_step": td * 1e3, "bound": "hbm", "GBps": dbytes / td / 1e9, "frac": dbytes / td / 1e9 / HBM_PEAK_GBS,
+                            "kernel": "dec8_kernel<int8, fused cast>"}
+        del dws
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out["decode_M1"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         from oracle import c_ref
         rng = np.random.default_rng(1)
@@ -593,7 +619,7 @@ def _fp8_layer_fns(device, shard_of, layers, ms, gen):
 def config_fp8_shards(stream, device, args):
     """configs[3], one GPU's share of the work: the Llama-3-70B TP=8 shard linears (no collective on one GPU)."""
     gen = torch.Generator(device=device).manual_seed(2)
-    layers, ms = 80, (1, 128, 2048)
+    layers, ms = args.fp8_layers, (1, 128, 2048)
     wts, step = _fp8_layer_fns(device, 8, layers, ms, gen)
     wbytes = sum(ns * ks for _, ns, ks, _, _ in wts)
     res = {}
@@ -1000,6 +1026,9 @@ def main():
             flat["int8_dyn_tokens_per_s"] = c["int8_dyn_bs128x2048"]["value"]
             flat["int8_dyn_gemm_frac_of_int8_mfma_peak"] = c["int8_dyn_bs128x2048"]["roofline"]["frac"]
             flat["int8_dyn_end_to_end_frac_of_int8_mfma_peak"] = c["int8_dyn_bs128x2048"]["roofline"]["end_to_end_TOPs"] / MFMA_8BIT_PEAK_TOPS
+            if "frac" in c["int8_dyn_bs128x2048"].get("decode_M1", {}):
+                flat["int8_decode_M1_tokens_per_s"] = c["int8_dyn_bs128x2048"]["decode_M1"]["tokens_per_s"]
+                flat["int8_decode_M1_frac_of_hbm_peak"] = c["int8_dyn_bs128x2048"]["decode_M1"]["frac"]
         if "fp8_tp8_shards" in c and "by_M" in c["fp8_tp8_shards"]:
             for mk, r in c["fp8_tp8_shards"]["by_M"].items():
                 flat[f"fp8_shards_{mk}_tokens_per_s"] = r["tokens_per_s"]

@@ -30,22 +30,23 @@ f=$(find $O/prof_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/int4_ker
 echo "== rocprof pmc, headline (separate passes) =="
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_pmc_fetch -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_pmc_write -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_write.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/prof_pmc_sq -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_sq.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_pmc_sq2 -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_sq2.log 2>&1
+[ "${AO_PROFILE_FULL:-0}" = 1 ] && timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $O/prof_pmc_sq -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_sq.log 2>&1
+[ "${AO_PROFILE_FULL:-0}" = 1 ] && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/prof_pmc_sq2 -o int4 -- $HEAD_CMD --steps 2 > $O/rocprof_pmc_sq2.log 2>&1
 echo "== rocprof pmc + stats, secondary configs (one bench.py process per config; FETCH_SIZE and WRITE_SIZE in separate passes) =="
 CFG_CMD="python $R/bench.py --warmup 1 --steps 2 --no-cpu-baseline --no-second-layout --no-stack-baseline --no-subclass-graph"
-# (fp8: its FETCH_SIZE pass did not finish in 900 s under counter collection in this round's first profile run -- not repeated; `traffic` stays null for it)
-for c in int4_bs128 int8 mx; do
-  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_cfg_${c}_fetch -o cfg -- $CFG_CMD --configs $c > $O/rocprof_cfg_${c}_fetch.log 2>&1
-  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_cfg_${c}_write -o cfg -- $CFG_CMD --configs $c > $O/rocprof_cfg_${c}_write.log 2>&1
+# (fp8: under counter collection the 80-layer config did not finish in 900 s in round 3; the counters are per launch, so 4 layers do)
+for c in int4_bs128 int8 mx fp8; do
+  EXTRA=""; [ $c = fp8 ] && EXTRA="--fp8-layers 4"
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_cfg_${c}_fetch -o cfg -- $CFG_CMD --configs $c $EXTRA > $O/rocprof_cfg_${c}_fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_cfg_${c}_write -o cfg -- $CFG_CMD --configs $c $EXTRA > $O/rocprof_cfg_${c}_write.log 2>&1
   python $R/scripts/pmc_summary.py $O/prof_cfg_${c}_fetch $O/prof_cfg_${c}_write -o $O/cfg_${c}_pmc.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --configs $c --steps 2" > /dev/null
 done
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg_stats -o cfg -- $CFG_CMD --configs int4_bs128,fp8,mx > $O/rocprof_cfg_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg_stats -o cfg -- $CFG_CMD --configs int4_bs128,fp8,mx --fp8-layers 8 > $O/rocprof_cfg_stats.log 2>&1
 f=$(find $O/prof_cfg_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/configs_kernel_stats.csv && head -8 "$f" | cut -c1-160
 O=$O python - <<'PY'
 import json, os
 O = os.environ["O"]
-dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8_kernel", "mx": "mx_stream_kernel"}
+dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8_kernel", "mx": "mx_stream_kernel", "fp8": "gemm8_p8_kernel"}
 out = {"source": "scripts/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes per config; FETCH x1024 x2 (gfx950), WRITE x1024 (uncalibrated); "
                  "mean over the dispatches of the config's dominant kernel", "configs": {}}
 for c, k in dom.items():
@@ -59,11 +60,15 @@ for c, k in dom.items():
         out["configs"][c] = {"kernel": k, "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "hbm_read_bytes_per_launch": e.get("hbm_read_bytes_per_launch"),
                              "hbm_write_bytes_per_launch": e.get("hbm_write_bytes_per_launch"), "dispatches": e.get("dispatches"),
                              "other_kernels": {kk: vv.get("hbm_bytes_per_launch") for kk, vv in d.items() if kk != k}}
-out["configs"]["fp8"] = {"kernel": "gemm8_p8_kernel", "hbm_bytes_per_launch": None,
-                         "note": "FETCH_SIZE pass of this config exceeded 900 s under counter collection (first round-3 profile run); not collected"}
 json.dump(out, open(f"{O}/configs_pmc.json", "w"), indent=1)
 print({c: (round(v.get("hbm_bytes_per_launch") or 0) if isinstance(v, dict) else v) for c, v in out["configs"].items()})
 PY
+cd $R
+python scripts/pmc_summary.py $O/prof_pmc_fetch $O/prof_pmc_write -o $O/int4_pmc.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 2 --no-configs" | grep -A8 '"int4_mm_kernel"' | head -12
+find $O -name "*counter_collection.csv" -size +6M -delete 2>/dev/null; find $O -name "*kernel_trace.csv" -size +6M -delete 2>/dev/null
+# the parts below did not change in round 4 (GEMM MFMA-busy counters, SQ counters of the int4 decode kernel, tile-shape sweeps): AO_PROFILE_FULL=1 re-collects them
+[ "${AO_PROFILE_FULL:-0}" = 1 ] || { echo "== round-4 micro-benchmarks =="; for b in 1 16; do timeout 300 python tools/bench_fp8_int4.py --batch $b 2>/dev/null | grep "^{"; done > $O/fp8_int4.jsonl; timeout 300 python tools/bench_dec8.py --ms 1 > $O/dec8.jsonl 2>/dev/null; du -sh $O; exit 0; }
+cd /tmp
 echo "== rocprof 8-bit GEMM: stats + MFMA-busy pmc =="
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_gemm_stats -o gemm8 -- python $R/tools/bench_8bit.py --which int8,fp8l --m 8192 --iters 5 > $O/rocprof_gemm_stats.log 2>&1
 f=$(find $O/prof_gemm_stats -name "*kernel_stats.csv" | head -1); cp "$f" $O/gemm8_kernel_stats.csv; head -5 "$f" | cut -c1-200
