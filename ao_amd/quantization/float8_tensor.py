@@ -176,6 +176,64 @@ def _(func, types, args, kwargs):
     return Float8Tensor(qdata, scale, block_size, t0.dtype_, t0.act_quant_kwargs, t0.act_pre_scale)
 
 
+def _like(self, qdata, scale):
+    """A Float8Tensor over (qdata, scale) with this one's kwargs; block sizes follow from the two shapes."""
+    bs = [qdata.shape[i] // scale.shape[i] for i in range(qdata.dim())]
+    return Float8Tensor(qdata, scale, bs, self.dtype_, self.act_quant_kwargs, self.act_pre_scale)
+
+
+@implements(aten.view.default)
+def _(func, types, args, kwargs):
+    """reference :863-906: 3-D <-> 2-D with the last dimension kept (MoE experts flattened / restored), or a same-rank view with
+    matching (or -1) sizes; the scale is reshaped block for block."""
+    self, size = args[0], list(args[1])
+    shape = list(self.shape)
+    if len(shape) == 3 and len(size) == 2:
+        assert shape[-1] == size[-1], f"Only support reshaping when last dimension matches, requested: reshaping from {shape} to {size}"
+        return _like(self, self.qdata.reshape(*size), self.scale.reshape(-1, self.scale.shape[-1]))
+    if len(shape) == 2 and len(size) == 3:
+        assert shape[-1] == size[-1], f"Only support reshaping when last dimension matches, requested: reshaping from {shape} to {size}"
+        q = self.qdata.reshape(*size)
+        bs = [1, self.block_size[0], self.block_size[1]]
+        return _like(self, q, self.scale.reshape(*[q.shape[i] // bs[i] for i in range(3)]))
+    assert len(shape) == len(size) and all(x == y or y == -1 for x, y in zip(shape, size)), (
+        f"Only support viewing with match dimensions or -1, got: {shape}, {size}")
+    return _like(self, self.qdata.reshape(*size), self.scale)
+
+
+@implements(aten.squeeze.dim)
+def _(func, types, args, kwargs):
+    """reference :909-928"""
+    self, dim = args[0], args[1]
+    assert dim == 0, f"Only dim == 0 is supported, got: {dim}"
+    return _like(self, self.qdata.squeeze(dim=dim), self.scale.squeeze(dim=dim))
+
+
+@implements(aten.unsqueeze.default)
+def _(func, types, args, kwargs):
+    """reference :953-971"""
+    self, dim = args[0], args[1]
+    return _like(self, self.qdata.unsqueeze(dim=dim), self.scale.unsqueeze(dim=dim))
+
+
+@implements(aten.split.Tensor)
+def _(func, types, args, kwargs):
+    """reference :1013-1078 (torch.chunk / split of a merged weight back into its parts): along a dimension with one scale per element
+    the scales are split too, along a blocked dimension every chunk keeps the scale (its block is the chunk)."""
+    self, size = args[0], args[1]
+    dim = args[2] if len(args) > 2 else kwargs.get("dim", 0)
+    assert isinstance(size, int), "unimplemented"
+    dim = dim % self.dim()
+    qs = torch.split(self.qdata, size, dim)
+    if self.scale.shape[dim] == 1 and self.block_size[dim] == self.shape[dim]:
+        scales = [self.scale] * len(qs)
+    elif self.scale.shape[dim] == self.shape[dim] and self.block_size[dim] == 1:
+        scales = torch.split(self.scale, size, dim)
+    else:
+        raise AssertionError(f"`aten.split.Tensor` with {dim=} and {self.scale.shape=} is not yet implemented")
+    return [_like(self, q, sc) for q, sc in zip(qs, scales)]
+
+
 def _float8_linear(x, w, bias):
     """reference :278-469 -> preprocess_data / preprocess_scale -> _scaled_mm(A row-major,
     B = W.t() column-major, scale_a [M,1], scale_b [1,N], bias, out_dtype, use_fast_accum)."""

@@ -168,7 +168,7 @@ def rocprof_avg_us(kernel_substr):
     return total_ns / calls / 1e3, os.path.relpath(path, ROOT)
 
 
-def pmc_traffic_of(config_key):
+def pmc_traffic_of(config_key, workload=None):
     """HBM bytes per launch of a secondary config's dominant kernel from the committed rocprofv3 PMC summary
     (profiles/configs_pmc_<round>.json, scripts/gpu_profile.sh: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes)."""
     path = os.path.join(ROOT, "profiles", f"configs_pmc_{ROUND}.json")
@@ -179,6 +179,9 @@ def pmc_traffic_of(config_key):
     e = d.get("configs", {}).get(config_key)
     if not e:
         return None, None
+    if workload is not None:  # a config that times more than one workload in one process (MX): its dispatches split by order
+        w = e.get("by_workload", {}).get(workload)
+        return (w.get("hbm_bytes_per_launch"), f"{os.path.relpath(path, ROOT)}: {e.get('kernel', '?')} ({workload})") if w else (None, None)
     return e.get("hbm_bytes_per_launch"), f"{os.path.relpath(path, ROOT)}: {e.get('kernel', '?')}"
 
 
@@ -712,6 +715,7 @@ def config_mx(stream, device, args):
                                      "every expert's weights are read (SURVEY.md 8(d): 484.4 MB per w1)",
                          "value": 64 / tu, "unit": "tokens/s", "ms_per_step": tu * 1e3,
                          "roofline": {"bound": "hbm", "achieved": bts_u / tu / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bts_u / tu / 1e9 / HBM_PEAK_GBS,
+                                      "traffic": pmc_traffic_of("mx", "uniform16")[0], "traffic_source": pmc_traffic_of("mx", "uniform16")[1],
                                       "algorithmic_bytes_per_step": bts_u, "timing": "hipGraph replay wall time of the whole step (activation casts included)"}}}
     if not args.no_cpu_baseline:
         from oracle import c_ref

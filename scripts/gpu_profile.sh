@@ -60,6 +60,31 @@ for c, k in dom.items():
         out["configs"][c] = {"kernel": k, "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"), "hbm_read_bytes_per_launch": e.get("hbm_read_bytes_per_launch"),
                              "hbm_write_bytes_per_launch": e.get("hbm_write_bytes_per_launch"), "dispatches": e.get("dispatches"),
                              "other_kernels": {kk: vv.get("hbm_bytes_per_launch") for kk, vv in d.items() if kk != k}}
+# the MX config times TWO workloads in one process: the first half of mx_stream_kernel's dispatches is the multinomial draw (3 of 8 experts
+# hit), the second half 16 tokens on every expert -- split them (the config's roofline line quotes the multinomial half)
+try:
+    import csv, glob
+    def _vals(d, counter):
+        rows = []
+        for f in glob.glob(f"{O}/{d}/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f, newline="")):
+                if "mx_stream_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        return [v for _, v in sorted(rows)]
+    fe, wr = _vals("prof_cfg_mx_fetch", "FETCH_SIZE"), _vals("prof_cfg_mx_write", "WRITE_SIZE")
+    h = len(fe) // 2
+    if h and len(wr) == len(fe) and "mx" in out["configs"] and "hbm_bytes_per_launch" in out["configs"]["mx"]:
+        by = {}
+        for name, (fa, wa) in {"multinomial": (fe[:h], wr[:h]), "uniform16": (fe[h:], wr[h:])}.items():
+            rd, ww = sum(fa) / len(fa) * 1024 * 2, sum(wa) / len(wa) * 1024
+            by[name] = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": ww, "hbm_bytes_per_launch": rd + ww, "dispatches": len(fa)}
+        m = out["configs"]["mx"]
+        m["note"] = "first half of the kernel's dispatches = the multinomial draw, second half = 16 tokens on every expert; the top-level fields are the multinomial half (all-dispatch mean: %.0f)" % m["hbm_bytes_per_launch"]
+        m["by_workload"] = by
+        for k in ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch"):
+            m[k] = by["multinomial"][k]
+except Exception as e:  # noqa: BLE001
+    out["configs"].setdefault("mx", {})["split_error"] = repr(e)
 json.dump(out, open(f"{O}/configs_pmc.json", "w"), indent=1)
 print({c: (round(v.get("hbm_bytes_per_launch") or 0) if isinstance(v, dict) else v) for c, v in out["configs"].items()})
 PY
