@@ -33,49 +33,52 @@ def _worker(rank, world, port, q):
 
         dev = "cuda"
         g = torch.Generator().manual_seed(11)  # same tensors on every rank
-        hidden, ffn, m = 512, 1024, 5
-        x = torch.randn(m, hidden, generator=g).to(torch.bfloat16)
+        hidden, ffn = 512, 1024
         w_up = (torch.randn(ffn, hidden, generator=g) * 0.05).to(torch.bfloat16)
         w_down = (torch.randn(hidden, ffn, generator=g) * 0.05).to(torch.bfloat16)
         res = {}
-        for kind, cfg in (("int8", Int8DynamicActivationInt8WeightConfig()), ("fp8", Float8DynamicActivationFloat8WeightConfig(granularity=PerRow())),
+        # m = 5: amax all-reduce + accumulator all-reduce + one epilogue;  m = 128 (round 4): reduce-scatter -> epilogue on m / world rows ->
+        # all-gather, with the real kernels on both ranks (gloo has no reduce-scatter: all-reduce + slice stands in for it)
+        for m in (5, 128):
+          x = torch.randn(m, hidden, generator=g).to(torch.bfloat16)
+          for kind, cfg in (("int8", Int8DynamicActivationInt8WeightConfig()), ("fp8", Float8DynamicActivationFloat8WeightConfig(granularity=PerRow())),
                           ("int4", Int4WeightOnlyConfig(group_size=128, int4_packing_format="tile_packed_to_4d"))):
-            up = torch.nn.Linear(hidden, ffn, bias=False, device=dev, dtype=torch.bfloat16)
-            down = torch.nn.Linear(ffn, hidden, bias=False, device=dev, dtype=torch.bfloat16)
-            with torch.no_grad():
-                up.weight.copy_(w_up)
-                down.weight.copy_(w_down)
-            quantize_(up, cfg)
-            quantize_(down, cfg)
-            col = parallel.shard_linear_(up, "colwise")                              # N split, no exchange
-            row = parallel.shard_linear_(down, "rowwise", input_is_parallel=True)    # K split, exact protocol for the 8-bit kinds
-            h_local = col(x.to(dev))                                                  # [m, ffn / world]
-            y = row(h_local)                                                          # all ranks: [m, hidden]
-            parts = [torch.empty_like(h_local) for _ in range(world)]
-            dist.all_gather(parts, h_local.contiguous())
-            h_seen = torch.cat(parts, dim=1).float().cpu().numpy()                    # the activation the row-parallel linear was given
-            # reference on the host: unsharded linears with the oracle's arithmetic
-            xn, un, dn = x.float().numpy(), w_up.float().numpy(), w_down.float().numpy()
-            if kind == "int8":
-                h = I8.linear(xn, un)
-                yr = I8.linear(h_seen, dn)
-            elif kind == "fp8":
-                h = F8.linear(xn, un)
-                yr = F8.linear(h_seen, dn)
-            else:
-                def lin4(a, w):
-                    s, z = R4.choose_qparams_tinygemm(w, 128)
-                    qd = R4.convert_weight_to_int4pack(R4.nibble_pack(R4.quantize_tinygemm(w, s, z, 128)))
-                    return R4.weight_int4pack_mm(a, qd, 128, R4.pack_scales_and_zeros(s, z))
-                h = lin4(xn, un)
-                yr = lin4(h_seen, dn)
-            n0, n1 = col.rows
-            hl = h_local.float().cpu().numpy()
-            yn = y.float().cpu().numpy()
-            rel_h = float(np.linalg.norm(hl - h[:, n0:n1]) / np.linalg.norm(h[:, n0:n1]))
-            rel_y = float(np.linalg.norm(yn - yr) / np.linalg.norm(yr))
-            exact = bool(np.array_equal(yn, yr.astype(np.float32)))
-            res[kind] = (rel_h, rel_y, exact)
+              up = torch.nn.Linear(hidden, ffn, bias=False, device=dev, dtype=torch.bfloat16)
+              down = torch.nn.Linear(ffn, hidden, bias=False, device=dev, dtype=torch.bfloat16)
+              with torch.no_grad():
+                  up.weight.copy_(w_up)
+                  down.weight.copy_(w_down)
+              quantize_(up, cfg)
+              quantize_(down, cfg)
+              col = parallel.shard_linear_(up, "colwise")                              # N split, no exchange
+              row = parallel.shard_linear_(down, "rowwise", input_is_parallel=True)    # K split, exact protocol for the 8-bit kinds
+              h_local = col(x.to(dev))                                                  # [m, ffn / world]
+              y = row(h_local)                                                          # all ranks: [m, hidden]
+              parts = [torch.empty_like(h_local) for _ in range(world)]
+              dist.all_gather(parts, h_local.contiguous())
+              h_seen = torch.cat(parts, dim=1).float().cpu().numpy()                    # the activation the row-parallel linear was given
+              # reference on the host: unsharded linears with the oracle's arithmetic
+              xn, un, dn = x.float().numpy(), w_up.float().numpy(), w_down.float().numpy()
+              if kind == "int8":
+                  h = I8.linear(xn, un)
+                  yr = I8.linear(h_seen, dn)
+              elif kind == "fp8":
+                  h = F8.linear(xn, un)
+                  yr = F8.linear(h_seen, dn)
+              else:
+                  def lin4(a, w):
+                      s, z = R4.choose_qparams_tinygemm(w, 128)
+                      qd = R4.convert_weight_to_int4pack(R4.nibble_pack(R4.quantize_tinygemm(w, s, z, 128)))
+                      return R4.weight_int4pack_mm(a, qd, 128, R4.pack_scales_and_zeros(s, z))
+                  h = lin4(xn, un)
+                  yr = lin4(h_seen, dn)
+              n0, n1 = col.rows
+              hl = h_local.float().cpu().numpy()
+              yn = y.float().cpu().numpy()
+              rel_h = float(np.linalg.norm(hl - h[:, n0:n1]) / np.linalg.norm(h[:, n0:n1]))
+              rel_y = float(np.linalg.norm(yn - yr) / np.linalg.norm(yr))
+              exact = bool(np.array_equal(yn, yr.astype(np.float32)))
+              res[(kind, m)] = (rel_h, rel_y, exact)
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -96,12 +99,13 @@ def test_tp_linears_two_ranks_one_gpu_vs_unsharded_oracle():
         assert p.exitcode == 0
     out = dict(q.get() for _ in range(world))
     for rank in range(world):
-        r = out[rank]
-        assert r["int8"][0] == 0.0 and r["int8"][2], r["int8"]        # int8: column shard and exact row-parallel result bit-exact
-        assert r["fp8"][0] <= 1e-3 and r["fp8"][1] <= 1e-3, r["fp8"]  # fp8: within the BASELINE tolerance of the unsharded oracle
-        # int4 weight-only: the op's contract is a bf16 output, so each rank's partial sum is rounded to bf16 before the all-reduce adds
-        # them in bf16 -- what a caller of the reference's F.linear(x_shard, w_shard) + all_reduce gets too; one bf16 ulp is 3.9e-3
-        assert r["int4"][0] <= 1e-3 and r["int4"][1] <= 4e-3, r["int4"]
+        for m in (5, 128):
+            r = {k: out[rank][(k, m)] for k in ("int8", "fp8", "int4")}
+            assert r["int8"][0] == 0.0 and r["int8"][2], (m, r["int8"])        # int8: column shard and exact row-parallel result bit-exact
+            assert r["fp8"][0] <= 1e-3 and r["fp8"][1] <= 1e-3, (m, r["fp8"])  # fp8: within the BASELINE tolerance of the unsharded oracle
+            # int4 weight-only: the op's contract is a bf16 output, so each rank's partial sum is rounded to bf16 before the all-reduce adds
+            # them in bf16 -- what a caller of the reference's F.linear(x_shard, w_shard) + all_reduce gets too; one bf16 ulp is 3.9e-3
+            assert r["int4"][0] <= 1e-3 and r["int4"][1] <= 4e-3, (m, r["int4"])
 
 
 def _ep_worker(rank, world, port, q):
