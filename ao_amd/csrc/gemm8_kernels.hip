@@ -525,7 +525,10 @@ extern "C" int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float*
     return dec8_scaled(false, a, scale_a, b, scale_b, bias, y, M, N, K, (hipStream_t)stream);  // round 4: full-line register ring
   if (M > 16 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only && g_gemm8_tm == 0 && !g_gemm8_force_regstage && mid8_takes(M, N, K))
     return mid8_scaled(false, a, scale_a, b, scale_b, bias, y, M, N, K, (hipStream_t)stream);  // round 4: 16 < M <= 256, few output tiles
-  const bool rb = fp8_rowwise_rb_preferred(M, N, K) && (M > 64 || K >= 4096 || fp8_rowwise_rb_forced());
+  // (round 4, cold weights -- every call of the replay reads another copy: the LDS-staged kernel wins from 33 rows on at every K of the
+  // 70B / TP8 shards, down 8192 x 3584 at M = 64: 14.0 us against 20.9 through the per-tile kernel, o 8192 x 1024: 8.5 against 9.2; the
+  // round-1 rule -- "only from K >= 4096 at 32 < M <= 64" -- had been measured on ONE re-used weight, i.e. out of the Infinity Cache)
+  const bool rb = fp8_rowwise_rb_preferred(M, N, K) && (M > 32 || fp8_rowwise_rb_forced());
   if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb)) && !(fp8_rowwise_rb_forced() && rb) && !g_gemm8_tiled_only)
     return fp8_rowwise_stream(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
   if (rb) return fp8_rowwise_rb(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
