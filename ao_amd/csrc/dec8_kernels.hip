@@ -25,6 +25,7 @@
 #include "common.h"
 #include "quant_math.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace ao {
@@ -54,8 +55,12 @@ constexpr int kXV = 4;                      // 16-byte activation vectors a thre
 // XFAST: a wave holds the activation slice of its own k-run in registers (DYN: M == 1; pre-quantized: M x DEPTH <= 32) -- those loads
 // go out first, the ring behind them, cast / copy run under the weights' flight and stay wave-private.  Otherwise the workgroup-wide
 // cast / copy loops run first and the ring is requested after them.
-template <bool INT8, bool DYN, int DEPTH, bool XFAST, bool HALF>
+// LOOP: any K % 128 == 0 -- a wave's run is ceil / floor (K / 128 / waves) steps, walked with the DEPTH-deep ring refilled slot by slot
+// (steady state branch-free, so the compiler still counts its vmcnt waits; the drain has uniform branches).  K of the popular models
+// that do not factor into <= 16 waves x {8, 7, 4, 2, 1} steps take it: Llama-2-7B's 11008 (86 steps), Llama-3-70B's unsharded 28672.
+template <bool INT8, bool DYN, int DEPTH, bool XFAST, bool HALF, bool LOOP = false>
 __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
+  static_assert(!(LOOP && XFAST), "the loop form casts / copies the activation workgroup-wide");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,33 +73,29 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
   float* rs = wmax + nwaves * 16;                                               // [16]
 
   const int ntile = blockIdx.x;
-  const int ks0 = wave * DEPTH;  // this wave's first 128-k step
+  const int ksteps = p.K >> 7;
+  const int ks0 = LOOP ? (ksteps * wave) / nwaves : wave * DEPTH;  // this wave's first 128-k step
+  const int ks1 = LOOP ? (ksteps * (wave + 1)) / nwaves : ks0 + DEPTH;
   const int kq = lane >> 4, nl = lane & 15;
 
   struct Stage {
     u32x4 b0, b1;
   };
   Stage st[DEPTH];
+  // lane l: HALF -- row l & 15, pieces kq and 4 + kq of the step (the operand layout);  else row (l >> 3) of the tile's rows 0..7 (b0) /
+  // 8..15 (b1), chunk l & 7 of the step's 128 bytes: full lines
+  const uint8_t* brow = (HALF ? p.b + ((size_t)ntile * 16 + nl) * p.K + kq * 16 : p.b + ((size_t)ntile * 16 + (lane >> 3)) * p.K + (lane & 7) * 16) +
+                        (size_t)ks0 * 128;  // the wave's first step; steps are addressed relative to it (straight-line form: immediates)
+  const size_t b1off = HALF ? (size_t)64 : (size_t)8 * p.K;
+  auto issue_step = [&](Stage& s, int rel) {
+    s.b0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + rel * 128));
+    s.b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + b1off + rel * 128));
+    __builtin_amdgcn_sched_barrier(0);  // request order = consumption order (VMEM returns in order)
+  };
   auto issue_ring = [&]() {
-    if constexpr (HALF) {
-      const uint8_t* brow = p.b + ((size_t)ntile * 16 + nl) * p.K + kq * 16 + (size_t)ks0 * 128;
+    const int last = max(ks1 - ks0 - 1, 0);  // (LOOP: a wave with fewer than DEPTH steps re-reads its last one, unused)
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        st[d].b0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + d * 128));
-        st[d].b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + d * 128 + 64));
-        __builtin_amdgcn_sched_barrier(0);  // request order = consumption order (VMEM returns in order)
-      }
-    } else {
-      // lane l: row (l >> 3) of the tile's rows 0..7 (b0) / 8..15 (b1), chunk l & 7 of the step's 128 bytes
-      const uint8_t* brow = p.b + ((size_t)ntile * 16 + (lane >> 3)) * p.K + (lane & 7) * 16 + (size_t)ks0 * 128;
-      const size_t half = (size_t)8 * p.K;
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        st[d].b0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + d * 128));
-        st[d].b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + half + d * 128));
-        __builtin_amdgcn_sched_barrier(0);  // request order = consumption order (VMEM returns in order)
-      }
-    }
+    for (int d = 0; d < DEPTH; ++d) issue_step(st[d], LOOP ? min(d, last) : d);
     // nothing that waits for an earlier load (the activation's) may be scheduled above the ring's requests
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -191,23 +192,22 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
 
   // ---- 2. one pass of the ring: transpose a step through the slab, multiply
   // rows >= M of the A operand alias row 0: they only reach output rows that are never stored
-  const char* arow = xq + (nl < p.M ? nl : 0) * stride + kq * 16 + ks0 * 128;
+  const char* arow = xq + (nl < p.M ? nl : 0) * stride + kq * 16 + ks0 * 128;  // relative steps, like the weights
   char* wr0 = slab + (lane >> 3) * kSlabStride + (lane & 7) * 16;  // this lane's piece of rows 0..7; rows 8..15: + 8 rows
   const char* rd = slab + nl * kSlabStride + kq * 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};  // int8: int32 bit patterns
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
+  auto consume = [&](const Stage& sg, int rel) {
     u32x4 b0, b1;
     if constexpr (HALF) {
-      b0 = st[d].b0; b1 = st[d].b1;
+      b0 = sg.b0; b1 = sg.b1;
     } else {
-      *reinterpret_cast<u32x4*>(wr0) = st[d].b0;
-      *reinterpret_cast<u32x4*>(wr0 + 8 * kSlabStride) = st[d].b1;
+      *reinterpret_cast<u32x4*>(wr0) = sg.b0;
+      *reinterpret_cast<u32x4*>(wr0 + 8 * kSlabStride) = sg.b1;
       b0 = *reinterpret_cast<const u32x4*>(rd);
       b1 = *reinterpret_cast<const u32x4*>(rd + 64);
     }
-    const u32x4 a0 = *reinterpret_cast<const u32x4*>(arow + d * 128);
-    const u32x4 a1 = *reinterpret_cast<const u32x4*>(arow + d * 128 + 64);
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(arow + rel * 128);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(arow + rel * 128 + 64);
     if constexpr (INT8) {
       i32x4 c = __builtin_bit_cast(i32x4, acc);
       c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, b0), c, 0, 0, 0);
@@ -218,6 +218,31 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
       const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
       acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc, 0, 0, 0, 127, 0, 127);
     }
+  };
+  if constexpr (!LOOP) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) consume(st[d], d);
+  } else {
+    const int n = ks1 - ks0;
+    int r = 0;
+    for (; r + 2 * DEPTH <= n; r += DEPTH) {  // steady state: every consumed slot is refilled, no branch in the body
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        consume(st[d], r + d);
+        issue_step(st[d], r + d + DEPTH);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {  // drain: fewer than 2 DEPTH steps left
+      if (r + d < n) {
+        consume(st[d], r + d);
+        if (r + d + DEPTH < n) issue_step(st[d], r + d + DEPTH);
+      }
+    }
+    r += DEPTH;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (r + d < n) consume(st[d], r + d);
   }
 
   // ---- 3. split-K reduction across waves (wave order: reproducible), scales, store
@@ -248,6 +273,7 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
 
 struct Dec8Shape {
   int waves, depth;
+  bool loop;  // K does not factor: the ring is refilled in a loop (depth 4)
 };
 
 // K = 128 * depth * waves: the deepest ring of {8, 7, 4, 2, 1} that leaves at most 16 waves.  (Measured on the 70B / TP8 fp8 shards and the
@@ -262,11 +288,14 @@ bool dec8_shape(int64_t K, int forced_depth, Dec8Shape* out) {
     if (ksteps % d != 0) continue;
     const int w = ksteps / d;
     if (w >= 1 && w <= 16) {
-      *out = Dec8Shape{w, d};
+      *out = Dec8Shape{w, d, false};
       return true;
     }
   }
-  return false;
+  if (forced_depth != 0) return false;
+  // no such factorization (K = 11008: 86 steps, K = 28672: 224 steps): up to 16 waves walk uneven runs with a 4-deep ring in a loop
+  *out = Dec8Shape{(int)std::min<int64_t>(16, std::max<int64_t>(1, ksteps / 4)), 4, true};
+  return true;
 }
 
 size_t dec8_lds(int64_t M, int64_t K, int waves) {
@@ -286,7 +315,18 @@ int launch_dec8_h(const Dec8Args& p, int waves, bool half, hipStream_t stream) {
 }
 
 template <bool INT8, bool DYN>
+int launch_dec8_loop(const Dec8Args& p, int waves, hipStream_t stream) {
+  const size_t smem = dec8_lds(p.M, p.K, waves);
+  auto kern = dec8_kernel<INT8, DYN, 4, false, false, true>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(dec8_kernel)")) return rc;
+  ao::launch(kern, dim3((unsigned)(p.N / 16)), dim3(waves * 64), smem, stream, p);
+  AO_LAUNCH_CHECK("dec8_kernel launch");
+  return AO_OK;
+}
+
+template <bool INT8, bool DYN>
 int launch_dec8(const Dec8Args& p, const Dec8Shape& s, hipStream_t stream) {
+  if (s.loop) return launch_dec8_loop<INT8, DYN>(p, s.waves, stream);
   const bool xfast = DYN ? (p.M == 1) : (p.M * s.depth * 8 <= kXV * 64);
   const bool half = g_dec8_mode == 290;
 #define AO_DEC8_CASE(D)                                                                      \

@@ -140,7 +140,9 @@ def test_fused_dynamic_linear_equals_cast_plus_matmul(kind, m, n, k, bias):
 
 @pytest.mark.parametrize("kind", ["int8", "fp8"])
 @pytest.mark.parametrize("m,n,k,bias", [(1, 1280, 8192, False), (1, 512, 1024, True), (1, 256, 3584, False), (2, 64, 4096, True), (5, 48, 896, True),
-                                        (16, 32, 2048, False), (3, 64, 14336, False), (1, 16, 128, True), (16, 16, 3968, True), (7, 80, 256, False)])
+                                        (16, 32, 2048, False), (3, 64, 14336, False), (1, 16, 128, True), (16, 16, 3968, True), (7, 80, 256, False),
+                                        # K that does not factor into <= 16 waves x {8, 7, 4, 2, 1} steps: the loop form (Llama-2-7B's 11008, 70B's unsharded 28672)
+                                        (1, 64, 11008, False), (4, 32, 128 * 17, True), (16, 48, 128 * 19, True), (1, 128, 28672, False), (2, 32, 128 * 23, False)])
 def test_decode_kernel_every_form(kind, m, n, k, bias):
     """Round 4: the straight-line decode kernel (dec8_kernels.hip: weights as full lines in a register ring, transposed through a
     wave-private LDS slab) in every ring depth it is built with, with half-line loads, and against the round-3 kernels: int8 bit-exact
