@@ -192,8 +192,10 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   const int S = SPLITK ? (int)gridDim.z : 1, ks = SPLITK ? (int)blockIdx.z : 0;
   const int pb0 = SPLITK ? (int)(((long long)kblocks * ks) / S) : 0;  // this part's k-blocks
   const int pbn = SPLITK ? (int)(((long long)kblocks * (ks + 1)) / S) - pb0 : kblocks;
-  const int kb0 = pb0 + (pbn * wave) / nwaves;
-  const int kb1 = pb0 + (pbn * (wave + 1)) / nwaves;
+  // straight-line form: every wave owns exactly DEPTH blocks (the host checked K = 128 DEPTH waves) -- no division by the runtime wave count
+  constexpr bool kFixedRun = STRAIGHT && !SPLITK && TILES == 1;
+  const int kb0 = kFixedRun ? wave * DEPTH : pb0 + (pbn * wave) / nwaves;
+  const int kb1 = kFixedRun ? kb0 + DEPTH : pb0 + (pbn * (wave + 1)) / nwaves;
 
   char* slab = smem + wave * SLAB;
   float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
@@ -211,6 +213,12 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   const int n = ntile * 16 + (lane & 15);
   const int kq = lane >> 4;
   const u32x4* wp = qdata + (size_t)ntile * kblocks * 64 + lane;
+  // the same stream as a wave-uniform base + a 32-bit lane offset (global_load saddr form: no 64-bit VALU address per request)
+  // straight-line form: the weight stream through a buffer descriptor -- SGPR base + SGPR block offset + one 32-bit lane offset, so a
+  // request costs no 64-bit VALU address
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(qdata) + (size_t)ntile * kblocks * 1024), 0, kblocks * 1024, 0x00020000);
+  const uint32_t wlane = (uint32_t)lane * 16u;
   const uint16_t* xrow0 = x + (size_t)m0 * K;
 
   // LDS addresses
@@ -240,8 +248,17 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   // straight-line code and the compiler can use counted s_waitcnt vmcnt(N).
   const int last_row = rows - 1;
   auto issue = [&](Stage& s, int kb, int t = 0) {
-    s.w = __builtin_nontemporal_load(wp + ((size_t)t * kblocks + kb) * 64);
     const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
+    if constexpr (kFixedRun && MAXM == 1) {
+      // measured (profiles/int4_addr_ab_r04.txt, three alternating processes on one box): weights through the descriptor 812 -> 818 tok/s;
+      // the scale / zero word and the x slice through descriptors too 796 -- those two stay plain global loads
+      s.w = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)wlane, kb * 1024, 2 /* nt: streamed once */));
+#pragma unroll
+      for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
+      s.xr.v[0] = *reinterpret_cast<const uint32_t*>(xrow0 + (size_t)kb * 128 + lane * 2);
+      return;
+    }
+    s.w = __builtin_nontemporal_load(wp + ((size_t)t * kblocks + kb) * 64);
 #pragma unroll
     for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n + 16 * t];
     if (MAXM <= 4) {
@@ -373,7 +390,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   // wave with fewer than DEPTH blocks just re-reads its last one, unused)
   const int kb_last = max(kb1 - 1, kb0);
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) issue(st[d], min(kb0 + d, kb_last));
+  for (int d = 0; d < DEPTH; ++d) issue(st[d], kFixedRun ? kb0 + d : min(kb0 + d, kb_last));
 
   // ring slots as compile-time indices (the slot's parity picks the x slab under SCHED 2)
   auto for_slots = [&](auto&& f) {

@@ -992,7 +992,7 @@ def main():
         }
         if stack is not None:
             out["stack_baseline"] = stack
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks of a multi-GPU run would sit in the barrier
             port = cpu_baseline_int4(args.batch)
             ref = reference_cpu_baseline_int4() if args.batch == 1 else None
             if ref is not None and "value" in ref:
