@@ -88,8 +88,13 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int tile_c = min(tile, ntiles - 1);  // tiles past N alias the last one; never stored
   const int ksteps = p.K >> 7;
   const int S = gridDim.z, ks = blockIdx.z;
-  const int k0 = (int)(((long long)ksteps * ks) / S);
-  const int nk = (int)(((long long)ksteps * (ks + 1)) / S) - k0;
+  // (32-bit: ksteps < 2^24 and S <= 16 -- the 64-bit division this used to be was ~300 scalar instructions at the head of every workgroup)
+  const int k0 = (int)(((unsigned)ksteps * (unsigned)ks) / (unsigned)S);
+  const int nk = (int)(((unsigned)ksteps * (unsigned)(ks + 1)) / (unsigned)S) - k0;
+  // Two more round-4 A/Bs on this kernel, both dropped (profiles/rb8_ab_r04.txt, cold 70B / TP8 shards at M = 128 / 64): the two weight
+  // DMAs (and the two activation DMAs) of a stage behind ONE M0 write: +- 0.1 us here and on the MX stream-K kernel; the epilogue's
+  // scales requested ahead of the meeting (at the head of the kernel, behind the loop, or behind the drain -- handed on through LDS):
+  // + 2 us per launch in all three placements.
   // rows of this workgroup: [m0, m_end) -- a slab of the matrix, or of one expert's token group.  Grouped kinds: blockIdx.y
   // enumerates the NON-EMPTY slabs in (expert, slab) order -- the y-th one is found from the group ends on the device, so the
   // grid needs ceil(M / BM) + E rows at most (not E x the slabs of the largest possible group) and an expert without tokens

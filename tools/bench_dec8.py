@@ -67,6 +67,22 @@ def main():
                 x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
                 xq, xs = quant(x)
                 for v in [int(v) for v in args.variants.split(",")]:
+                    if v < 0:  # -1: PyTorch core's own kernel (hipBLASLt) on the same cold copies -- what torchao-on-ROCm runs today
+                        rec = {"kind": kind, "shape": name, "N": n, "K": k, "M": m, "variant": "core", "copies": copies}
+                        try:
+                            if kind == "fp8":
+                                xs2 = xs.reshape(m, 1).contiguous()
+                                core = [lambda wq=wq, wsc=wsc: torch._scaled_mm(xq, wq.t(), scale_a=xs2, scale_b=wsc.reshape(1, n), out_dtype=torch.bfloat16, use_fast_accum=True)
+                                        for wq, wsc in ws]
+                            else:
+                                core = [lambda wq=wq: torch._int_mm(xq, wq.t()) for wq, wsc in ws]
+                            t = graph_time(core)
+                            rec["mm_us"] = round(t * 1e6, 2)
+                            rec["mm_TBps"] = round(n * k / t / 1e12, 3)
+                        except Exception as e:  # noqa: BLE001
+                            rec["error"] = repr(e)[:200]
+                        print(json.dumps(rec), flush=True)
+                        continue
                     lib.ao_gemm8_set_variant(v)
                     try:
                         if kind == "fp8":
