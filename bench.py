@@ -84,6 +84,7 @@ def parse_args():
     ap.add_argument("--fp8-layers", type=int, default=80, help="fp8 shard config: layers (80 = Llama-3-70B; counter-collection passes use fewer)")
     ap.add_argument("--no-stack-baseline", action="store_true", help="skip the PyTorch-core (what torchao-on-ROCm runs today) timing")
     ap.add_argument("--no-subclass-graph", action="store_true", help="skip the quantize_()-subclass + F.linear graph timing (a13)")
+    ap.add_argument("--tp-timeout", type=int, default=int(os.environ.get("AO_BENCH_TP_TIMEOUT", "240")), help="seconds the TP leg of a multi-GPU run may take before every rank leaves and rank 0 prints the line without it")
     ap.add_argument("--tp-one-shot", action="store_true", help="TP config: accumulator all-reduces of <= 1 MiB through the symmetric-memory one-shot path (prototype; default RCCL)")
     return ap.parse_args()
 
@@ -949,15 +950,7 @@ def main():
                 except Exception as e:  # noqa: BLE001 -- a secondary config must not take the headline line down
                     configs[name] = {"error": repr(e)}
                 torch.cuda.empty_cache()
-    if (world > 1 or args.force_tp) and "tp" in want and args.batch == 1:
-        model.io = {}
-        try:
-            tp = config_fp8_tp(stream, device, args, dist, world)
-        except Exception as e:  # noqa: BLE001
-            tp = {"error": repr(e)}
-        if rank == 0:
-            configs["fp8_tp"] = tp
-
+    out = None
     if rank == 0:
         bytes_step = model.bytes_per_step(args.batch)
         roofline_tok_s = HBM_PEAK_GBS * 1e9 / bytes_step * args.batch
@@ -1043,12 +1036,40 @@ def main():
             if "uniform16" in c["mxfp8_mixtral_bs64"]:
                 flat["mxfp8_mixtral_uniform16_tokens_per_s"] = c["mxfp8_mixtral_bs64"]["uniform16"]["value"]
                 flat["mxfp8_mixtral_uniform16_frac_of_hbm_peak"] = c["mxfp8_mixtral_bs64"]["uniform16"]["roofline"]["frac"]
-        if "fp8_tp" in c and "by_M" in c["fp8_tp"]:
-            for mk, r in c["fp8_tp"]["by_M"].items():
-                flat[f"fp8_tp_{mk}_tokens_per_s"] = r["tokens_per_s"]
-                flat[f"fp8_tp_{mk}_allreduce_ms_per_8_layers"] = r["allreduce_ms_per_8_layers"]
         out.update({k_: v for k_, v in flat.items() if v is not None})
-    if dist is not None:
+    if (world > 1 or args.force_tp) and "tp" in want and args.batch == 1:
+        # The TP leg is the only part of a multi-GPU run with collectives in it.  It runs LAST, with the headline line already assembled,
+        # under a watchdog: should a rank hang in it (a rendezvous or a peer mapping that this code has never seen on the node at hand), every
+        # rank leaves after --tp-timeout seconds and rank 0 still prints the line, with the leg marked as timed out.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out.setdefault("configs", {})["fp8_tp"] = {"error": "timed out after %d s: a rank hung in the TP leg (headline unaffected)" % args.tp_timeout}
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+
+        dog = threading.Timer(args.tp_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        model.io = {}
+        try:
+            tp = config_fp8_tp(stream, device, args, dist, world)
+        except Exception as e:  # noqa: BLE001
+            tp = {"error": repr(e)}
+        if rank == 0:
+            out.setdefault("configs", {})["fp8_tp"] = tp
+            if "by_M" in tp:
+                for mk, r in tp["by_M"].items():
+                    out[f"fp8_tp_{mk}_tokens_per_s"] = r["tokens_per_s"]
+                    out[f"fp8_tp_{mk}_allreduce_ms_per_8_layers"] = r["allreduce_ms_per_8_layers"]
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001
+            print(f"warning: process group shutdown: {e!r}", file=sys.stderr)
+        dog.cancel()
+    elif dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
