@@ -772,7 +772,10 @@ bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
   if (K % 128 != 0 || N % 16 != 0 || M * K >= (1ll << 32) || N * K >= (1ll << 32)) return false;
   if (g_fp8_rb_force == 1) return false;
   if (g_fp8_rb_force >= 2) return true;
-  return ((N + 127) / 128) * ((M + 127) / 128) < 190;
+  // up to one 128 x 128 workgroup per CU (one round of the chip).  Round 4 (profiles/fp8_dispatch_sweep_r04.txt, cold 70B / TP8 shards): the bound
+  // was 190, and the 224 - 256 tiles of M = 512 fell to the 4-wave two-stage tile kernel -- gate_up 73.6 us against 44.3 here (hipBLASLt
+  // 47.5), down 39.8 / 23.6 (24.4), o 20.9 / 11.7 (11.5); from two rounds on (M = 1024: 448 - 512 tiles) the tiled kernels are level or ahead
+  return ((N + 127) / 128) * ((M + 127) / 128) <= 256;
 }
 
 namespace {
