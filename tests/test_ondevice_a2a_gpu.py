@@ -38,6 +38,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
+    torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = {"rank": rank}
     try:

@@ -24,6 +24,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
+    torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ao_amd import parallel
@@ -112,6 +113,7 @@ def _ep_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
+    torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ao_amd.prototype.ep import a2a_combine_hp_fwd, a2a_dispatch_mxfp8_fwd, exchange_split_sizes
@@ -166,6 +168,7 @@ def _oneshot_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
+    torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ao_amd.parallel import OneShotAllReduce
