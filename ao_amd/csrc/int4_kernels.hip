@@ -1333,6 +1333,9 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     }
     if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
     if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
+    // round 4: an 8-row build between the 4- and the 16-row one (half the x requests, LDS staging and slab of the 16-row build for batches
+    // of 5 .. 8; mode 88 = the 16-row build as before, for A/B)
+    if (M <= 8 && g_tune_mode != 88) return launch_mm<G, 8>(x, qdata, sz, y, M, N, K, stream);
     return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
   }
   // 4 < M: int4_mm_rb_kernel on slabs of 16 / 32 / 64 / 128 rows (MT m-tiles: only the rows that exist are staged, read and

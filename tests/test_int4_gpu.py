@@ -107,7 +107,7 @@ def _mm_case(m, n, k, g, seed):
 
 
 @pytest.mark.parametrize("g", [32, 64, 128, 256])
-@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 16, 17, 33])
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 33])
 def test_mm_vs_oracle(m, g):
     y, y_ref = _mm_case(m, 64, 1024, g, 100 * m + g)
     assert y.shape == y_ref.shape
