@@ -479,6 +479,28 @@ extern "C" int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const i
   return launch_gemm8<EPI_INT8_SCALED>(p, (hipStream_t)stream);
 }
 
+// Which kernel the product dispatch of ao_fp8_scaled_mm / ao_int8_scaled_mm takes for a shape (host logic only: no launch, no GPU) -- the
+// rules of the two entry points above and below, restated without the tuning overrides.  tests/test_host_dispatch.py pins the table.
+extern "C" const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 16 != 0) return "invalid";
+  if (M <= 16 && dec8_takes(M, N, K)) return "dec8_kernel";
+  if (M > 16 && mid8_takes(M, N, K)) return "mid8_kernel";
+  const bool rb_shape = N % 16 == 0 && fp8_rowwise_rb_preferred(M, N, K);
+  if (int8) {
+    if (N % 16 == 0 && K % 128 == 0 && M <= 32) return "stream8_kernel";
+    if (rb_shape) return "rb8_kernel";
+  } else {
+    if (N % 16 != 0) return "invalid";
+    const bool rb = rb_shape && M > 32;
+    if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb))) return "stream8_kernel";
+    if (rb) return "rb8_kernel";
+  }
+  if (K % BK != 0) return "gemm8_kernel";  // register-staged tiles (K % 128 != 0)
+  const int64_t big = ((N + 255) / 256) * ((M + 255) / 256);
+  if (big >= 160 && gemm8_p8_fits(M, N, K)) return "gemm8_p8_kernel";
+  return big >= 512 ? "gemm8_dma_kernel<256x256>" : "gemm8_dma_kernel<128x128>";
+}
+
 extern "C" int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, int64_t M, int64_t N, int64_t K,
                               void* stream) {
   if (int rc = check_gemm_shape(__func__, M, N, K)) return rc;

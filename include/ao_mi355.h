@@ -127,6 +127,10 @@ int ao_gemm8_set_variant(int variant);
 /* Name of the kernel ao_int4_weight_int4pack_mm launches for this problem (product dispatch, no
  * tuning override): what a profiler's kernel table should be matched against.  Static string. */
 const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size);
+/* Which kernel ao_fp8_scaled_mm (int8 = 0) / ao_int8_scaled_mm (int8 = 1) dispatches a shape to: "dec8_kernel" (M <= 16), "mid8_kernel",
+ * "stream8_kernel", "rb8_kernel" (up to 256 tiles of 128 x 128), "gemm8_p8_kernel" / "gemm8_dma_kernel<...>" / "gemm8_kernel" (tiled), or
+ * "invalid".  Host logic only (no launch): bench / tests label their measurements with it.  DESIGN.md 4.4-4.5g. */
+const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int64_t K);
 /* Profiling only: device buffer [workgroups][16] of s_memtime stamps written by the trace builds of the batched
  * kernels (int4: tuning mode 65S; fp8 rowwise mid-M kernel: whenever the pointer is set); NULL disables. */
 int ao_int4_set_trace(unsigned long long* trace_dev);

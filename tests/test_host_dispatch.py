@@ -1,0 +1,62 @@
+"""CPU: the dispatch tables of the 8-bit and int4 linears, through the library's host-only introspection entries (no launch, no GPU).
+
+DESIGN.md 4.4-4.5g describes which kernel serves which (M, N, K) band and why (each boundary was measured); these tests pin the table so
+that a change of a rule shows up as a diff here.  Shapes: Llama-3-70B TP = 8 shards and Llama-3-8B linears of BASELINE.json's configs.
+"""
+import pytest
+
+from ao_amd import _lib
+
+TABLE = [
+    # decode: the straight-line register-ring kernel while the activation slab fits (M (K + 16) <= 64 KiB), else the round-3 per-tile kernel
+    ((1, 7168, 8192), "dec8_kernel"),
+    ((4, 8192, 1024), "dec8_kernel"),
+    ((16, 8192, 1024), "dec8_kernel"),
+    ((16, 7168, 8192), "stream8_kernel"),
+    # 17 .. 32 rows on long K: the register-ring mid-M kernel; short K stays with the per-tile kernel
+    ((17, 1280, 8192), "mid8_kernel"),
+    ((32, 1280, 8192), "mid8_kernel"),
+    ((32, 8192, 1024), "stream8_kernel"),
+    # from 33 rows: the LDS-staged weight-streaming kernel up to one 128 x 128 workgroup per CU (256 tiles; round 4: was 190)
+    ((33, 8192, 1024), "rb8_kernel"),
+    ((64, 7168, 8192), "rb8_kernel"),
+    ((64, 28672, 4096), "rb8_kernel"),
+    ((128, 8192, 3584), "rb8_kernel"),
+    ((128, 28672, 4096), "rb8_kernel"),
+    ((512, 7168, 8192), "rb8_kernel"),
+    ((512, 8192, 1024), "rb8_kernel"),
+    ((2048, 1280, 8192), "rb8_kernel"),
+    # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on
+    ((768, 7168, 8192), "gemm8_dma_kernel<128x128>"),
+    ((1024, 7168, 8192), "gemm8_dma_kernel<128x128>"),
+    ((2048, 4096, 4096), "gemm8_dma_kernel<128x128>"),
+    ((2048, 7168, 8192), "gemm8_p8_kernel"),
+    ((16384, 14336, 4096), "gemm8_p8_kernel"),
+    ((16384, 4096, 14336), "gemm8_p8_kernel"),
+    # K not a multiple of 128: the register-staged tile kernel
+    ((2048, 4096, 4000), "gemm8_kernel"),
+    ((0, 64, 1024), "invalid"),
+]
+
+
+@pytest.mark.parametrize("int8", [0, 1])
+def test_8bit_dispatch_table(int8):
+    lib = _lib.lib()
+    got = {shape: lib.ao_gemm8_kernel_name(int8, *shape).decode() for shape, _ in TABLE}
+    assert got == dict(TABLE)
+
+
+def test_fp8_needs_n_multiple_of_16_int8_does_not():
+    lib = _lib.lib()
+    assert lib.ao_gemm8_kernel_name(0, 128, 200, 1024).decode() == "invalid"
+    assert lib.ao_gemm8_kernel_name(1, 128, 200, 1024).decode() == "gemm8_dma_kernel<128x128>"
+
+
+def test_int4_dispatch_bands():
+    lib = _lib.lib()
+    name = lambda m, n, k: lib.ao_int4_mm_kernel_name(m, n, k, 128).decode()  # noqa: E731
+    # per-tile kernel (1-, 4-, 8- and 16-row builds) up to 16 rows; wide weights (>= 1024 n-tiles) switch to the batched kernel from 5 rows
+    assert [name(m, 14336, 4096) for m in (1, 4, 5, 8, 16)] == ["int4_mm_kernel"] * 5
+    assert [name(m, 28672, 4096) for m in (1, 4)] == ["int4_mm_kernel"] * 2
+    assert [name(m, 28672, 4096) for m in (5, 16)] == ["int4_mm_rb_kernel"] * 2
+    assert name(17, 4096, 4096) == "int4_mm_rb_kernel" and name(128, 14336, 4096) == "int4_mm_rb_kernel"
