@@ -20,6 +20,7 @@ int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale
 
 // rb8_kernels.hip: weight-streaming kernels for problems with few output tiles
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
+void rb8_set_wave_grid(bool two_by_four);  // rb8_kernels.hip
 void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
 extern thread_local int g_mx_variant;  // stream8_kernels.hip
@@ -451,7 +452,8 @@ extern "C" int ao_gemm8_set_variant(int variant) {
   g_mid8_mode = (variant >= 300 && variant <= 329) ? variant : 0;
   g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16 || variant == 32) ? variant : 0;
   // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
-  fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : (variant != 0 && variant < 110) ? 1 : 0);
+  fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : (variant != 0 && variant < 110 && variant != 103) ? 1 : 0);
+  rb8_set_wave_grid(variant != 103);  // 103: the weight-streaming kernel's round-3 wave arrangement (1 x 8), product dispatch otherwise
   return AO_OK;
 }
 

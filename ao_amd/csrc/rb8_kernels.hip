@@ -62,8 +62,14 @@ struct Rb8Args {
 // MT = 16-row m-tiles per slab (8, 4, 2): small batches / token groups stage, read and multiply only the rows they can have.
 // QS (MX): k steps per scale fetch -- 1: a dword DMA per row, step and operand; 4: one 16-byte DMA per row and FOUR steps, two slots
 // per wave and operand (K % 512 == 0, no K split).  The dword DMAs cost a quarter of the decode kernel (mx_stream_kernel below).
-template <int WAVES, int KIND, int MT = 8, bool TRACE = false, bool SLIM = false, int QS = 1>
+// SM (round 4, rowwise kinds, 8 waves x 128 rows): the waves stand 2 (m halves) x 4 (pairs of n-tiles) instead of 1 x 8 -- wave (wm, wn)
+// multiplies m-tiles 4 wm .. 4 wm + 3 by n-tiles 2 wn, 2 wn + 1.  Same DMAs, same rings, same LDS layout (wave w still FETCHES n-tile w
+// and its eighth of the activation tile; the step's barrier already orders everybody's fetches before anybody's reads), same 8
+// accumulators and MFMAs per wave and step -- but 4 + 2 operand fragments to read per step instead of 8 + 1: 12 ds_read_b128 for 18,
+// on a loop that is bound by the LDS reads (144 KiB per step and workgroup at 128 B / clk against 512 cycles of MFMA per SIMD).
+template <int WAVES, int KIND, int MT = 8, bool TRACE = false, bool SLIM = false, int QS = 1, bool SM = false>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
+  static_assert(!SM || (WAVES == 8 && MT == 8 && (KIND == RB8_FP8 || KIND == RB8_INT8)), "rb8_kernel: the 2 x 4 wave arrangement is built for 8 waves x 128 rows, rowwise kinds");
   constexpr int SCL = SLIM ? 64 : 256;  // bytes of one scale slot (one dword per row: 16 rows -> 64 B; unmasked DMAs write 256)
   static_assert(QS == 1 || (QS == 4 && KIND == RB8_MX && !SLIM), "rb8_kernel: 4-step scale fetches are an MX form");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [13] group found, [14] addresses ready
@@ -224,6 +230,38 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     issue_a((stage == 0) ? 2 : stage - 1, k + 2);
     issue_w((wstage == 0) ? kWStages - 1 : wstage - 1, k + kWStages - 1);
     const char* A = smem + stage * kABuf;
+    if constexpr (SM) {
+      // wave (wm, wn): n-tiles 2 wn + j (fetched by waves 2 wn + j), m-tiles 4 wm + i; acc[2 i + j]
+      const int wm = wave & 1, wn = wave >> 1;
+      u32x4 b0[2], b1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* Wj = smem + kStages * kABuf + ((2 * wn + j) * kWStages + wstage) * 2048;
+        b0[j] = *reinterpret_cast<const u32x4*>(Wj + pa);
+        b1[j] = *reinterpret_cast<const u32x4*>(Wj + (pa ^ 64));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + (4 * wm + i) * 2048 + pa);
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + (4 * wm + i) * 2048 + (pa ^ 64));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (INT8) {
+            i32x4 c = __builtin_bit_cast(i32x4, acc[2 * i + j]);
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, b0[j]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, b1[j]), c, 0, 0, 0);
+            acc[2 * i + j] = __builtin_bit_cast(f32x4, c);
+          } else {
+            const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+            const i32x8 bfj = {(int)b0[j].x, (int)b0[j].y, (int)b0[j].z, (int)b0[j].w, (int)b1[j].x, (int)b1[j].y, (int)b1[j].z, (int)b1[j].w};
+            acc[2 * i + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bfj, acc[2 * i + j], 0, 0, 0, 127, 0, 127);
+          }
+        }
+      }
+      stage = (stage == 2) ? 0 : stage + 1;
+      wstage = (wstage == kWStages - 1) ? 0 : wstage + 1;
+      continue;
+    }
     const char* W = smem + kStages * kABuf + (wave * kWStages + wstage) * 2048;
     const u32x4 b0 = *reinterpret_cast<const u32x4*>(W + pa);  // the n-tile's 16 rows are laid out like an m-tile
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(W + (pa ^ 64));
@@ -295,6 +333,39 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   if (TRACE) ts[11] = __builtin_amdgcn_s_memtime();
 
   // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
+  if constexpr (SM) {
+    const int wm = wave & 1, wn = wave >> 1;
+    uint16_t* __restrict__ y = p.y;
+    float sbj[2], biasj[2];
+    int nj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int tj = blockIdx.x * WAVES + 2 * wn + j;
+      nj[j] = (tj < ntiles) ? tj * 16 + nl : -1;
+      sbj[j] = p.scale_b[min(tj, ntiles - 1) * 16 + nl];
+      biasj[j] = p.bias != nullptr ? bf16_lo_to_f32(p.bias[min(tj, ntiles - 1) * 16 + nl]) : 0.f;
+    }
+    float sa[16];  // all row scales first: the stores below must not sit between dependent loads
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sa[i] = p.scale_a[min(m0 + (4 * wm + (i >> 2)) * 16 + kq * 4 + (i & 3), p.M - 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + (4 * wm + i) * 16 + kq * 4 + r;
+          if (m < m_end && nj[j] >= 0) {
+            float v;
+            if constexpr (INT8) v = round_bf16((float)__builtin_bit_cast(i32x4, acc[2 * i + j])[r] * sa[i * 4 + r]) * sbj[j];
+            else v = acc[2 * i + j][r] * sa[i * 4 + r] * sbj[j];
+            if (p.bias != nullptr) v += biasj[j];
+            y[(size_t)m * p.N + nj[j]] = f32_to_bf16_bits(v);
+          }
+        }
+    dump();
+    return;
+  }
   if (tile >= ntiles) { dump(); return; }
   const int n = tile * 16 + nl;
   uint16_t* __restrict__ y = p.y;
@@ -702,6 +773,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 }
 
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
+thread_local bool g_rb8_sm = true;  // rb8_kernel's 2 x 4 wave arrangement where it is built (ao_gemm8_set_variant 103: off)
 
 template <int WAVES, int KIND, int MT = 8, bool SLIM = false, int QS = 1>
 int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
@@ -730,6 +802,10 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   }
   p.trace = g_fp8_rb_trace;
   auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS>;
+  if constexpr (WAVES == 8 && MT == 8 && (KIND == RB8_FP8 || KIND == RB8_INT8) && !SLIM && QS == 1) {
+    // the 2 x 4 wave arrangement (fewer operand fragments per MFMA); ao_gemm8_set_variant(103): the 1 x 8 form, for A/B
+    if (g_rb8_sm) kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS, true> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS, true>;
+  }
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(rb8_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("rb8_kernel launch");
@@ -762,6 +838,7 @@ thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 
 }  // namespace
 
 void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
+void rb8_set_wave_grid(bool two_by_four) { g_rb8_sm = two_by_four; }
 void mx_rb_set_slim(bool on) { g_mx_slim_off = !on; }
 void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = quad; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
