@@ -394,6 +394,12 @@ int launch_gemm8_dma_tm(const Gemm8Args& p, hipStream_t stream) {
   return AO_OK;
 }
 
+// the shapes the phase-interleaved 256 x 256 kernel takes from the two-stage tile kernels (product rule; see launch_gemm8_dma)
+bool gemm8_p8_band(int64_t M, int64_t N, int64_t K) {
+  const int64_t big = ((N + 255) / 256) * ((M + 255) / 256), t128 = ((N + 127) / 128) * ((M + 127) / 128);
+  return big >= 160 || (big >= 128 && (K <= 4096 || t128 > 512));
+}
+
 template <int EPI>
 int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
   // variants (ao_gemm8_set_variant): 2 = 128 x 128 tile / 4 waves; 4 = 256 x 128 / 4 waves (one wave per SIMD:
@@ -407,7 +413,9 @@ int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
   // Measured on the Llama-3-8B shapes (profiles/gemm8_variants_r02.txt, TOP/s int8, this kernel vs the two-stage kernels):
   // M = 8192: 2046 / 2084 / 2492 / 2796 vs 1557 / 1508 / 1777 / 2153; M = 2048: qkv (192 tiles) 1832 vs 1210, gate_up 2148 vs 1566,
   // but o / down (128 tiles: half the CUs idle) 1350 / 1710 vs 1330 / 1834; M = 512: gate_up (224 tiles) 2122 vs 1231.
-  if ((g_gemm8_tm == 32 || (g_gemm8_tm == 0 && big >= 160)) && gemm8_p8_fits(p.M, p.N, p.K))
+  // Round 4 (profiles/gemm8_p8_band_r04.jsonl, cold weights): at 128 .. 159 such tiles it also wins while K <= 4096 (1024 x 8192 x 1024: 24.3 -> 20.2 us;
+  // K = 8192 / 14336: 2 - 7 % behind) and whenever the 128 x 128 grid would need a second round of the chip (> 512 tiles: 1280 x 7168 x 8192 129 -> 84 us)
+  if ((g_gemm8_tm == 32 || (g_gemm8_tm == 0 && gemm8_p8_band(p.M, p.N, p.K))) && gemm8_p8_fits(p.M, p.N, p.K))
     return gemm8_p8((int)EPI, p.a, p.b, p.row_scale, p.col_scale, p.bias, p.out, p.M, p.N, p.K, stream);
   if (g_gemm8_tm == 8 || (g_gemm8_tm == 0 && big >= 512)) return launch_gemm8_dma_tm<EPI, 4, 4>(p, stream);
   return launch_gemm8_dma_tm<EPI, 2, 2>(p, stream);
@@ -499,7 +507,7 @@ extern "C" const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int6
   }
   if (K % BK != 0) return "gemm8_kernel";  // register-staged tiles (K % 128 != 0)
   const int64_t big = ((N + 255) / 256) * ((M + 255) / 256);
-  if (big >= 160 && gemm8_p8_fits(M, N, K)) return "gemm8_p8_kernel";
+  if (gemm8_p8_band(M, N, K) && gemm8_p8_fits(M, N, K)) return "gemm8_p8_kernel";
   return big >= 512 ? "gemm8_dma_kernel<256x256>" : "gemm8_dma_kernel<128x128>";
 }
 
