@@ -39,6 +39,7 @@ constexpr int w_stages(int waves, int kind, int mt, bool slim = false) { return 
 
 // RB8_FP8_GROUPED: rowwise e4m3 like RB8_FP8, rows grouped by expert like RB8_MX (Float8Tensor's _grouped_mm, float8_tensor.py:1085-1122)
 enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2, RB8_FP8_GROUPED = 3 };
+constexpr bool GROUPED_KIND(int kind) { return kind == RB8_MX || kind == RB8_FP8_GROUPED; }
 
 struct Rb8Args {
   const uint8_t* a;       // [M][K] e4m3 / int8
@@ -55,6 +56,9 @@ struct Rb8Args {
   float* ws;
   unsigned* tickets;
   unsigned long long* trace;  // profiling build only
+  // round 5, rowwise kinds with K parts: xcd = 1 -- a 1-D grid of 8 * split * ceil(gx * gy / 8) workgroups in which the `split` parts of
+  // an output tile have ids that agree mod 8 (splitk.h: xcd_grid_decode), so that they run on ONE XCD and meet in its L2
+  int xcd, gx, gy, split;
 };
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
@@ -90,10 +94,21 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
   const int ntiles = p.N >> 4;
-  const int tile = blockIdx.x * WAVES + wave;
+  // (bx, by): the workgroup's column tile and slab; ks of S: its K part.  Three-dimensional grid, or the XCD-aware one-dimensional one
+  int bx = blockIdx.x, by = blockIdx.y, ks = blockIdx.z, S = gridDim.z, gx = gridDim.x;
+  if constexpr (!GROUPED_KIND(KIND)) {
+    if (p.xcd) {
+      int t;
+      S = p.split; gx = p.gx;
+      xcd_grid_decode(blockIdx.x, S, t, ks);
+      if (t >= p.gx * p.gy) return;  // uniform, before any DMA or barrier
+      by = t / gx; bx = t - by * gx;
+    }
+  }
+  const bool local = !GROUPED_KIND(KIND) && p.xcd != 0;
+  const int tile = bx * WAVES + wave;
   const int tile_c = min(tile, ntiles - 1);  // tiles past N alias the last one; never stored
   const int ksteps = p.K >> 7;
-  const int S = gridDim.z, ks = blockIdx.z;
   // (32-bit: ksteps < 2^24 and S <= 16 -- the 64-bit division this used to be was ~300 scalar instructions at the head of every workgroup)
   const int k0 = (int)(((unsigned)ksteps * (unsigned)ks) / (unsigned)S);
   const int nk = (int)(((unsigned)ksteps * (unsigned)(ks + 1)) / (unsigned)S) - k0;
@@ -105,10 +120,10 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // enumerates the NON-EMPTY slabs in (expert, slab) order -- the y-th one is found from the group ends on the device, so the
   // grid needs ceil(M / BM) + E rows at most (not E x the slabs of the largest possible group) and an expert without tokens
   // costs nothing.
-  int m0 = blockIdx.y * BM, m_end = p.M, expert = 0;
+  int m0 = by * BM, m_end = p.M, expert = 0;
   if constexpr (GROUPED) {
     if (p.offs != nullptr) {
-      int y = blockIdx.y, found = -1, begin = 0, end = 0;
+      int y = by, found = -1, begin = 0, end = 0;
       for (int e0 = 0; e0 < p.E && found < 0; e0 += 64) {  // 64 experts per pass: lane e owns expert e0 + e
         const int e = e0 + lane;
         const int lo = (e > 0 && e < p.E) ? p.offs[e - 1] : 0;
@@ -209,17 +224,34 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     }
   };
   if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
+  // FIRST (round 5, rowwise kinds with 6 weight stages): the operands of step 0 are requested first -- a(0) w(0) | a(1) w(1) | w(2) w(3) w(4)
+  // instead of w(0) w(1) w(2) | a(0) w(3) | a(1) w(4) -- and steps 0 and 1 wait only for what they read (everything younger than w(1):
+  // the three weight stages and, at step 1, a(2) w(5)); a workgroup's 112 priming DMAs take ~6 k cycles to issue, of which step 0 used to
+  // wait for the last one's data.  From step 2 on the order is the steady state's.
+  constexpr bool FIRST = !GROUPED && kWStages == 6;
   if constexpr (QS == 4) issue_s(0, 0);  // then the block of steps 4 j + 4 .. at the head of step 4 j + 1 (older than a(4 j + 3): landed by then)
+  if constexpr (FIRST) {
+    issue_a(0, 0); issue_w(0, 0);
+    issue_a(1, 1); issue_w(1, 1);
 #pragma unroll
-  for (int i = 0; i < kWStages - 3; ++i) issue_w(i, i);
-  issue_a(0, 0); issue_w(kWStages - 3, kWStages - 3);
-  issue_a(1, 1); issue_w(kWStages - 2, kWStages - 2);
+    for (int i = 2; i < kWStages - 1; ++i) issue_w(i, i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < kWStages - 3; ++i) issue_w(i, i);
+    issue_a(0, 0); issue_w(kWStages - 3, kWStages - 3);
+    issue_a(1, 1); issue_w(kWStages - 2, kWStages - 2);
+  }
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
   int stage = 0, wstage = 0;
   for (int k = 0; k < nk; ++k) {
     // (3 weight stages: w(k) is issued right behind a(k), so only a(k + 1) and w(k + 1) -- one stage -- may still be in flight)
     // (QS == 4: at k % 4 == 2 the two scale requests of step k - 1 are younger than a(k) too)
     if constexpr (QS == 4) { if ((k & 3) == 2) wait_vmcnt<LPSC + 2 + 2>(); else wait_vmcnt<LPSC + 2>(); }
+    else if constexpr (FIRST) {
+      // step 0: younger than w(0) are a(1) w(1) w(2) w(3) w(4); step 1: younger than w(1) are w(2) w(3) w(4) a(2) w(5); step k >= 2: a(k)
+      // was issued at step k - 2, behind it w(k + 3), a(k + 1), w(k + 4)
+      if (k < 2) wait_vmcnt<AD + 8>(); else wait_vmcnt<LPSC + 2>();
+    }
     else if constexpr (kWStages >= 4) wait_vmcnt<LPSC + 2 + (MX ? 1 : 0)>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading step k - 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -314,7 +346,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   auto dump = [&] {
     if (TRACE && p.trace != nullptr && tid == 0) {
       ts[12] = __builtin_amdgcn_s_memtime();
-      unsigned long long* t = p.trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
+      unsigned long long* t = p.trace + (p.xcd ? (size_t)blockIdx.x : ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)) * 16;
       for (int i = 0; i < 16; ++i) t[i] = ts[i];
     }
   };
@@ -323,8 +355,17 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // through one CU's memory path)
   bool go_on = true;
   if (S > 1) {
-    if (!GROUPED && S > 4) go_on = split_k_meet2<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem));
-    else go_on = split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem));
+    const int otile = by * gx + bx;
+    int* flag = reinterpret_cast<int*>(smem);
+    if constexpr (!GROUPED) {
+      // round 5: all parts on one XCD (p.xcd): the parked tiles stay in that XCD's L2 (splitk.h, LOCAL)
+      if (local) go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8, 4, true>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
+                                 : split_k_meet<MT, 64 * WAVES, INT8, true>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
+      else go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
+                           : split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
+    } else {
+      go_on = split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
+    }
   }
   if (!go_on) {
     dump();
@@ -333,6 +374,57 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   if (TRACE) ts[11] = __builtin_amdgcn_s_memtime();
 
   // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
+  if constexpr (!GROUPED) {
+    // Round 5: the scaled tile goes through the (now idle) LDS and leaves as 16-byte row pieces.  The direct form below stores two bytes
+    // per lane and instruction -- 32 store instructions per wave, 256 per workgroup, each a pass through the CU's one address path
+    // (~5.7 k cycles of the round-4 trace) -- this one 4 per wave.  Row scales come in once per workgroup (one load per row, through LDS)
+    // instead of 16 - 32 loads per lane.  Same arithmetic, same bits.
+    if (p.N % 8 == 0) {
+      constexpr int BNW = 16 * WAVES;            // columns of the workgroup's tile
+      constexpr int RS = BNW * 2 + 16;           // staging row stride in bytes (+ 16: the 4 kq row groups of a b16 write land 8 banks apart)
+      float* sa_lds = reinterpret_cast<float*>(smem + BM * RS);
+      __syncthreads();  // (the meeting's flag word is dead; every wave is past the loop's last LDS read)
+      if (tid < BM) sa_lds[tid] = p.scale_a[min(m0 + tid, p.M - 1)];
+      __syncthreads();
+      auto put = [&](int mt, int ntl, const f32x4& c) {  // m-tile mt of the slab, n-tile ntl of the workgroup's tile
+        const int col = min(bx * BNW + ntl * 16 + nl, p.N - 1);
+        const float sbv = p.scale_b[col];
+        const float bv = p.bias != nullptr ? bf16_lo_to_f32(p.bias[col]) : 0.f;
+        const f32x4 sa4 = *reinterpret_cast<const f32x4*>(sa_lds + mt * 16 + kq * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v;
+          if constexpr (INT8) v = round_bf16((float)__builtin_bit_cast(i32x4, c)[r] * sa4[r]) * sbv;
+          else v = c[r] * sa4[r] * sbv;
+          if (p.bias != nullptr) v += bv;
+          *reinterpret_cast<uint16_t*>(smem + (mt * 16 + kq * 4 + r) * RS + (ntl * 16 + nl) * 2) = f32_to_bf16_bits(v);
+        }
+      };
+      if constexpr (SM) {
+        const int wm = wave & 1, wn = wave >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) put(4 * wm + i, 2 * wn + j, acc[2 * i + j]);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) put(mt, wave, acc[mt]);
+      }
+      __syncthreads();
+      constexpr int PPR = BNW / 8;  // 16-byte pieces per row
+      uint16_t* __restrict__ yo = p.y;
+#pragma unroll
+      for (int it = 0; it < (BM * PPR) / (64 * WAVES); ++it) {
+        const int c = it * (64 * WAVES) + tid;
+        const int row = c / PPR, piece = c - row * PPR;
+        const int m = m0 + row, n = bx * BNW + piece * 8;
+        if (m < m_end && n + 8 <= p.N)
+          *reinterpret_cast<u32x4*>(yo + (size_t)m * p.N + n) = *reinterpret_cast<const u32x4*>(smem + row * RS + piece * 16);
+      }
+      dump();
+      return;
+    }
+  }
   if constexpr (SM) {
     const int wm = wave & 1, wn = wave >> 1;
     uint16_t* __restrict__ y = p.y;
@@ -340,7 +432,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     int nj[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int tj = blockIdx.x * WAVES + 2 * wn + j;
+      const int tj = bx * WAVES + 2 * wn + j;
       nj[j] = (tj < ntiles) ? tj * 16 + nl : -1;
       sbj[j] = p.scale_b[min(tj, ntiles - 1) * 16 + nl];
       biasj[j] = p.bias != nullptr ? bf16_lo_to_f32(p.bias[min(tj, ntiles - 1) * 16 + nl]) : 0.f;
@@ -773,6 +865,8 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 }
 
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
+// A/B knobs of the rowwise weight-streaming kernel (ao_gemm8_set_tuning; 0 = product rule): column-tile width, K parts, same-XCD meeting
+thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_local = 0;  // local: 0 product (on where the device allows), 1 off
 thread_local bool g_rb8_sm = true;  // rb8_kernel's 2 x 4 wave arrangement where it is built (ao_gemm8_set_variant 103: off)
 
 template <int WAVES, int KIND, int MT = 8, bool SLIM = false, int QS = 1>
@@ -799,6 +893,12 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
                grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y * tks <= kSplitMaxTickets - 8, "rb8: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
     if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * slots * BN * BM)) return rc;
+    if (!kGrouped && g_rb8_local != 1 && splitk_xcd_local_ok()) {
+      // all K parts of a tile on one XCD: ids that agree mod 8 (measured per device, checked per tile: splitk.h)
+      p.xcd = 1; p.gx = (int)grid.x; p.gy = (int)grid.y; p.split = split;
+      const unsigned tiles = grid.x * grid.y;
+      grid = dim3(8u * (unsigned)split * ((tiles + 7u) / 8u));
+    }
   }
   p.trace = g_fp8_rb_trace;
   auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS>;
@@ -839,6 +939,7 @@ thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 
 
 void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
 void rb8_set_wave_grid(bool two_by_four) { g_rb8_sm = two_by_four; }
+void rb8_set_tuning(int bn, int split, int local_off) { g_rb8_bn = bn; g_rb8_split = split; g_rb8_local = local_off; }
 void mx_rb_set_slim(bool on) { g_mx_slim_off = !on; }
 void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = quad; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
@@ -869,13 +970,15 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
   const bool wide = ((N + 127) / 128) * slabs * std::min<int64_t>(16, std::max<int64_t>(1, ksteps / 4)) >= 190;
   const bool narrow = !wide || g_fp8_rb_force == 3;
-  const int bn = narrow ? 64 : 128;
+  const int bn = (g_rb8_bn == 32 || g_rb8_bn == 64 || g_rb8_bn == 128) ? g_rb8_bn : narrow ? 64 : 128;
   const int64_t base = ((N + bn - 1) / bn) * slabs;
   const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * bm) * 4 / 5;  // (x 4 / 5: the two-level meeting parks S + S / 4 tiles)
   const int64_t target = (g_fp8_rb_force == 3) ? 512 : 256;
-  const int split = (int)std::max<int64_t>(1, std::min<int64_t>({target / base, fit, 16, ksteps / 4}));
-  if (bm == 64) return narrow ? launch_rb8<4, KIND, 4>(p, split, stream) : launch_rb8<8, KIND, 4>(p, split, stream);
-  return narrow ? launch_rb8<4, KIND, 8>(p, split, stream) : launch_rb8<8, KIND, 8>(p, split, stream);
+  int split = (int)std::max<int64_t>(1, std::min<int64_t>({target / base, fit, 16, ksteps / 4}));
+  if (g_rb8_split > 0) split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)g_rb8_split, fit, 16, ksteps}));
+  if (bn == 32) return (bm == 64) ? launch_rb8<2, KIND, 4>(p, split, stream) : launch_rb8<2, KIND, 8>(p, split, stream);
+  if (bm == 64) return bn == 64 ? launch_rb8<4, KIND, 4>(p, split, stream) : launch_rb8<8, KIND, 4>(p, split, stream);
+  return bn == 64 ? launch_rb8<4, KIND, 8>(p, split, stream) : launch_rb8<8, KIND, 8>(p, split, stream);
 }
 
 }  // namespace

@@ -124,6 +124,18 @@ int ao_int4_set_tuning(int waves_per_block, int mode);
  * (the product's form, forced), 118 / 114 / 129 / 128 its other shapes, 113 one workgroup per tile, 112 the round-2 form
  * (ao_amd/csrc/rb8_kernels.hip).  Thread-local, like ao_int4_set_tuning. */
 int ao_gemm8_set_variant(int variant);
+/* Profiling only, key / value (every setting computes the SAME result as the product; 0 = product rule; thread-local):
+ *   key 1  column-tile width of the rowwise weight-streaming kernel (rb8_kernel): 32, 64 or 128
+ *   key 2  its K parts (1 .. 16)
+ *   key 3  1 = never the same-XCD split-K meeting (the write-through, placement-independent one of rounds 1-4 instead)
+ *   key 4  the pipelined 128 x 128 tile kernel (gemm8_pipe_kernel): 1 = never, 2 = wherever the shape allows
+ * An unknown key is an error.  DESIGN.md 4.5h. */
+int ao_gemm8_set_tuning(int key, int value);
+/* 1 when the current device was measured to place workgroup b of a grid on XCD b % 8 (or has one XCD) -- the split-K kernels then put
+ * the K parts of an output tile on one XCD and let them meet in its L2 (checked again per tile on the device; a violation traps);
+ * -1 when it was measured not to, or AO_MI355_XCD_LOCAL=0; 0 before the first split-K launch of the process on the device (the probe
+ * runs with the first workspace allocation).  ao_amd/csrc/splitk.h, DESIGN.md 4.5h. */
+int ao_xcd_local_state(void);
 /* Name of the kernel ao_int4_weight_int4pack_mm launches for this problem (product dispatch, no
  * tuning override): what a profiler's kernel table should be matched against.  Static string. */
 const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size);

@@ -609,3 +609,77 @@ def test_gemm8_phase_interleaved_kernel_race_screen(m, n, k):
         assert torch.equal(got, want), (run, int((got != want).sum()))
         assert _rel(np_from_torch_bf16(got_f), np_from_torch_bf16(want_f)) <= 1e-3
         assert _rel(np_from_torch_bf16((raw * fs * hs.t()).to(torch.bfloat16)), np_from_torch_bf16(want_f)) <= 2e-3
+
+
+# ---- round 5: the same-XCD split-K meeting, the LDS-transposed epilogue, the 32-column tiles ------------------------------------------------
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+@pytest.mark.parametrize("m,n,k,bias", [(128, 1280, 8192, False), (200, 1296, 2048, True), (33, 8192, 1024, False), (128, 4096, 4096, True),
+                                        (512, 1280, 8192, False), (97, 48, 3584, True)])
+def test_rb8_same_xcd_meeting_every_form(kind, m, n, k, bias):
+    """The weight-streaming kernel with its K parts on one XCD (plain stores into that XCD's L2, device-side placement check) against the
+    write-through meeting of rounds 1-4 and against the oracle, over tile widths 32 / 64 / 128 and 1 .. 16 K parts: the same parts are
+    added in the same order, so every form gives the same bits (int8: the oracle's)."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    x = _randn_bf16((m, k), 31 * m + k)
+    w = _randn_bf16((n, k), 37 * n + k, 0.05)
+    b = _randn_bf16((n,), 7) if bias else None
+    bd = None if b is None else b.to(DEV)
+    if kind == "int8":
+        xq, xs = ops.int8_quantize_rowwise(x.to(DEV))
+        wq, ws = ops.int8_quantize_rowwise(w.to(DEV))
+        run = lambda: ops.int8_scaled_mm(xq, xs, wq, ws, bd)  # noqa: E731
+        y_ref = I.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+    else:
+        xq, xs = ops.fp8_quantize_rowwise(x.to(DEV))
+        wq, ws = ops.fp8_quantize_rowwise(w.to(DEV))
+        run = lambda: ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t(), bd)  # noqa: E731
+        y_ref = F.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+    outs = {}
+    try:
+        lib.ao_gemm8_set_variant(101)  # always the weight-streaming kernel
+        for bn in (32, 64, 128):
+            for split in (1, 2, 5, 16):
+                for off in (0, 1):
+                    lib.ao_gemm8_set_tuning(1, bn)
+                    lib.ao_gemm8_set_tuning(2, split)
+                    lib.ao_gemm8_set_tuning(3, off)
+                    outs[(bn, split, off)] = run().clone()
+    finally:
+        lib.ao_gemm8_set_variant(0)
+        for key in (1, 2, 3):
+            lib.ao_gemm8_set_tuning(key, 0)
+    torch.cuda.synchronize()
+    for (bn, split, off), y in outs.items():
+        assert torch.equal(y, outs[(bn, split, 1)]), f"same-XCD meeting differs from the write-through one at bn={bn} split={split}"
+    yn = np_from_torch_bf16(outs[(128, 1, 0)])
+    if kind == "int8":
+        for key, y in outs.items():
+            assert np.array_equal(np_from_torch_bf16(y), y_ref), f"int8 not bit-exact at {key}"
+    else:
+        for key, y in outs.items():
+            assert _rel(np_from_torch_bf16(y), y_ref) <= 1e-3, f"fp8 off at {key}"
+    assert lib.ao_xcd_local_state() != 0  # the probe ran with the first split-K workspace
+    assert np.isfinite(yn).all()
+
+
+@pytest.mark.parametrize("kind", ["int8", "fp8"])
+def test_rb8_same_xcd_meeting_fresh_data_every_launch(kind):
+    """The parked tiles live in an XCD's L2 between the parts' stores and the last arriver's loads: launches that alternate between two
+    weights of one shape (same workspace slots, same tickets) must each see their own parts -- a stale line from the launch before would
+    give the other weight's result.  50 alternations inside one hipGraph-free stream, outputs compared with each weight's own result."""
+    m, n, k = 128, 1280, 8192
+    x = _randn_bf16((m, k), 1)
+    quant = ops.int8_quantize_rowwise if kind == "int8" else ops.fp8_quantize_rowwise
+    xq, xs = quant(x.to(DEV))
+    wa, wb = quant(_randn_bf16((n, k), 2, 0.05).to(DEV)), quant(_randn_bf16((n, k), 3, 0.05).to(DEV))
+    mm = (lambda wq, ws: ops.int8_scaled_mm(xq, xs, wq, ws)) if kind == "int8" else (lambda wq, ws: ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t()))
+    ya, yb = mm(*wa).clone(), mm(*wb).clone()
+    assert not torch.equal(ya, yb)
+    outs = []
+    for i in range(50):
+        outs.append(mm(*(wa if i % 2 == 0 else wb)))
+    torch.cuda.synchronize()
+    for i, y in enumerate(outs):
+        assert torch.equal(y, ya if i % 2 == 0 else yb), f"launch {i} saw another launch's parts"
