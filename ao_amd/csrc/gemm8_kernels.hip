@@ -21,7 +21,7 @@ int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale
 // rb8_kernels.hip: weight-streaming kernels for problems with few output tiles
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void rb8_set_wave_grid(bool two_by_four);  // rb8_kernels.hip
-void rb8_set_tuning(int bn, int split, int local_off);
+void rb8_set_tuning(int bn, int split, int local_off, int ablate, int bm);
 void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
 extern thread_local int g_mx_variant;  // stream8_kernels.hip
@@ -468,9 +468,9 @@ extern "C" int ao_gemm8_set_variant(int variant) {
 
 namespace ao { namespace { thread_local int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0}; } }
 extern "C" int ao_gemm8_set_tuning(int key, int value) {
-  AO_REQUIRE(key >= 1 && key <= 4, "ao_gemm8_set_tuning: unknown key %d", key);
+  AO_REQUIRE(key >= 1 && key <= 6, "ao_gemm8_set_tuning: unknown key %d", key);
   g_tune[key] = value;
-  rb8_set_tuning(g_tune[1], g_tune[2], g_tune[3]);
+  rb8_set_tuning(g_tune[1], g_tune[2], g_tune[3], g_tune[5], g_tune[6]);
   return AO_OK;
 }
 

@@ -31,12 +31,14 @@ constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
 // weight ring (per wave), filled kWStages - 1 steps ahead: the HBM stream needs the bytes in flight.  6 stages; 5 for the
 // 8-wave MX form, whose scale rings would otherwise push the workgroup past 160 KiB of LDS
 // (also 5 for the 64-row MX slab, which then fits two workgroups per CU)
-constexpr int w_stages(int waves, int kind, int mt, bool slim = false) { return slim ? 3 : (kind == 2 && (waves == 8 || mt == 4)) ? 5 : 6; }
-// SLIM (round 3, MX decode groups: 4 waves, 64-row slabs): 3 weight stages and 64-byte scale slots (only the 16 lanes that carry
-// distinct rows issue the scale DMAs) -> 49.5 KiB of LDS, THREE workgroups per CU instead of two.  With few experts hit the grid is
-// 672 workgroups: two per CU ran them as a full round plus a 31 %-full one at 66 % of the all-experts rate; three per CU keeps
-// every workgroup resident from the start (and the same ~48 KiB of weight bytes in flight per CU: 3 x 4 waves x 2 steps x 2 KiB).
-
+constexpr int w_stages(int waves, int kind, int mt, bool slim = false) {
+  return slim ? 3 : (kind == 2 && (waves == 8 || mt == 4)) ? 5 : ((kind == 0 || kind == 1) && mt == 16 && waves == 8) ? 3 : 6;
+}
+// Activation ring: 3 stages (2 steps ahead).  Round 5 measured 5 / 4 stages for the rowwise kinds (the ring's depth looked like the
+// loop's bound: 1100 cycles per step for every tile width, ~ half an LDS-DMA round trip): the step time did not move -- it is the sum
+// of one wave's own barrier + issue + fragment-read + MFMA chain (timing probes of the traced build: 430 + 125 + 250 + 256 cycles at
+// 32 columns), not a latency -- and the longer priming cost 3 % on the short-K shapes.  256-row slabs (mt = 16): a stage is 32 KiB.
+constexpr int a_stages(int waves, int kind, int mt) { return kStages; }
 // RB8_FP8_GROUPED: rowwise e4m3 like RB8_FP8, rows grouped by expert like RB8_MX (Float8Tensor's _grouped_mm, float8_tensor.py:1085-1122)
 enum Rb8Kind { RB8_FP8 = 0, RB8_INT8 = 1, RB8_MX = 2, RB8_FP8_GROUPED = 3 };
 constexpr bool GROUPED_KIND(int kind) { return kind == RB8_MX || kind == RB8_FP8_GROUPED; }
@@ -59,6 +61,7 @@ struct Rb8Args {
   // round 5, rowwise kinds with K parts: xcd = 1 -- a 1-D grid of 8 * split * ceil(gx * gy / 8) workgroups in which the `split` parts of
   // an output tile have ids that agree mod 8 (splitk.h: xcd_grid_decode), so that they run on ONE XCD and meet in its L2
   int xcd, gx, gy, split;
+  int ablate;  // profiling build (TRACE) only: 1 no MFMAs, 2 no fragment reads, 4 no weight DMAs, 8 no activation DMAs -- wrong results, timing probes
 };
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
@@ -73,7 +76,8 @@ struct Rb8Args {
 // on a loop that is bound by the LDS reads (144 KiB per step and workgroup at 128 B / clk against 512 cycles of MFMA per SIMD).
 template <int WAVES, int KIND, int MT = 8, bool TRACE = false, bool SLIM = false, int QS = 1, bool SM = false>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
-  static_assert(!SM || (WAVES == 8 && MT == 8 && (KIND == RB8_FP8 || KIND == RB8_INT8)), "rb8_kernel: the 2 x 4 wave arrangement is built for 8 waves x 128 rows, rowwise kinds");
+  static_assert(!SM || (WAVES == 8 && (MT == 8 || MT == 16) && (KIND == RB8_FP8 || KIND == RB8_INT8)), "rb8_kernel: the 2 x 4 wave arrangement is built for 8 waves x 128 / 256 rows, rowwise kinds");
+  constexpr int MH = MT / 2;  // SM: m-tiles per wave (wave (wm, wn): m-tiles MH wm .. + MH - 1, n-tiles 2 wn, 2 wn + 1; acc[2 i + j])
   constexpr int SCL = SLIM ? 64 : 256;  // bytes of one scale slot (one dword per row: 16 rows -> 64 B; unmasked DMAs write 256)
   static_assert(QS == 1 || (QS == 4 && KIND == RB8_MX && !SLIM), "rb8_kernel: 4-step scale fetches are an MX form");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [13] group found, [14] addresses ready
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   constexpr int BM = 16 * MT;
   constexpr int RPW = BM / WAVES;   // MX: activation-scale rows fetched per wave
   constexpr int kWStages = w_stages(WAVES, KIND, MT, SLIM);
+  constexpr int KA = a_stages(WAVES, KIND, MT);  // activation ring
   static_assert(!SLIM || (KIND == RB8_MX && BM / WAVES == 16), "SLIM: 16 activation-scale rows per wave");
   // [3][128][128 B] a | [WAVES][6][2 KiB] b | MX: [3][WAVES][256 B] a scales | [WAVES][6][256 B] b scales
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -170,16 +175,16 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   }
   const uint8_t* brows = p.b + ((size_t)expert * p.N + (size_t)tile_c * 16) * p.K;
   const uint32_t a_lds = lds_offset(smem);
-  const uint32_t w_lds = a_lds + kStages * kABuf + wave * (kWStages * 2048);
+  const uint32_t w_lds = a_lds + KA * kABuf + wave * (kWStages * 2048);
   // MX block scales: one dword (4 e8m0 bytes = the 4 blocks of a 128-k step) per row and step.  Wave w fetches the dwords of
   // activation rows RPW w .. + RPW - 1 (lanes past RPW repeat them into slots nobody reads) and of its own 16 weight rows.
   const uint32_t kb32 = (uint32_t)(p.K >> 5);
   const uint32_t asoff = MX ? (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32 : 0u;
   const uint32_t bsoff = (uint32_t)nl * kb32;
   const uint8_t* bsrows = MX ? p.b_mx + ((size_t)expert * p.N + (size_t)tile_c * 16) * kb32 : nullptr;
-  const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (kWStages * 2048);
+  const uint32_t as_lds = a_lds + KA * kABuf + WAVES * (kWStages * 2048);
   constexpr int ASB = (QS == 1) ? SCL : RPW * 16, BSB = 256;  // QS == 4: slot bytes (activation rows of a wave, its 16 weight rows: 16 B each)
-  const uint32_t bs_lds = (QS == 1) ? as_lds + kStages * WAVES * SCL + wave * (kWStages * SCL) : as_lds + 2 * WAVES * ASB + wave * (2 * BSB);
+  const uint32_t bs_lds = (QS == 1) ? as_lds + KA * WAVES * SCL + wave * (kWStages * SCL) : as_lds + 2 * WAVES * ASB + wave * (2 * BSB);
   auto issue_s = [&](int slot, int k) {  // QS == 4: the scales of steps k .. k + 3 (k % 4 == 0); past the end: the last block again
     const int kk = k0 + min(k, nk - 4);
     if (lane < RPW) dma_b128_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (slot * WAVES + wave) * ASB);
@@ -194,6 +199,37 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     }
   };
 
+  // ROLES (round 5, rowwise kinds): the lower half of the waves fetches the activation tile, the upper half the weights (two n-tiles
+  // each).  VMEM retires in order per wave: a wave that requests w(k + 5) and then a(k + 2) cannot see a(k + 2) land before w(k + 5) has,
+  // so the weight ring's five stages of HBM latency cover were really two (the round-5 trace: 1100 ticks per step whatever the tile
+  // width -- half an HBM round trip).  With the kinds apart, an activation wave waits for L2 hits only and a weight wave has its whole
+  // ring in flight; the step's barrier publishes both, as before.  Same LDS layout, same MFMAs, same bits.
+  constexpr bool ROLES = !GROUPED;
+  const bool is_a = wave < WAVES / 2;
+  const uint8_t* brows2[2] = {nullptr, nullptr};
+  uint32_t w_lds2[2] = {0u, 0u};
+  if constexpr (ROLES) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nt = max(2 * (wave - WAVES / 2) + j, 0);  // (activation waves: unused)
+      brows2[j] = p.b + (size_t)min(bx * WAVES + nt, ntiles - 1) * 16 * p.K;
+      w_lds2[j] = a_lds + KA * kABuf + nt * (kWStages * 2048);
+    }
+  }
+  // the epilogue's scales, requested before anything else (one row scale, one column scale, one bias value per thread at most) and
+  // handed on through LDS after the loop: by then they have long landed, and the tail has no memory round trip left but its stores
+  float pre_sa = 0.f, pre_sb = 0.f;
+  uint32_t pre_bias = 0u;  // bf16 bits: converted in the epilogue (a use here would make the compiler wait for the load at the kernel's head)
+  if constexpr (!GROUPED) {
+    // (every part: any of them may turn out to be the last arriver)
+    if (tid < BM) pre_sa = p.scale_a[min(m0 + tid, p.M - 1)];
+    if (tid < 16 * WAVES) {
+      const int col = min(bx * (16 * WAVES) + tid, p.N - 1);
+      pre_sb = p.scale_b[col];
+      if (p.bias != nullptr) pre_bias = p.bias[col];
+    }
+  }
+
   f32x4 acc[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -207,34 +243,44 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   // activation DMAs per wave and stage for the m-tiles this slab really has (8 rows each; with fewer 8-row blocks than waves
   // the last waves re-fetch the group's last row into rows nobody reads): a 32-row group in a 64-row slab costs the workgroup
   // 4 activation DMAs per step, not 8 -- the activation tile is half of what a CU's texture path moves per step
-  constexpr int AD = (2 * MTC >= WAVES) ? 2 * MTC / WAVES : 1;
+  // (ROLES: the activation tile's 2 MTC DMAs are shared out among the WAVES / 2 activation waves)
+  constexpr int AD = ROLES ? 4 * MTC / WAVES : (2 * MTC >= WAVES) ? 2 * MTC / WAVES : 1;
+  static_assert(AD >= 1, "rb8_kernel: every fetching wave issues the same number of DMAs per stage");
   constexpr int LPSC = AD + 2 + ((MX && QS == 1) ? 2 : 0);
   uint32_t aoff[AD];
 #pragma unroll
   for (int i = 0; i < AD; ++i) {
-    const int row = 8 * (AD * wave + i) + (lane >> 3);
-    aoff[i] = (uint32_t)min(m0 + row, m_end - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
+    const int row = 8 * (AD * wave + i) + (lane >> 3);  // (ROLES: wave < WAVES / 2 covers the tile; the weight waves never issue these)
+    aoff[i] = (uint32_t)min(m0 + min(row, BM - 1), m_end - 1) * (uint32_t)p.K + ((((lane & 7) ^ (row >> 1)) & 7) << 4);
   }
   auto issue_a = [&](int stage, int k) {  // k clamped: the fills past the end re-read the last step (unused)
     const int kk = k0 + min(k, nk - 1);
+    if (TRACE && (p.ablate & 8)) return;
 #pragma unroll
     for (int i = 0; i < AD; ++i) dma_b128_s(p.a + (size_t)kk * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
     if constexpr (MX && QS == 1) {
       if (!SLIM || lane < 16) dma_b32_s(p.a_mx + (size_t)kk * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
     }
   };
-  if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
-  // FIRST (round 5, rowwise kinds with 6 weight stages): the operands of step 0 are requested first -- a(0) w(0) | a(1) w(1) | w(2) w(3) w(4)
-  // instead of w(0) w(1) w(2) | a(0) w(3) | a(1) w(4) -- and steps 0 and 1 wait only for what they read (everything younger than w(1):
-  // the three weight stages and, at step 1, a(2) w(5)); a workgroup's 112 priming DMAs take ~6 k cycles to issue, of which step 0 used to
-  // wait for the last one's data.  From step 2 on the order is the steady state's.
-  constexpr bool FIRST = !GROUPED && kWStages == 6;
-  if constexpr (QS == 4) issue_s(0, 0);  // then the block of steps 4 j + 4 .. at the head of step 4 j + 1 (older than a(4 j + 3): landed by then)
-  if constexpr (FIRST) {
-    issue_a(0, 0); issue_w(0, 0);
-    issue_a(1, 1); issue_w(1, 1);
+  auto issue_w2 = [&](int stage, int k) {  // ROLES: a weight wave's two n-tiles
+    const int kk = k0 + min(k, nk - 1);
+    if (TRACE && (p.ablate & 4)) return;
 #pragma unroll
-    for (int i = 2; i < kWStages - 1; ++i) issue_w(i, i);
+    for (int j = 0; j < 2; ++j) {
+      dma_b128_nt_s(brows2[j] + (size_t)kk * 128, boff[0], w_lds2[j] + stage * 2048);
+      dma_b128_nt_s(brows2[j] + (size_t)kk * 128, boff[1], w_lds2[j] + stage * 2048 + 1024);
+    }
+  };
+  if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
+  if constexpr (QS == 4) issue_s(0, 0);  // then the block of steps 4 j + 4 .. at the head of step 4 j + 1 (older than a(4 j + 3): landed by then)
+  if constexpr (ROLES) {
+    if (is_a) {
+#pragma unroll
+      for (int i = 0; i < KA - 1; ++i) issue_a(i, i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < kWStages - 1; ++i) issue_w2(i, i);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < kWStages - 3; ++i) issue_w(i, i);
@@ -243,15 +289,102 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   }
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
   int stage = 0, wstage = 0;
+  if constexpr (ROLES) {
+    // Round 5: the step's operand fragments are double-buffered in REGISTERS.  The round-5 trace showed 1000 - 1200 ticks per step for every
+    // tile width, ring depth and fetch split -- the time of one wave's own instruction chain: the compiler emitted the step as four
+    // "ds_read x 4-6, wait, MFMA x 2" groups, an LDS round trip in front of each (one or two waves per SIMD, all parked at the same
+    // barrier: nothing else to issue).  Now step k + 1's barrier, its ring refills and ALL its fragment reads are issued before step
+    // k's MFMAs, which run from registers read a step earlier: the LDS latency sits under 8 MFMAs (256 matrix cycles) instead of
+    // between them.  Same products into the same accumulators in the same order: same bits.
+    constexpr int NA = SM ? MH : MTC, NB = SM ? 2 : 1;
+    struct Frags { u32x4 a0[NA], a1[NA], b0[NB], b1[NB]; };
+    const int wm = wave & 1, wn = wave >> 1;  // (SM)
+    int ksync = 0;  // the next step to synchronise
+    auto sync_issue_read = [&](Frags& f) {
+      // step ksync's operands have landed (an activation wave may have a(k + 1) .. a(k + KA - 2) in flight, a weight wave
+      // w(k + 1) .. w(k + kWStages - 2), four DMAs a stage) and everyone has finished READING step ksync - 1 (lgkmcnt(0) before the
+      // barrier): its slots are refilled, then this step's fragments are requested
+      static_assert(AD * (KA - 2) <= 63 && 4 * (kWStages - 2) <= 63, "rb8_kernel: vmcnt is a 6-bit counter");
+      if (is_a) wait_vmcnt<AD * (KA - 2)>(); else wait_vmcnt<4 * (kWStages - 2)>();
+      // (the LDS wait as a BUILTIN, not inside the asm: the compiler's wait-count pass has to see it, or it takes the fragments read
+      // a step ago for still in flight behind the new reads and waits for those in front of every MFMA -- lgkmcnt(13) .. (0))
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt, expcnt untouched
+      asm volatile("s_barrier" ::: "memory");
+      if (TRACE && ksync < 8) ts[2 + ksync] = __builtin_amdgcn_s_memtime();
+      if (is_a) issue_a((stage == 0) ? KA - 1 : stage - 1, ksync + KA - 1);
+      else issue_w2((wstage == 0) ? kWStages - 1 : wstage - 1, ksync + kWStages - 1);
+      const char* A = smem + stage * kABuf;
+      if (TRACE && (p.ablate & 2)) {
+      } else if constexpr (SM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const char* Wj = smem + KA * kABuf + ((2 * wn + j) * kWStages + wstage) * 2048;
+          f.b0[j] = *reinterpret_cast<const u32x4*>(Wj + pa);
+          f.b1[j] = *reinterpret_cast<const u32x4*>(Wj + (pa ^ 64));
+        }
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+          f.a0[i] = *reinterpret_cast<const u32x4*>(A + (MH * wm + i) * 2048 + pa);
+          f.a1[i] = *reinterpret_cast<const u32x4*>(A + (MH * wm + i) * 2048 + (pa ^ 64));
+        }
+      } else {
+        const char* W = smem + KA * kABuf + (wave * kWStages + wstage) * 2048;
+        f.b0[0] = *reinterpret_cast<const u32x4*>(W + pa);
+        f.b1[0] = *reinterpret_cast<const u32x4*>(W + (pa ^ 64));
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) {
+          f.a0[mt] = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
+          f.a1[mt] = *reinterpret_cast<const u32x4*>(A + mt * 2048 + (pa ^ 64));
+        }
+      }
+      stage = (stage == KA - 1) ? 0 : stage + 1;
+      wstage = (wstage == kWStages - 1) ? 0 : wstage + 1;
+      ++ksync;
+      __builtin_amdgcn_sched_barrier(0);  // the reads are ISSUED here, ahead of the MFMAs of the step before
+    };
+    auto one = [&](f32x4& c, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+      if constexpr (INT8) {  // acc holds int32 bit patterns
+        i32x4 ci = __builtin_bit_cast(i32x4, c);
+        ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a0), __builtin_bit_cast(i32x4, b0), ci, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a1), __builtin_bit_cast(i32x4, b1), ci, 0, 0, 0);
+        c = __builtin_bit_cast(f32x4, ci);
+      } else {
+        const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+        const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, c, 0, 0, 0, 127, 0, 127);
+      }
+    };
+    auto mma = [&](const Frags& f) {
+      if (TRACE && (p.ablate & 3)) {
+      } else if constexpr (SM) {
+#pragma unroll
+        for (int i = 0; i < MH; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) one(acc[2 * i + j], f.a0[i], f.a1[i], f.b0[j], f.b1[j]);
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MTC; ++mt) one(acc[mt], f.a0[mt], f.a1[mt], f.b0[0], f.b1[0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    Frags f0, f1;
+    sync_issue_read(f0);
+    // (the explicit LDS waits on the paths WITHOUT new reads are for the compiler's wait-count pass: where paths merge it assumes the
+    // worst of them, and would put lgkmcnt waits for the NEW reads in front of every MFMA of the old fragments)
+    for (int k = 0; k < nk; k += 2) {
+      if (k + 1 < nk) sync_issue_read(f1); else __builtin_amdgcn_s_waitcnt(0xC07F);
+      mma(f0);
+      if (k + 1 < nk) {
+        if (k + 2 < nk) sync_issue_read(f0); else __builtin_amdgcn_s_waitcnt(0xC07F);
+        mma(f1);
+      }
+    }
+    return;
+  }
   for (int k = 0; k < nk; ++k) {
     // (3 weight stages: w(k) is issued right behind a(k), so only a(k + 1) and w(k + 1) -- one stage -- may still be in flight)
     // (QS == 4: at k % 4 == 2 the two scale requests of step k - 1 are younger than a(k) too)
     if constexpr (QS == 4) { if ((k & 3) == 2) wait_vmcnt<LPSC + 2 + 2>(); else wait_vmcnt<LPSC + 2>(); }
-    else if constexpr (FIRST) {
-      // step 0: younger than w(0) are a(1) w(1) w(2) w(3) w(4); step 1: younger than w(1) are w(2) w(3) w(4) a(2) w(5); step k >= 2: a(k)
-      // was issued at step k - 2, behind it w(k + 3), a(k + 1), w(k + 4)
-      if (k < 2) wait_vmcnt<AD + 8>(); else wait_vmcnt<LPSC + 2>();
-    }
     else if constexpr (kWStages >= 4) wait_vmcnt<LPSC + 2 + (MX ? 1 : 0)>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading step k - 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -259,7 +392,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     if constexpr (QS == 4) {
       if ((k & 3) == 1) issue_s(((k >> 2) + 1) & 1, (k & ~3) + 4);
     }
-    issue_a((stage == 0) ? 2 : stage - 1, k + 2);
+    issue_a((stage == 0) ? KA - 1 : stage - 1, k + KA - 1);
     issue_w((wstage == 0) ? kWStages - 1 : wstage - 1, k + kWStages - 1);
     const char* A = smem + stage * kABuf;
     if constexpr (SM) {
@@ -268,7 +401,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       u32x4 b0[2], b1[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const char* Wj = smem + kStages * kABuf + ((2 * wn + j) * kWStages + wstage) * 2048;
+        const char* Wj = smem + KA * kABuf + ((2 * wn + j) * kWStages + wstage) * 2048;
         b0[j] = *reinterpret_cast<const u32x4*>(Wj + pa);
         b1[j] = *reinterpret_cast<const u32x4*>(Wj + (pa ^ 64));
       }
@@ -290,23 +423,23 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
           }
         }
       }
-      stage = (stage == 2) ? 0 : stage + 1;
+      stage = (stage == KA - 1) ? 0 : stage + 1;
       wstage = (wstage == kWStages - 1) ? 0 : wstage + 1;
       continue;
     }
-    const char* W = smem + kStages * kABuf + (wave * kWStages + wstage) * 2048;
+    const char* W = smem + KA * kABuf + (wave * kWStages + wstage) * 2048;
     const u32x4 b0 = *reinterpret_cast<const u32x4*>(W + pa);  // the n-tile's 16 rows are laid out like an m-tile
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(W + (pa ^ 64));
     const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
     // MX: the scale byte of lane group kq is that of 32-k block kq of the step (operand layout probed on gfx950, stream8_kernels.hip)
-    [[maybe_unused]] const char* AS = smem + kStages * kABuf + WAVES * (kWStages * 2048) +
+    [[maybe_unused]] const char* AS = smem + KA * kABuf + WAVES * (kWStages * 2048) +
                                       ((QS == 1) ? stage * WAVES * SCL : ((k >> 2) & 1) * WAVES * ASB + (k & 3) * 4);
     int sb = 127;
     if constexpr (MX && QS == 1)
-      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + kStages * WAVES * SCL +
+      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + KA * kABuf + WAVES * (kWStages * 2048) + KA * WAVES * SCL +
                                                     (wave * kWStages + wstage) * SCL + nl * 4) >> (8 * kq)) & 0xff;
     if constexpr (MX && QS == 4)
-      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + kStages * kABuf + WAVES * (kWStages * 2048) + 2 * WAVES * ASB +
+      sb = (int)(*reinterpret_cast<const uint32_t*>(smem + KA * kABuf + WAVES * (kWStages * 2048) + 2 * WAVES * ASB +
                                                     (wave * 2 + ((k >> 2) & 1)) * BSB + nl * 16 + (k & 3) * 4) >> (8 * kq)) & 0xff;
 #pragma unroll
     for (int mt = 0; mt < MTC; ++mt) {
@@ -327,7 +460,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
         acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, sa, 0, sb);
       }
     }
-    stage = (stage == 2) ? 0 : stage + 1;
+    stage = (stage == KA - 1) ? 0 : stage + 1;
     wstage = (wstage == kWStages - 1) ? 0 : wstage + 1;
   }
   };
@@ -359,9 +492,9 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     int* flag = reinterpret_cast<int*>(smem);
     if constexpr (!GROUPED) {
       // round 5: all parts on one XCD (p.xcd): the parked tiles stay in that XCD's L2 (splitk.h, LOCAL)
-      if (local) go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8, 4, true>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
+      if (local) go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8, (MT >= 16 ? 2 : 4), true>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
                                  : split_k_meet<MT, 64 * WAVES, INT8, true>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
-      else go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
+      else go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8, (MT >= 16 ? 2 : 4)>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
                            : split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
     } else {
       go_on = split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
@@ -383,13 +516,16 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       constexpr int BNW = 16 * WAVES;            // columns of the workgroup's tile
       constexpr int RS = BNW * 2 + 16;           // staging row stride in bytes (+ 16: the 4 kq row groups of a b16 write land 8 banks apart)
       float* sa_lds = reinterpret_cast<float*>(smem + BM * RS);
+      float* sb_lds = sa_lds + BM;
+      float* bias_lds = sb_lds + BNW;
       __syncthreads();  // (the meeting's flag word is dead; every wave is past the loop's last LDS read)
-      if (tid < BM) sa_lds[tid] = p.scale_a[min(m0 + tid, p.M - 1)];
+      if (tid < BM) sa_lds[tid] = pre_sa;
+      asm volatile("" : "+v"(pre_bias));  // (opaque until here: the compiler otherwise converts -- and waits for the load -- at the kernel's head)
+      if (tid < BNW) { sb_lds[tid] = pre_sb; bias_lds[tid] = bf16_lo_to_f32(pre_bias); }
       __syncthreads();
       auto put = [&](int mt, int ntl, const f32x4& c) {  // m-tile mt of the slab, n-tile ntl of the workgroup's tile
-        const int col = min(bx * BNW + ntl * 16 + nl, p.N - 1);
-        const float sbv = p.scale_b[col];
-        const float bv = p.bias != nullptr ? bf16_lo_to_f32(p.bias[col]) : 0.f;
+        const float sbv = sb_lds[ntl * 16 + nl];
+        const float bv = bias_lds[ntl * 16 + nl];
         const f32x4 sa4 = *reinterpret_cast<const f32x4*>(sa_lds + mt * 16 + kq * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -403,9 +539,9 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       if constexpr (SM) {
         const int wm = wave & 1, wn = wave >> 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MH; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) put(4 * wm + i, 2 * wn + j, acc[2 * i + j]);
+          for (int j = 0; j < 2; ++j) put(MH * wm + i, 2 * wn + j, acc[2 * i + j]);
       } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) put(mt, wave, acc[mt]);
@@ -866,7 +1002,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 // A/B knobs of the rowwise weight-streaming kernel (ao_gemm8_set_tuning; 0 = product rule): column-tile width, K parts, same-XCD meeting
-thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_local = 0;  // local: 0 product (on where the device allows), 1 off
+thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_local = 0, g_rb8_ablate = 0, g_rb8_bm = 0;  // local: 0 product (on where the device allows), 1 off
 thread_local bool g_rb8_sm = true;  // rb8_kernel's 2 x 4 wave arrangement where it is built (ao_gemm8_set_variant 103: off)
 
 template <int WAVES, int KIND, int MT = 8, bool SLIM = false, int QS = 1>
@@ -880,9 +1016,10 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
                                             : (unsigned)std::min<int64_t>((int64_t)p.slabs * p.E, (p.M + BM - 1) / BM + p.E);
   dim3 grid((unsigned)((p.N + BN - 1) / BN), gy, (unsigned)split), block(64 * WAVES);
   constexpr int kWStages = w_stages(WAVES, KIND, MT, SLIM);
-  constexpr size_t smem = (size_t)kStages * MT * 2048 + (size_t)WAVES * kWStages * 2048 +
+  constexpr int KA = a_stages(WAVES, KIND, MT);
+  constexpr size_t smem = (size_t)KA * MT * 2048 + (size_t)WAVES * kWStages * 2048 +
                           ((KIND != RB8_MX) ? 0 : (QS == 4) ? (size_t)2 * 16 * MT * 16 + (size_t)WAVES * 2 * 256
-                                                            : (size_t)(kStages + kWStages) * WAVES * (SLIM ? 64 : 256));
+                                                            : (size_t)(KA + kWStages) * WAVES * (SLIM ? 64 : 256));
   static_assert(!SLIM || 3 * smem <= 160 * 1024, "SLIM: three workgroups per CU");
   static_assert(smem <= 160 * 1024, "rb8_kernel: LDS");
   if (split > 1) {
@@ -901,10 +1038,11 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
     }
   }
   p.trace = g_fp8_rb_trace;
+  p.ablate = g_rb8_ablate;
   auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS>;
-  if constexpr (WAVES == 8 && MT == 8 && (KIND == RB8_FP8 || KIND == RB8_INT8) && !SLIM && QS == 1) {
+  if constexpr (WAVES == 8 && (MT == 8 || MT == 16) && (KIND == RB8_FP8 || KIND == RB8_INT8) && !SLIM && QS == 1) {
     // the 2 x 4 wave arrangement (fewer operand fragments per MFMA); ao_gemm8_set_variant(103): the 1 x 8 form, for A/B
-    if (g_rb8_sm) kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS, true> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS, true>;
+    if (g_rb8_sm || MT == 16) kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS, true> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS, true>;
   }
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(rb8_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, p);
@@ -939,7 +1077,7 @@ thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 
 
 void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
 void rb8_set_wave_grid(bool two_by_four) { g_rb8_sm = two_by_four; }
-void rb8_set_tuning(int bn, int split, int local_off) { g_rb8_bn = bn; g_rb8_split = split; g_rb8_local = local_off; }
+void rb8_set_tuning(int bn, int split, int local_off, int ablate, int bm) { g_rb8_bn = bn; g_rb8_split = split; g_rb8_local = local_off; g_rb8_ablate = ablate; g_rb8_bm = bm; }
 void mx_rb_set_slim(bool on) { g_mx_slim_off = !on; }
 void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = quad; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
@@ -953,10 +1091,45 @@ bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
   // up to one 128 x 128 workgroup per CU (one round of the chip).  Round 4 (profiles/fp8_dispatch_sweep_r04.txt, cold 70B / TP8 shards): the bound
   // was 190, and the 224 - 256 tiles of M = 512 fell to the 4-wave two-stage tile kernel -- gate_up 73.6 us against 44.3 here (hipBLASLt
   // 47.5), down 39.8 / 23.6 (24.4), o 20.9 / 11.7 (11.5); from two rounds on (M = 1024: 448 - 512 tiles) the tiled kernels are level or ahead
-  return ((N + 127) / 128) * ((M + 127) / 128) <= 256;
+  // (round 5: also where 256-row slabs fit one round -- M ~ 1024 on the 70B / TP8 shards -- see rb8_run)
+  return ((N + 127) / 128) * ((M + 127) / 128) <= 256 || (M > 896 && M <= 1024 && ((N + 127) / 128) * ((M + 255) / 256) <= 256);
 }
 
 namespace {
+
+// The tile width and K split of a rowwise launch (round 5).  Rounds 1-4 took 128-column tiles where they gave ~half a chip of workgroups
+// and 64-column ones otherwise, with K cut until the grid approached 256 workgroups (up to 16 parts).  The round-5 sweep over
+// (width, parts) next to hipBLASLt (profiles/midm_sweep_r05.jsonl: 8 shapes x M = 128 .. 1024, cold) says the choice is a trade between
+// three costs, which this model prices in microseconds and minimises:
+//   * the k loop: steps per workgroup x ~0.33 us (32 columns) / 0.35 (64) / 0.52 (128) -- one wave's barrier + issue + fragment-read +
+//     MFMA chain per step -- but never less than the weight bytes at ~5.8 TB/s;
+//   * the meeting of the K parts: ~3.2 us for 2 - 4 parts (one level), ~4.5 us from 5 on (two levels), + 0.4 us per extra part of a
+//     128-column tile (the last arriver's gather);
+//   (constants fitted to the sweep: the model's pick is within 0.2 % of the best measured form on average over the 32 cells)
+//   * a fixed ~5.5 us per round of the chip (launch, priming, first data, epilogue), and rounds = ceil(workgroups / 256).
+// Narrow tiles re-stage the activation tile once per tile (more steps in total); wide tiles need more K parts to fill the chip.
+struct Rb8Plan { int bn, split; };
+inline Rb8Plan rb8_plan(int64_t M, int64_t N, int64_t K, int bm) {
+  const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
+  const double hbm_us = (double)N * (double)K / 5.85e6;  // weight bytes at 5.85 TB/s
+  Rb8Plan best{128, 1};
+  double best_t = 1e30;
+  for (int bn : {128, 64, 32}) {
+    if (bm == 256 && bn == 32) continue;  // (256-row slabs are built with 64- and 128-column tiles)
+    const int64_t tiles = ((N + bn - 1) / bn) * slabs;
+    const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (tiles * bn * bm) * 4 / 5;  // (x 4 / 5: the two-level meeting parks S + S / 4 tiles)
+    const double c = (bn == 32 ? 0.333 : bn == 64 ? 0.35 : 0.52) * (bm == 256 ? 1.6 : 1.0);
+    for (int S : {1, 2, 3, 4, 6, 8}) {
+      if (S > 1 && (S > fit || S > std::max<int64_t>(1, ksteps / 4))) continue;
+      const int64_t wgs = tiles * S, rounds = (wgs + 255) / 256, steps = (ksteps + S - 1) / S;
+      const double loop = std::max((double)steps * c * (double)rounds, hbm_us);
+      const double meet = S == 1 ? 0.0 : (S <= 4 ? 3.17 : 4.53) + 0.4 * (S - 1) * bn / 128.0 * (bm / 128.0);
+      const double t = 5.5 * (double)rounds + loop + meet;
+      if (t < best_t) { best_t = t; best = Rb8Plan{bn, S}; }
+    }
+  }
+  return best;
+}
 
 template <int KIND>
 int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M,
@@ -964,18 +1137,22 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   Rb8Args p{};
   p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.y = y;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  // slabs of 64 rows for M <= 64, else 128.  128-column tiles while they give ~half a chip of workgroups before splitting,
-  // else 64-column tiles; K cut into at most 16 parts of >= 4 steps so that the grid approaches one workgroup per CU
-  const int bm = (M <= 64) ? 64 : 128;
+  // slabs of 64 rows for M <= 64, else 128; (round 5) 256 rows where 128-row slabs would need a second round of the chip and 256-row
+  // ones do not (897 .. 1024 rows -- what was measured -- on the 70B / TP8 shards: a step's fixed cost -- the barrier, the waits, ~430 cycles whatever the tile -- is
+  // then spread over twice the MFMAs: o 8192 x 1024 20.1 -> 18.6 us, gate_up 78.9 -> 71.2, down 41.6 -> 38.3).  g_rb8_bm forces 128 / 256.
+  const int64_t t128 = ((N + 127) / 128) * ((M + 127) / 128), t256 = ((N + 127) / 128) * ((M + 255) / 256);
+  const int bm = (M <= 64) ? 64 : (g_rb8_bm == 128) ? 128 : (g_rb8_bm == 256 || (t128 > 256 && t256 <= 256 && M > 896 && M <= 1024)) ? 256 : 128;
   const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
-  const bool wide = ((N + 127) / 128) * slabs * std::min<int64_t>(16, std::max<int64_t>(1, ksteps / 4)) >= 190;
-  const bool narrow = !wide || g_fp8_rb_force == 3;
-  const int bn = (g_rb8_bn == 32 || g_rb8_bn == 64 || g_rb8_bn == 128) ? g_rb8_bn : narrow ? 64 : 128;
+  Rb8Plan plan = rb8_plan(M, N, K, bm);
+  if (g_fp8_rb_force == 3) plan.bn = 64;
+  int bn = (g_rb8_bn == 32 || g_rb8_bn == 64 || g_rb8_bn == 128) ? g_rb8_bn : plan.bn;
+  if (bm == 256 && bn == 32) bn = 64;
   const int64_t base = ((N + bn - 1) / bn) * slabs;
-  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * bm) * 4 / 5;  // (x 4 / 5: the two-level meeting parks S + S / 4 tiles)
-  const int64_t target = (g_fp8_rb_force == 3) ? 512 : 256;
-  int split = (int)std::max<int64_t>(1, std::min<int64_t>({target / base, fit, 16, ksteps / 4}));
+  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * bm) * 4 / 5;
+  int split = (bn == plan.bn) ? plan.split : (int)std::max<int64_t>(1, std::min<int64_t>({256 / base, fit, 16, ksteps / 4}));
   if (g_rb8_split > 0) split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)g_rb8_split, fit, 16, ksteps}));
+  split = (int)std::max<int64_t>(1, std::min<int64_t>(split, fit));
+  if (bm == 256) return (bn == 128) ? launch_rb8<8, KIND, 16>(p, split, stream) : launch_rb8<4, KIND, 16>(p, split, stream);
   if (bn == 32) return (bm == 64) ? launch_rb8<2, KIND, 4>(p, split, stream) : launch_rb8<2, KIND, 8>(p, split, stream);
   if (bm == 64) return bn == 64 ? launch_rb8<4, KIND, 4>(p, split, stream) : launch_rb8<8, KIND, 4>(p, split, stream);
   return bn == 64 ? launch_rb8<4, KIND, 8>(p, split, stream) : launch_rb8<8, KIND, 8>(p, split, stream);

@@ -67,12 +67,23 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
   const __amdgpu_buffer_rsrc_t rws =
       __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * S * (kPartBytes / 4), 0, S * kPartBytes, 0x00020000);
   // `active` = false: a wave that holds no accumulators (a DMA-producer wave) only takes part in the workgroup barriers
+  // (round 5) the stores read their data from VGPR copies that are pinned (asm operands) until the stores are out: with the accumulators in
+  // AGPRs -- the 256-row slabs -- the compiler stages each store's data through scratch VGPRs and re-used one for the NEXT store's address
+  // one instruction later (tests/test_isa_structure.py caught it): the same hazard as below, on registers the old pin did not cover
+  f32x4 parked[NREG];
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) {
+    parked[r] = acc[r];
+    asm volatile("" : "+v"(parked[r]));
+  }
   if (active) {
 #pragma unroll
     for (int r = 0; r < NREG; ++r)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kPark);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, parked[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kPark);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through (LOCAL: acknowledged by the L2) before the ticket is taken
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(parked[r]));
   // The accumulators stay LIVE until the stores have completed.  Round 3: hipcc re-used a data register of a just-issued
   // `buffer_store_dwordx4 v[6:9], v32, s[8:11], s1 offen sc1` for the next store's address in the very next instruction
   // (`v_or_b32 v8, 0x2000, v32`); LLVM knows that hazard only for stores WITHOUT an SGPR soffset, gfx950 showed it with one: now and
@@ -148,12 +159,18 @@ __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, uns
       __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * slots * (kPartBytes / 4), 0, slots * kPartBytes, 0x00020000);
   unsigned* tk = tickets + (size_t)tile * (1 + NG);  // [0] second level, [1 + g] group g
   auto park = [&](int slot) {
+    f32x4 parked[NREG];  // VGPR copies, pinned until the stores are out (see split_k_meet)
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      parked[r] = acc[r];
+      asm volatile("" : "+v"(parked[r]));
+    }
 #pragma unroll
     for (int r = 0; r < NREG; ++r)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r]), rws, tid * 16 + r * kRegBytes, slot * kPartBytes, kPark);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, parked[r]), rws, tid * 16 + r * kRegBytes, slot * kPartBytes, kPark);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through (LOCAL: acknowledged by the L2) before the ticket is taken
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(acc[r]));  // the data registers stay untouched until the stores are out
+    for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(parked[r]));  // the data registers stay untouched until the stores are out
     __syncthreads();
   };
   auto last_of = [&](unsigned* t, int n) {

@@ -128,7 +128,10 @@ int ao_gemm8_set_variant(int variant);
  *   key 1  column-tile width of the rowwise weight-streaming kernel (rb8_kernel): 32, 64 or 128
  *   key 2  its K parts (1 .. 16)
  *   key 3  1 = never the same-XCD split-K meeting (the write-through, placement-independent one of rounds 1-4 instead)
- *   key 4  the pipelined 128 x 128 tile kernel (gemm8_pipe_kernel): 1 = never, 2 = wherever the shape allows
+ *   key 4  reserved
+ *   key 5  timing probes of the TRACED build of rb8_kernel only (ao_int4_set_trace set; results are wrong): bit 0 no MFMAs, 1 no fragment
+ *          reads, 2 no weight DMAs, 3 no activation DMAs -- the product build ignores it
+ *   key 6  slab height of rb8_kernel above 64 rows: 128 or 256
  * An unknown key is an error.  DESIGN.md 4.5h. */
 int ao_gemm8_set_tuning(int key, int value);
 /* 1 when the current device was measured to place workgroup b of a grid on XCD b % 8 (or has one XCD) -- the split-K kernels then put

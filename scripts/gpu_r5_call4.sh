@@ -1,0 +1,26 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/c4; mkdir -p $O; cd $R
+echo "== tests =="; timeout 900 python -m pytest tests/test_8bit_gpu.py tests/test_baseline_scale_gpu.py tests/test_fuzz_gpu.py -q -x --timeout 600 2>&1 | tail -4 | tee $O/tests.log
+{
+timeout 120 python tools/fp8_rb_trace.py 1024 8192 1024 101 "6=256"
+timeout 120 python tools/fp8_rb_trace.py 1024 7168 8192 101 "6=256"
+timeout 120 python tools/fp8_rb_trace.py 512 8192 3584 101 "6=256"
+} 2>&1 | grep -v amdgpu.ids > $O/trace.txt
+grep -E "^M=|per workgroup|storing|mean ticks" $O/trace.txt
+F="default,rb+bm128"; for bn in 64 128; do for s in 0 1 2 4; do F="$F,rb+bm256+bn$bn+s$s"; done; done
+echo "== sweep =="; timeout 1200 python tools/midm_sweep.py --ms 256,512,1024 --forms $F > $O/sweep.jsonl 2>$O/sweep.err; tail -2 $O/sweep.err
+python - <<'PY'
+import json,os
+p=os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"),"gpurun_out/c4/sweep.jsonl")
+rows=[json.loads(l) for l in open(p) if l.startswith("{") and "form" in l]
+key=lambda r:(r["shape"],r["M"]); seen=[]
+for r in rows:
+    if key(r) not in seen: seen.append(key(r))
+for k in seen:
+    rs=[r for r in rows if key(r)==k and "us" in r]
+    core=[r for r in rs if r["form"]=="core"][0]["us"]; d=[r for r in rs if r["form"]=="default"][0]["us"]
+    best=min((r for r in rs if r["form"] not in ("core",)), key=lambda r:r["us"])
+    top=sorted((r for r in rs if r["form"] not in ("core","default")), key=lambda r:r["us"])[:5]
+    print(k, f"core={core} default={d} best={best['form']}={best['us']} ratio={core/best['us']:.2f} |", " ".join(f"{r['form'][3:]}={r['us']}" for r in top))
+PY

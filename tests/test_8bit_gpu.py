@@ -639,21 +639,23 @@ def test_rb8_same_xcd_meeting_every_form(kind, m, n, k, bias):
     outs = {}
     try:
         lib.ao_gemm8_set_variant(101)  # always the weight-streaming kernel
-        for bn in (32, 64, 128):
-            for split in (1, 2, 5, 16):
-                for off in (0, 1):
-                    lib.ao_gemm8_set_tuning(1, bn)
-                    lib.ao_gemm8_set_tuning(2, split)
-                    lib.ao_gemm8_set_tuning(3, off)
-                    outs[(bn, split, off)] = run().clone()
+        for bm in ((128, 256) if m > 64 else (0,)):  # 256-row slabs (also with fewer rows than a slab)
+            for bn in (32, 64, 128):
+                for split in (1, 2, 5, 16):
+                    for off in (0, 1):
+                        lib.ao_gemm8_set_tuning(1, bn)
+                        lib.ao_gemm8_set_tuning(2, split)
+                        lib.ao_gemm8_set_tuning(3, off)
+                        lib.ao_gemm8_set_tuning(6, bm)
+                        outs[(bm, bn, split, off)] = run().clone()
     finally:
         lib.ao_gemm8_set_variant(0)
-        for key in (1, 2, 3):
+        for key in (1, 2, 3, 6):
             lib.ao_gemm8_set_tuning(key, 0)
     torch.cuda.synchronize()
-    for (bn, split, off), y in outs.items():
-        assert torch.equal(y, outs[(bn, split, 1)]), f"same-XCD meeting differs from the write-through one at bn={bn} split={split}"
-    yn = np_from_torch_bf16(outs[(128, 1, 0)])
+    for (bm, bn, split, off), y in outs.items():
+        assert torch.equal(y, outs[(bm, bn, split, 1)]), f"same-XCD meeting differs from the write-through one at bm={bm} bn={bn} split={split}"
+    yn = np_from_torch_bf16(next(iter(outs.values())))
     if kind == "int8":
         for key, y in outs.items():
             assert np.array_equal(np_from_torch_bf16(y), y_ref), f"int8 not bit-exact at {key}"

@@ -26,9 +26,12 @@ TABLE = [
     ((512, 7168, 8192), "rb8_kernel"),
     ((512, 8192, 1024), "rb8_kernel"),
     ((2048, 1280, 8192), "rb8_kernel"),
-    # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on (from 128 at short K / > 512 small tiles)
+    # round 5: up to 1024 rows also where 256-row slabs fit one round of the chip although 128-row ones would not
     ((768, 7168, 8192), "gemm8_dma_kernel<128x128>"),
-    ((1024, 7168, 8192), "gemm8_dma_kernel<128x128>"),
+    ((1024, 7168, 8192), "rb8_kernel"),
+    ((1024, 8192, 1024), "rb8_kernel"),
+    # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on (from 128 at short K / > 512 small tiles)
+    ((1024, 28672, 4096), "gemm8_p8_kernel"),
     ((2048, 4096, 14336), "gemm8_dma_kernel<128x128>"),
     ((2048, 4096, 4096), "gemm8_p8_kernel"),   # 128 tiles of 256 x 256 and K <= 4096 (round 4)
     ((1280, 7168, 8192), "gemm8_p8_kernel"),   # 140 such tiles, but 560 of 128 x 128: a second round of the chip otherwise

@@ -47,6 +47,8 @@ def parse_form(name):
             v, t = FORMS[part]
             variant = v or variant
             tun.update(t)
+        elif part.startswith("bm"):  # slab height
+            tun[6] = int(part[2:])
         elif part.startswith("v"):
             variant = int(part[1:])
         elif part.startswith("s"):  # K parts
@@ -127,7 +129,7 @@ def main():
                     y_ref = None
                     for fname, (variant, tun) in forms:
                         lib.ao_gemm8_set_variant(variant)
-                        for key in (1, 2, 3, 4):
+                        for key in (1, 2, 3, 4, 5, 6):
                             lib.ao_gemm8_set_tuning(key, tun.get(key, 0))
                         rec = dict(base, form=fname, kernel=lib.ao_gemm8_kernel_name(0 if kind == "fp8" else 1, m, n, k).decode() if fname == "default" else None)
                         try:
@@ -151,7 +153,7 @@ def main():
                             rec["error"] = repr(e)[:200]
                         finally:
                             lib.ao_gemm8_set_variant(0)
-                            for key in (1, 2, 3, 4):
+                            for key in (1, 2, 3, 4, 5, 6):
                                 lib.ao_gemm8_set_tuning(key, 0)
                         print(json.dumps(rec), flush=True)
                     if m == int(args.ms.split(",")[0]):
