@@ -15,10 +15,11 @@
 //   * per step and wave: 2 weight loads + NA activation loads (issued G resp. PA steps ahead), 2 + NA ds_write_b128, 2 + 2 MT
 //     ds_read_b128, MT (fp8) or 2 MT (int8) MFMAs, ONE LDS-only barrier;
 //   * K parts meet through the two-level meeting of splitk.h (groups of four parts: two dependent round trips instead of S / 4);
-//   * FUSED: before its k loop every workgroup takes rows of x from a ticket counter -- amax -> scale -> codes with quant_math.h's
-//     arithmetic, written through (sc1) to a scratch copy in the stream's workspace -- until none are left, then waits for the
-//     `done` counter.  The wait only ever depends on rows a RUNNING workgroup has taken, so no co-residency is assumed; the weight
-//     ring is requested first, so the cast runs under the weights' flight.  One launch per linear instead of two.
+//   * the dynamic-activation entry points (ao_*_dynamic_linear at 16 < M <= 256) run the stand-alone per-row cast into a scratch
+//     area of the stream's split-K workspace and then this kernel on it: two launches behind one call.  Round 4 built the cast INTO the
+//     kernel (rows shared out through a ticket counter, a grid-wide wait before the k loop): it measured 15 - 20 us slower per linear
+//     than cast + matmul (profiles/mid8_sweep_r04.txt) and its ticket / time-out paths were the round-4 advisor's two
+//     findings; round 5 removed it.
 #include "common.h"
 #include "quant_math.h"
 #include "splitk.h"
@@ -33,19 +34,15 @@ namespace {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 struct Mid8Args {
-  const uint8_t* a;        // [M][K] codes (FUSED: the scratch copy the prologue writes)
-  const uint16_t* x;       // FUSED: bf16 [M][K]
+  const uint8_t* a;        // [M][K] codes
   const uint8_t* b;        // [N][K]
-  const float* scale_a;    // [M] (FUSED: scratch)
+  const float* scale_a;    // [M]
   const float* scale_b;    // [N]
   const uint16_t* bias;    // [N] bf16 or null
   uint16_t* y;             // [M][N] bf16
   int M, N, K;
   float* ws;               // split-K parts
   unsigned* tickets;
-  uint8_t* xq;             // FUSED scratch: codes [M][K]
-  float* xs;               // FUSED scratch: scales [M]
-  unsigned* sync;          // FUSED: [0] next row, [1] rows done, [2] workgroups past the wait (the last one re-zeroes all three)
 };
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -55,7 +52,7 @@ constexpr int kSlab = 16 * kRow;   // 2304 B per wave
 constexpr int kPA = 2;             // activation steps requested ahead (L2 hits)
 
 
-template <bool INT8, int MT, int G, bool FUSED>
+template <bool INT8, int MT, int G>
 __global__ __launch_bounds__(512, 4) void mid8_kernel(Mid8Args p) {
   constexpr int BM = 16 * MT;
   constexpr int AROWS = (BM < 64) ? 64 : BM;  // rows of the LDS activation tile (512 threads fetch 64 rows per pass)
@@ -96,78 +93,7 @@ __global__ __launch_bounds__(512, 4) void mid8_kernel(Mid8Args p) {
   for (int g = 0; g < G; ++g) issue_w(wr[g], g);
   __builtin_amdgcn_sched_barrier(0);
 
-  // ---- FUSED: the per-row cast, shared out by a ticket counter (see the header).  A workgroup takes one row per ticket and casts
-  // it with all 512 threads: the row (K <= 16384: at most 4 vectors of 8 bf16 per thread) stays in registers between amax and cast.
-  // Control flow around the s_barriers must be UNIFORM in the compiler's eyes (inline-asm barriers, a ticket loop): the first version
-  // took the ticket under `if (tid == 0)` and read it back from LDS as a plain value -- the loop counted as divergent, the
-  // structurizer rotated the lane-0 blocks around the back edge and sent the other lanes of wave 0 into the next iteration's
-  // s_barrier ahead of lane 0: the workgroup hung.  Now: a scalar branch on the wave index, all 64 lanes of wave 0 add 1 (the compiler
-  // folds that into ONE atomic add of 64 by the first lane, so the counters advance in units of 64) and readfirstlane hands the
-  // ticket to the scalar unit; every lane stores the same ticket / scale to the same address instead of branching on the lane.
-  if constexpr (FUSED) {
-    __shared__ float s_part[8];
-    __shared__ int s_row;
-    constexpr int XV = 4;
-    const int nvec = p.K >> 3;  // 8 bf16 per 16 B; <= XV * 512 (host)
-    for (;;) {
-      if (wave == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&p.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_row = __builtin_amdgcn_readfirstlane((int)old) >> 6;
-      }
-      lds_barrier();
-      const int r = __builtin_amdgcn_readfirstlane(s_row);
-      if (r >= p.M) break;
-      const u32x4* xr = reinterpret_cast<const u32x4*>(p.x + (size_t)r * p.K);
-      u32x4 xv[XV];
-#pragma unroll
-      for (int i = 0; i < XV; ++i) xv[i] = xr[min(tid + i * 512, nvec - 1)];  // clamped, unconditional
-      float m = 0.f;
-      bool has_nan = false;
-#pragma unroll
-      for (int i = 0; i < XV; ++i) m = fmaxf(m, amax8(xv[i], has_nan));
-      if (has_nan) m = INFINITY;
-      m = wave_max(m);
-      s_part[wave] = m;  // (every lane: same value, same address)
-      lds_barrier();
-      float mm = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) mm = fmaxf(mm, s_part[w]);
-      const float s = INT8 ? int8_row_scale(mm) : fp8_row_scale(mm);
-      const float inv = 1.0f / s;
-      unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.xq + (size_t)r * p.K);
-#pragma unroll
-      for (int i = 0; i < XV; ++i) {
-        const int idx = tid + i * 512;
-        if (idx < nvec) {
-          const u32x2 q = INT8 ? int8_quant8(xv[i], inv) : fp8_quant8(xv[i], s);
-          __hip_atomic_store(dst + idx, ((unsigned long long)q.y << 32) | q.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: written through
-        }
-      }
-      __hip_atomic_store(p.xs + r, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (drains this wave's part of the weight ring too: it has long landed by now)
-      lds_barrier();                                      // every wave's stores are out before the row counts as done
-      if (wave == 0) __hip_atomic_fetch_add(&p.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (tid == 0) {
-      // (bounded: a bug here must not hang the device -- after 2 s of the 100 MHz clock the wait gives up and marks sync[3])
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(&p.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 64u * (unsigned)p.M) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(&p.sync[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-      // the last workgroup past the wait leaves the counters at zero for the next launch on this stream
-      const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-      if (__hip_atomic_fetch_add(&p.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-        __hip_atomic_store(&p.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&p.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&p.sync[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    lds_barrier();
-  }
-
   // ---- activation tile: thread t fetches chunk t & 7 of rows (t >> 3) + 64 i (clamped into the matrix: rows past M are never stored)
-  // (FUSED: the scratch codes were written through by other workgroups -- the agent-scope (sc1) cache policy on these loads)
   uint32_t aoff[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) aoff[i] = (uint32_t)min(m0 + (tid >> 3) + 64 * i, p.M - 1) * (uint32_t)p.K + (tid & 7) * 16;
@@ -177,7 +103,7 @@ __global__ __launch_bounds__(512, 4) void mid8_kernel(Mid8Args p) {
   auto load_a = [&](u32x4 (&dst)[NA], int k) {
     const uint32_t so = (uint32_t)(k0 + min(k, nk - 1)) * 128u;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)aoff[i], (int)so, FUSED ? 16 /* sc1 */ : 0));
+    for (int i = 0; i < NA; ++i) dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)aoff[i], (int)so, 0));
   };
   auto store_a = [&](const u32x4 (&src)[NA], int buf) {
 #pragma unroll
@@ -242,15 +168,14 @@ __global__ __launch_bounds__(512, 4) void mid8_kernel(Mid8Args p) {
   // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
   const int n = tile * 16 + nl;
   uint16_t* __restrict__ y = p.y;
-  const float* __restrict__ scale_a = FUSED ? p.xs : p.scale_a;
+  const float* __restrict__ scale_a = p.scale_a;
   const float sb = p.scale_b[n];
   const float bias = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
   float sa[4 * MT];  // all row scales first: the stores below must not sit between dependent loads
 #pragma unroll
   for (int i = 0; i < 4 * MT; ++i) {
     const int m = min(m0 + (i >> 2) * 16 + kq * 4 + (i & 3), p.M - 1);
-    if constexpr (FUSED) sa[i] = __hip_atomic_load(scale_a + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else sa[i] = scale_a[m];
+    sa[i] = scale_a[m];
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -304,36 +229,29 @@ bool mid8_plan(int64_t M, int64_t N, int64_t K, Mid8Plan* out) {
   return true;
 }
 
-template <bool INT8, int MT, bool FUSED>
+template <bool INT8, int MT>
 int launch_mid8(Mid8Args p, int split, hipStream_t stream) {
   constexpr int BM = 16 * MT, AROWS = (BM < 64) ? 64 : BM;
   constexpr size_t smem = (size_t)2 * AROWS * kRow + 8 * kSlab;
   const dim3 grid((unsigned)((p.N + 127) / 128), (unsigned)((p.M + BM - 1) / BM), (unsigned)split), block(512);
   const size_t tiles = (size_t)grid.x * grid.y;
   const size_t part_floats = (split > 1) ? tiles * (split + (split + 3) / 4) * 128 * BM : 0;
-  const size_t scratch_floats = FUSED ? ((size_t)p.M * p.K + 15) / 16 * 4 + (size_t)((p.M + 3) / 4 * 4) : 0;
-  if (split > 1 || FUSED) {
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, part_floats + scratch_floats)) return rc;
-    if constexpr (FUSED) {
-      p.xq = reinterpret_cast<uint8_t*>(p.ws + part_floats);
-      p.xs = p.ws + part_floats + ((size_t)p.M * p.K + 15) / 16 * 4;
-      p.sync = p.tickets + kSplitMaxTickets - 4;  // the last tickets of the stream's workspace: zero between launches
-      p.a = p.xq;
-    }
+  if (split > 1) {
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, part_floats)) return rc;
   }
-  auto kern = mid8_kernel<INT8, MT, kG, FUSED>;
+  auto kern = mid8_kernel<INT8, MT, kG>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(mid8_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, p);
   AO_LAUNCH_CHECK("mid8_kernel launch");
   return AO_OK;
 }
 
-template <bool INT8, bool FUSED>
+template <bool INT8>
 int run_mid8(const Mid8Args& p, const Mid8Plan& plan, hipStream_t stream) {
   switch (plan.mt) {
-    case 2: return launch_mid8<INT8, 2, FUSED>(p, plan.split, stream);
-    case 4: return launch_mid8<INT8, 4, FUSED>(p, plan.split, stream);
-    default: return launch_mid8<INT8, 8, FUSED>(p, plan.split, stream);
+    case 2: return launch_mid8<INT8, 2>(p, plan.split, stream);
+    case 4: return launch_mid8<INT8, 4>(p, plan.split, stream);
+    default: return launch_mid8<INT8, 8>(p, plan.split, stream);
   }
 }
 
@@ -355,20 +273,28 @@ int mid8_scaled(bool int8, const void* a, const float* scale_a, const void* b, c
   Mid8Args p{};
   p.a = static_cast<const uint8_t*>(a); p.b = static_cast<const uint8_t*>(b); p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.y = y;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  return int8 ? run_mid8<true, false>(p, plan, stream) : run_mid8<false, false>(p, plan, stream);
+  return int8 ? run_mid8<true>(p, plan, stream) : run_mid8<false>(p, plan, stream);
 }
 
+// ao_*_dynamic_linear at 16 < M <= 256: the per-row cast (the stand-alone kernel: same arithmetic, same bits) into a scratch area BEHIND
+// the parts of the meeting in the stream's split-K workspace, then the kernel above on it -- stream-ordered, two launches.
 int mid8_dynamic(bool int8, const uint16_t* x, const void* b, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M, int64_t N, int64_t K,
                  hipStream_t stream) {
   Mid8Plan plan;
-  if (K > 16384 || !mid8_plan(M, N, K, &plan)) {  // (the fused cast holds a row in 4 x 512 vectors of 8)
+  if (K > 16384 || !mid8_plan(M, N, K, &plan)) {
     set_error("mid8_dynamic: shape M=%lld N=%lld K=%lld not covered", (long long)M, (long long)N, (long long)K);
     return AO_ERR_INVALID_ARGUMENT;
   }
-  Mid8Args p{};
-  p.x = x; p.b = static_cast<const uint8_t*>(b); p.scale_b = scale_b; p.bias = bias; p.y = y;
-  p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  return int8 ? run_mid8<true, true>(p, plan, stream) : run_mid8<false, true>(p, plan, stream);
+  const size_t tiles = (size_t)((N + 127) / 128) * (size_t)((M + 16 * plan.mt - 1) / (16 * plan.mt));
+  const size_t part_floats = (plan.split > 1) ? tiles * (plan.split + (plan.split + 3) / 4) * 128 * 16 * plan.mt : 0;
+  const size_t code_floats = ((size_t)M * K + 15) / 16 * 4, scale_floats = (size_t)((M + 3) / 4 * 4);
+  float* ws = nullptr;
+  unsigned* tickets = nullptr;
+  if (int rc = splitk_workspace(stream, &ws, &tickets, part_floats + code_floats + scale_floats)) return rc;
+  uint8_t* xq = reinterpret_cast<uint8_t*>(ws + part_floats);
+  float* xs = ws + part_floats + code_floats;
+  if (int rc = int8 ? ao_int8_quantize_rowwise(x, reinterpret_cast<int8_t*>(xq), xs, M, K, stream) : ao_fp8_quantize_rowwise(x, xq, xs, M, K, stream)) return rc;
+  return mid8_scaled(int8, xq, xs, b, scale_b, bias, y, M, N, K, stream);
 }
 
 }  // namespace ao

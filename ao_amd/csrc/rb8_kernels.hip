@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 // A/B knobs of the rowwise weight-streaming kernel (ao_gemm8_set_tuning; 0 = product rule): column-tile width, K parts, same-XCD meeting
-thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_local = 0, g_rb8_ablate = 0, g_rb8_bm = 0;  // local: 0 product (on where the device allows), 1 off
+thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_local = 0, g_rb8_ablate = 0, g_rb8_bm = 0;  // local: 0 product (off), 1 off, 2 on where the device allows
 thread_local bool g_rb8_sm = true;  // rb8_kernel's 2 x 4 wave arrangement where it is built (ao_gemm8_set_variant 103: off)
 
 template <int WAVES, int KIND, int MT = 8, bool SLIM = false, int QS = 1>
@@ -1030,8 +1030,12 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
                grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y * tks <= kSplitMaxTickets - 8, "rb8: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
     if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * slots * BN * BM)) return rc;
-    if (!kGrouped && g_rb8_local != 1 && splitk_xcd_local_ok()) {
-      // all K parts of a tile on one XCD: ids that agree mod 8 (measured per device, checked per tile: splitk.h)
+    // All K parts of a tile on one XCD (ids that agree mod 8; measured per device, checked per tile: splitk.h) and the parked tiles in that
+    // XCD's L2.  Built and parity-clean, but OPT-IN (ao_gemm8_set_tuning(3, 2)): next to the write-through meeting it measured +- 2 % on all
+    // 40 cells of profiles/midm_sweep_r05.jsonl -- the meeting's cost is its three dependent round trips (stores acknowledged -> ticket ->
+    // gather), each ~1 us under load whether it ends in the XCD's L2 or at the fabric -- so the product keeps the protocol that depends on
+    // no placement at all.
+    if (!kGrouped && g_rb8_local == 2 && splitk_xcd_local_ok()) {
       p.xcd = 1; p.gx = (int)grid.x; p.gy = (int)grid.y; p.split = split;
       const unsigned tiles = grid.x * grid.y;
       grid = dim3(8u * (unsigned)split * ((tiles + 7u) / 8u));

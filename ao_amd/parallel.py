@@ -89,6 +89,7 @@ class OneShotAllReduce:
         own, ptrs, self._keep, self.memory = peer_mem.exchange(
             [(2 * self.max_bytes, peer_mem.FINEGRAINED), (lib.ao_allreduce_flag_bytes(), peer_mem.UNCACHED)], self.group, device,
             force_fallback=self._force_coarse)
+        peer_mem.require_coherent(self.memory, self.group, device)  # (raises -> ok stays False, `why` says why: RCCL serves the calls)
         self._staging, self._flags = own
         self._state = torch.zeros(lib.ao_allreduce_state_bytes() // 4, dtype=torch.int32, device=device)
         self._scratch = torch.empty(self.max_bytes, dtype=torch.uint8, device=device)  # contiguous, 16-byte aligned stand-in

@@ -121,3 +121,29 @@ def exchange(specs: Sequence[Tuple[int, int]], group, device, force_fallback: bo
                 keep.append(st)
                 ptrs[i][r] = st.data_ptr()
     return own_t, ptrs, keep, f"coarse-grained fallback: {why}"
+
+
+def spans_devices(group, device) -> bool:
+    """True when the ranks of `group` sit on more than one physical GPU (or that cannot be established).  Collective (one object
+    all-gather): every rank names its host and the GPU's UUID / PCI bus id."""
+    import socket
+
+    try:
+        props = torch.cuda.get_device_properties(device)
+        ident = (socket.gethostname(), str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_bus_id', -1)}:{getattr(props, 'pci_device_id', -1)}")
+    except Exception:  # noqa: BLE001
+        ident = None
+    gathered = [None] * dist.get_world_size(group)
+    dist.all_gather_object(gathered, ident, group=group)
+    return any(g is None for g in gathered) or len(set(gathered)) > 1
+
+
+def require_coherent(memory: str, group, device):
+    """the coarse-grained fallback of exchange() (torch allocations + CUDA-IPC storage sharing) is only known to work between
+    processes that share ONE GPU -- its L2 makes them coherent.  Across GPUs a spin on such memory can read a stale flag forever
+    (csrc/peer_sync.h): every call would run into the wait bound and poison its output.  Raise instead, so that the callers' setup
+    fails (`ok = False`, `why` says so) and they use RCCL.  Collective."""
+    if memory.startswith("coarse-grained fallback") and spans_devices(group, device):
+        raise RuntimeError("peer buffers fell back to coarse-grained memory (" + memory + ") and the group spans more than one GPU: "
+                           "flag polling across devices needs uncached / fine-grained allocations; using the process group's collectives instead")
+

@@ -177,6 +177,7 @@ class OnDeviceAllToAllV:
             own, ptrs, self._keep, self.memory = peer_mem.exchange(
                 [(self.max_rows * dim, peer_mem.FINEGRAINED), (self.max_rows * (dim // BLOCK), peer_mem.FINEGRAINED),
                  (8 * world, peer_mem.FINEGRAINED), (lib.ao_moe_a2a_flag_bytes(), peer_mem.UNCACHED)], self.group, device)
+            peer_mem.require_coherent(self.memory, self.group, device)  # (raises -> ok stays False: the RCCL all-to-all serves the calls)
             self._data = own[0].view(self.max_rows, dim)
             self._scales = own[1].view(self.max_rows, dim // BLOCK)
             self._splits = own[2].view(torch.int64)

@@ -1,5 +1,10 @@
 from .config import (  # noqa: F401
     AOBaseConfig,
+    Float8MMConfig,
+    Float8PackingFormat,
+    KernelPreference,
+    config_from_dict,
+    config_to_dict,
     Float8DynamicActivationFloat8WeightConfig,
     Float8DynamicActivationInt4WeightConfig,
     FqnToConfig,

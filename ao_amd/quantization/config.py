@@ -9,7 +9,11 @@ from .quant_primitives import MappingType
 
 
 class AOBaseConfig:
-    """Marker base class: a config selects a per-module transform in quantize_."""
+    """Base class of the workflow configs: a config selects a per-module transform in quantize_ (reference torchao/core/config.py:27).
+    `version` is an INSTANCE attribute in the subclasses that bump it (several versions of one config co-exist in checkpoints); 1 is
+    the default of those that never did.  JSON (de)serialisation: config_to_dict / config_from_dict below."""
+
+    version: int = 1
 
 
 class Int4PackingFormat(str, enum.Enum):
@@ -113,38 +117,89 @@ class Int8StaticActivationInt8WeightConfig(AOBaseConfig):
         return QuantizeTensorToInt8Kwargs(granularity=self.granularity[0], mapping_type=self.act_mapping_type, reduce_range=self.reduce_range)
 
 
+class KernelPreference(str, enum.Enum):
+    """reference quantize_/common/kernel_preference.py:17-47.  One kernel family exists on MI355X: AUTO and TORCH both mean it; the
+    others name libraries that are not this backend."""
+    AUTO = "auto"
+    TORCH = "torch"
+    MSLK = "mslk"
+    EMULATED = "emulated"
+    DEEPGEMM = "deepgemm"
+    TRITON = "triton"
+
+
+class Float8PackingFormat(str, enum.Enum):
+    """reference float8_packing_format.py:19-40 (PLAIN is what this backend implements; the 2:4-sparse formats are out of scope)."""
+    PLAIN = "plain"
+    SPARSE_CUTLASS = "sparse_cutlass"
+    SPARSE_2D_DATA_2D_METADATA = "sparse_2d_data_2d_metadata"
+    SPARSE_2D_DATA_1D_METADATA = "sparse_2d_data_1d_metadata"
+
+
+@dataclass
+class Float8MMConfig:
+    """reference float8/inference.py:26-39 (a NamedTuple there): carried for (de)serialisation; fp32 accumulation on the scaled MFMA is
+    what runs whatever use_fast_accum says, and K is never padded (K % 16 == 0 is required, as the reference's skip rule has it)."""
+    emulate: bool = False
+    use_fast_accum: bool = False
+    pad_inner_dim: bool = False
+
+
 @dataclass
 class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
-    """float8 e4m3 dynamic activation x float8 weight (reference quant_api.py:1112-1297).  granularity: None = PerTensor for
-    both (the reference's default), PerRow() (the BASELINE configuration), or [activation, weight] of the same type."""
+    """float8 e4m3 dynamic activation x float8 weight (reference quant_api.py:1112-1297; same fields in the same order, so that a
+    config the reference serialised decodes here).  granularity: None = PerTensor for both (the reference's default), PerRow() (the
+    BASELINE configuration), or [activation, weight] of the same type."""
 
+    activation_dtype: object = None  # torch.float8_e4m3fn (None: that); gfx950 implements OCP e4m3fn only
+    weight_dtype: object = None
     granularity: Optional[Union[Granularity, List[Granularity]]] = None
-    activation_value_lb: Optional[float] = None  # bounds on the activation amax the scale is calculated from (reference :1126-1127)
-    activation_value_ub: Optional[float] = None
-    # accepted for source compatibility with the reference's call sites; there is one kernel family on MI355X (fp32 accumulation on
+    packing_format: Optional[Float8PackingFormat] = Float8PackingFormat.PLAIN
+    # accepted for source / checkpoint compatibility with the reference; there is one kernel family on MI355X (fp32 accumulation on
     # the scaled MFMA whatever use_fast_accum says, no mslk / torch choice to make), so neither changes what runs
     mm_config: Optional[object] = None
-    kernel_preference: object = "auto"
+    activation_value_lb: Optional[float] = None  # bounds on the activation amax the scale is calculated from (reference :1126-1127)
+    activation_value_ub: Optional[float] = None
+    kernel_preference: object = KernelPreference.AUTO
     set_inductor_config: bool = False
     version: int = 2
+    alg_id: int = 0
 
     def __post_init__(self):
+        import torch
+
         act, weight = _normalize_granularity(self.granularity, PerTensor, "Float8DynamicActivationFloat8WeightConfig")
         if type(act) is not type(weight):
             raise ValueError(f"Different granularities for activation and weight are not supported: {act}, {weight}")
         self.granularity = [act, weight]
+        self.activation_dtype = torch.float8_e4m3fn if self.activation_dtype is None else self.activation_dtype
+        self.weight_dtype = torch.float8_e4m3fn if self.weight_dtype is None else self.weight_dtype
+        if self.activation_dtype != torch.float8_e4m3fn or self.weight_dtype != torch.float8_e4m3fn:
+            raise NotImplementedError(f"Float8DynamicActivationFloat8WeightConfig on MI355X implements float8_e4m3fn for both operands, got "
+                                      f"{self.activation_dtype} / {self.weight_dtype}")
+        self.packing_format = Float8PackingFormat(self.packing_format) if self.packing_format is not None else Float8PackingFormat.PLAIN
+        if self.packing_format != Float8PackingFormat.PLAIN:
+            raise NotImplementedError(f"Float8 packing format {self.packing_format.value}: 2:4 sparsity is outside SURVEY.md section 8")
+        self.kernel_preference = KernelPreference(self.kernel_preference)
+        if self.kernel_preference not in (KernelPreference.AUTO, KernelPreference.TORCH):
+            raise NotImplementedError(f"kernel_preference {self.kernel_preference.value} names a library that is not this backend; use AUTO")
+        if self.mm_config is None:
+            self.mm_config = Float8MMConfig(use_fast_accum=True)
 
 
 @dataclass
 class Float8DynamicActivationInt4WeightConfig(AOBaseConfig):
     """float8 e4m3 rowwise dynamic activation x int4 groupwise (symmetric) weight (reference quant_api.py:630-699: group_size 128).
 
-    `int4_packing_format`: "preshuffled" (the reference's default, :646) or "plain".  The reference's preshuffled tensor is the same
-    quantization in a layout pre-arranged for its H100 kernel; the MI355X counterpart of that is the PLAIN `Int4Tensor` carrying its
-    gfx950 compute layout (tile-packed codes + stacked scale / zero, built once at from_hp) -- both values produce it, so the
-    reference's default config runs unchanged.  The checkpoint-format nibbles stay available (`release_plain_()` drops them)."""
+    `int4_packing_format`: "plain" (the default HERE) or "preshuffled".  Both build the PLAIN `Int4Tensor` (reference
+    int4_tensor.py: qdata / scale / zero_point) carrying its gfx950 compute layout (tile-packed codes + stacked scale / zero, built once at
+    from_hp); its state_dict IS the reference's PLAIN format.  The REFERENCE's default is "preshuffled" (:646): an
+    `Int4PreshuffledTensor` (qdata / group_scale / row_scale, a layout pre-arranged for its H100 WGMMA kernel through un-vendored mslk
+    ops).  That tensor class and checkpoint layout are NOT produced here -- "preshuffled" is accepted so that the reference's default
+    call sites run, as an alias of "plain"; a checkpoint saved under it does not round-trip with upstream's preshuffled checkpoints
+    (ADVICE r4), which is why the default names the format that is actually written."""
 
-    int4_packing_format: Int4PackingFormat = Int4PackingFormat.PRESHUFFLED
+    int4_packing_format: Int4PackingFormat = Int4PackingFormat.PLAIN
     group_size: int = 128
 
     def __post_init__(self):
@@ -174,3 +229,92 @@ class FqnToConfig(AOBaseConfig):
 
 
 ModuleFqnToConfig = FqnToConfig  # the reference keeps the old name (quant_api.py:1598)
+
+
+
+# ---- JSON (de)serialisation of configs (reference torchao/core/config.py:69-305: same wire format) -----------------------------------
+# {"_type": <class name>, "_version": <int>, "_data": {field: value, ...}}; enums {"_type": <enum class>, "_data": <member NAME>};
+# torch.dtype {"_type": "torch.dtype", "_data": "bfloat16"}; granularities and kwargs dataclasses like configs; lists and dicts element
+# by element; tuples are refused (JSON would turn them into lists silently).  Only class NAMES are stored: they are resolved against this
+# package's own modules, never imported from a path in the file.
+def _encode(value):
+    import dataclasses
+
+    import torch
+
+    if isinstance(value, AOBaseConfig) or (dataclasses.is_dataclass(value) and not isinstance(value, type)):
+        if dataclasses.is_dataclass(value):
+            items = [(f.name, getattr(value, f.name)) for f in dataclasses.fields(value)]
+        else:
+            items = list(vars(value).items())
+        return {"_type": type(value).__name__, "_version": getattr(value, "version", 1),
+                "_data": {k: _encode(v) for k, v in items if k != "version" and not k.startswith("_")}}
+    if isinstance(value, enum.Enum):
+        return {"_type": type(value).__name__, "_data": value.name}
+    if isinstance(value, torch.dtype):
+        return {"_type": "torch.dtype", "_data": str(value).split(".")[-1]}
+    if isinstance(value, tuple):
+        raise NotImplementedError(f"Tuples will be serialized as List in JSON, so we recommend to use Lists instead to avoid surprises. got: {value}")
+    if isinstance(value, list):
+        return [_encode(v) for v in value]
+    if isinstance(value, dict):
+        return {k: _encode(v) for k, v in value.items()}
+    if value is None or isinstance(value, (bool, int, float, str)):
+        return value
+    if isinstance(value, torch.Tensor):
+        raise TypeError("tensors inside a config (static activation scales) are checkpoint data, not configuration: save them with the state_dict")
+    raise TypeError(f"Object of type {type(value).__name__} is not JSON serializable")
+
+
+def config_to_dict(config):
+    if not isinstance(config, AOBaseConfig):
+        raise TypeError(f"Expected AOBaseConfig instance, got {type(config)}")
+    return _encode(config)
+
+
+def _resolve(name):
+    import importlib
+
+    for mod in ("ao_amd.quantization.config", "ao_amd.quantization.granularity", "ao_amd.quantization.quant_primitives",
+                "ao_amd.quantization.int8_tensor", "ao_amd.quantization.float8_tensor", "ao_amd.prototype.mx"):
+        try:
+            cls = getattr(importlib.import_module(mod), name)
+        except (ImportError, AttributeError):
+            continue
+        if isinstance(cls, type):
+            return cls
+    raise ValueError(f"Failed to find class {name} in any of the allowed modules of ao_amd")
+
+
+def config_from_dict(data):
+    import warnings
+
+    if not isinstance(data, dict):
+        raise TypeError(f"Expected dictionary, got {type(data)}")
+    if "_type" not in data or "_data" not in data:
+        raise ValueError("Input dictionary missing required '_type' or '_data' fields")
+    name, payload = data["_type"], data["_data"]
+    if name == "torch.dtype":
+        import torch
+
+        return getattr(torch, payload)
+    cls = _resolve(name)
+    if not isinstance(payload, dict):
+        return getattr(cls, payload) if issubclass(cls, enum.Enum) else cls(payload)
+
+    def dec(v):
+        if isinstance(v, dict):
+            return config_from_dict(v) if ("_type" in v and "_data" in v) else {k: dec(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [dec(x) for x in v]
+        return v
+
+    kwargs = {k: dec(v) for k, v in payload.items()}
+    stored, current = data.get("_version", 1), getattr(cls, "version", 1)
+    if stored != current:
+        warnings.warn(f"Stored version is not the same as current default version of the config: {stored=}, {current=}, please check the deprecation warning")
+        kwargs["version"] = stored
+    try:
+        return cls(**kwargs)
+    except Exception as e:  # noqa: BLE001
+        raise ValueError(f"Failed to create instance of {cls.__name__}: {e}") from e

@@ -20,12 +20,29 @@ __all__ = ["Float8Tensor", "QuantizeTensorToFloat8Kwargs"]
 
 
 def _require_bf16_activation(x, what):
-    """The reference quantizes the activation in ITS dtype (fp16 scales are upcast on purpose, int8_tensor.py:311-317); the MI355X
+    """The reference quantizes the activation in ITS dtype (fp16 scales are upcast on purpose, int8_tensor.py:311-317); the fused MI355X
     casts take bfloat16 only, and a silent .to(bfloat16) would round fp16 / fp32 activations before the scale is taken -- not the
-    reference's arithmetic.  Refuse instead of approximating."""
+    reference's arithmetic.  The default PerRow dynamic linear has a correct slow path for fp16 / fp32 (`_linear_other_dtype`); the
+    variants that do not (static / bounded / tensorwise / grouped) refuse instead of approximating."""
     if x.dtype != torch.bfloat16:
         raise NotImplementedError(f"{what} on MI355X takes bfloat16 activations, got {x.dtype}: cast the activation explicitly "
                                   "(x.to(torch.bfloat16)) if that rounding is acceptable")
+
+
+def _linear_other_dtype(x2, w, bias):
+    """fp16 / fp32 activations (the reference supports them, float8_tensor.py:349-355 + :167-253): the cast in the activation's
+    OWN dtype with the reference's op sequence -- scale = (amax / 448) in x.dtype, widened to fp32 (_choose_scale_float8); codes =
+    sat_cast(f32(x) / scale) (_quantize_affine_float8) -- as torch ops on the device, then the raw e4m3 x e4m3 -> fp32 GEMM of this
+    library and aten::_scaled_mm's epilogue (acc * scale_a * scale_b + bias) in fp32, out in the activation's dtype.  Three extra
+    elementwise passes: the fused bf16 kernels stay the fast path."""
+    amax = x2.abs().amax(dim=-1, keepdim=True)
+    scale = (amax / 448.0).to(torch.float32)
+    xq = (x2.to(torch.float32) / scale).clamp(min=-448.0, max=448.0).to(torch.float8_e4m3fn)
+    acc = ops.fp8_mm_f32(xq, w.qdata.t())
+    y = acc * scale * w.scale.reshape(1, -1).to(torch.float32)
+    if bias is not None:
+        y = y + bias.to(torch.float32)
+    return y.to(x2.dtype)
 
 
 @dataclass
@@ -247,10 +264,14 @@ def _float8_linear(x, w, bias):
             "use Float8DynamicActivationFloat8WeightConfig"
         )
     _check(w.act_quant_kwargs.granularity, w.act_quant_kwargs.float8_dtype)
-    _require_bf16_activation(x, "Float8Tensor dynamic-activation linear")
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     n = w.qdata.shape[0]
     w_tensorwise = w.scale.numel() == 1
+    act0 = w.act_quant_kwargs
+    if (x.dtype in (torch.float16, torch.float32) and isinstance(act0.granularity, PerRow) and not w_tensorwise and w.qdata.dim() == 2
+            and act0.hp_value_lb is None and act0.hp_value_ub is None and x2.shape[0] > 0):
+        return _linear_other_dtype(x2, w, bias).reshape(*x.shape[:-1], n).to(out_dtype)
+    _require_bf16_activation(x, "Float8Tensor dynamic-activation linear")
     if isinstance(w.act_quant_kwargs.granularity, PerTensor) != w_tensorwise:
         # reference quant_api.py:1123: "Currently both quantizations need to be the same type"
         raise NotImplementedError("Float8Tensor linear: activation and weight granularities must both be PerRow or both PerTensor")

@@ -21,12 +21,31 @@ __all__ = ["Int8Tensor", "QuantizeTensorToInt8Kwargs"]
 
 
 def _require_bf16_activation(x, what):
-    """The reference quantizes the activation in ITS dtype (fp16 scales are upcast on purpose, int8_tensor.py:311-317); the MI355X
+    """The reference quantizes the activation in ITS dtype (fp16 scales are upcast on purpose, int8_tensor.py:311-317); the fused MI355X
     casts take bfloat16 only, and a silent .to(bfloat16) would round fp16 / fp32 activations before the scale is taken -- not the
-    reference's arithmetic.  Refuse instead of approximating."""
+    reference's arithmetic.  The default (PerRow, symmetric, dynamic) linear has a correct slow path for fp16 / fp32
+    (`_linear_other_dtype`); the other variants refuse instead of approximating."""
     if x.dtype != torch.bfloat16:
         raise NotImplementedError(f"{what} on MI355X takes bfloat16 activations, got {x.dtype}: cast the activation explicitly "
                                   "(x.to(torch.bfloat16)) if that rounding is acceptable")
+
+
+def _linear_other_dtype(x2, w, bias):
+    """fp16 / fp32 activations (the reference supports them): Int8Tensor.from_hp's arithmetic in the activation's OWN dtype as
+    torch ops on the device -- choose_qparams_affine SYMMETRIC (quant_primitives.py:1534-1562: amax / 127.5, clamped at fp32 eps, fp32
+    scale) and quantize_affine (:479-481: round(x * (1 / scale))) -- then this library's int8 x int8 -> int32 GEMM and the reference's
+    epilogue (int8_tensor.py:311-357: the row scale applied in fp32, cast to the activation dtype, times the weight scale)."""
+    mn, mx = x2.amin(dim=-1, keepdim=True), x2.amax(dim=-1, keepdim=True)
+    zero = torch.zeros_like(mn)
+    amax = torch.max(-torch.min(mn, zero), torch.max(mx, zero))
+    scale = torch.clamp(amax / 127.5, min=torch.finfo(torch.float32).eps).to(torch.float32)
+    q = torch.clamp(torch.round(x2 * (1.0 / scale)), -128, 127).to(torch.int8)
+    c = ops.int_mm(q, w.qdata.t())
+    y = (c.to(torch.float32) * scale).to(x2.dtype)
+    y = y * w._row_scale().flatten()
+    if bias is not None:
+        y = y + bias
+    return y.to(x2.dtype)
 
 
 @dataclass
@@ -170,9 +189,12 @@ def _(func, types, args, kwargs):
     if w.zero_point is not None:
         raise NotImplementedError("Int8Tensor linear on MI355X takes symmetric weights (asymmetric is an ACTIVATION option in the reference)")
     assert w.qdata.dim() == 2, "F.linear takes a 2-D weight: select an expert of a 3-D weight first (weight[e])"
-    _require_bf16_activation(x, "Int8Tensor dynamic-activation linear")
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     n = w.qdata.shape[0]
+    if (x.dtype in (torch.float16, torch.float32) and w.act_quant_scale is None and _mapping(act.mapping_type) == MappingType.SYMMETRIC
+            and isinstance(act.granularity, PerRow) and x2.shape[0] > 0):
+        return _linear_other_dtype(x2, w, bias).reshape(*x.shape[:-1], n).to(out_dtype)
+    _require_bf16_activation(x, "Int8Tensor dynamic-activation linear")
     if x2.shape[0] == 0:
         y = x2.new_zeros((0, n))
     else:

@@ -127,7 +127,8 @@ int ao_gemm8_set_variant(int variant);
 /* Profiling only, key / value (every setting computes the SAME result as the product; 0 = product rule; thread-local):
  *   key 1  column-tile width of the rowwise weight-streaming kernel (rb8_kernel): 32, 64 or 128
  *   key 2  its K parts (1 .. 16)
- *   key 3  1 = never the same-XCD split-K meeting (the write-through, placement-independent one of rounds 1-4 instead)
+ *   key 3  2 = the same-XCD split-K meeting where the device's workgroup placement allows it (opt-in; 0 / 1: the write-through,
+ *          placement-independent one)
  *   key 4  reserved
  *   key 5  timing probes of the TRACED build of rb8_kernel only (ao_int4_set_trace set; results are wrong): bit 0 no MFMAs, 1 no fragment
  *          reads, 2 no weight DMAs, 3 no activation DMAs -- the product build ignores it

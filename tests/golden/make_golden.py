@@ -320,7 +320,45 @@ def make_moe_permute():
     print("moe_permute.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def make_other_dtypes():
+    """fp16 / fp32 ACTIVATIONS on the dynamic-activation 8-bit linears (the reference quantizes them in their own dtype): the
+    reference's own quantize_() + F.linear on CPU tensors for int8; for fp8 -- whose linear asserts a GPU -- its Float8Tensor.from_hp
+    on activation and weight and aten::_scaled_mm's arithmetic (acc * scale_a * scale_b, out in the activation dtype) on its codes."""
+    from torchao.quantization import Int8DynamicActivationInt8WeightConfig, PerRow, quantize_
+    from torchao.quantization.quantize_.workflows.float8.float8_tensor import Float8Tensor
+
+    gen = torch.Generator().manual_seed(21)
+    out = {}
+    n, k = 64, 256
+    w = (torch.randn(n, k, generator=gen) * 0.05).to(torch.bfloat16)
+    out["w"] = bits(w)
+    for name, dt in (("f16", torch.float16), ("f32", torch.float32)):
+        x = (torch.randn(5, k, generator=gen) * 2).to(dt)
+        x[0, :4] = torch.tensor([0.0, -0.0, 1e-4, 60000.0 if dt == torch.float16 else 3e30]).to(dt)
+        out[f"x_{name}"] = x.numpy().copy()
+        # nn.Linear keeps its weight in the activation dtype, as a model in that dtype would: the reference quantizes THAT tensor
+        lin = torch.nn.Linear(k, n, bias=False, dtype=dt)
+        with torch.no_grad():
+            lin.weight.copy_(w.to(dt))
+        quantize_(lin, Int8DynamicActivationInt8WeightConfig())
+        out[f"int8_wq_{name}"] = lin.weight.qdata.numpy().copy()
+        out[f"int8_ws_{name}"] = lin.weight.scale.float().numpy().copy()
+        with torch.no_grad():
+            out[f"int8_y_{name}"] = lin(x).float().numpy().copy()
+        wq = Float8Tensor.from_hp(w, torch.float8_e4m3fn, PerRow())
+        xq = Float8Tensor.from_hp(x, torch.float8_e4m3fn, PerRow())
+        out[f"fp8_xq_{name}"] = xq.qdata.view(torch.uint8).numpy().copy()
+        out[f"fp8_xs_{name}"] = xq.scale.float().numpy().copy()
+        acc = xq.qdata.float() @ wq.qdata.float().t()
+        out[f"fp8_y_{name}"] = (acc * xq.scale.float() * wq.scale.float().t()).to(dt).float().numpy().copy()
+    out["fp8_wq"] = wq.qdata.view(torch.uint8).numpy().copy()
+    out["fp8_ws"] = wq.scale.float().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "other_dtypes.npz"), **out)
+    print("other_dtypes.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
 def make_rest():
+    make_other_dtypes()
     make_int8_fp8()
     make_int8_fp8_variants()
     make_mx()

@@ -642,7 +642,7 @@ def test_rb8_same_xcd_meeting_every_form(kind, m, n, k, bias):
         for bm in ((128, 256) if m > 64 else (0,)):  # 256-row slabs (also with fewer rows than a slab)
             for bn in (32, 64, 128):
                 for split in (1, 2, 5, 16):
-                    for off in (0, 1):
+                    for off in (2, 1):  # 2: parts on one XCD, meeting in its L2; 1: the write-through meeting
                         lib.ao_gemm8_set_tuning(1, bn)
                         lib.ao_gemm8_set_tuning(2, split)
                         lib.ao_gemm8_set_tuning(3, off)
@@ -677,11 +677,22 @@ def test_rb8_same_xcd_meeting_fresh_data_every_launch(kind):
     xq, xs = quant(x.to(DEV))
     wa, wb = quant(_randn_bf16((n, k), 2, 0.05).to(DEV)), quant(_randn_bf16((n, k), 3, 0.05).to(DEV))
     mm = (lambda wq, ws: ops.int8_scaled_mm(xq, xs, wq, ws)) if kind == "int8" else (lambda wq, ws: ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t()))
-    ya, yb = mm(*wa).clone(), mm(*wb).clone()
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    ya, yb = mm(*wa).clone(), mm(*wb).clone()  # (the product's write-through meeting)
     assert not torch.equal(ya, yb)
     outs = []
-    for i in range(50):
-        outs.append(mm(*(wa if i % 2 == 0 else wb)))
+    try:
+        lib.ao_gemm8_set_variant(101)
+        lib.ao_gemm8_set_tuning(3, 2)  # the same-XCD meeting
+        lib.ao_gemm8_set_tuning(2, 6)
+        for i in range(50):
+            outs.append(mm(*(wa if i % 2 == 0 else wb)))
+    finally:
+        lib.ao_gemm8_set_variant(0)
+        lib.ao_gemm8_set_tuning(3, 0)
+        lib.ao_gemm8_set_tuning(2, 0)
     torch.cuda.synchronize()
     for i, y in enumerate(outs):
         assert torch.equal(y, ya if i % 2 == 0 else yb), f"launch {i} saw another launch's parts"

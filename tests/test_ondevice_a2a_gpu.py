@@ -37,9 +37,10 @@ def _inputs(rank, call, world, dim, max_rows):
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
+    per_gpu = os.environ.get("AO_TEST_ONE_GPU_PER_RANK") == "1"  # tests/test_multigpu_gpu.py: one process per GPU over RCCL
+    torch.cuda.set_device(rank if per_gpu else 0)
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("nccl" if per_gpu else "gloo", rank=rank, world_size=world)
     out = {"rank": rank}
     try:
         from ao_amd.prototype import ep

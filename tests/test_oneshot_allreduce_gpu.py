@@ -48,9 +48,10 @@ def _expected(world, call, n, dtype, op="sum"):
 def _worker(rank, world, port, q, coarse=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
+    per_gpu = os.environ.get("AO_TEST_ONE_GPU_PER_RANK") == "1"  # tests/test_multigpu_gpu.py: one process per GPU over RCCL
+    torch.cuda.set_device(rank if per_gpu else 0)
     torch.set_num_threads(2)  # up to eight of these share the host: the checker's CPU tensors must not fan out over every core each
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("nccl" if per_gpu else "gloo", rank=rank, world_size=world)
     out = {"rank": rank}
     try:
         from ao_amd import parallel
@@ -159,8 +160,9 @@ def _late_worker(rank, world, port, q):
     """Rank 1 never calls: rank 0's kernel must give up after the (shortened) timeout, poison its output and report it."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per_gpu = os.environ.get("AO_TEST_ONE_GPU_PER_RANK") == "1"  # tests/test_multigpu_gpu.py: one process per GPU over RCCL
+    torch.cuda.set_device(rank if per_gpu else 0)
+    dist.init_process_group("nccl" if per_gpu else "gloo", rank=rank, world_size=world)
     out = {"rank": rank}
     try:
         from ao_amd import _lib, parallel

@@ -23,9 +23,10 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
+    per_gpu = os.environ.get("AO_TEST_ONE_GPU_PER_RANK") == "1"  # tests/test_multigpu_gpu.py: one process per GPU over RCCL
+    torch.cuda.set_device(rank if per_gpu else 0)
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("nccl" if per_gpu else "gloo", rank=rank, world_size=world)
     try:
         from ao_amd import parallel
         from ao_amd.quantization import (Float8DynamicActivationFloat8WeightConfig, Int4WeightOnlyConfig,
@@ -112,9 +113,10 @@ def test_tp_linears_two_ranks_one_gpu_vs_unsharded_oracle():
 def _ep_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
+    per_gpu = os.environ.get("AO_TEST_ONE_GPU_PER_RANK") == "1"  # tests/test_multigpu_gpu.py: one process per GPU over RCCL
+    torch.cuda.set_device(rank if per_gpu else 0)
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("nccl" if per_gpu else "gloo", rank=rank, world_size=world)
     try:
         from ao_amd.prototype.ep import a2a_combine_hp_fwd, a2a_dispatch_mxfp8_fwd, exchange_split_sizes
         from ao_amd.prototype.mx import MXFP8ExpertWeights, _to_mxfp8_then_scaled_grouped_mm
@@ -167,9 +169,10 @@ def test_ep_dispatch_two_ranks_one_gpu():
 def _oneshot_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
+    per_gpu = os.environ.get("AO_TEST_ONE_GPU_PER_RANK") == "1"  # tests/test_multigpu_gpu.py: one process per GPU over RCCL
+    torch.cuda.set_device(rank if per_gpu else 0)
     torch.set_num_threads(2)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("nccl" if per_gpu else "gloo", rank=rank, world_size=world)
     try:
         from ao_amd.parallel import OneShotAllReduce
 

@@ -25,16 +25,14 @@ SHAPES = {
 # name -> (variant, {tuning key: value})
 FORMS = {
     "default": (0, {}),
+    "local": (0, {3: 2}),       # the same-XCD meeting (opt-in)
     "nolocal": (0, {3: 1}),
     "bn32": (0, {1: 32}),
     "bn64": (0, {1: 64}),
     "bn128": (0, {1: 128}),
     "rb": (101, {}),            # the weight-streaming kernel forced
-    "rb_nolocal": (101, {3: 1}),
     "tile": (100, {}),          # never a weight-streaming kernel
     "p8": (32, {}),
-    "pipe": (0, {4: 2}),        # the pipelined 128 x 128 tile kernel wherever the shape allows
-    "nopipe": (0, {4: 1}),
 }
 
 
