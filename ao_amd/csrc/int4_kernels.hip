@@ -798,238 +798,274 @@ thread_local unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_in
 thread_local int g_tune_wpb = 0;
 
 // ---------------------------------------------------------------------------
-// Round 3: int4_mm_kh_kernel -- the batched kernel with two symmetric, software-pipelined waves per SIMD ("K-half waves").
+// Round 5: int4_mm_w32_kernel -- the batched kernel on 128 x 128 tiles with v_mfma_f32_32x32x16_bf16.
 //
-// What the round-3 measurements say about a SIMD of gfx950 (profiles/kh_trace_r03.txt, profiles/int4_kh_ablation_r03.txt):
-//   * instructions of the waves of a SIMD issue one at a time (~4.4 cycles each); a v_mfma_f32_16x16x32_bf16 keeps the matrix pipe
-//     for 16 cycles, and in that shadow 2 - 3 OTHER instructions can issue -- but only if they are next in some wave's stream.  A wave
-//     whose next instruction is another MFMA stalls at the issue port and the other waves' VALU work waits behind it: a
-//     "multiplying" wave next to a "dequantising" wave on one SIMD simply add up (measured: 64 x 128 tile, VALU + MFMA time = the sum);
-//   * so the exact dequant (92 VALU per packed n-tile block), the A-fragment reads and the MFMAs only overlap when ONE instruction
-//     stream interleaves them, and a lone wave per SIMD then stalls on every LDS / barrier latency (the round-2 kernel: ~1650
-//     cycles per k-block for 512 cycles of MFMA);
-//   * a DMA-producer wave pays ~170 cycles per global_load_lds while the LDS is busy with fragment reads: 10 per producer and
-//     k-block made the producers the critical path.
-// Hence: 8 waves = (n-tile t, K-half e): wave (t, e) owns n-tile t and the phases 2e, 2e + 1 (64 of the 128 k) of every k-block --
-// per k-block 2 MT MFMAs, two packed words to dequantise, 2 MT A-fragment reads, and its share of the stage's DMAs (x rows +
-// the tile's packed block (e = 0) or scale / zero words (e = 1)).  Every wave runs the SAME hand-interleaved stream: slot i =
-// one MFMA of k-block kb + one ds_read (the other phase's / the next k-block's A fragment) + one chunk of the dequant of k-block
-// kb + 1 + now and then one DMA of stage kb + 3; two such waves per SIMD fill each other's stalls.  Rings are 4 deep (x and w):
-// stage kb + 1 is in LDS when k-block kb starts ("all but the youngest stage's DMAs have landed" before each barrier).
-// The K-halves' accumulators meet in LDS after the loop (e = 0 + e = 1, fixed order), then the usual split-K meeting / store.
+// int4_mm_rb_kernel above multiplies 16 x 16 x 32: per k-block and n-tile a wave issues 32 MFMAs and reads 32 A fragments (one
+// ds_read_b128 each) -- at one consumer wave per SIMD the k-block is the SUM of its MFMA issue (512 cycles), its fragment reads (~512)
+// and its exact dequant (~300), DESIGN.md 4.3b.  The 32 x 32 x 16 instruction does twice the work per issue and per A fragment:
+//   * a wave owns TWO n-tiles (32 columns) and all 128 rows: lane (n = lane & 31, g = lane >> 5) -- tile t = n >> 4, nl = n & 15 --
+//     reads the 16 bytes (words j = 0 .. 3) of packed lanes (nl, kq = 2 g) and (nl, 2 g + 1) of its tile's block: the 8 words whose
+//     runs k = 32 j + 16 h + 8 g + {0 .. 7} are contiguous per (j, h) -- one 16-byte chunk of x, chunk 4 j + 2 h + g.  MFMA step
+//     s = 2 j + h (8 per k-block) multiplies the two lane groups' chunks 2 s + g: B = the 8 dequantised weights (word j, half h of
+//     both packed lanes), A = chunk 2 s + g of the lane's row of each 32-row m-tile -- ONE ds_read_b128;
+//   * per k-block and wave: 32 MFMAs of 32 cycles for 32 columns (was 64 of 16), 32 fragment reads (was 64), the same 8 words of
+//     exact dequant -- whose four stages per word ride in the MFMAs' issue shadow, one stage per MFMA, a word pair ahead;
+//   * workgroup = 4 such waves (+ 4 DMA-producer waves): 128 x 128 outputs; x tile and weight rings exactly as above (same LDS-DMA
+//     layouts, same swizzle, same waits); narrow weights cut K and meet through splitk.h.
+// Same products, fp32 accumulation in a different order than the 16 x 16 kernel: <= 1e-3 of the oracle like it.
 // ---------------------------------------------------------------------------
-constexpr int kKhStages = 4;  // x and w rings
-// VAR (profiling): 0 product; 1 every DMA behind its own M0 write, dealt one per slot; 6 no DMAs at all (wrong results)
-template <int G, int MT, int VAR = 0>
-__global__ __launch_bounds__(512, 2) void int4_mm_kh_kernel(
+template <int G, bool PROD, int ABL = 0>
+__global__ __launch_bounds__(PROD ? 512 : 256) void int4_mm_w32_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M,
-    int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets) {
+    int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets, unsigned long long* __restrict__ trace) {
+  constexpr int WAVES = 4, NT = 2;
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
-  constexpr int WBLK = 1024 + NG * 256;    // one n-tile's share of a stage: packed block + NG x 64 scale/zero words
-  constexpr int KS = kKhStages;
-  constexpr int XD = 4 * MT / 8;           // x DMAs per wave and stage (4 rows each)
-  constexpr int ABUF = MT * 4096;          // one x stage: 16 MT rows x 256 B
-  constexpr int XRING = KS * ABUF;
-  constexpr int NSLOT = 2 * MT;            // MFMAs per wave and k-block
-  constexpr int LPS0 = XD + 1, LPS1 = XD + NG;  // DMAs per stage of an e = 0 / e = 1 wave
-  static_assert(LPS1 <= NSLOT / (MT == 8 ? 2 : 1), "every DMA piece of a stage gets a slot");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [KS][16 MT rows][256 B] x | [4 tiles][KS][WBLK]
+  constexpr int WBLK = 1024 + NG * 256;
+  constexpr int WST = NT * WBLK;
+  constexpr int ADMA = 8;                  // x DMAs per wave and stage (4 rows each: 128 rows / 4 waves)
+  constexpr int ABUF = 128 * 256;          // one x stage
+  constexpr int WDMAS = NT * (1 + NG);
+  constexpr int LPS = ADMA + WDMAS;
+  constexpr int KW = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3][128 rows][256 B] x | [4 waves][3][WST]
+  unsigned long long ts[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (ABL == 5) ts[0] = __builtin_amdgcn_s_memtime();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t = wave_id & 3, e = wave_id >> 2;
-  const int nl = lane & 15, grp = lane >> 4;
-  const int m0 = blockIdx.y * (16 * MT);
+  const bool producer = PROD && wave_id >= WAVES;
+  const int wave = producer ? wave_id - WAVES : wave_id;
+  const int nl = lane & 15, lt = (lane >> 4) & 1, g = lane >> 5;
+  const int m0 = blockIdx.y * 128;
   const int ntiles = N >> 4;
   const int kblocks = K >> 7;
-  const int tile = blockIdx.x * 4 + t;
-  const int wtile = min(tile, ntiles - 1);  // tiles past N alias the last one; their columns are never stored
+  const int tile0 = blockIdx.x * (WAVES * NT) + wave * NT;
   const int S = gridDim.z, ks = blockIdx.z;
   const int kb0 = (int)(((long long)kblocks * ks) / S);
   const int nkb = (int)(((long long)kblocks * (ks + 1)) / S) - kb0;
-  const uint32_t a_lds = lds_offset(smem);
-  const uint32_t w_lds = a_lds + XRING + t * (KS * WBLK);
-  const int out_tile = blockIdx.y * gridDim.x + blockIdx.x;
-  int* flag = reinterpret_cast<int*>(smem + XRING);  // a weight-ring word: free once the loop is over
+  const s16x4 ident = identity_fragment(lane);
 
-  // x DMA i of this wave fills rows 4 (XD wave + i) + (lane >> 4), chunk position lane & 15 (source-swizzled, see int4_mm_rb_kernel)
-  uint32_t aoff[XD];
+  uint32_t aoff[ADMA];
 #pragma unroll
-  for (int i = 0; i < XD; ++i) {
-    const int row = 4 * (XD * wave_id + i) + (lane >> 4);
+  for (int i = 0; i < ADMA; ++i) {
+    const int row = 4 * (ADMA * wave + i) + (lane >> 4);
     aoff[i] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)K * 2u + (((lane & 15) ^ (row & 15)) << 4);
   }
-  // DMA piece d of k-block kb into ring slot `slot`: x pieces first, then the tile's packed block (e = 0) or scale/zero words (e = 1)
-  auto issue_piece = [&](auto d_c, int slot, int kb) {
-    constexpr int d = decltype(d_c)::value;
-    if (VAR == 6) return;
-    const int k = kb0 + min(kb, nkb - 1);  // k-blocks past the end re-read the last one (unused)
-    if constexpr (d < XD) {
-      if constexpr (VAR == 1) {
-        dma_b128_s(x + (size_t)k * 128, aoff[d], a_lds + slot * ABUF + (XD * wave_id + d) * 1024);
-      } else if constexpr (d == 0) {  // the wave's x pieces of the stage: one M0 write
-        const char* src = reinterpret_cast<const char*>(x + (size_t)k * 128);
-        if constexpr (XD == 4) dma_b128_x4(src, aoff[0], aoff[1], aoff[2], aoff[3], a_lds + slot * ABUF + (XD * wave_id) * 1024);
-        else dma_b128_x2(src, aoff[0], aoff[1], a_lds + slot * ABUF + (XD * wave_id) * 1024);
-      }
+  const uint32_t a_lds = lds_offset(smem);
+  const uint32_t w_lds = a_lds + 3 * ABUF + wave * (KW * WST);
+  auto issue_one = [&](auto idx_c, int stage, int kb, int wstage, int kbw) {
+    constexpr int idx = decltype(idx_c)::value;
+    if constexpr (idx < ADMA) {
+      const int k = kb0 + min(kb, nkb - 1);
+      dma_b128_s(x + (size_t)k * 128, aoff[idx], a_lds + stage * ABUF + (ADMA * wave + idx) * 1024);
     } else {
-      const uint32_t dst = w_lds + slot * WBLK;
-      if (e == 0) {
-        if constexpr (d == XD) dma_b128_nt_s(qdata + ((size_t)wtile * kblocks + k) * 64, lane * 16, dst);
+      const int k = kb0 + min(kbw, nkb - 1);
+      constexpr int t = (idx - ADMA) / (1 + NG), part = (idx - ADMA) % (1 + NG);
+      const int tile = min(tile0 + t, ntiles - 1);
+      const uint32_t dst = w_lds + wstage * WST + t * WBLK;
+      if constexpr (part == 0) {
+        dma_b128_nt_s(qdata + ((size_t)tile * kblocks + k) * 64, lane * 16, dst);
       } else {
-        if constexpr (d - XD < NG) {
-          const int kg0 = (G >= 128) ? ((k * 128) / G) : (k * NG);
-          dma_b32_s(sz + (size_t)(kg0 + (d - XD)) * N + wtile * 16, nl * 4, dst + 1024 + (d - XD) * 256);
-        }
+        const int kg0 = (G >= 128) ? ((k * 128) / G) : (k * NG);
+        dma_b32_s(sz + (size_t)(kg0 + part - 1) * N + tile * 16, nl * 4, dst + 1024 + (part - 1) * 256);
       }
     }
   };
-  auto issue_stage = [&](int slot, int kb) {
-    [&]<int... D>(std::integer_sequence<int, D...>) { (issue_piece(std::integral_constant<int, D>{}, slot, kb), ...); }
-    (std::make_integer_sequence<int, (LPS1 > LPS0 ? LPS1 : LPS0)>{});
+  auto issue_x = [&](int stage, int kb) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, I>{}, stage, kb, 0, 0), ...); }
+    (std::make_integer_sequence<int, ADMA>{});
   };
-  auto wait_stage = [&] {  // everything but this wave's youngest stage has landed
-    if (VAR == 6) return;
-    if (e == 0) wait_vmcnt<LPS0>(); else wait_vmcnt<LPS1>();
+  auto issue_w = [&](int wstage, int kbw) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(std::integral_constant<int, ADMA + I>{}, 0, 0, wstage, kbw), ...); }
+    (std::make_integer_sequence<int, WDMAS>{});
   };
 
-  const s16x4 ident = identity_fragment(lane);
-  f32x4 acc[MT];
+  if (producer) {
+    // issue order and waits of int4_mm_rb_kernel's producers (KW = 3): w(0) | x(0) w(1) | x(1), then per k-block x(kb + 2), w(kb + 2)
+    issue_w(0, 0);
+    issue_x(0, 0); issue_w(1, 1);
+    issue_x(1, 1);
+    int stage = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+      wait_vmcnt<LPS>();
+      asm volatile("s_barrier" ::: "memory");
+      const int refill = (stage == 0) ? 2 : stage - 1;
+      issue_x(refill, kb + 2);
+      issue_w(refill, kb + 2);
+      stage = (stage == 2) ? 0 : stage + 1;
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (S > 1) {
+      f32x4 none[16];
+      (void)split_k_meet<16, 64 * WAVES>(none, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem), false);
+    }
+    return;
+  }
+
+  f32x16 acc[4];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // lane (row r = nl, group g = 2a + t'): A operand of phase p = 2e + h: chunk 2p ^ (8a | t') of row r, at position chunk ^ r
-  const int ga = grp >> 1, gt = grp & 1;
-  const int pbase = (nl * 256 + ((((ga << 3) | gt) ^ nl) << 4)) ^ (e << 6);  // ^ (h << 5) per phase, + 4096 per m-tile
-  const int wbase = ((2 * gt) * 16 + nl) * 16 + 8 * ga + 4 * e;              // word 2a + e of packed lane (n, 2t'); second piece: + 256
-  const int zg = (G >= 128) ? 0 : (G == 64) ? ga : 2 * ga + e;
-  const char* Wring = smem + XRING + t * (KS * WBLK);
-  auto a_frag = [&](int slot, int h, int mt) -> u32x4 {
-    return *reinterpret_cast<const u32x4*>(smem + slot * ABUF + (pbase ^ (h << 5)) + mt * 4096);
-  };
-
-  issue_stage(0, 0); issue_stage(1, 1); issue_stage(2, 2);
-  wait_stage();
-  asm volatile("s_barrier" ::: "memory");  // stages 0 and 1 are in LDS
-
-  u32x4 a0[MT], a1[MT];     // A fragments of the wave's two phases (h = 0, 1)
-  u32x4 bcur[2], bnext[2];  // B operands of h = 0, 1: this k-block's, the next one's (being dequantised)
-  uint32_t wq[2], wz;       // the next k-block's two packed words and its scale / zero word
-  DequantPipe dq[2];
-  auto load_words = [&](int slot) {
-    const char* Wst = Wring + slot * WBLK;
-    wq[0] = *reinterpret_cast<const uint32_t*>(Wst + wbase);
-    wq[1] = *reinterpret_cast<const uint32_t*>(Wst + wbase + 256);
-    wz = *reinterpret_cast<const uint32_t*>(Wst + 1024 + zg * 256 + nl * 4);
-  };
-  // chunk c = (stage c / 2, word c & 1) of the dequant pipeline
-  auto dequant_chunk = [&](auto c_c) {
-    constexpr int cc = decltype(c_c)::value;
-    const float sc = bf16_lo_to_f32(wz), zp = bf16_hi_to_f32(wz);
-    dequant_stage<cc / 2>(dq[cc & 1], wq[cc & 1], sc, -8.0f * sc, zp, ident);
-  };
-  auto take_next = [&] {
-    bnext[0] = u32x4{dq[0].out[0], dq[0].out[1], dq[1].out[0], dq[1].out[1]};
-    bnext[1] = u32x4{dq[0].out[2], dq[0].out[3], dq[1].out[2], dq[1].out[3]};
-  };
-  // k-block 0's operands, not overlapped with anything (once per launch)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) a0[mt] = a_frag(0, 0, mt);
-  load_words(0);
-  [&]<int... C>(std::integer_sequence<int, C...>) { (dequant_chunk(std::integral_constant<int, C>{}), ...); }(std::make_integer_sequence<int, 8>{});
-  take_next();
-  bcur[0] = bnext[0]; bcur[1] = bnext[1];
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // slot of dequant chunk c, of DMA piece d
-  constexpr int CH0 = (MT == 8) ? 3 : 1;  // first slot with dequant work (the words are read in slot 0)
-  auto chunk_slot = [](int cc) constexpr { return CH0 + (cc * (NSLOT - 1 - CH0)) / 7; };
-  auto piece_slot = [](int d) constexpr { return (MT == 8) ? 2 * d : d; };
+  // A fragment of step s, m-tile mt: chunk 2 s + g of row 32 mt + (lane & 31), at position chunk ^ (row & 15) = chunk ^ nl
+  const int arow = (lane & 31) * 256;
+  // the lane's packed words: 16 bytes of packed lanes (nl, 2 g) and (nl, 2 g + 1) of tile lt
+  const int wbase = lt * WBLK + ((2 * g) * 16 + nl) * 16;
 
-  int stage = 0;
-  for (int kb = 0; kb < nkb; ++kb) {
-    const int next = (stage == KS - 1) ? 0 : stage + 1;
-    const int fill = (stage == 0) ? KS - 1 : stage - 1;  // (kb + 3) % KS
+  auto kblock = [&](int stage, int refill, int kb) {
+    const char* A = smem + stage * ABUF;
+    const char* Wst = smem + 3 * ABUF + (wave * KW + stage) * WST;
+    const u32x4 pa = *reinterpret_cast<const u32x4*>(Wst + wbase);
+    const u32x4 pb = *reinterpret_cast<const u32x4*>(Wst + wbase + 256);
+    float sc[NG], zp[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const uint32_t z = *reinterpret_cast<const uint32_t*>(Wst + lt * WBLK + 1024 + q * 256 + nl * 4);
+      sc[q] = bf16_lo_to_f32(z); zp[q] = bf16_hi_to_f32(z);
+    }
+    const uint32_t word[4][2] = {{pa.x, pb.x}, {pa.y, pb.y}, {pa.z, pb.z}, {pa.w, pb.w}};  // [j][which packed lane]
+    constexpr auto group_of = [](int j) constexpr { return (G >= 128) ? 0 : (G == 64) ? (j >> 1) : j; };
+    DequantPipe dq[2][2];  // [j & 1][which]: word j is dequantised while word j - 1 multiplies
+    // ABL (laboratory builds only, wrong results): 1 no 32 x 32 x 16 MFMAs, 2 no dequant, 3 no A-fragment reads; 5 = product + s_memtime stamps
+    auto stage_of = [&](auto st_c, auto j_c, auto which_c) {  // (compile-time indices: everything stays in registers)
+      constexpr int j = decltype(j_c)::value, which = decltype(which_c)::value, q = group_of(j);
+      if (ABL == 2) {
+        if constexpr (decltype(st_c)::value == 3) { DequantPipe& d = dq[j & 1][which]; d.out[0] = word[j][which]; d.out[1] = d.out[0] + 1; d.out[2] = d.out[0] ^ 5; d.out[3] = d.out[0] + 7; }
+        return;
+      }
+      dequant_stage<decltype(st_c)::value>(dq[j & 1][which], word[j][which], sc[q], -8.0f * sc[q], zp[q], ident);
+    };
+    auto read_a = [&](int s, int mt) {
+      if (ABL == 3) return u32x4{(uint32_t)s, (uint32_t)mt, pa.x, pb.y};
+      return *reinterpret_cast<const u32x4*>(A + mt * (32 * 256) + arow + ((((2 * s + g) ^ nl) & 15) << 4));
+    };
+    // word 0 first (nothing to hide it behind: its data landed with this k-block's barrier)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    stage_of(I0{}, I0{}, I0{}); stage_of(I1{}, I0{}, I0{}); stage_of(std::integral_constant<int, 2>{}, I0{}, I0{}); stage_of(std::integral_constant<int, 3>{}, I0{}, I0{});
+    stage_of(I0{}, I0{}, I1{}); stage_of(I1{}, I0{}, I1{}); stage_of(std::integral_constant<int, 2>{}, I0{}, I1{}); stage_of(std::integral_constant<int, 3>{}, I0{}, I1{});
+    // A fragments are requested AHD slots ahead (an LDS round trip is ~100 cycles, an MFMA 32): a ring of AHD + 1 registers quads
+    constexpr int AHD = 3;
+    u32x4 aq[AHD + 1];
+#pragma unroll
+    for (int i = 0; i < AHD; ++i) aq[i] = read_a(i >> 2, i & 3);
     [&]<int... SL>(std::integer_sequence<int, SL...>) {
       (([&] {
-         constexpr int sl = SL;
+         constexpr int sl = SL, s = sl >> 2, mt = sl & 3, j = s >> 1, h = s & 1;  // slot = (step s, m-tile mt)
          __builtin_amdgcn_sched_barrier(0);
-         if constexpr (sl == 0) load_words(next);
-         // one DMA of stage kb + 3
-         [&]<int... D>(std::integer_sequence<int, D...>) {
-           (([&] { if constexpr (piece_slot(D) == sl) issue_piece(std::integral_constant<int, D>{}, fill, kb + 3); }()), ...);
-         }(std::make_integer_sequence<int, (LPS1 > LPS0 ? LPS1 : LPS0)>{});
-         // one A fragment: this k-block's second phase, then the next k-block's first
-         if constexpr (sl < MT) a1[sl] = a_frag(stage, 1, sl); else a0[sl - MT] = a_frag(next, 0, sl - MT);
-         // dequant of k-block kb + 1
-         [&]<int... C>(std::integer_sequence<int, C...>) {
-           (([&] { if constexpr (chunk_slot(C) == sl) dequant_chunk(std::integral_constant<int, C>{}); }()), ...);
-         }(std::make_integer_sequence<int, 8>{});
-         if constexpr (sl < MT)
-           acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0[sl]), __builtin_bit_cast(bf16x8, bcur[0]), acc[sl], 0, 0, 0);
-         else
-           acc[sl - MT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[sl - MT]), __builtin_bit_cast(bf16x8, bcur[1]), acc[sl - MT], 0, 0, 0);
+         if constexpr (sl + AHD < 32) aq[(sl + AHD) % (AHD + 1)] = read_a((sl + AHD) >> 2, (sl + AHD) & 3);
+         const u32x4 a_cur = aq[sl % (AHD + 1)];
+         if constexpr (!PROD && sl < LPS) issue_one(std::integral_constant<int, sl>{}, refill, kb + 2, refill, kb + 2);
+         if constexpr (j < 3) {  // the 8 slots of word j carry the 8 stage calls of word j + 1: slot (h, mt) -> which = h, stage = mt
+           stage_of(std::integral_constant<int, mt>{}, std::integral_constant<int, (j < 3 ? j + 1 : 3)>{}, std::integral_constant<int, h>{});
+         }
+         const DequantPipe& d0 = dq[j & 1][0];
+         const DequantPipe& d1 = dq[j & 1][1];
+         const u32x4 bv = {d0.out[2 * h], d0.out[2 * h + 1], d1.out[2 * h], d1.out[2 * h + 1]};
+         if (ABL == 1) acc[mt][0] += bits_to_f32(a_cur.x ^ bv.x ^ a_cur.y ^ a_cur.z ^ a_cur.w ^ bv.y ^ bv.z ^ bv.w);
+         else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur), __builtin_bit_cast(bf16x8, bv), acc[mt], 0, 0, 0);
        }()),
        ...);
-    }(std::make_integer_sequence<int, NSLOT>{});
+    }(std::make_integer_sequence<int, 32>{});
     __builtin_amdgcn_sched_barrier(0);
-    take_next();
-    bcur[0] = bnext[0]; bcur[1] = bnext[1];
-    stage = next;
-    wait_stage();  // stage kb + 2 of this wave's DMAs has landed (only stage kb + 3's may be in flight)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // k-block kb is done everywhere; stages kb + 1, kb + 2 are in LDS
-  }
-  wait_vmcnt<0>();  // the clamped fills past the end still write LDS
-  asm volatile("s_barrier" ::: "memory");
+  };
 
-  // the two K-halves meet: e = 1 parks its tile in LDS, e = 0 adds it (fixed order)
-  f32x4* park = reinterpret_cast<f32x4*>(smem) + (t * MT) * 64 + lane;
-  if (e == 1) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) park[i * 64] = acc[i];
+  if constexpr (!PROD) {
+    issue_w(0, 0);
+    issue_x(0, 0); issue_w(1, 1);
+    issue_x(1, 1);
   }
-  __syncthreads();
-  if (e == 0) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] += park[i * 64];
+  if (ABL == 5) ts[1] = __builtin_amdgcn_s_memtime();
+  int stage = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if constexpr (!PROD) wait_vmcnt<LPS>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ABL == 5 && kb < 8) ts[2 + kb] = __builtin_amdgcn_s_memtime();
+    kblock(stage, (stage == 0) ? 2 : stage - 1, kb);
+    stage = (stage == 2) ? 0 : stage + 1;
   }
-  if (S > 1) {
-    if (!split_k_meet<MT, 256>(acc, ws, tickets, out_tile, S, ks, tid, flag, e == 0)) return;
-  }
-  if (e != 0 || tile >= ntiles) return;
-  // D layout of the 16x16 tile: lane (col = nl, group g) holds rows 4 g + {0..3}
-  const int nn = tile * 16 + nl;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + mt * 16 + grp * 4 + r;
-      if (m < M) y[(size_t)m * N + nn] = f32_to_bf16_bits(acc[mt][r]);
+  if constexpr (!PROD) wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (ABL == 5) ts[10] = __builtin_amdgcn_s_memtime();
+  auto dump = [&] {
+    if (ABL == 5 && trace != nullptr && tid == 0) {
+      ts[12] = __builtin_amdgcn_s_memtime();
+      unsigned long long* t = trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
+      for (int i = 0; i < 13; ++i) t[i] = ts[i];
     }
+  };
+
+  if (S > 1) {
+    f32x4 part[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = f32x4{acc[i >> 2][4 * (i & 3)], acc[i >> 2][4 * (i & 3) + 1], acc[i >> 2][4 * (i & 3) + 2], acc[i >> 2][4 * (i & 3) + 3]};
+    if (!split_k_meet<16, 64 * WAVES>(part, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
+      dump();
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[i >> 2][4 * (i & 3)] = part[i].x; acc[i >> 2][4 * (i & 3) + 1] = part[i].y;
+      acc[i >> 2][4 * (i & 3) + 2] = part[i].z; acc[i >> 2][4 * (i & 3) + 3] = part[i].w;
+    }
+  }
+  if (ABL == 5) ts[11] = __builtin_amdgcn_s_memtime();
+
+  // D layout of the 32 x 32 tile: lane (col = lane & 31, g) holds rows (r & 3) + 8 (r >> 2) + 4 g, r = 0 .. 15.  Through the idle LDS
+  // and out as 16-byte row pieces (the direct form would be 64 two-byte stores per lane).
+  {
+    constexpr int RS = 128 * 2 + 16;  // staging row stride in bytes
+    const int col = wave * 32 + (lane & 31);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
+        *reinterpret_cast<uint16_t*>(smem + row * RS + col * 2) = f32_to_bf16_bits(acc[mt][r]);
+      }
+    // (only the consumer waves are here: the producers left after the loop's last barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // NOTE: see the launch: the barrier counts the waves still alive
+#pragma unroll
+    for (int it = 0; it < (128 * 16) / 256; ++it) {
+      const int c = it * 256 + tid;
+      const int row = c >> 4, piece = c & 15;
+      const int m = m0 + row, n = blockIdx.x * 128 + piece * 8;
+      if (m < M && n + 8 <= N)
+        *reinterpret_cast<u32x4*>(y + (size_t)m * N + n) = *reinterpret_cast<const u32x4*>(smem + row * RS + piece * 16);
+    }
+  }
+  dump();
 }
 
-template <int G, int MT, int VAR = 0>
-int launch_mm_kh(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
-                 hipStream_t stream) {
+template <int G, bool PROD, int ABL = 0>
+int launch_mm_w32(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
+                  hipStream_t stream) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
-  constexpr int BN = 64, BM = 16 * MT;
-  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)split), block(512);
-  constexpr size_t smem = (size_t)kKhStages * MT * 4096 + (size_t)4 * kKhStages * (1024 + NG * 256);
-  static_assert(smem <= 160 * 1024, "int4_mm_kh_kernel: LDS");
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)split), block(PROD ? 512 : 256);
+  constexpr size_t smem = (size_t)3 * 128 * 256 + (size_t)4 * 3 * 2 * (1024 + NG * 256);
+  static_assert(smem <= 160 * 1024, "int4_mm_w32_kernel: LDS");
   float* ws = nullptr;
   unsigned* tickets = nullptr;
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "int4_mm_kh: %u x %u tiles x %d parts exceed the split-K workspace",
-               grid.x, grid.y, split);
-    AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "int4_mm_kh: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
+    AO_REQUIRE((int64_t)grid.x * grid.y * split <= kSplitMaxTiles, "int4_mm_w32: %u x %u tiles x %d parts exceed the split-K workspace", grid.x, grid.y, split);
+    AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets - 8, "int4_mm_w32: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * 128 * 128)) return rc;
   }
-  auto kern = int4_mm_kh_kernel<G, MT, VAR>;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_kh_kernel)")) return rc;
+  auto kern = int4_mm_w32_kernel<G, PROD, ABL>;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_w32_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)M,
-             (int)N, (int)K, ws, tickets);
-  AO_LAUNCH_CHECK("int4_mm_kh_kernel launch");
+             (int)N, (int)K, ws, tickets, g_mm_trace);
+  AO_LAUNCH_CHECK("int4_mm_w32_kernel launch");
   return AO_OK;
 }
+
+
+// (round 5: int4_mm_kh_kernel -- round 3's K-half-wave form, modes 84S / 85S / 86x, measured 3 % behind the product and never dispatched --
+// was removed; DESIGN.md 4.3b keeps its measurements, git history its source.)
 
 template <int G, int WAVES, int NT, int MT = 8, int ABL = 0, bool PROD = false>
 int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
@@ -1389,28 +1425,41 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     if (kind == 1) return launch_mm_rb<G, 4, 2, 4, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
     if (kind == 2) return launch_mm_rb<G, 4, 2, 8>(x, qdata, sz, y, M, N, K, sp, stream);
     return launch_mm_rb<G, 4, 2, 8, 0, true>(x, qdata, sz, y, M, N, K, sp, stream);
-  } else if (g_tune_mode >= 840 && g_tune_mode < 860 && M > 16) {
-    // profiling (round 3): the K-half-wave kernel.  84S: 128-row slabs, 85S: 64-row slabs; S = K parts (0: fill ~256 workgroups)
-    const int rows = (g_tune_mode < 850) ? 128 : 64, s_req = g_tune_mode % 10;
-    const int64_t base8 = ((N + 63) / 64) * ((M + rows - 1) / rows);
-    const int64_t fit8 = (int64_t)kSplitMaxTiles * 128 * 128 / (base8 * 64 * rows);
-    const int sp = (int)std::max<int64_t>(1, s_req == 0 ? std::min<int64_t>({256 / base8, fit8, 8, kblocks / 8}) : std::min<int64_t>({(int64_t)s_req, kblocks, fit8}));
-    if (rows == 128) return launch_mm_kh<G, 8>(x, qdata, sz, y, M, N, K, sp, stream);
-    return launch_mm_kh<G, 4>(x, qdata, sz, y, M, N, K, sp, stream);
-  } else if (g_tune_mode >= 860 && g_tune_mode < 880 && M > 16) {
-    const int64_t base8 = ((N + 63) / 64) * ((M + 127) / 128);
-    const int64_t fit8 = (int64_t)kSplitMaxTiles * 128 * 128 / (base8 * 64 * 128);
-    const int sp = (int)std::max<int64_t>(1, std::min<int64_t>({256 / base8, fit8, 8, kblocks / 8}));
-    if (g_tune_mode < 870) return launch_mm_kh<G, 8, 1>(x, qdata, sz, y, M, N, K, sp, stream);
-#ifdef AO_LAB  // no DMAs at all (wrong results)
-    return launch_mm_kh<G, 8, 6>(x, qdata, sz, y, M, N, K, sp, stream);
-#else
-    return launch_mm_kh<G, 8, 1>(x, qdata, sz, y, M, N, K, sp, stream);
+  } else if (g_tune_mode >= 920 && g_tune_mode < 940 && M > 64) {
+    // round 5: the 128 x 128 / 32 x 32 x 16 kernel.  92S fused, 93S with DMA-producer waves; S = K parts (0: fill ~256 workgroups)
+    const int s_req = g_tune_mode % 10;
+    const int64_t base8 = ((N + 127) / 128) * ((M + 127) / 128);
+    const int64_t fit8 = (int64_t)kSplitMaxTiles / base8;
+    const int sp = (int)std::max<int64_t>(1, s_req == 0 ? std::min<int64_t>({256 / base8, fit8, 8, kblocks / 4}) : std::min<int64_t>({(int64_t)s_req, kblocks, fit8}));
+    if (g_tune_mode < 930) return launch_mm_w32<G, false>(x, qdata, sz, y, M, N, K, sp, stream);
+    return launch_mm_w32<G, true>(x, qdata, sz, y, M, N, K, sp, stream);
+  } else if (g_tune_mode >= 940 && g_tune_mode < 950 && M > 64) {
+    // profiling: 945 = the producer form with s_memtime stamps; 941 / 942 / 943 (laboratory library only: wrong results) = without the
+    // 32 x 32 x 16 MFMAs / the dequant / the A-fragment reads.  One K part.
+    if constexpr (G == 128) {
+#ifdef AO_LAB
+      if (g_tune_mode == 941) return launch_mm_w32<G, true, 1>(x, qdata, sz, y, M, N, K, 1, stream);
+      if (g_tune_mode == 942) return launch_mm_w32<G, true, 2>(x, qdata, sz, y, M, N, K, 1, stream);
+      if (g_tune_mode == 943) return launch_mm_w32<G, true, 3>(x, qdata, sz, y, M, N, K, 1, stream);
 #endif
+      if (g_tune_mode == 945) return launch_mm_w32<G, true, 5>(x, qdata, sz, y, M, N, K, 1, stream);
+    }
+    return launch_mm_w32<G, true>(x, qdata, sz, y, M, N, K, 1, stream);
   } else if (g_tune_mode >= 700 && g_tune_mode < 800) {
     mt = 1 << std::min(3, (g_tune_mode - 700) / 10);
     waves = (g_tune_wpb == 8 && mt >= 2) ? 8 : 4;
     forced_split = std::max(1, g_tune_mode % 10);
+  }
+  // Round 5: the 128 x 128 / 32 x 32 x 16 kernel with DMA-producer waves (int4_mm_w32_kernel) from 129 rows on, and on wide weights
+  // (>= 64 column tiles) from 65 rows.  profiles/int4_w32_ab_r05.jsonl, cold, us (this dispatch before -> after): M = 256 qkv 32.8 -> 26.9,
+  // o 21.6 -> 21.5, gate 49.2 -> 37.9, down 56.1 -> 44.2; M = 2048 gate 320 -> 281, down 301 -> 267; M = 128 gate 29.0 -> 28.2 (qkv, o, down
+  // stay: 48 / 32 column tiles need 5 - 8 K parts of 64 KiB partial tiles to fill the chip, 20.4 / 15.0 / 31.7 vs 22.0 / 21.7 / 34.1).
+  // Mode 911: never (the round-4 dispatch, for A/B).
+  if (g_tune_mode != 911 && g_tune_mode < 600 && forced_split == 0 && waves == 0 && M > 64 && (M > 128 || (N + 127) / 128 >= 64)) {
+    const int64_t base8 = ((N + 127) / 128) * ((M + 127) / 128);
+    const int64_t fit8 = (int64_t)kSplitMaxTiles / base8;
+    const int sp = (int)std::max<int64_t>(1, std::min<int64_t>({256 / base8, fit8, 8, kblocks / 4}));
+    return launch_mm_w32<G, true>(x, qdata, sz, y, M, N, K, sp, stream);
   }
   const int64_t slabs = (M + 16 * mt - 1) / (16 * mt);
   if (waves == 0) waves = (mt >= 2 && ((N + 127) / 128) * slabs >= 190) ? 8 : 4;
@@ -1458,6 +1507,8 @@ using namespace ao;
 
 extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size) {
   (void)group_size;
+  (void)K;
+  if (M > 64 && (M > 128 || (N + 127) / 128 >= 64)) return "int4_mm_w32_kernel";  // round 5: 128 x 128 tiles, 32 x 32 x 16 MFMAs
   if (M > 16 || (M > 4 && (N >> 4) >= 1024)) return "int4_mm_rb_kernel";
   return "int4_mm_kernel";
 }

@@ -64,4 +64,7 @@ def test_int4_dispatch_bands():
     assert [name(m, 14336, 4096) for m in (1, 4, 5, 8, 16)] == ["int4_mm_kernel"] * 5
     assert [name(m, 28672, 4096) for m in (1, 4)] == ["int4_mm_kernel"] * 2
     assert [name(m, 28672, 4096) for m in (5, 16)] == ["int4_mm_rb_kernel"] * 2
-    assert name(17, 4096, 4096) == "int4_mm_rb_kernel" and name(128, 14336, 4096) == "int4_mm_rb_kernel"
+    assert name(17, 4096, 4096) == "int4_mm_rb_kernel" and name(128, 6144, 4096) == "int4_mm_rb_kernel"
+    # round 5: the 128 x 128 / 32 x 32 x 16 kernel from 129 rows on, and on wide weights (>= 64 column tiles of 128) from 65 rows
+    assert name(128, 14336, 4096) == "int4_mm_w32_kernel" and name(129, 4096, 4096) == "int4_mm_w32_kernel" and name(2048, 4096, 14336) == "int4_mm_w32_kernel"
+    assert name(64, 14336, 4096) == "int4_mm_rb_kernel"
