@@ -38,8 +38,10 @@ struct P8Args {
   void* out;               // bf16 / int32 / fp32 [M][N]
   int M, N, K;
   int tiles_m, tiles_n;
+  int group_rows;  // tile rows an XCD's consecutive workgroups walk together (4; ao_gemm8_set_tuning(4, v) for A/B)
 };
 
+thread_local int g_p8_group_rows = 0;  // 0 = 4 (product)
 constexpr int kHalf = 16384;          // one half tile: 128 rows x 128 B
 constexpr int kBuf = 4 * kHalf;       // A-lo, A-hi, B-lo, B-hi of one K tile
 constexpr int kEpiStride = 144;       // bytes per row of a wave's 128 x 64 bf16 staging region (128 + 16: conflict-free b16 writes)
@@ -55,14 +57,15 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int nl = lane & 15, kq = lane >> 4;
 
-  // workgroup -> tile: blocks of one XCD (id % 8) take consecutive tiles, tiles ordered in groups of 8 tile rows that walk
+  // workgroup -> tile: blocks of one XCD (id % 8) take consecutive tiles, tiles ordered in groups of GR (= 4: round-5 sweep) tile rows that walk
   // the N direction together (a group shares its A panels in the XCD's L2 and streams B once)
   int wg = blockIdx.x;
   const int nwg = gridDim.x;
   if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  const int group = 8 * p.tiles_n;
-  const int g0 = (wg / group) * 8;
-  const int gsz = min(8, p.tiles_m - g0);
+  const int GR = p.group_rows;
+  const int group = GR * p.tiles_n;
+  const int g0 = (wg / group) * GR;
+  const int gsz = min(GR, p.tiles_m - g0);
   const int tm = g0 + (wg % group) % gsz, tn = (wg % group) / gsz;
   const int m0 = tm * 256, n0 = tn * 256;
   const int ktiles = p.K >> 7;
@@ -269,6 +272,9 @@ template <int EPI>
 int launch_p8(P8Args p, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
+  // round 5 sweep (profiles/p8_group_rows_r05.jsonl): 4 tile rows per group measured 0 .. 7 % ahead of 8 on the Llama-3-8B int8 shapes at
+  // M = 16384 (an XCD's L2 then holds 4 MB of A panels, its size, instead of 8 MB) and level elsewhere
+  p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8_kernel<EPI>), kSmem, "hipFuncSetAttribute(gemm8_p8_kernel)")) return rc;
   ao::launch(gemm8_p8_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kSmem, stream, p);
   AO_LAUNCH_CHECK("gemm8_p8_kernel launch");
@@ -279,6 +285,7 @@ int launch_p8(P8Args p, hipStream_t stream) {
 
 // epi: 0 int8 scaled (bf16 out), 1 int32 out, 2 fp8 rowwise (bf16 out), 3 fp8 raw fp32 out.  K % 128 == 0, N % 8 == 0,
 // 256 * K < 4 GiB (32-bit in-tile offsets).
+void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }
 bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K) { return K % 128 == 0 && N % 8 == 0 && 256 * K < (1ll << 32) && M > 0 && N > 0; }
 
 int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,

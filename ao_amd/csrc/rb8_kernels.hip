@@ -1126,6 +1126,7 @@ inline Rb8Plan rb8_plan(int64_t M, int64_t N, int64_t K, int bm) {
     for (int S : {1, 2, 3, 4, 6, 8}) {
       if (S > 1 && (S > fit || S > std::max<int64_t>(1, ksteps / 4))) continue;
       const int64_t wgs = tiles * S, rounds = (wgs + 255) / 256, steps = (ksteps + S - 1) / S;
+      if (S > 1 && wgs > 256) continue;  // K is never cut into a second round of the chip (1280 x 8192 at M = 2048: 3 parts 52 us, one 45)
       const double loop = std::max((double)steps * c * (double)rounds, hbm_us);
       const double meet = S == 1 ? 0.0 : (S <= 4 ? 3.17 : 4.53) + 0.4 * (S - 1) * bn / 128.0 * (bm / 128.0);
       const double t = 5.5 * (double)rounds + loop + meet;

@@ -129,7 +129,7 @@ int ao_gemm8_set_variant(int variant);
  *   key 2  its K parts (1 .. 16)
  *   key 3  2 = the same-XCD split-K meeting where the device's workgroup placement allows it (opt-in; 0 / 1: the write-through,
  *          placement-independent one)
- *   key 4  reserved
+ *   key 4  tile rows an XCD's workgroups of gemm8_p8_kernel walk together (product: 4)
  *   key 5  timing probes of the TRACED build of rb8_kernel only (ao_int4_set_trace set; results are wrong): bit 0 no MFMAs, 1 no fragment
  *          reads, 2 no weight DMAs, 3 no activation DMAs -- the product build ignores it
  *   key 6  slab height of rb8_kernel above 64 rows: 128 or 256
