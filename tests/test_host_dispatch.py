@@ -27,7 +27,10 @@ TABLE = [
     ((512, 8192, 1024), "rb8_kernel"),
     ((2048, 1280, 8192), "rb8_kernel"),
     # round 5: up to 1024 rows also where 256-row slabs fit one round of the chip although 128-row ones would not
-    ((768, 7168, 8192), "gemm8_dma_kernel<128x128>"),
+    ((768, 7168, 8192), "gemm8_dma_kernel<128x128>"),  # 641 .. 896 rows: 256-row slabs only at K <= 4096 (measured: 74.9 -> 95.8 us here)
+    ((768, 8192, 1024), "rb8_kernel"),
+    ((768, 8192, 3584), "rb8_kernel"),
+    ((640, 8192, 1024), "gemm8_dma_kernel<128x128>"),
     ((1024, 7168, 8192), "rb8_kernel"),
     ((1024, 8192, 1024), "rb8_kernel"),
     # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on (from 128 at short K / > 512 small tiles)
