@@ -16,10 +16,14 @@
 namespace ao {
 bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K);  // gemm8_p8_kernels.hip (epi numbering = enum Epilogue)
 void gemm8_p8_set_group_rows(int v);
+void gemm8_p8_set_split(int v);
 int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
              int64_t M, int64_t N, int64_t K, hipStream_t stream);
 
 // rb8_kernels.hip: weight-streaming kernels for problems with few output tiles
+int gemm8_p8h(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
+              int64_t M, int64_t N, int64_t K, hipStream_t stream);
+bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K);
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void rb8_set_wave_grid(bool two_by_four);  // rb8_kernels.hip
 void rb8_set_tuning(int bn, int split, int local_off, int ablate, int bm);
@@ -417,6 +421,8 @@ int launch_gemm8_dma(const Gemm8Args& p, hipStream_t stream) {
   // but o / down (128 tiles: half the CUs idle) 1350 / 1710 vs 1330 / 1834; M = 512: gate_up (224 tiles) 2122 vs 1231.
   // Round 4 (profiles/gemm8_p8_band_r04.jsonl, cold weights): at 128 .. 159 such tiles it also wins while K <= 4096 (1024 x 8192 x 1024: 24.3 -> 20.2 us;
   // K = 8192 / 14336: 2 - 7 % behind) and whenever the 128 x 128 grid would need a second round of the chip (> 512 tiles: 1280 x 7168 x 8192 129 -> 84 us)
+  if ((g_gemm8_tm == 33 && gemm8_p8_fits(p.M, p.N, p.K)) || (g_gemm8_tm == 0 && gemm8_p8h_band(p.M, p.N, p.K)))  // the 256 x 128 phase-interleaved form (33 forces it)
+    return gemm8_p8h((int)EPI, p.a, p.b, p.row_scale, p.col_scale, p.bias, p.out, p.M, p.N, p.K, stream);
   if ((g_gemm8_tm == 32 || (g_gemm8_tm == 0 && gemm8_p8_band(p.M, p.N, p.K))) && gemm8_p8_fits(p.M, p.N, p.K))
     return gemm8_p8((int)EPI, p.a, p.b, p.row_scale, p.col_scale, p.bias, p.out, p.M, p.N, p.K, stream);
   if (g_gemm8_tm == 8 || (g_gemm8_tm == 0 && big >= 512)) return launch_gemm8_dma_tm<EPI, 4, 4>(p, stream);
@@ -460,7 +466,7 @@ extern "C" int ao_gemm8_set_variant(int variant) {
   g_dec8_mode = (variant >= 200 && variant <= 299) ? variant : 0;
   // the register-ring mid-M kernel (mid8_kernels.hip): 300 never, 301 wherever the shape allows, 310 + S: S K-parts forced
   g_mid8_mode = (variant >= 300 && variant <= 329) ? variant : 0;
-  g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16 || variant == 32) ? variant : 0;
+  g_gemm8_tm = (variant == 2 || variant == 4 || variant == 8 || variant == 16 || variant == 32 || variant == 33) ? variant : 0;
   // the fp8 weight-streaming mid-M kernel: 101 always, 100 or any explicit GEMM variant never, 0 by shape
   fp8_rowwise_rb_set_mode(variant == 101 ? 2 : variant == 102 ? 3 : (variant != 0 && variant < 110 && variant != 103) ? 1 : 0);
   rb8_set_wave_grid(variant != 103);  // 103: the weight-streaming kernel's round-3 wave arrangement (1 x 8), product dispatch otherwise
@@ -469,10 +475,11 @@ extern "C" int ao_gemm8_set_variant(int variant) {
 
 namespace ao { namespace { thread_local int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0}; } }
 extern "C" int ao_gemm8_set_tuning(int key, int value) {
-  AO_REQUIRE(key >= 1 && key <= 6, "ao_gemm8_set_tuning: unknown key %d", key);
+  AO_REQUIRE(key >= 1 && key <= 7, "ao_gemm8_set_tuning: unknown key %d", key);
   g_tune[key] = value;
   rb8_set_tuning(g_tune[1], g_tune[2], g_tune[3], g_tune[5], g_tune[6]);
   gemm8_p8_set_group_rows(g_tune[4]);
+  gemm8_p8_set_split(g_tune[7]);
   return AO_OK;
 }
 
@@ -518,6 +525,7 @@ extern "C" const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int6
   }
   if (K % BK != 0) return "gemm8_kernel";  // register-staged tiles (K % 128 != 0)
   const int64_t big = ((N + 255) / 256) * ((M + 255) / 256);
+  if (gemm8_p8h_band(M, N, K)) return "gemm8_p8h_kernel";
   if (gemm8_p8_band(M, N, K) && gemm8_p8_fits(M, N, K)) return "gemm8_p8_kernel";
   return big >= 512 ? "gemm8_dma_kernel<256x256>" : "gemm8_dma_kernel<128x128>";
 }

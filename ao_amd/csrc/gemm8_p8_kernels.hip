@@ -21,6 +21,7 @@
 //     LDS so that every lane stores 16 contiguous bytes (128-byte rows per 8 lanes) instead of 2.
 #include "common.h"
 #include "lds_dma.h"
+#include "splitk.h"
 
 namespace ao {
 namespace {
@@ -39,9 +40,13 @@ struct P8Args {
   int M, N, K;
   int tiles_m, tiles_n;
   int group_rows;  // tile rows an XCD's consecutive workgroups walk together (4; ao_gemm8_set_tuning(4, v) for A/B)
+  int split;       // K parts per output tile (round 5): the parts meet through split_k_meet2, the last arriver runs the epilogue
+  float* ws;
+  unsigned* tickets;
 };
 
 thread_local int g_p8_group_rows = 0;  // 0 = 4 (product)
+thread_local int g_p8_split = 0;       // 0 = by shape (p8_split below), n = n K parts wherever they fit
 constexpr int kHalf = 16384;          // one half tile: 128 rows x 128 B
 constexpr int kBuf = 4 * kHalf;       // A-lo, A-hi, B-lo, B-hi of one K tile
 constexpr int kEpiStride = 144;       // bytes per row of a wave's 128 x 64 bf16 staging region (128 + 16: conflict-free b16 writes)
@@ -62,13 +67,19 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
   int wg = blockIdx.x;
   const int nwg = gridDim.x;
   if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  // K parts: the S parts of a tile are consecutive work items (of one XCD when the grid is a multiple of 8)
+  const int S = p.split;
+  const int ks = wg % S;
+  wg /= S;
   const int GR = p.group_rows;
   const int group = GR * p.tiles_n;
   const int g0 = (wg / group) * GR;
   const int gsz = min(GR, p.tiles_m - g0);
   const int tm = g0 + (wg % group) % gsz, tn = (wg % group) / gsz;
   const int m0 = tm * 256, n0 = tn * 256;
-  const int ktiles = p.K >> 7;
+  const int ktiles_all = p.K >> 7;
+  const int kb = (int)((int64_t)ks * ktiles_all / S);                      // this part's first K tile
+  const int ktiles = (int)((int64_t)(ks + 1) * ktiles_all / S) - kb;       // >= 1: launchers keep S <= K / 128
 
   // DMA sources.  Half tile rows 16 w + 8 i + (lane >> 3), i = 0, 1; lane lands at chunk position lane & 7.
   uint32_t aoff[2][2], boff[2][2];  // [half][i]: byte offset from the tile's first row, k = 0
@@ -81,8 +92,8 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
       aoff[h][i] = (uint32_t)(min(m0 + h * 128 + row, p.M - 1) - m0) * (uint32_t)p.K + chunk;
       boff[h][i] = (uint32_t)(min(n0 + h * 128 + row, p.N - 1) - n0) * (uint32_t)p.K + chunk;
     }
-  const uint8_t* abase = p.a + (size_t)m0 * p.K;
-  const uint8_t* bbase = p.b + (size_t)n0 * p.K;
+  const uint8_t* abase = p.a + (size_t)m0 * p.K + (size_t)kb * 128;
+  const uint8_t* bbase = p.b + (size_t)n0 * p.K + (size_t)kb * 128;
   const uint32_t lds0 = lds_offset(smem);
   // half tile j of the stream: tile j / 4; order A-lo, B-hi, B-lo, A-hi; slots [A-lo, A-hi, B-lo, B-hi]
   auto issue = [&](int tile, int which) {  // which: 0 A-lo, 1 B-hi, 2 B-lo, 3 A-hi
@@ -213,6 +224,13 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
   }
   __builtin_amdgcn_sched_barrier(0);
+  if (S > 1) {
+    // the K parts meet (csrc/splitk.h): parked through to memory in part order, the last arriver of the tile sums them in part order
+    // -- the result does not depend on who arrives when -- and goes on to the epilogue
+    if (!split_k_meet2<32, 512, IS_INT, 2, false, 8>(reinterpret_cast<f32x4(&)[32]>(acc), p.ws, p.tickets, tm * p.tiles_n + tn, S, ks, tid,
+                                                       reinterpret_cast<int*>(smem)))
+      return;
+  }
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------
   // D layout of the 16 x 16 MFMA: lane (col = nl, kq) holds rows 4 kq + {0..3}
@@ -268,6 +286,233 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// gemm8_p8h_kernel (round 5): the same phase-interleaved scheme on a 256 (M) x 128 (N) tile, for problems whose 256 x 256 tiles would leave
+// half the chip idle (M <= 1024 on the TP shards: 28 .. 128 such tiles) while 256 x 128 tiles fill one round of it.
+//   * 8 waves = 4 (m) x 2 (n): wave 4 g + s owns rows 64 s .. 64 s + 63 and columns 64 g .. 64 g + 63 (4 x 4 MFMA tiles, 64 accumulator
+//     VGPRs).  A 64 x 64 wave tile reads (64 + 64) x 128 B of fragments per K tile -- 16 KiB, against 20 KiB for the 128 x 32 wave tile the
+//     weight-streaming kernel uses at this workgroup tile: the loop is LDS-bound (176 KiB of reads + DMA writes per K tile at 128 B / clock
+//     = 1375 cycles for 1024 cycles of MFMA per SIMD), so the wave shape that reads least wins.
+//   * a K tile is TWO phases of 8 fp8 (16 int8) MFMAs: n-lo (all A fragments + the two n-lo B fragments read: 12 ds_read_b128), n-hi (4
+//     reads).  Wave group g = 1 runs one barrier behind g = 0, as the two wave rows of the 256 x 256 kernel do: every SIMD holds one
+//     wave of each group, one multiplies while the other reads and issues.
+//   * three K tiles of [A-lo | A-hi | B] half tiles resident (144 KiB): tile t + 2 is fetched during tile t into the buffer tile t - 1
+//     left -- every wave finished reading that one a full K tile earlier, whatever the stagger -- 4 DMA instructions in the first phase, 2 in
+//     the second, then vmcnt(6): tile t + 1 has landed, tile t + 2's six stay in flight.
+// Everything else (source swizzle, asm-pinned fp8 MFMAs, LDS-transposed epilogue, workgroup -> tile order) as in the kernel above.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+constexpr int kHBuf = 3 * kHalf;                    // one K tile: A-lo, A-hi, B
+constexpr int kHSmem = 3 * kHBuf;                   // 147456 B (three K tiles; the epilogue's 8 x 64 x 144 B fit inside)
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
+  constexpr bool IS_INT = (EPI == P8_INT8_SCALED || EPI == P8_INT32);
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, s = wave & 3;
+  const int nl = lane & 15, kq = lane >> 4;
+
+  int wg = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const int GR = p.group_rows;
+  const int group = GR * p.tiles_n;
+  const int g0 = (wg / group) * GR;
+  const int gsz = min(GR, p.tiles_m - g0);
+  const int tm = g0 + (wg % group) % gsz, tn = (wg % group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 128;
+  const int ktiles = p.K >> 7;
+
+  // DMA sources: half-tile rows 16 w + 8 i + (lane >> 3), chunk position lane & 7 holds global chunk (lane & 7) ^ ((row >> 1) & 7)
+  uint32_t aoff[2][2], boff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * wave + 8 * i + (lane >> 3);
+    const uint32_t chunk = (uint32_t)(((lane & 7) ^ (row >> 1)) & 7) << 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) aoff[h][i] = (uint32_t)(min(m0 + h * 128 + row, p.M - 1) - m0) * (uint32_t)p.K + chunk;
+    boff[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)p.K + chunk;
+  }
+  const char* abase = reinterpret_cast<const char*>(p.a) + (size_t)m0 * p.K;
+  const char* bbase = reinterpret_cast<const char*>(p.b) + (size_t)n0 * p.K;
+  const uint32_t lds0 = lds_offset(smem);
+  auto issue = [&](int tile, int which) {  // which: 0 A-lo, 1 A-hi, 2 B
+    if (tile >= ktiles) return;
+    const uint32_t dst = lds0 + (tile % 3) * kHBuf + which * kHalf + wave * 2048;
+    if (which == 2) dma_b128_x2(bbase + (size_t)tile * 128, boff[0], boff[1], dst);
+    else dma_b128_x2(abase + (size_t)tile * 128, aoff[which][0], aoff[which][1], dst);
+  };
+
+  const int pos_lo = ((kq ^ (nl >> 1)) & 7) << 4;
+  const int a_frag = (s >> 1) * kHalf + ((s & 1) * 64 + nl) * 128 + pos_lo;
+  const int b_frag = 2 * kHalf + (g * 64 + nl) * 128 + pos_lo;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 af[4][2], bf[4][2];
+
+  auto load_a = [&](const char* buf) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int off = a_frag + mt * 16 * 128;
+      af[mt][0] = *reinterpret_cast<const u32x4*>(buf + off);
+      af[mt][1] = *reinterpret_cast<const u32x4*>(buf + (off ^ 64));
+    }
+  };
+  auto load_b = [&](const char* buf, int nj) {
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) {
+      const int nt = nj * 2 + n2;
+      const int off = b_frag + nt * 16 * 128;
+      bf[nt][0] = *reinterpret_cast<const u32x4*>(buf + off);
+      bf[nt][1] = *reinterpret_cast<const u32x4*>(buf + (off ^ 64));
+    }
+  };
+  const int unit_scale = 127;  // E8M0 1.0
+  auto multiply = [&](int nj) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) {
+        const int nt = nj * 2 + n2;
+        f32x4& c = acc[mt][nt];
+        if constexpr (IS_INT) {
+          c = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[mt][0]), __builtin_bit_cast(i32x4, bf[nt][0]),
+                                                                             __builtin_bit_cast(i32x4, c), 0, 0, 0));
+        } else {
+          const i32x8 av = {(int)af[mt][0].x, (int)af[mt][0].y, (int)af[mt][0].z, (int)af[mt][0].w,
+                            (int)af[mt][1].x, (int)af[mt][1].y, (int)af[mt][1].z, (int)af[mt][1].w};
+          const i32x8 bv = {(int)bf[nt][0].x, (int)bf[nt][0].y, (int)bf[nt][0].z, (int)bf[nt][0].w,
+                            (int)bf[nt][1].x, (int)bf[nt][1].y, (int)bf[nt][1].z, (int)bf[nt][1].w};
+          // volatile asm keeps the MFMAs inside their phase (see gemm8_p8_kernel)
+          asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(av), "v"(bv), "v"(unit_scale));
+        }
+      }
+    if constexpr (IS_INT) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int nt = nj * 2 + n2;
+          f32x4& c = acc[mt][nt];
+          c = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, af[mt][1]), __builtin_bit_cast(i32x4, bf[nt][1]),
+                                                                             __builtin_bit_cast(i32x4, c), 0, 0, 0));
+        }
+    }
+  };
+  auto seam = [&] {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: K tiles 0 and 1 entirely; wait for tile 0
+  issue(0, 0); issue(0, 1); issue(0, 2); issue(1, 0); issue(1, 1); issue(1, 2);
+  if (ktiles > 1) wait_vmcnt<6>(); else wait_vmcnt<0>();
+  asm volatile("s_barrier" ::: "memory");
+  if (g == 1) asm volatile("s_barrier" ::: "memory");  // the stagger: wave group 1 runs one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int t = 0; t < ktiles; ++t) {
+    const char* buf = smem + (t % 3) * kHBuf;
+    // ---- phase 0: all rows x n-lo; reads every A fragment and the n-lo B fragments; fetches the A halves of tile t + 2 --------------------
+    load_b(buf, 0); __builtin_amdgcn_sched_barrier(0); load_a(buf);
+    issue(t + 2, 0); issue(t + 2, 1);
+    seam();
+    __builtin_amdgcn_s_setprio(1); multiply(0); __builtin_amdgcn_s_setprio(0);
+    seam();
+    // ---- phase 1: all rows x n-hi; fetches B of tile t + 2; tile t + 1 must have landed before the next phase reads it ----------------------
+    load_b(buf, 1);
+    issue(t + 2, 2);
+    if (t + 2 < ktiles) wait_vmcnt<6>(); else wait_vmcnt<0>();
+    seam();
+    __builtin_amdgcn_s_setprio(1); multiply(1); __builtin_amdgcn_s_setprio(0);
+    seam();
+  }
+  if (g == 0) asm volatile("s_barrier" ::: "memory");  // group 0 catches up: from here on the LDS is free for every wave
+  if constexpr (!IS_INT) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // asm MFMA results -> VALU / VMEM readers (see gemm8_p8_kernel)
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile ---------------------------------------------------------
+  const int rbase = m0 + s * 64, cbase = n0 + g * 64;
+  if constexpr (EPI == P8_INT32 || EPI == P8_FP8_RAW) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = rbase + mt * 16 + kq * 4 + r, n = cbase + nt * 16 + nl;
+          if (m < p.M && n < p.N) reinterpret_cast<uint32_t*>(p.out)[(size_t)m * p.N + n] = __builtin_bit_cast(u32x4, acc[mt][nt])[r];
+        }
+  } else {
+    float cs[4], bias[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = min(cbase + nt * 16 + nl, p.N - 1);
+      cs[nt] = p.col_scale[n];
+      bias[nt] = p.bias != nullptr ? bf16_lo_to_f32(p.bias[n]) : 0.f;
+    }
+    char* region = smem + wave * (64 * kEpiStride);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float rs[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rs[r] = p.row_scale[min(rbase + mt * 16 + kq * 4 + r, p.M - 1)];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v;
+          if constexpr (EPI == P8_INT8_SCALED) {
+            v = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt][nt])[r] * rs[r]) * cs[nt];  // (int8_tensor.py:315-359)
+          } else {
+            v = acc[mt][nt][r] * rs[r] * cs[nt];
+          }
+          if (p.bias != nullptr) v += bias[nt];
+          *reinterpret_cast<uint16_t*>(region + (mt * 16 + kq * 4 + r) * kEpiStride + (nt * 16 + nl) * 2) = f32_to_bf16_bits(v);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 8 + (lane >> 3), piece = lane & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(region + row * kEpiStride + piece * 16);
+      const int m = rbase + row, n = cbase + piece * 8;
+      if (m < p.M && n + 8 <= p.N) *reinterpret_cast<u32x4*>(out + (size_t)m * p.N + n) = v;
+    }
+  }
+}
+
+template <int EPI>
+int launch_p8h(P8Args p, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 127) / 128;
+  p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
+  p.split = 1;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<EPI>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
+  ao::launch(gemm8_p8h_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+  AO_LAUNCH_CHECK("gemm8_p8h_kernel launch");
+  return AO_OK;
+}
+
+// K parts of a launch (ao_gemm8_set_tuning key 7; the product launches ONE part): a 256 x 256 fp32 partial tile is 256 KiB, so S parts move
+// S x 512 KiB per tile through memory at the meeting -- 1024 x 7168 x 8192 with 2 parts: 112 MB, ~25 us, on top of a 38 us k loop (77 us
+// unsplit, 66 split, hipBLASLt 64; profiles/p8_split_sweep_r05.jsonl).  Ahead of the product dispatch only on the Llama-3-8B down_proj
+// (K = 14336) at 768 - 2048 rows before the 256 x 128 form below took those shapes; kept as a measured tuning form.
+int p8_split(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256), ktiles = K / 128;
+  const int64_t fit = std::min<int64_t>({256 / tiles, ktiles, 16, (int64_t)(kSplitSlotFloats / ((size_t)tiles * 256 * 256)) * 4 / 5,
+                                         (int64_t)kSplitMaxTickets / (tiles * 5)});
+  if (g_p8_split > 0) return (int)std::max<int64_t>(1, std::min<int64_t>(g_p8_split, fit));
+  return 1;
+}
+
 template <int EPI>
 int launch_p8(P8Args p, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
@@ -275,8 +520,13 @@ int launch_p8(P8Args p, hipStream_t stream) {
   // round 5 sweep (profiles/p8_group_rows_r05.jsonl): 4 tile rows per group measured 0 .. 7 % ahead of 8 on the Llama-3-8B int8 shapes at
   // M = 16384 (an XCD's L2 then holds 4 MB of A panels, its size, instead of 8 MB) and level elsewhere
   p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
+  p.split = p8_split(p.M, p.N, p.K);
+  if (p.split > 1) {
+    const int NG = (p.split + 3) / 4;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)p.tiles_m * p.tiles_n * (p.split + NG) * 256 * 256)) return rc;
+  }
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8_kernel<EPI>), kSmem, "hipFuncSetAttribute(gemm8_p8_kernel)")) return rc;
-  ao::launch(gemm8_p8_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kSmem, stream, p);
+  ao::launch(gemm8_p8_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split)), dim3(512), kSmem, stream, p);
   AO_LAUNCH_CHECK("gemm8_p8_kernel launch");
   return AO_OK;
 }
@@ -285,12 +535,33 @@ int launch_p8(P8Args p, hipStream_t stream) {
 
 // epi: 0 int8 scaled (bf16 out), 1 int32 out, 2 fp8 rowwise (bf16 out), 3 fp8 raw fp32 out.  K % 128 == 0, N % 8 == 0,
 // 256 * K < 4 GiB (32-bit in-tile offsets).
-void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }
 bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K) { return K % 128 == 0 && N % 8 == 0 && 256 * K < (1ll << 32) && M > 0 && N > 0; }
+// The shapes the 256 x 128 form takes (product rule, fp8 and int8): more than half a round and at most one round of the chip in 256 x 128 tiles,
+// above 128 rows.  profiles/p8h_sweep_r05.jsonl (fp8, cold weights, 8 shapes x M = 256 .. 2048): inside the band it is ahead of every other
+// kernel of the library in all 14 cells (1.1 - 1.5 x) and of hipBLASLt in 13 (o 8192 x 1024 at M = 1024: 0.98); at exactly 128 tiles it loses
+// to the weight-streaming kernel in all 4 cells measured, below that by more.
+bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  return M > 128 && tiles > 128 && tiles <= 256 && gemm8_p8_fits(M, N, K);
+}
+void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }
+void gemm8_p8_set_split(int v) { g_p8_split = v; }
+
+// the 256 x 128 form (same epi numbering and shape limits)
+int gemm8_p8h(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
+              int64_t M, int64_t N, int64_t K, hipStream_t stream) {
+  P8Args p{a, b, row_scale, col_scale, bias, out, (int)M, (int)N, (int)K, 0, 0, 0, 1, nullptr, nullptr};
+  switch (epi) {
+    case P8_INT8_SCALED: return launch_p8h<P8_INT8_SCALED>(p, stream);
+    case P8_INT32: return launch_p8h<P8_INT32>(p, stream);
+    case P8_FP8_ROWWISE: return launch_p8h<P8_FP8_ROWWISE>(p, stream);
+    default: return launch_p8h<P8_FP8_RAW>(p, stream);
+  }
+}
 
 int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
              int64_t M, int64_t N, int64_t K, hipStream_t stream) {
-  P8Args p{a, b, row_scale, col_scale, bias, out, (int)M, (int)N, (int)K, 0, 0};
+  P8Args p{a, b, row_scale, col_scale, bias, out, (int)M, (int)N, (int)K, 0, 0, 0, 1, nullptr, nullptr};
   switch (epi) {
     case P8_INT8_SCALED: return launch_p8<P8_INT8_SCALED>(p, stream);
     case P8_INT32: return launch_p8<P8_INT32>(p, stream);

@@ -1087,14 +1087,12 @@ void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = qua
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
 bool fp8_rowwise_rb_forced() { return g_fp8_rb_force >= 2; }
 
-// 256-row slabs (round 5): where 128-row slabs would need a second round of the chip and 256-row ones do not -- measured at 897 .. 1024 rows
-// on every K (M = 1024: o 8192 x 1024 20.1 -> 18.6 us, gate_up 7168 x 8192 78.9 -> 71.2, down 41.6 -> 38.3, qkv 6144 x 4096 45.9 -> 40.5) and
-// at 641 .. 896 rows for K <= 4096 (M = 768: o 22.8 -> 17.3, down 8192 x 3584 41.4 -> 36.2, qkv8b 44.2 -> 39.1; gate_up at K = 8192 loses:
-// 74.9 -> 95.8 and stays on the tile kernel).  profiles/midm_sweep_r05.jsonl, midm_forms_r05.jsonl.
-bool rb8_slab256(int64_t M, int64_t N, int64_t K) {
-  const int64_t t128 = ((N + 127) / 128) * ((M + 127) / 128), t256 = ((N + 127) / 128) * ((M + 255) / 256);
-  return t128 > 256 && t256 <= 256 && M <= 1024 && (M > 896 || (M > 640 && K <= 4096));
-}
+// 256-row slabs (round 5; ao_gemm8_set_tuning key 6): where 128-row slabs would need a second round of the chip and 256-row ones do not they
+// measured ahead of the tile kernels (M = 1024: o 8192 x 1024 20.1 -> 18.6 us, gate_up 7168 x 8192 78.9 -> 71.2, down 41.6 -> 38.3, qkv
+// 6144 x 4096 45.9 -> 40.5; profiles/midm_sweep_r05.jsonl, midm_forms_r05.jsonl) -- and behind the phase-interleaved 256 x 128 GEMM built
+// later in the round (gemm8_p8h_kernel: 14.7 / 56.0 / 30.6 / 31.3 on the same four), which takes exactly these shapes
+// (gemm8_p8h_band: more than 128 and at most 256 tiles of 256 x 128).  The slab form stays as a tuning form.
+bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K);  // gemm8_p8_kernels.hip
 
 // True when this kernel is the better choice: the 128 x 128 GEMM grid would leave most of the chip idle (same rule for int8).
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
@@ -1104,8 +1102,8 @@ bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
   // up to one 128 x 128 workgroup per CU (one round of the chip).  Round 4 (profiles/fp8_dispatch_sweep_r04.txt, cold 70B / TP8 shards): the bound
   // was 190, and the 224 - 256 tiles of M = 512 fell to the 4-wave two-stage tile kernel -- gate_up 73.6 us against 44.3 here (hipBLASLt
   // 47.5), down 39.8 / 23.6 (24.4), o 20.9 / 11.7 (11.5); from two rounds on (M = 1024: 448 - 512 tiles) the tiled kernels are level or ahead
-  // (round 5: also where 256-row slabs fit one round -- M ~ 1024 on the 70B / TP8 shards -- see rb8_run)
-  return ((N + 127) / 128) * ((M + 127) / 128) <= 256 || (rb8_slab256(M, N, K));
+  // (round 5: minus the shapes the 256 x 128 phase-interleaved GEMM takes)
+  return ((N + 127) / 128) * ((M + 127) / 128) <= 256 && !gemm8_p8h_band(M, N, K);
 }
 
 namespace {
@@ -1154,7 +1152,7 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   // slabs of 64 rows for M <= 64, else 128; (round 5) 256 rows where 128-row slabs would need a second round of the chip and 256-row
   // ones do not (897 .. 1024 rows -- what was measured -- on the 70B / TP8 shards: a step's fixed cost -- the barrier, the waits, ~430 cycles whatever the tile -- is
   // then spread over twice the MFMAs: o 8192 x 1024 20.1 -> 18.6 us, gate_up 78.9 -> 71.2, down 41.6 -> 38.3).  g_rb8_bm forces 128 / 256.
-  const int bm = (M <= 64) ? 64 : (g_rb8_bm == 128) ? 128 : (g_rb8_bm == 256 || rb8_slab256(M, N, K)) ? 256 : 128;
+  const int bm = (M <= 64) ? 64 : (g_rb8_bm == 128) ? 128 : (g_rb8_bm == 256) ? 256 : 128;
   const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
   Rb8Plan plan = rb8_plan(M, N, K, bm);
   if (g_fp8_rb_force == 3) plan.bn = 64;

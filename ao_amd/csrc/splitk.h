@@ -147,7 +147,9 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
 // order: reproducible.  Workspace per tile: S + ceil(S / 4) parked parts; tickets per tile: 1 + ceil(S / 4).
 // ---------------------------------------------------------------------------
 // UMAX: parts gathered per round trip (4 x NREG x 4 VGPRs: callers that run four waves per SIMD pass 2 for 8-register tiles)
-template <int NREG, int NTHR, bool INT = false, int UMAX = 4, bool LOCAL = false>
+// RC (round 5): registers per batch.  A 256 x 256 tile on 512 threads is 32 registers of 4 floats per thread (128 VGPRs): parked and gathered
+// in batches of RC registers so that neither the pinned store copies nor the gather's landing registers double the tile.
+template <int NREG, int NTHR, bool INT = false, int UMAX = 4, bool LOCAL = false, int RC = NREG>
 __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
   constexpr int kSc1 = 16;
   constexpr int kPark = LOCAL ? 0 : kSc1;  // LOCAL: see split_k_meet
@@ -158,19 +160,41 @@ __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, uns
   const __amdgpu_buffer_rsrc_t rws =
       __builtin_amdgcn_make_buffer_rsrc(ws + (size_t)tile * slots * (kPartBytes / 4), 0, slots * kPartBytes, 0x00020000);
   unsigned* tk = tickets + (size_t)tile * (1 + NG);  // [0] second level, [1 + g] group g
+  static_assert(NREG % RC == 0, "batches of RC registers");
   auto park = [&](int slot) {
-    f32x4 parked[NREG];  // VGPR copies, pinned until the stores are out (see split_k_meet)
+    if constexpr (RC == NREG) {
+      f32x4 parked[NREG];  // VGPR copies, pinned until the stores are out (see split_k_meet)
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      parked[r] = acc[r];
-      asm volatile("" : "+v"(parked[r]));
+      for (int r = 0; r < NREG; ++r) {
+        parked[r] = acc[r];
+        asm volatile("" : "+v"(parked[r]));
+      }
+#pragma unroll
+      for (int r = 0; r < NREG; ++r)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, parked[r]), rws, tid * 16 + r * kRegBytes, slot * kPartBytes, kPark);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through (LOCAL: acknowledged by the L2) before the ticket is taken
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(parked[r]));  // the data registers stay untouched until the stores are out
+    } else {
+      // in batches: the copies of a batch stay pinned across 16 idle cycles behind its last store (what the stream-K kernel's in-loop
+      // park does, DESIGN 4.10: the store has read its data registers by then), then the next batch may take the registers over
+#pragma unroll
+      for (int r0 = 0; r0 < NREG; r0 += RC) {
+        f32x4 parked[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+          parked[r] = acc[r0 + r];
+          asm volatile("" : "+v"(parked[r]));
+        }
+#pragma unroll
+        for (int r = 0; r < RC; ++r)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, parked[r]), rws, tid * 16 + (r0 + r) * kRegBytes, slot * kPartBytes, kPark);
+        asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < RC; ++r) asm volatile("" ::"v"(parked[r]));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-#pragma unroll
-    for (int r = 0; r < NREG; ++r)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, parked[r]), rws, tid * 16 + r * kRegBytes, slot * kPartBytes, kPark);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through (LOCAL: acknowledged by the L2) before the ticket is taken
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(parked[r]));  // the data registers stay untouched until the stores are out
     __syncthreads();
   };
   auto last_of = [&](unsigned* t, int n) {
@@ -194,27 +218,31 @@ __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, uns
   auto gather = [&](int first, int n) {
     constexpr int U = UMAX;
 #pragma unroll
-    for (int u0 = 0; u0 < 4; u0 += U) {
-      if (u0 > 0 && u0 >= n) break;  // uniform
-      f32x4 v[U][NREG];
+    for (int r0 = 0; r0 < NREG; r0 += RC) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int u0 = 0; u0 < 4; u0 += U) {
+        if (u0 > 0 && u0 >= n) break;  // uniform
+        f32x4 v[U][RC];
 #pragma unroll
-        for (int r = 0; r < NREG; ++r)
-          v[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, (first + min(u0 + u, n - 1)) * kPartBytes, kSc1));
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool keep = u0 + u < n;
+          for (int r = 0; r < RC; ++r)
+            v[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + (r0 + r) * kRegBytes, (first + min(u0 + u, n - 1)) * kPartBytes, kSc1));
 #pragma unroll
-        for (int r = 0; r < NREG; ++r) {
-          if (u0 + u == 0) {
-            acc[r] = v[0][r];
-          } else if constexpr (INT) {
-            const i32x4 a = __builtin_bit_cast(i32x4, acc[r]), b = __builtin_bit_cast(i32x4, v[u][r]);
-            acc[r] = __builtin_bit_cast(f32x4, i32x4{a.x + (keep ? b.x : 0), a.y + (keep ? b.y : 0), a.z + (keep ? b.z : 0), a.w + (keep ? b.w : 0)});
-          } else {
-            acc[r].x += keep ? v[u][r].x : 0.f; acc[r].y += keep ? v[u][r].y : 0.f;
-            acc[r].z += keep ? v[u][r].z : 0.f; acc[r].w += keep ? v[u][r].w : 0.f;
+        for (int u = 0; u < U; ++u) {
+          const bool keep = u0 + u < n;
+#pragma unroll
+          for (int r = 0; r < RC; ++r) {
+            f32x4& d = acc[r0 + r];
+            if (u0 + u == 0) {
+              d = v[0][r];
+            } else if constexpr (INT) {
+              const i32x4 a = __builtin_bit_cast(i32x4, d), b = __builtin_bit_cast(i32x4, v[u][r]);
+              d = __builtin_bit_cast(f32x4, i32x4{a.x + (keep ? b.x : 0), a.y + (keep ? b.y : 0), a.z + (keep ? b.z : 0), a.w + (keep ? b.w : 0)});
+            } else {
+              d.x += keep ? v[u][r].x : 0.f; d.y += keep ? v[u][r].y : 0.f;
+              d.z += keep ? v[u][r].z : 0.f; d.w += keep ? v[u][r].w : 0.f;
+            }
           }
         }
       }

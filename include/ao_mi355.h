@@ -133,6 +133,7 @@ int ao_gemm8_set_variant(int variant);
  *   key 5  timing probes of the TRACED build of rb8_kernel only (ao_int4_set_trace set; results are wrong): bit 0 no MFMAs, 1 no fragment
  *          reads, 2 no weight DMAs, 3 no activation DMAs -- the product build ignores it
  *   key 6  slab height of rb8_kernel above 64 rows: 128 or 256
+ *   key 7  K parts of gemm8_p8_kernel (1 .. 16, clamped to what fits one round of the chip and the split-K workspace)
  * An unknown key is an error.  DESIGN.md 4.5h. */
 int ao_gemm8_set_tuning(int key, int value);
 /* 1 when the current device was measured to place workgroup b of a grid on XCD b % 8 (or has one XCD) -- the split-K kernels then put

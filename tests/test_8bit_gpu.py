@@ -580,8 +580,9 @@ def test_gemm8_every_kernel_variant(variant, m, n, k):
     assert _rel(np_from_torch_bf16(yf), F.linear(x.float().numpy(), w.float().numpy(), b.float().numpy())) <= 1e-3
 
 
-@pytest.mark.parametrize("m,n,k", [(2048, 4096, 4096), (4096, 1024, 14336), (1000, 784, 2048)])
-def test_gemm8_phase_interleaved_kernel_race_screen(m, n, k):
+@pytest.mark.parametrize("variant", [32, 33])  # 256 x 256 tiles; 256 x 128 tiles (round 5)
+@pytest.mark.parametrize("m,n,k", [(2048, 4096, 4096), (4096, 1024, 14336), (1000, 784, 2048), (768, 1296, 128), (130, 208, 384)])
+def test_gemm8_phase_interleaved_kernel_race_screen(m, n, k, variant):
     """gemm8_p8_kernel (variant 32): staggered wave rows, counted vmcnt, LDS slots refilled two phases after their last read --
     an ordering mistake would show as rare wrong tiles.  The int8 GEMM is exact, so ANY difference from the two-stage kernel
     (variant 8) in any of 6 runs on fresh random operands is a failure; fp8 within accumulation order."""
@@ -600,7 +601,7 @@ def test_gemm8_phase_interleaved_kernel_race_screen(m, n, k):
             lib.ao_gemm8_set_variant(8)
             want = ops.int_mm(a, b.t())
             want_f = ops.fp8_scaled_mm(fq, hq.t(), fs, hs.t())
-            lib.ao_gemm8_set_variant(32)
+            lib.ao_gemm8_set_variant(variant)
             got = ops.int_mm(a, b.t())
             got_f = ops.fp8_scaled_mm(fq, hq.t(), fs, hs.t())
             raw = ops.fp8_mm_f32(fq, hq.t())
@@ -696,3 +697,49 @@ def test_rb8_same_xcd_meeting_fresh_data_every_launch(kind):
     torch.cuda.synchronize()
     for i, y in enumerate(outs):
         assert torch.equal(y, ya if i % 2 == 0 else yb), f"launch {i} saw another launch's parts"
+
+
+# ---- round 5: K parts for the phase-interleaved 256 x 256 GEMM ------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k,bias", [(1024, 7168, 8192, False), (768, 1280, 4096, True), (512, 4096, 4096, False), (300, 528, 2048, True),
+                                        (256, 28672, 4096, False)])
+def test_gemm8_p8_split_k_every_part_count(m, n, k, bias):
+    """gemm8_p8_kernel with its K range shared among 1 .. 16 workgroups per 256 x 256 tile (split_k_meet2 in batches of 8 registers: the
+    parts parked through to memory, summed in part order by the last arriver).  int8: integer partial sums, so every part count gives the
+    UNSPLIT kernel's bits (int32 output and the scaled bf16 epilogue -- the oracle's bits); fp8: fp32 partial sums in a fixed order --
+    reproducible run to run, <= 1e-3 from the oracle, the raw fp32 output within fp32 summation noise of the unsplit one."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    x = _randn_bf16((m, k), 41 * m + k)
+    w = _randn_bf16((n, k), 43 * n + k, 0.05)
+    b = _randn_bf16((n,), 9) if bias else None
+    bd = None if b is None else b.to(DEV)
+    xq8, xs8 = ops.int8_quantize_rowwise(x.to(DEV))
+    wq8, ws8 = ops.int8_quantize_rowwise(w.to(DEV))
+    xqf, xsf = ops.fp8_quantize_rowwise(x.to(DEV))
+    wqf, wsf = ops.fp8_quantize_rowwise(w.to(DEV))
+    outs = {}
+    try:
+        lib.ao_gemm8_set_variant(8)  # the two-stage tile kernel
+        want32 = ops.int_mm(xq8, wq8.t()).clone()
+        lib.ao_gemm8_set_variant(32)  # always the 256 x 256 kernel
+        for split in (1, 2, 3, 4, 5, 8, 13, 16):
+            lib.ao_gemm8_set_tuning(7, split)
+            for rep in range(2):
+                outs[(split, rep)] = (ops.int_mm(xq8, wq8.t()).clone(), ops.int8_scaled_mm(xq8, xs8, wq8, ws8, bd).clone(),
+                                      ops.fp8_scaled_mm(xqf, wqf.t(), xsf, wsf.t(), bd).clone(), ops.fp8_mm_f32(xqf, wqf.t()).clone())
+    finally:
+        lib.ao_gemm8_set_variant(0)
+        lib.ao_gemm8_set_tuning(7, 0)
+    torch.cuda.synchronize()
+    i32, y8, yf, raw = outs[(1, 0)]
+    assert torch.equal(i32, want32), "the unsplit 256 x 256 kernel differs from the two-stage tile kernel"
+    y8_ref = I.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+    yf_ref = F.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+    for (split, rep), (a, c, d, e) in outs.items():
+        assert torch.equal(a, i32), f"int32 differs at {split} parts"
+        assert torch.equal(c, y8), f"int8 epilogue differs at {split} parts"
+        assert torch.equal(d, outs[(split, 0)][2]) and torch.equal(e, outs[(split, 0)][3]), f"fp8 not reproducible at {split} parts"
+        assert _rel(np_from_torch_bf16(d), yf_ref) <= 1e-3, f"fp8 off at {split} parts"
+        assert float((e - raw).abs().max()) <= 1e-4 * float(raw.abs().max()), f"fp8 raw sums off at {split} parts"
+    assert np.array_equal(np_from_torch_bf16(y8), y8_ref)

@@ -26,17 +26,21 @@ TABLE = [
     ((512, 7168, 8192), "rb8_kernel"),
     ((512, 8192, 1024), "rb8_kernel"),
     ((2048, 1280, 8192), "rb8_kernel"),
-    # round 5: up to 1024 rows also where 256-row slabs fit one round of the chip although 128-row ones would not
-    ((768, 7168, 8192), "gemm8_dma_kernel<128x128>"),  # 641 .. 896 rows: 256-row slabs only at K <= 4096 (measured: 74.9 -> 95.8 us here)
-    ((768, 8192, 1024), "rb8_kernel"),
-    ((768, 8192, 3584), "rb8_kernel"),
-    ((640, 8192, 1024), "gemm8_dma_kernel<128x128>"),
-    ((1024, 7168, 8192), "rb8_kernel"),
-    ((1024, 8192, 1024), "rb8_kernel"),
+    # round 5: more than 128 and at most 256 tiles of 256 x 128 (above 128 rows): the phase-interleaved 256 x 128 GEMM
+    ((768, 7168, 8192), "gemm8_p8h_kernel"),
+    ((768, 8192, 1024), "gemm8_p8h_kernel"),
+    ((640, 8192, 1024), "gemm8_p8h_kernel"),
+    ((1024, 7168, 8192), "gemm8_p8h_kernel"),
+    ((1024, 8192, 1024), "gemm8_p8h_kernel"),
+    ((256, 28672, 4096), "gemm8_p8h_kernel"),
+    ((2048, 4096, 14336), "gemm8_p8h_kernel"),
+    ((2048, 4096, 4096), "gemm8_p8h_kernel"),
+    ((1024, 4096, 4096), "rb8_kernel"),          # exactly 128 such tiles: the weight-streaming kernel
+    ((128, 28672, 4096), "rb8_kernel"),          # 128 rows: never
     # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on (from 128 at short K / > 512 small tiles)
     ((1024, 28672, 4096), "gemm8_p8_kernel"),
-    ((2048, 4096, 14336), "gemm8_dma_kernel<128x128>"),
-    ((2048, 4096, 4096), "gemm8_p8_kernel"),   # 128 tiles of 256 x 256 and K <= 4096 (round 4)
+    ((2048, 8192, 4096), "gemm8_p8_kernel"),   # 256 tiles of 256 x 256
+    ((512, 16512, 4096), "gemm8_p8_kernel"),   # 130 tiles of 256 x 256 and K <= 4096 (round 4); 258 tiles of 256 x 128 would need a second round
     ((1280, 7168, 8192), "gemm8_p8_kernel"),   # 140 such tiles, but 560 of 128 x 128: a second round of the chip otherwise
     ((2048, 7168, 8192), "gemm8_p8_kernel"),
     ((16384, 14336, 4096), "gemm8_p8_kernel"),

@@ -59,6 +59,12 @@ def test_gemm8_p8_mfmas_stay_inside_their_phases(tmp_path):
         # every MFMA group sits between two barriers (the seams), the fragment reads come in two groups, the DMAs in four pairs
         assert len(re.findall(r"\|M+\|", seq)) + (1 if seq.startswith("M") or seq.endswith("M") else 0) >= 3, seq
         assert seq.count("D") >= 6, (epi, seq)  # (8 per K tile; a rotated loop leaves the last pair outside the backward branch's span)
+    # the 256 x 128 form (round 5): two phases per K tile, the same seams
+    for epi, per_phase in ((0, 16), (1, 16), (2, 8), (3, 8)):
+        seq = _loop_ops(asm, f"_ZN2ao12_GLOBAL__N_116gemm8_p8h_kernelILi{epi}EEEvNS0_6P8ArgsE")
+        groups = [len(g) for g in re.findall(r"M+", seq)]
+        assert groups == [per_phase] * 2, f"EPI {epi}: the K tile's MFMAs are not two phases of {per_phase}: {seq}"
+        assert seq.count("|") == 4 and seq.count("r") == 16 and seq.count("D") >= 4, (epi, seq)
 
 
 def _device_disassembly(tmp_path):
@@ -129,7 +135,7 @@ def test_fp8_gemm_covers_the_mfma_to_epilogue_hazard_explicitly(tmp_path):
     checked = 0
     for block in re.split(r"\n(?=[0-9a-f]+ <)", asm):
         head = block.split("\n", 1)[0]
-        if "gemm8_p8_kernel" not in head:
+        if "gemm8_p8_kernel" not in head and "gemm8_p8h_kernel" not in head:
             continue
         ins = [l.split("//")[0].strip() for l in block.split("\n")[1:] if l.split("//")[0].strip()]
         if not any(t.startswith("v_mfma_scale_f32_16x16x128_f8f6f4") for t in ins):
@@ -139,4 +145,4 @@ def test_fp8_gemm_covers_the_mfma_to_epilogue_hazard_explicitly(tmp_path):
         # nothing matrix-pipe-related is issued behind the cover
         assert not any(t.startswith("v_mfma") for t in ins[pairs[-1]:]) or len(pairs) >= 1
         checked += 1
-    assert checked >= 2, "no fp8 instantiation of gemm8_p8_kernel found"
+    assert checked >= 4, "fp8 instantiations of gemm8_p8_kernel / gemm8_p8h_kernel not found"
