@@ -17,6 +17,7 @@ namespace ao {
 bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K);  // gemm8_p8_kernels.hip (epi numbering = enum Epilogue)
 void gemm8_p8_set_group_rows(int v);
 void gemm8_p8_set_split(int v);
+void gemm8_p8h_set_form(int v);
 int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
              int64_t M, int64_t N, int64_t K, hipStream_t stream);
 
@@ -473,13 +474,14 @@ extern "C" int ao_gemm8_set_variant(int variant) {
   return AO_OK;
 }
 
-namespace ao { namespace { thread_local int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0}; } }
+namespace ao { namespace { thread_local int g_tune[16] = {0}; } }
 extern "C" int ao_gemm8_set_tuning(int key, int value) {
-  AO_REQUIRE(key >= 1 && key <= 7, "ao_gemm8_set_tuning: unknown key %d", key);
+  AO_REQUIRE(key >= 1 && key <= 8, "ao_gemm8_set_tuning: unknown key %d", key);
   g_tune[key] = value;
   rb8_set_tuning(g_tune[1], g_tune[2], g_tune[3], g_tune[5], g_tune[6]);
   gemm8_p8_set_group_rows(g_tune[4]);
   gemm8_p8_set_split(g_tune[7]);
+  gemm8_p8h_set_form(g_tune[8]);
   return AO_OK;
 }
 

@@ -46,6 +46,7 @@ struct P8Args {
 };
 
 thread_local int g_p8_group_rows = 0;  // 0 = 4 (product)
+thread_local int g_p8h_form = 0;      // lab: loop forms of gemm8_p8h_kernel (fp8 rowwise only)
 thread_local int g_p8_split = 0;       // 0 = by shape (p8_split below), n = n K parts wherever they fit
 constexpr int kHalf = 16384;          // one half tile: 128 rows x 128 B
 constexpr int kBuf = 4 * kHalf;       // A-lo, A-hi, B-lo, B-hi of one K tile
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
 constexpr int kHBuf = 3 * kHalf;                    // one K tile: A-lo, A-hi, B
 constexpr int kHSmem = 3 * kHBuf;                   // 147456 B (three K tiles; the epilogue's 8 x 64 x 144 B fit inside)
 
-template <int EPI>
+template <int EPI, int FORM = 0>
 __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
   constexpr bool IS_INT = (EPI == P8_INT8_SCALED || EPI == P8_INT32);
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -417,21 +418,66 @@ __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
   if (g == 1) asm volatile("s_barrier" ::: "memory");  // the stagger: wave group 1 runs one barrier behind
   __builtin_amdgcn_sched_barrier(0);
 
+  if constexpr (FORM == 2) {  // (lab form) B-lo of tile 0 in registers before the loop
+    load_b(smem, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   for (int t = 0; t < ktiles; ++t) {
     const char* buf = smem + (t % 3) * kHBuf;
-    // ---- phase 0: all rows x n-lo; reads every A fragment and the n-lo B fragments; fetches the A halves of tile t + 2 --------------------
-    load_b(buf, 0); __builtin_amdgcn_sched_barrier(0); load_a(buf);
-    issue(t + 2, 0); issue(t + 2, 1);
-    seam();
-    __builtin_amdgcn_s_setprio(1); multiply(0); __builtin_amdgcn_s_setprio(0);
-    seam();
-    // ---- phase 1: all rows x n-hi; fetches B of tile t + 2; tile t + 1 must have landed before the next phase reads it ----------------------
-    load_b(buf, 1);
-    issue(t + 2, 2);
-    if (t + 2 < ktiles) wait_vmcnt<6>(); else wait_vmcnt<0>();
-    seam();
-    __builtin_amdgcn_s_setprio(1); multiply(1); __builtin_amdgcn_s_setprio(0);
-    seam();
+    if constexpr (FORM == 0) {
+      // ---- phase 0: all rows x n-lo; reads every A fragment and the n-lo B fragments; fetches the A halves of tile t + 2 ------------------
+      load_b(buf, 0); __builtin_amdgcn_sched_barrier(0); load_a(buf);
+      issue(t + 2, 0); issue(t + 2, 1);
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(0); __builtin_amdgcn_s_setprio(0);
+      seam();
+      // ---- phase 1: all rows x n-hi; fetches B of tile t + 2; tile t + 1 must have landed before the next phase reads it --------------------
+      load_b(buf, 1);
+      issue(t + 2, 2);
+      if (t + 2 < ktiles) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(1); __builtin_amdgcn_s_setprio(0);
+      seam();
+    } else if constexpr (FORM == 1) {
+      // (lab form) all six fetches of tile t + 2 in phase 0: B gets 1.75 K tiles of flight instead of 1.0 -- 3 - 9 % slower
+      load_b(buf, 0); __builtin_amdgcn_sched_barrier(0); load_a(buf);
+      issue(t + 2, 0); issue(t + 2, 1); issue(t + 2, 2);
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(0); __builtin_amdgcn_s_setprio(0);
+      seam();
+      load_b(buf, 1);
+      if (t + 2 < ktiles) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(1); __builtin_amdgcn_s_setprio(0);
+      seam();
+    } else if constexpr (FORM == 2) {
+      // (lab form) 8 + 8 fragment reads: phase 0 reads A (t), phase 1 reads B-hi (t) and B-lo (t + 1); tile t + 1 landed by the end of phase 0
+      // -- 5 - 15 % slower
+      load_a(buf);
+      issue(t + 2, 0); issue(t + 2, 1); issue(t + 2, 2);
+      if (t + 2 < ktiles) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(0); __builtin_amdgcn_s_setprio(0);
+      seam();
+      load_b(buf, 1);
+      if (t + 1 < ktiles) load_b(smem + ((t + 1) % 3) * kHBuf, 0);
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(1); __builtin_amdgcn_s_setprio(0);
+      seam();
+    } else {
+      // (lab form) 12 reads + one fetch in phase 0, 4 reads + two fetches in phase 1: level (+- 2 %)
+      load_b(buf, 0); __builtin_amdgcn_sched_barrier(0); load_a(buf);
+      issue(t + 2, 0);
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(0); __builtin_amdgcn_s_setprio(0);
+      seam();
+      load_b(buf, 1);
+      issue(t + 2, 1); issue(t + 2, 2);
+      if (t + 2 < ktiles) wait_vmcnt<6>(); else wait_vmcnt<0>();
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(1); __builtin_amdgcn_s_setprio(0);
+      seam();
+    }
   }
   if (g == 0) asm volatile("s_barrier" ::: "memory");  // group 0 catches up: from here on the LDS is free for every wave
   if constexpr (!IS_INT) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // asm MFMA results -> VALU / VMEM readers (see gemm8_p8_kernel)
@@ -495,6 +541,23 @@ int launch_p8h(P8Args p, hipStream_t stream) {
   p.tiles_n = (p.N + 127) / 128;
   p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
   p.split = 1;
+#ifdef AO_LAB  // the measured-and-rejected loop forms (profiles/p8h_loop_forms_r05.jsonl) only exist in the laboratory build
+  if (EPI == P8_FP8_ROWWISE && g_p8h_form == 1) {
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<P8_FP8_ROWWISE, 1>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
+    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 1>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+    return AO_OK;
+  }
+  if (EPI == P8_FP8_ROWWISE && g_p8h_form == 3) {
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<P8_FP8_ROWWISE, 3>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
+    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 3>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+    return AO_OK;
+  }
+  if (EPI == P8_FP8_ROWWISE && g_p8h_form == 2) {
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<P8_FP8_ROWWISE, 2>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
+    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 2>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+    return AO_OK;
+  }
+#endif
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<EPI>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
   ao::launch(gemm8_p8h_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
   AO_LAUNCH_CHECK("gemm8_p8h_kernel launch");
@@ -546,6 +609,7 @@ bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K) {
 }
 void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }
 void gemm8_p8_set_split(int v) { g_p8_split = v; }
+void gemm8_p8h_set_form(int v) { g_p8h_form = v; }
 
 // the 256 x 128 form (same epi numbering and shape limits)
 int gemm8_p8h(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,

@@ -119,7 +119,7 @@ int ao_int4_quantize_tinygemm(const uint16_t* w, int32_t* qdata,
 int ao_int4_set_tuning(int waves_per_block, int mode);
 /* Profiling only: 0 = product dispatch of the 8-bit GEMMs (LDS-DMA staged kernel when K % 128 == 0),
  * 1 = force the register-staged kernel, 2 / 4 / 8 = force the LDS-DMA kernel with 128x128, 256x128 (4 waves), 256x256 (8 waves) tiles,
- * 32 = the phase-interleaved 256x256 kernel; 100 / 101 / 102 = the fp8 weight-streaming kernel never / always / always with 64-column tiles; 103 = its round-3 wave arrangement (1 x 8);
+ * 32 = the phase-interleaved 256x256 kernel, 33 = its 256x128 form (gemm8_p8h_kernel); 100 / 101 / 102 = the fp8 weight-streaming kernel never / always / always with 64-column tiles; 103 = its round-3 wave arrangement (1 x 8);
  * MXFP8 grouped mm: 110 always the LDS-staged kernels, 111 never (A-stationary / per-tile kernels); decode-size groups: 119 stream-K
  * (the product's form, forced), 118 / 114 / 129 / 128 its other shapes, 113 one workgroup per tile, 112 the round-2 form
  * (ao_amd/csrc/rb8_kernels.hip).  Thread-local, like ao_int4_set_tuning. */
@@ -134,6 +134,7 @@ int ao_gemm8_set_variant(int variant);
  *          reads, 2 no weight DMAs, 3 no activation DMAs -- the product build ignores it
  *   key 6  slab height of rb8_kernel above 64 rows: 128 or 256
  *   key 7  K parts of gemm8_p8_kernel (1 .. 16, clamped to what fits one round of the chip and the split-K workspace)
+ *   key 8  loop form of gemm8_p8h_kernel, laboratory build only (the product build ignores it)
  * An unknown key is an error.  DESIGN.md 4.5h. */
 int ao_gemm8_set_tuning(int key, int value);
 /* 1 when the current device was measured to place workgroup b of a grid on XCD b % 8 (or has one XCD) -- the split-K kernels then put

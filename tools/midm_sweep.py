@@ -127,7 +127,7 @@ def main():
                     y_ref = None
                     for fname, (variant, tun) in forms:
                         lib.ao_gemm8_set_variant(variant)
-                        for key in (1, 2, 3, 4, 5, 6):
+                        for key in (1, 2, 3, 4, 5, 6, 7, 8):
                             lib.ao_gemm8_set_tuning(key, tun.get(key, 0))
                         rec = dict(base, form=fname, kernel=lib.ao_gemm8_kernel_name(0 if kind == "fp8" else 1, m, n, k).decode() if fname == "default" else None)
                         try:
@@ -151,7 +151,7 @@ def main():
                             rec["error"] = repr(e)[:200]
                         finally:
                             lib.ao_gemm8_set_variant(0)
-                            for key in (1, 2, 3, 4, 5, 6):
+                            for key in (1, 2, 3, 4, 5, 6, 7, 8):
                                 lib.ao_gemm8_set_tuning(key, 0)
                         print(json.dumps(rec), flush=True)
                     if m == int(args.ms.split(",")[0]):
