@@ -61,7 +61,7 @@ def test_gemm8_p8_mfmas_stay_inside_their_phases(tmp_path):
         assert seq.count("D") >= 6, (epi, seq)  # (8 per K tile; a rotated loop leaves the last pair outside the backward branch's span)
     # the 256 x 128 form (round 5): two phases per K tile, the same seams
     for epi, per_phase in ((0, 16), (1, 16), (2, 8), (3, 8)):
-        seq = _loop_ops(asm, f"_ZN2ao12_GLOBAL__N_116gemm8_p8h_kernelILi{epi}EEEvNS0_6P8ArgsE")
+        seq = _loop_ops(asm, f"_ZN2ao12_GLOBAL__N_116gemm8_p8h_kernelILi{epi}ELi0EEEvNS0_6P8ArgsE")
         groups = [len(g) for g in re.findall(r"M+", seq)]
         assert groups == [per_phase] * 2, f"EPI {epi}: the K tile's MFMAs are not two phases of {per_phase}: {seq}"
         assert seq.count("|") == 4 and seq.count("r") == 16 and seq.count("D") >= 4, (epi, seq)
