@@ -318,13 +318,18 @@ __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
   int wg = blockIdx.x;
   const int nwg = gridDim.x;
   if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
+  const int S = p.split;  // K parts: consecutive work items (see gemm8_p8_kernel)
+  const int ks = wg % S;
+  wg /= S;
   const int GR = p.group_rows;
   const int group = GR * p.tiles_n;
   const int g0 = (wg / group) * GR;
   const int gsz = min(GR, p.tiles_m - g0);
   const int tm = g0 + (wg % group) % gsz, tn = (wg % group) / gsz;
   const int m0 = tm * 256, n0 = tn * 128;
-  const int ktiles = p.K >> 7;
+  const int ktiles_all = p.K >> 7;
+  const int kb = (int)((int64_t)ks * ktiles_all / S);
+  const int ktiles = (int)((int64_t)(ks + 1) * ktiles_all / S) - kb;
 
   // DMA sources: half-tile rows 16 w + 8 i + (lane >> 3), chunk position lane & 7 holds global chunk (lane & 7) ^ ((row >> 1) & 7)
   uint32_t aoff[2][2], boff[2];
@@ -336,8 +341,8 @@ __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
     for (int h = 0; h < 2; ++h) aoff[h][i] = (uint32_t)(min(m0 + h * 128 + row, p.M - 1) - m0) * (uint32_t)p.K + chunk;
     boff[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)p.K + chunk;
   }
-  const char* abase = reinterpret_cast<const char*>(p.a) + (size_t)m0 * p.K;
-  const char* bbase = reinterpret_cast<const char*>(p.b) + (size_t)n0 * p.K;
+  const char* abase = reinterpret_cast<const char*>(p.a) + (size_t)m0 * p.K + (size_t)kb * 128;
+  const char* bbase = reinterpret_cast<const char*>(p.b) + (size_t)n0 * p.K + (size_t)kb * 128;
   const uint32_t lds0 = lds_offset(smem);
   auto issue = [&](int tile, int which) {  // which: 0 A-lo, 1 A-hi, 2 B
     if (tile >= ktiles) return;
@@ -482,6 +487,11 @@ __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
   if (g == 0) asm volatile("s_barrier" ::: "memory");  // group 0 catches up: from here on the LDS is free for every wave
   if constexpr (!IS_INT) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // asm MFMA results -> VALU / VMEM readers (see gemm8_p8_kernel)
   __builtin_amdgcn_sched_barrier(0);
+  if (S > 1) {  // the K parts meet: 128 KiB per part, summed in part order by the last arriver, which goes on to the epilogue
+    if (!split_k_meet2<16, 512, IS_INT, 2, false, 8>(reinterpret_cast<f32x4(&)[16]>(acc), p.ws, p.tickets, tm * p.tiles_n + tn, S, ks, tid,
+                                                       reinterpret_cast<int*>(smem)))
+      return;
+  }
 
   // ---- epilogue: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile ---------------------------------------------------------
   const int rbase = m0 + s * 64, cbase = n0 + g * 64;
@@ -535,31 +545,55 @@ __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
   }
 }
 
+// K parts of the 256 x 128 form (key 7 forces a count).  A part parks 128 KiB, half of the 256 x 256 kernel's, and on LONG K with few tiles
+// that pays (profiles/p8h_split_sweep_r05.jsonl, fp8, cold; us, before -> with parts, hipBLASLt): K >= 8192, at least 512 rows, at most 128
+// tiles, 2 - 4 parts (never more: 4 is the best count wherever more would fit) that make at least 128 workgroups --
+//   qkv shard 1280 x 8192: M = 1024 29.5 -> 27.2 (27.8), M = 2048 45.2 -> 33.1 (42.3); down_proj 4096 x 14336: M = 512 48.0 -> 42.0 (49.4),
+//   768 71.6 -> 58.1 (76.3), 1024 72.2 -> 62.5 (76.7); gate_up shard 7168 x 8192 at M = 512: 44.6 -> 42.6 (48.0).
+// At K <= 4096 the parts lose in every cell (a part's loop is then shorter than its meeting), as do grids below 128 workgroups.
+int p8h_split_rule(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128);
+  if (K < 8192 || M < 512 || tiles > 128) return 1;
+  const int64_t S = std::min<int64_t>(4, 256 / tiles);
+  return (S >= 2 && tiles * S >= 128) ? (int)S : 1;
+}
+int p8h_split(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128), ktiles = K / 128;
+  const int64_t fit = std::min<int64_t>({256 / tiles, ktiles, 16, (int64_t)(kSplitSlotFloats / ((size_t)tiles * 256 * 128)) * 4 / 5,
+                                         (int64_t)kSplitMaxTickets / (tiles * 5)});
+  if (g_p8_split > 0) return (int)std::max<int64_t>(1, std::min<int64_t>(g_p8_split, fit));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(p8h_split_rule(M, N, K), fit));
+}
+
 template <int EPI>
 int launch_p8h(P8Args p, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 127) / 128;
   p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
-  p.split = 1;
+  p.split = p8h_split(p.M, p.N, p.K);
+  if (p.split > 1) {
+    const int NG = (p.split + 3) / 4;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)p.tiles_m * p.tiles_n * (p.split + NG) * 256 * 128)) return rc;
+  }
 #ifdef AO_LAB  // the measured-and-rejected loop forms (profiles/p8h_loop_forms_r05.jsonl) only exist in the laboratory build
   if (EPI == P8_FP8_ROWWISE && g_p8h_form == 1) {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<P8_FP8_ROWWISE, 1>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
-    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 1>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 1>, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split)), dim3(512), kHSmem, stream, p);
     return AO_OK;
   }
   if (EPI == P8_FP8_ROWWISE && g_p8h_form == 3) {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<P8_FP8_ROWWISE, 3>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
-    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 3>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 3>, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split)), dim3(512), kHSmem, stream, p);
     return AO_OK;
   }
   if (EPI == P8_FP8_ROWWISE && g_p8h_form == 2) {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<P8_FP8_ROWWISE, 2>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
-    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 2>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+    ao::launch(gemm8_p8h_kernel<P8_FP8_ROWWISE, 2>, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split)), dim3(512), kHSmem, stream, p);
     return AO_OK;
   }
 #endif
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8h_kernel<EPI>), kHSmem, "hipFuncSetAttribute(gemm8_p8h_kernel)")) return rc;
-  ao::launch(gemm8_p8h_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kHSmem, stream, p);
+  ao::launch(gemm8_p8h_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split)), dim3(512), kHSmem, stream, p);
   AO_LAUNCH_CHECK("gemm8_p8h_kernel launch");
   return AO_OK;
 }
@@ -605,7 +639,7 @@ bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K) { return K % 128 == 0 && N %
 // to the weight-streaming kernel in all 4 cells measured, below that by more.
 bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128);
-  return M > 128 && tiles > 128 && tiles <= 256 && gemm8_p8_fits(M, N, K);
+  return M > 128 && gemm8_p8_fits(M, N, K) && ((tiles > 128 && tiles <= 256) || p8h_split_rule(M, N, K) > 1);  // (the rule: with K parts, below)
 }
 void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }
 void gemm8_p8_set_split(int v) { g_p8_split = v; }

@@ -357,7 +357,37 @@ def make_other_dtypes():
     print("other_dtypes.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def make_configs():
+    """torchao/core/config.py:69-305 config_to_dict: the {"_type", "_version", "_data"} dicts the REFERENCE writes for the configs of
+    the SURVEY section-8 path (tests/test_host_api.py decodes them with this package's config_from_dict and compares its own encoder's
+    output with them)."""
+    import json
+
+    from torchao.core.config import config_to_dict
+    from torchao.quantization import (Float8DynamicActivationFloat8WeightConfig, Float8DynamicActivationInt4WeightConfig, FqnToConfig,
+                                      Int4WeightOnlyConfig, Int8DynamicActivationInt8WeightConfig, PerRow)
+    from torchao.quantization.quant_primitives import MappingType
+
+    cfgs = {
+        "int4_default": Int4WeightOnlyConfig(),
+        "int4_tile": Int4WeightOnlyConfig(group_size=32, int4_packing_format="tile_packed_to_4d"),
+        "int4_hqq": Int4WeightOnlyConfig(group_size=64, int4_packing_format="tile_packed_to_4d", int4_choose_qparams_algorithm="hqq"),
+        "int8_dyn": Int8DynamicActivationInt8WeightConfig(),
+        "int8_dyn_asym": Int8DynamicActivationInt8WeightConfig(act_mapping_type=MappingType.ASYMMETRIC, granularity=[PerRow(), PerRow()]),
+        "fp8_default": Float8DynamicActivationFloat8WeightConfig(),
+        "fp8_row": Float8DynamicActivationFloat8WeightConfig(granularity=PerRow()),
+        "fp8_int4": Float8DynamicActivationInt4WeightConfig(),
+    }
+    cfgs["fqn"] = FqnToConfig({"re:.*q_proj": Int4WeightOnlyConfig(group_size=64), "lm_head": None,
+                               "_default": Float8DynamicActivationFloat8WeightConfig(granularity=PerRow())})
+    out = {k: config_to_dict(v) for k, v in cfgs.items()}
+    with open(os.path.join(HERE, "configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("configs.json", len(out), "configs")
+
+
 def make_rest():
+    make_configs()
     make_other_dtypes()
     make_int8_fp8()
     make_int8_fp8_variants()

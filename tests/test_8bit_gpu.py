@@ -702,8 +702,9 @@ def test_rb8_same_xcd_meeting_fresh_data_every_launch(kind):
 # ---- round 5: K parts for the phase-interleaved 256 x 256 GEMM ------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k,bias", [(1024, 7168, 8192, False), (768, 1280, 4096, True), (512, 4096, 4096, False), (300, 528, 2048, True),
                                         (256, 28672, 4096, False)])
-def test_gemm8_p8_split_k_every_part_count(m, n, k, bias):
-    """gemm8_p8_kernel with its K range shared among 1 .. 16 workgroups per 256 x 256 tile (split_k_meet2 in batches of 8 registers: the
+@pytest.mark.parametrize("variant", [32, 33])  # 256 x 256 tiles; 256 x 128 tiles
+def test_gemm8_p8_split_k_every_part_count(m, n, k, bias, variant):
+    """gemm8_p8_kernel / gemm8_p8h_kernel with the K range shared among 1 .. 16 workgroups per tile (split_k_meet2 in batches of 8 registers: the
     parts parked through to memory, summed in part order by the last arriver).  int8: integer partial sums, so every part count gives the
     UNSPLIT kernel's bits (int32 output and the scaled bf16 epilogue -- the oracle's bits); fp8: fp32 partial sums in a fixed order --
     reproducible run to run, <= 1e-3 from the oracle, the raw fp32 output within fp32 summation noise of the unsplit one."""
@@ -722,7 +723,7 @@ def test_gemm8_p8_split_k_every_part_count(m, n, k, bias):
     try:
         lib.ao_gemm8_set_variant(8)  # the two-stage tile kernel
         want32 = ops.int_mm(xq8, wq8.t()).clone()
-        lib.ao_gemm8_set_variant(32)  # always the 256 x 256 kernel
+        lib.ao_gemm8_set_variant(variant)  # always the phase-interleaved kernel of that tile
         for split in (1, 2, 3, 4, 5, 8, 13, 16):
             lib.ao_gemm8_set_tuning(7, split)
             for rep in range(2):

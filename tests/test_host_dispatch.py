@@ -23,9 +23,9 @@ TABLE = [
     ((64, 28672, 4096), "rb8_kernel"),
     ((128, 8192, 3584), "rb8_kernel"),
     ((128, 28672, 4096), "rb8_kernel"),
-    ((512, 7168, 8192), "rb8_kernel"),
+    ((512, 4096, 4096), "rb8_kernel"),
     ((512, 8192, 1024), "rb8_kernel"),
-    ((2048, 1280, 8192), "rb8_kernel"),
+    ((768, 1280, 8192), "rb8_kernel"),
     # round 5: more than 128 and at most 256 tiles of 256 x 128 (above 128 rows): the phase-interleaved 256 x 128 GEMM
     ((768, 7168, 8192), "gemm8_p8h_kernel"),
     ((768, 8192, 1024), "gemm8_p8h_kernel"),
@@ -36,6 +36,12 @@ TABLE = [
     ((2048, 4096, 14336), "gemm8_p8h_kernel"),
     ((2048, 4096, 4096), "gemm8_p8h_kernel"),
     ((1024, 4096, 4096), "rb8_kernel"),          # exactly 128 such tiles: the weight-streaming kernel
+    # ... and with 2 - 4 K parts on long K (>= 8192) from 512 rows where that makes 128 .. 256 workgroups
+    ((512, 7168, 8192), "gemm8_p8h_kernel"),
+    ((1024, 1280, 8192), "gemm8_p8h_kernel"),
+    ((2048, 1280, 8192), "gemm8_p8h_kernel"),
+    ((768, 4096, 14336), "gemm8_p8h_kernel"),
+    ((256, 7168, 8192), "rb8_kernel"),
     ((128, 28672, 4096), "rb8_kernel"),          # 128 rows: never
     # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on (from 128 at short K / > 512 small tiles)
     ((1024, 28672, 4096), "gemm8_p8_kernel"),

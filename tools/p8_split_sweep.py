@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--kinds", default="fp8")
     ap.add_argument("--splits", default="1,2,3,4,6,8,12,16")
     ap.add_argument("--no-half", action="store_true")
+    ap.add_argument("--variant", type=int, default=32, help="32: K parts of the 256 x 256 kernel; 33: of the 256 x 128 one")
     args = ap.parse_args()
     lib = _lib.lib()
     dev = torch.device("cuda", 0)
@@ -46,19 +47,19 @@ def main():
                         rec["core_error"] = repr(e)[:100]
                     rec["default"] = round(graph_time(calls) * 1e6, 1)
                     rec["default_kernel"] = lib.ao_gemm8_kernel_name(0 if kind == "fp8" else 1, m, n, k).decode()
-                    tiles = -(-m // 256) * -(-n // 256)
+                    tiles = -(-m // 256) * -(-n // (256 if args.variant == 32 else 128))
                     done = set()
                     try:
-                        lib.ao_gemm8_set_variant(32)
+                        lib.ao_gemm8_set_variant(args.variant)
                         for s in [int(v) for v in args.splits.split(",")]:
                             eff = max(1, min(s, 256 // tiles, k // 128))
                             if eff in done:
                                 continue
                             done.add(eff)
                             lib.ao_gemm8_set_tuning(7, eff)
-                            rec[f"p8_s{eff}"] = round(graph_time(calls) * 1e6, 1)
+                            rec[f"{'p8' if args.variant == 32 else 'p8h'}_s{eff}"] = round(graph_time(calls) * 1e6, 1)
                         lib.ao_gemm8_set_tuning(7, 0)
-                        if not args.no_half:
+                        if not args.no_half and args.variant == 32:
                             lib.ao_gemm8_set_variant(33)  # 256 x 128 tiles
                             rec["p8h"] = round(graph_time(calls) * 1e6, 1)
                     finally:
