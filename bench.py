@@ -778,7 +778,7 @@ def config_fp8_shards(stream, device, args):
                        "(qkv 1280x8192, o 8192x1024, gate_up 7168x8192, down 8192x3584), 80 layers, activation cast + scaled mm per linear",
            "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (per GPU, M = 2048, before the all-reduce)", "dtype": "e4m3 x e4m3 -> fp32, bf16 out",
            "by_M": res,
-           "roofline": {"kernel": "gemm8_p8_kernel<fp8> / gemm8_dma_kernel / rb8_kernel by shard shape", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
+           "roofline": {"kernel": "gemm8_p8_kernel<fp8> (o, gate_up, down shards) / gemm8_p8h_kernel<fp8> with 3 K parts (qkv shard) at M = 2048", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": res["M2048"]["frac"], "traffic": pmc_traffic_of("fp8")[0], "traffic_source": pmc_traffic_of("fp8")[1],
                         "measured_mfma_ceiling": _SPECS["fp8_measured_mfma_tops"] / 1e12, "frac_of_measured_ceiling": res["M2048"]["TFLOPs"] * 1e12 / _SPECS["fp8_measured_mfma_tops"],
                         "timing": "hipGraph replay wall time of the whole step (casts included)"}}

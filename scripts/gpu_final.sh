@@ -102,6 +102,8 @@ for f in glob.glob(O + "/prof_gemm_pmc/**/*counter_collection.csv", recursive=Tr
         n = row["Kernel_Name"]
         if "gemm8_p8_kernel" in n:
             k = "gemm8_p8_kernel<" + ("int8" if "<0>" in n or "<1>" in n else "fp8") + ">"
+        elif "gemm8_p8h_kernel" in n:
+            k = "gemm8_p8h_kernel<" + ("int8" if "<0," in n or "<1," in n else "fp8") + ">"
         elif "gemm8_dma_kernel" in n:
             k = "gemm8_dma_kernel"
         else:
@@ -123,7 +125,7 @@ PY
 find $O -name "*counter_collection.csv" -size +4M -delete 2>/dev/null; find $O -name "*kernel_trace.csv" -size +4M -delete 2>/dev/null
 cd $R
 echo "== full bench ==" ; ( time timeout 1200 python bench.py ) 2>$O/bench.err > $O/bench.json; tail -4 $O/bench.err; cut -c1-300 $O/bench.json; cp $O/bench.json $R/profiles/bench_$ROUND.json
-echo "== pytest gpu ==" ; timeout 1200 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tee $O/pytest_gpu.log | tail -4; cp $O/pytest_gpu.log $R/profiles/pytest_gpu_$ROUND.log
+echo "== pytest gpu ==" ; timeout 1200 python -m pytest tests -m gpu -q --timeout 600 --durations=15 2>&1 | tee $O/pytest_gpu.log | tail -4; cp $O/pytest_gpu.log $R/profiles/pytest_gpu_$ROUND.log
 echo "== smoke ==" ; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 echo "== TP over RCCL, world 1 ==" ; timeout 400 python bench.py --force-tp --configs tp --no-second-layout --no-cpu-baseline --steps 5 2>$O/tp.err > $O/bench_tp.json; python -c "
 import json; d=json.loads(open('$O/bench_tp.json').read().strip().splitlines()[-1]); json.dump({'fp8_tp': d['configs']['fp8_tp']}, open('$R/profiles/bench_${ROUND}_tp_world1.json','w'), indent=1); print({k: round(v['per_gpu_TFLOPs']) for k, v in d['configs']['fp8_tp']['by_M'].items()})"

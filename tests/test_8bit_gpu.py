@@ -700,8 +700,7 @@ def test_rb8_same_xcd_meeting_fresh_data_every_launch(kind):
 
 
 # ---- round 5: K parts for the phase-interleaved 256 x 256 GEMM ------------------------------------------------------------------------------
-@pytest.mark.parametrize("m,n,k,bias", [(1024, 7168, 8192, False), (768, 1280, 4096, True), (512, 4096, 4096, False), (300, 528, 2048, True),
-                                        (256, 28672, 4096, False)])
+@pytest.mark.parametrize("m,n,k,bias", [(1024, 7168, 8192, False), (768, 1280, 4096, True), (512, 1024, 4096, False), (300, 528, 2048, True)])
 @pytest.mark.parametrize("variant", [32, 33])  # 256 x 256 tiles; 256 x 128 tiles
 def test_gemm8_p8_split_k_every_part_count(m, n, k, bias, variant):
     """gemm8_p8_kernel / gemm8_p8h_kernel with the K range shared among 1 .. 16 workgroups per tile (split_k_meet2 in batches of 8 registers: the
@@ -723,6 +722,8 @@ def test_gemm8_p8_split_k_every_part_count(m, n, k, bias, variant):
     try:
         lib.ao_gemm8_set_variant(8)  # the two-stage tile kernel
         want32 = ops.int_mm(xq8, wq8.t()).clone()
+        want8 = ops.int8_scaled_mm(xq8, xs8, wq8, ws8, bd).clone()
+        wantf = ops.fp8_scaled_mm(xqf, wqf.t(), xsf, wsf.t(), bd).clone()
         lib.ao_gemm8_set_variant(variant)  # always the phase-interleaved kernel of that tile
         for split in (1, 2, 3, 4, 5, 8, 13, 16):
             lib.ao_gemm8_set_tuning(7, split)
@@ -735,8 +736,11 @@ def test_gemm8_p8_split_k_every_part_count(m, n, k, bias, variant):
     torch.cuda.synchronize()
     i32, y8, yf, raw = outs[(1, 0)]
     assert torch.equal(i32, want32), "the unsplit 256 x 256 kernel differs from the two-stage tile kernel"
-    y8_ref = I.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
-    yf_ref = F.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy())
+    # the CPU oracle where it takes seconds; the BASELINE-size shape is held to the unsplit kernels (themselves held to the oracle by
+    # tests/test_baseline_scale_gpu.py) -- numpy's integer matmul would take minutes there
+    small = m * n * k <= 1 << 32
+    y8_ref = I.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy()) if small else np_from_torch_bf16(want8)
+    yf_ref = F.linear(x.float().numpy(), w.float().numpy(), None if b is None else b.float().numpy()) if small else np_from_torch_bf16(wantf)
     for (split, rep), (a, c, d, e) in outs.items():
         assert torch.equal(a, i32), f"int32 differs at {split} parts"
         assert torch.equal(c, y8), f"int8 epilogue differs at {split} parts"
