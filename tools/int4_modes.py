@@ -4,7 +4,7 @@
     python tools/int4_modes.py [--modes 0,90,91,92] [--wpbs 0,4] [--layout merged|five] [--rounds 3]
 
 Tuning modes are compiled into the library for profiling (ao_int4_set_tuning is thread-local); the product dispatch is mode 0.
-The wrong-result ablation builds (90, 61S - 64S, 870, 910) exist only in the laboratory library: build it with
+The wrong-result ablation builds (90, 61S - 64S, 941 - 945) exist only in the laboratory library: build it with
 `python -m ao_amd.build --lab` and run this tool with AO_MI355_LIB=tools/bin/_C_mi355_lab.so.
 Prints one JSON line per (wpb, mode): tokens/s (median and best of the interleaved rounds), per-shape event-timed kernel
 durations, and the largest norm-relative difference of any linear's output against mode 0.
