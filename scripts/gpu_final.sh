@@ -93,35 +93,7 @@ print({c: (round(v.get("hbm_bytes_per_launch") or 0) if isinstance(v, dict) else
 PY
 echo "== rocprof 8-bit GEMM: MFMA-busy pmc =="
 timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/prof_gemm_pmc -o gemm8 -- python $R/tools/bench_8bit.py --which int8,fp8l --m 8192 --iters 3 > $O/rocprof_gemm_pmc.log 2>&1
-O=$O R=$R ROUND=$ROUND python - <<'PY'
-import csv, glob, json, os, collections
-O, R, ROUND = os.environ["O"], os.environ["R"], os.environ["ROUND"]
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(O + "/prof_gemm_pmc/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f, newline="")):
-        n = row["Kernel_Name"]
-        if "gemm8_p8_kernel" in n:
-            k = "gemm8_p8_kernel<" + ("int8" if "<0>" in n or "<1>" in n else "fp8") + ">"
-        elif "gemm8_p8h_kernel" in n:
-            k = "gemm8_p8h_kernel<" + ("int8" if "<0," in n or "<1," in n else "fp8") + ">"
-        elif "gemm8_dma_kernel" in n:
-            k = "gemm8_dma_kernel"
-        else:
-            continue
-        acc[(k, row.get("Grid_Size", ""))][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {}
-for (k, grid), c in acc.items():
-    e = {cn: sum(v) / len(v) for cn, v in c.items()}
-    e["dispatches"] = max(len(v) for v in c.values())
-    if e.get("SQ_BUSY_CYCLES", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in e:
-        e["MfmaUtil"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["SQ_BUSY_CYCLES"] / 32 * 1024)
-    out[k + " grid=" + grid] = e
-if out:
-    json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ... -- tools/bench_8bit.py --which int8,fp8l --m 8192 (round 5: tile-group height 4)", "kernels": out},
-              open(R + f"/profiles/gemm8_p8_pmc_mfma_{ROUND}.json", "w"), indent=1)
-for k, e in out.items():
-    print(k, "MfmaUtil", round(e.get("MfmaUtil", 0), 3), "dispatches", e["dispatches"])
-PY
+( cd $R; python scripts/pmc_mfma_summary.py $O/prof_gemm_pmc -o profiles/gemm8_p8_pmc_mfma_$ROUND.json --source "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ... -- tools/bench_8bit.py --which int8,fp8l --m 8192 (round 5: tile-group height 4)" )
 find $O -name "*counter_collection.csv" -size +4M -delete 2>/dev/null; find $O -name "*kernel_trace.csv" -size +4M -delete 2>/dev/null
 cd $R
 echo "== full bench ==" ; ( time timeout 1200 python bench.py ) 2>$O/bench.err > $O/bench.json; tail -4 $O/bench.err; cut -c1-300 $O/bench.json; cp $O/bench.json $R/profiles/bench_$ROUND.json
