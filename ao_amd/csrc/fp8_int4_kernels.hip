@@ -26,6 +26,7 @@ namespace ao {
 namespace {
 
 typedef long i64_t;
+thread_local int g_fp8_int4_mt = 0;  // A/B: m-tiles per workgroup forced (1, 2, 4); 0 = by M
 
 // FUSE (round 4, SURVEY 8 f1 for this path): the per-row e4m3 cast of the activation inside the launch -- x arrives as bf16 [M][K]
 // (M <= 16, M (K + 16) <= 64 KiB), is cast ONCE per workgroup into an LDS copy of the codes with quant_math.h's arithmetic (the bits of
@@ -34,21 +35,27 @@ typedef long i64_t;
 //      ring's, the one workgroup barrier is the amax exchange;
 //   2: 2 <= M <= 16 -- the workgroup casts the whole activation (two passes over the L2-resident rows), then the ring is requested.
 // Without it the stand-alone cast cost this path 28 % (818 -> 587 tok/s on the Llama-3-8B linears, profiles/fp8_int4_r03.jsonl).
-template <int G, int DEPTH, int FUSE = 0>
+// MT (round 5): 16-row m-tiles per workgroup, 1, 2 or 4 (FUSE == 0 only).  Rounds 3-4 ran one workgroup per 16 rows, so a batch of M rows
+// streamed, masked and scale-decoded every packed block ceil(M / 16) times; with MT m-tiles a block's B operands (the two mask
+// operations per word) and its (scale, zero) pair are built once and multiplied against MT activation tiles: MT x fewer weight
+// requests and nibble expansions per output.
+template <int G, int DEPTH, int FUSE = 0, int MT = 1>
 __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restrict__ xq, const float* __restrict__ x_scale,
                                                           const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz,
                                                           const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int M, int N, int K) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);  // groups per 128-k block
   constexpr int ROWSTRIDE = 128 + 16;             // bytes per staged x row ([kq][j] pairs of dwords), padded vs bank conflicts
-  constexpr int SLAB = 16 * ROWSTRIDE;
+  constexpr int SLAB16 = 16 * ROWSTRIDE;           // one m-tile's rows
+  constexpr int SLAB = MT * SLAB16;
+  static_assert(FUSE == 0 || MT == 1, "the fused cast holds at most 16 rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   const int ntile = blockIdx.x;
-  const int m0 = blockIdx.y * 16;
-  const int rows = min(16, M - m0);
+  const int m0 = blockIdx.y * (16 * MT);
+  const int rows = min(16 * MT, M - m0);
   const int kblocks = K >> 7;
   const int kb0 = (kblocks * wave) / nwaves;
   const int kb1 = (kblocks * (wave + 1)) / nwaves;
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
   // FUSE: [M][K + 16] codes | [nwaves][16] row maxima | [16] row scales, behind the reduction area
   const int cstride = K + 16;
-  char* codes = smem + nwaves * (SLAB + 1024);
+  char* codes = smem + nwaves * (SLAB + MT * 1024);
   float* wmax = reinterpret_cast<float*>(codes + ((M * cstride + 15) & ~15));
   float* rs = wmax + nwaves * 16;
 
@@ -64,7 +71,9 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   const int kq = lane >> 4;
   const u32x4* wp = qdata + (size_t)ntile * kblocks * 64 + lane;
   // x slice of a block: lane (r = lane >> 2, j = lane & 3) loads the 32 bytes x[m0 + r][kb * 128 + 32 j ..] (rows past M: the last row)
-  const uint8_t* xp = xq + (size_t)(m0 + min(lane >> 2, rows - 1)) * K + (lane & 3) * 32;
+  const uint8_t* xp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) xp[mt] = xq + (size_t)(m0 + min(16 * mt + (lane >> 2), rows - 1)) * K + (lane & 3) * 32;
   // ... and stores the dword pairs (d[kq'], d[4 + kq']) at [r][kq'][j]; lane (m, kq) reads its four pairs (j = 0..3) as 32 contiguous bytes
   char* st_base = slab + (lane >> 2) * ROWSTRIDE + (lane & 3) * 8;
   const char* a_base = slab + (lane & 15) * ROWSTRIDE + kq * 32;
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   struct Stage {
     u32x4 w;
     uint32_t sz[NG];
-    u32x4 x0, x1;
+    u32x4 x0[MT], x1[MT];
   };
   Stage st[DEPTH];
   auto issue = [&](Stage& s, int kb) {
@@ -81,46 +90,70 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
 #pragma unroll
     for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
     if constexpr (FUSE == 0) {
-      const u32x4* xs = reinterpret_cast<const u32x4*>(xp + (size_t)kb * 128);
-      s.x0 = xs[0];
-      s.x1 = xs[1];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const u32x4* xs = reinterpret_cast<const u32x4*>(xp[mt] + (size_t)kb * 128);
+        s.x0[mt] = xs[0];
+        s.x1[mt] = xs[1];
+      }
     }
   };
 
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const i64_t ones = 0x3838383838383838L;  // eight e4m3 1.0
   // FUSE: lane (r, j)'s 32 bytes of the block come from the LDS copy of the codes (rows past M: the last row)
   const char* cp = codes + min(lane >> 2, rows - 1) * cstride + (lane & 3) * 32;
   auto consume = [&](const Stage& s, int kb) {
-    // stage x: d0..d3 = tile 2j (kq 0..3), d4..d7 = tile 2j + 1
-    u32x4 x0, x1;
-    if constexpr (FUSE == 0) { x0 = s.x0; x1 = s.x1; }
-    else { x0 = *reinterpret_cast<const u32x4*>(cp + kb * 128); x1 = *reinterpret_cast<const u32x4*>(cp + kb * 128 + 16); }
-    const uint32_t d[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    // stage x: d0..d3 = tile 2j (kq 0..3), d4..d7 = tile 2j + 1 -- every m-tile into its own 16-row slab (wave-private LDS: DS operations
+    // of a wave complete in order, no barrier)
+    uint32_t xw[MT][8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(st_base + q * 32) = u32x2{d[q], d[4 + q]};
-    const u32x4 xa = *reinterpret_cast<const u32x4*>(a_base);       // (A0, B0, A1, B1)
-    const u32x4 xb = *reinterpret_cast<const u32x4*>(a_base + 16);  // (A2, B2, A3, B3)
-    const uint32_t xw[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    for (int mt = 0; mt < MT; ++mt) {
+      u32x4 x0, x1;
+      if constexpr (FUSE == 0) { x0 = s.x0[mt]; x1 = s.x1[mt]; }
+      else { x0 = *reinterpret_cast<const u32x4*>(cp + kb * 128); x1 = *reinterpret_cast<const u32x4*>(cp + kb * 128 + 16); }
+      const uint32_t d[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x2*>(st_base + mt * SLAB16 + q * 32) = u32x2{d[q], d[4 + q]};
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(a_base + mt * SLAB16);       // (A0, B0, A1, B1)
+      const u32x4 xb = *reinterpret_cast<const u32x4*>(a_base + mt * SLAB16 + 16);  // (A2, B2, A3, B3)
+      xw[mt][0] = xa.x; xw[mt][1] = xa.y; xw[mt][2] = xa.z; xw[mt][3] = xa.w;
+      xw[mt][4] = xb.x; xw[mt][5] = xb.y; xw[mt][6] = xb.z; xw[mt][7] = xb.w;
+    }
     const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
-    f32x4 pq = {0.f, 0.f, 0.f, 0.f}, px = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pq[MT], px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { pq[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; px[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       // B operand: bytes (v0, v4, v1, v5 | v2, v6, v3, v7) = k (t0, t1, t0 + 1, t1 + 1 | t0 + 2, t1 + 2, t0 + 3, t1 + 3)
       const uint32_t lo = wds[j] & 0x0F0F0F0Fu, hi = (wds[j] >> 4) & 0x0F0F0F0Fu;
-      // A operand in the same order: interleave the bytes of A_j = x[.., t0 ..+3] and B_j = x[.., t1 ..+3]
-      const uint32_t alo = __builtin_amdgcn_perm(xw[2 * j + 1], xw[2 * j], 0x05010400u);
-      const uint32_t ahi = __builtin_amdgcn_perm(xw[2 * j + 1], xw[2 * j], 0x07030602u);
-      const i64_t a = (i64_t)(((unsigned long)ahi << 32) | alo), b = (i64_t)(((unsigned long)hi << 32) | lo);
-      pq = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, pq, 0, 0, 0);
-      px = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, ones, px, 0, 0, 0);
+      const i64_t b = (i64_t)(((unsigned long)hi << 32) | lo);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        // A operand in the same order: interleave the bytes of A_j = x[.., t0 ..+3] and B_j = x[.., t1 ..+3]
+        const uint32_t alo = __builtin_amdgcn_perm(xw[mt][2 * j + 1], xw[mt][2 * j], 0x05010400u);
+        const uint32_t ahi = __builtin_amdgcn_perm(xw[mt][2 * j + 1], xw[mt][2 * j], 0x07030602u);
+        const i64_t a = (i64_t)(((unsigned long)ahi << 32) | alo);
+        pq[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, pq[mt], 0, 0, 0);
+        px[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, ones, px[mt], 0, 0, 0);
+      }
       if ((j + 1) * 32 % G == 0 || j == 3) {  // a group ends here (G >= 128: once per block)
         const int gi = (G >= 128) ? 0 : ((j * 32) / G);
         const float sc = bf16_lo_to_f32(s.sz[gi]), zp = bf16_hi_to_f32(s.sz[gi]);
         const float c0 = 512.0f * sc, c1 = zp - 8.0f * sc;
-        acc.x = fmaf(c0, pq.x, fmaf(c1, px.x, acc.x)); acc.y = fmaf(c0, pq.y, fmaf(c1, px.y, acc.y));
-        acc.z = fmaf(c0, pq.z, fmaf(c1, px.z, acc.z)); acc.w = fmaf(c0, pq.w, fmaf(c1, px.w, acc.w));
-        pq = f32x4{0.f, 0.f, 0.f, 0.f}; px = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4& a4 = acc[mt];
+          a4.x = fmaf(c0, pq[mt].x, fmaf(c1, px[mt].x, a4.x)); a4.y = fmaf(c0, pq[mt].y, fmaf(c1, px[mt].y, a4.y));
+          a4.z = fmaf(c0, pq[mt].z, fmaf(c1, px[mt].z, a4.z)); a4.w = fmaf(c0, pq[mt].w, fmaf(c1, px[mt].w, a4.w));
+          pq[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; px[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   };
@@ -213,18 +246,19 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
     if (kb + d < kb1) consume(st[d], kb + d);
   });
 
-  // cross-wave reduction: red[wave][row][col]; D layout: lane (col = lane & 15, group kq) holds rows 4 kq + {0..3}
-  {
-    float* r = red + wave * 256 + (kq * 4) * 16 + (lane & 15);
-    r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
+  // cross-wave reduction: red[wave][m-tile][row][col]; D layout: lane (col = lane & 15, group kq) holds rows 4 kq + {0..3}
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float* r = red + (wave * MT + mt) * 256 + (kq * 4) * 16 + (lane & 15);
+    r[0] = acc[mt].x; r[16] = acc[mt].y; r[32] = acc[mt].z; r[48] = acc[mt].w;
   }
   __syncthreads();
   const int tid = threadIdx.x;
-  if (tid < 256) {
-    const int row = tid >> 4, col = tid & 15;
+  for (int e = tid; e < MT * 256; e += blockDim.x) {
+    const int row = e >> 4, col = e & 15;  // (row = 16 mt + r: red's [m-tile][row] order)
     if (row < rows) {
       float sum = 0.f;
-      for (int w = 0; w < nwaves; ++w) sum += red[w * 256 + tid];
+      for (int w = 0; w < nwaves; ++w) sum += red[w * (MT * 256) + e];
       float v = sum * (FUSE != 0 ? rs[row] : x_scale[m0 + row]);
       if (bias != nullptr) v += bf16_lo_to_f32(bias[ntile * 16 + col]);
       y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(v);
@@ -243,7 +277,24 @@ int launch_fp8_int4(const uint8_t* xq, const float* x_scale, const int32_t* qdat
   const u32x4* qd = reinterpret_cast<const u32x4*>(qdata);
   const uint32_t* szw = reinterpret_cast<const uint32_t*>(sz);
   if (!fused) {
-    ao::launch(fp8_int4_mm_kernel<G, 4, 0>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+    // m-tiles per workgroup: 2 from 17 rows, 4 from 33 rows on K >= 8192 (ring depth 3 / 2: a deeper ring's x stages cost the occupancy);
+    // g_fp8_int4_mt (ao_int4_set_tuning mode 960 + MT) forces a count for A/B runs
+    // (profiles/fp8_int4_mt_ab_r05.jsonl: two m-tiles win at K = 4096 -- gate_proj at M = 128 64.6 -> 45.6 us -- four on K = 14336 from 33 rows:
+    // down_proj at M = 256 118.4 -> 78.3; four m-tiles on a 3-deep ring were 5 - 12 % behind the 2-deep form everywhere; all forms give the same bits)
+    const int mt = (g_fp8_int4_mt == 1 || g_fp8_int4_mt == 2 || g_fp8_int4_mt == 4) ? g_fp8_int4_mt : (M > 32 && K >= 8192) ? 4 : (M > 16) ? 2 : 1;
+    if (mt == 4) {
+      smem *= 4;
+      grid.y = (unsigned)((M + 63) / 64);
+      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fp8_int4_mm_kernel<G, 2, 0, 4>), smem, "hipFuncSetAttribute(fp8_int4_mm_kernel)")) return rc;
+      ao::launch(fp8_int4_mm_kernel<G, 2, 0, 4>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+    } else if (mt == 2) {
+      smem *= 2;
+      grid.y = (unsigned)((M + 31) / 32);
+      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fp8_int4_mm_kernel<G, 3, 0, 2>), smem, "hipFuncSetAttribute(fp8_int4_mm_kernel)")) return rc;
+      ao::launch(fp8_int4_mm_kernel<G, 3, 0, 2>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+    } else {
+      ao::launch(fp8_int4_mm_kernel<G, 4, 0>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+    }
   } else {
     smem += (size_t)((M * (K + 16) + 15) & ~(int64_t)15) + (size_t)(wpb * 16 + 16) * sizeof(float);
     // M == 1 with at most 16 blocks per wave: the wave-private form; else the workgroup-wide cast
@@ -277,6 +328,7 @@ int fp8_int4_check(const char* fn, int64_t M, int64_t N, int64_t K, int group_si
 }
 
 }  // namespace
+void fp8_int4_set_mt(int mt) { g_fp8_int4_mt = mt; }
 }  // namespace ao
 
 using namespace ao;

@@ -113,7 +113,7 @@ def test_fp8_activation_int4_weight_config():
 
 
 @pytest.mark.parametrize("g", [32, 64, 128, 256])
-@pytest.mark.parametrize("m", [1, 5, 16, 17, 40])
+@pytest.mark.parametrize("m", [1, 5, 16, 17, 40, 64, 100, 130])
 def test_fp8_int4_kernel_matches_oracle(m, g):
     """ao_fp8_int4_linear directly: symmetric AND asymmetric (zero-point) weights, bias, every group size, row counts around the
     16-row slab; <= 1e-3 rel against the float64 restatement (measured ~1e-6: fp32 group sums), > 90 % of outputs bit-identical."""
@@ -132,6 +132,16 @@ def test_fp8_int4_kernel_matches_oracle(m, g):
         want = P.fp8_int4_linear(F8.e4m3_to_f32(xq), xs, wt.qdata.cpu().numpy(), np_from_torch_bf16(wt.scale), np_from_torch_bf16(wt.zero_point), g, bias)
         rel = _rel(y, want)
         assert rel <= 1e-3 and np.mean(y == want) > 0.9, (symmetric, rel, float(np.mean(y == want)))
+        # round 5: 1, 2 or 4 m-tiles per workgroup (a block's nibble expansion shared by up to 64 rows) -- every wave still sums the same
+        # k-run in the same order, so all three forms give the same bits
+        from ao_amd import _lib
+        try:
+            for mode in (961, 962, 964):
+                _lib.lib().ao_int4_set_tuning(0, mode)
+                ym = np_from_torch_bf16(ops.fp8_int4_linear(xq_t, xs_t, qdata_tp, sz, g, torch_bf16_from_f32(bias).to(DEV)))
+                assert np.array_equal(ym, y), (symmetric, m, g, mode, "m-tiles per workgroup change the result")
+        finally:
+            _lib.lib().ao_int4_set_tuning(0, 0)
         # round 4: the one-op form on the bf16 activation (cast fused into the launch at M <= 16: the wave-private form at M = 1, the
         # workgroup-wide cast up to 16 rows; two launches beyond) gives the bits of cast + ao_fp8_int4_linear
         x_t = torch_bf16_from_f32(x).to(DEV)
