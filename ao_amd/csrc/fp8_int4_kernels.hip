@@ -27,6 +27,7 @@ namespace {
 
 typedef long i64_t;
 thread_local int g_fp8_int4_mt = 0;  // A/B: m-tiles per workgroup forced (1, 2, 4); 0 = by M
+thread_local bool g_fp8_int4_nt1 = false;  // A/B: one n-tile per workgroup
 
 // FUSE (round 4, SURVEY 8 f1 for this path): the per-row e4m3 cast of the activation inside the launch -- x arrives as bf16 [M][K]
 // (M <= 16, M (K + 16) <= 64 KiB), is cast ONCE per workgroup into an LDS copy of the codes with quant_math.h's arithmetic (the bits of
@@ -39,7 +40,10 @@ thread_local int g_fp8_int4_mt = 0;  // A/B: m-tiles per workgroup forced (1, 2,
 // streamed, masked and scale-decoded every packed block ceil(M / 16) times; with MT m-tiles a block's B operands (the two mask
 // operations per word) and its (scale, zero) pair are built once and multiplied against MT activation tiles: MT x fewer weight
 // requests and nibble expansions per output.
-template <int G, int DEPTH, int FUSE = 0, int MT = 1>
+// NT (round 5): 16-wide n-tiles per workgroup, 1 or 2.  The staged activation tiles, their byte interleave and the ones-operand MFMA that
+// yields sum_k xq per group do not depend on n: with two n-tiles per workgroup they are done once per 32 output columns (12 MFMAs per
+// block and m-tile instead of 16, half the LDS staging).
+template <int G, int DEPTH, int FUSE = 0, int MT = 1, int NT = 1>
 __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restrict__ xq, const float* __restrict__ x_scale,
                                                           const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz,
                                                           const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int M, int N, int K) {
@@ -47,13 +51,13 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   constexpr int ROWSTRIDE = 128 + 16;             // bytes per staged x row ([kq][j] pairs of dwords), padded vs bank conflicts
   constexpr int SLAB16 = 16 * ROWSTRIDE;           // one m-tile's rows
   constexpr int SLAB = MT * SLAB16;
-  static_assert(FUSE == 0 || MT == 1, "the fused cast holds at most 16 rows");
+  static_assert(FUSE == 0 || (MT == 1 && NT == 1), "the fused cast holds at most 16 rows, one n-tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  const int ntile = blockIdx.x;
+  const int ntile = blockIdx.x * NT;  // (first of NT)
   const int m0 = blockIdx.y * (16 * MT);
   const int rows = min(16 * MT, M - m0);
   const int kblocks = K >> 7;
@@ -63,13 +67,13 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
   // FUSE: [M][K + 16] codes | [nwaves][16] row maxima | [16] row scales, behind the reduction area
   const int cstride = K + 16;
-  char* codes = smem + nwaves * (SLAB + MT * 1024);
+  char* codes = smem + nwaves * (SLAB + MT * NT * 1024);
   float* wmax = reinterpret_cast<float*>(codes + ((M * cstride + 15) & ~15));
   float* rs = wmax + nwaves * 16;
 
-  const int n = ntile * 16 + (lane & 15);
+  const int n = ntile * 16 + (lane & 15);  // (+ 16 nt)
   const int kq = lane >> 4;
-  const u32x4* wp = qdata + (size_t)ntile * kblocks * 64 + lane;
+  const u32x4* wp = qdata + (size_t)ntile * kblocks * 64 + lane;  // (+ nt * kblocks * 64)
   // x slice of a block: lane (r = lane >> 2, j = lane & 3) loads the 32 bytes x[m0 + r][kb * 128 + 32 j ..] (rows past M: the last row)
   const uint8_t* xp[MT];
 #pragma unroll
@@ -79,16 +83,19 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   const char* a_base = slab + (lane & 15) * ROWSTRIDE + kq * 32;
 
   struct Stage {
-    u32x4 w;
-    uint32_t sz[NG];
+    u32x4 w[NT];
+    uint32_t sz[NT][NG];
     u32x4 x0[MT], x1[MT];
   };
   Stage st[DEPTH];
   auto issue = [&](Stage& s, int kb) {
-    s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
     const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
 #pragma unroll
-    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
+    for (int nt = 0; nt < NT; ++nt) {
+      s.w[nt] = __builtin_nontemporal_load(wp + (size_t)nt * kblocks * 64 + (size_t)kb * 64);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) s.sz[nt][i] = sz[(size_t)(kg0 + i) * N + n + 16 * nt];
+    }
     if constexpr (FUSE == 0) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -99,9 +106,11 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
     }
   };
 
-  f32x4 acc[MT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const i64_t ones = 0x3838383838383838L;  // eight e4m3 1.0
   // FUSE: lane (r, j)'s 32 bytes of the block come from the LDS copy of the codes (rows past M: the last row)
   const char* cp = codes + min(lane >> 2, rows - 1) * cstride + (lane & 3) * 32;
@@ -125,35 +134,50 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
       xw[mt][0] = xa.x; xw[mt][1] = xa.y; xw[mt][2] = xa.z; xw[mt][3] = xa.w;
       xw[mt][4] = xb.x; xw[mt][5] = xb.y; xw[mt][6] = xb.z; xw[mt][7] = xb.w;
     }
-    const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
-    f32x4 pq[MT], px[MT];
+    f32x4 pq[MT][NT], px[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { pq[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; px[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int mt = 0; mt < MT; ++mt) {
+      px[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) pq[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       // B operand: bytes (v0, v4, v1, v5 | v2, v6, v3, v7) = k (t0, t1, t0 + 1, t1 + 1 | t0 + 2, t1 + 2, t0 + 3, t1 + 3)
-      const uint32_t lo = wds[j] & 0x0F0F0F0Fu, hi = (wds[j] >> 4) & 0x0F0F0F0Fu;
-      const i64_t b = (i64_t)(((unsigned long)hi << 32) | lo);
+      i64_t b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const uint32_t wd = (j == 0) ? s.w[nt].x : (j == 1) ? s.w[nt].y : (j == 2) ? s.w[nt].z : s.w[nt].w;
+        const uint32_t lo = wd & 0x0F0F0F0Fu, hi = (wd >> 4) & 0x0F0F0F0Fu;
+        b[nt] = (i64_t)(((unsigned long)hi << 32) | lo);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         // A operand in the same order: interleave the bytes of A_j = x[.., t0 ..+3] and B_j = x[.., t1 ..+3]
         const uint32_t alo = __builtin_amdgcn_perm(xw[mt][2 * j + 1], xw[mt][2 * j], 0x05010400u);
         const uint32_t ahi = __builtin_amdgcn_perm(xw[mt][2 * j + 1], xw[mt][2 * j], 0x07030602u);
         const i64_t a = (i64_t)(((unsigned long)ahi << 32) | alo);
-        pq[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, pq[mt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pq[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b[nt], pq[mt][nt], 0, 0, 0);
         px[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, ones, px[mt], 0, 0, 0);
       }
       if ((j + 1) * 32 % G == 0 || j == 3) {  // a group ends here (G >= 128: once per block)
         const int gi = (G >= 128) ? 0 : ((j * 32) / G);
-        const float sc = bf16_lo_to_f32(s.sz[gi]), zp = bf16_hi_to_f32(s.sz[gi]);
-        const float c0 = 512.0f * sc, c1 = zp - 8.0f * sc;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          f32x4& a4 = acc[mt];
-          a4.x = fmaf(c0, pq[mt].x, fmaf(c1, px[mt].x, a4.x)); a4.y = fmaf(c0, pq[mt].y, fmaf(c1, px[mt].y, a4.y));
-          a4.z = fmaf(c0, pq[mt].z, fmaf(c1, px[mt].z, a4.z)); a4.w = fmaf(c0, pq[mt].w, fmaf(c1, px[mt].w, a4.w));
-          pq[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; px[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) {
+          const float sc = bf16_lo_to_f32(s.sz[nt][gi]), zp = bf16_hi_to_f32(s.sz[nt][gi]);
+          const float c0 = 512.0f * sc, c1 = zp - 8.0f * sc;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            f32x4& a4 = acc[mt][nt];
+            const f32x4 q4 = pq[mt][nt], x4 = px[mt];
+            a4.x = fmaf(c0, q4.x, fmaf(c1, x4.x, a4.x)); a4.y = fmaf(c0, q4.y, fmaf(c1, x4.y, a4.y));
+            a4.z = fmaf(c0, q4.z, fmaf(c1, x4.z, a4.z)); a4.w = fmaf(c0, q4.w, fmaf(c1, x4.w, a4.w));
+            pq[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) px[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -246,19 +270,22 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
     if (kb + d < kb1) consume(st[d], kb + d);
   });
 
-  // cross-wave reduction: red[wave][m-tile][row][col]; D layout: lane (col = lane & 15, group kq) holds rows 4 kq + {0..3}
+  // cross-wave reduction: red[wave][m-tile][n-tile][row][col]; D layout: lane (col = lane & 15, group kq) holds rows 4 kq + {0..3}
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    float* r = red + (wave * MT + mt) * 256 + (kq * 4) * 16 + (lane & 15);
-    r[0] = acc[mt].x; r[16] = acc[mt].y; r[32] = acc[mt].z; r[48] = acc[mt].w;
-  }
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float* r = red + ((wave * MT + mt) * NT + nt) * 256 + (kq * 4) * 16 + (lane & 15);
+      r[0] = acc[mt][nt].x; r[16] = acc[mt][nt].y; r[32] = acc[mt][nt].z; r[48] = acc[mt][nt].w;
+    }
   __syncthreads();
   const int tid = threadIdx.x;
-  for (int e = tid; e < MT * 256; e += blockDim.x) {
-    const int row = e >> 4, col = e & 15;  // (row = 16 mt + r: red's [m-tile][row] order)
+  for (int e = tid; e < MT * NT * 256; e += blockDim.x) {
+    const int tile = e >> 8, mt = tile / NT, nt = tile - mt * NT;
+    const int row = 16 * mt + ((e >> 4) & 15), col = 16 * nt + (e & 15);
     if (row < rows) {
       float sum = 0.f;
-      for (int w = 0; w < nwaves; ++w) sum += red[w * (MT * 256) + e];
+      for (int w = 0; w < nwaves; ++w) sum += red[w * (MT * NT * 256) + e];
       float v = sum * (FUSE != 0 ? rs[row] : x_scale[m0 + row]);
       if (bias != nullptr) v += bf16_lo_to_f32(bias[ntile * 16 + col]);
       y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(v);
@@ -277,24 +304,27 @@ int launch_fp8_int4(const uint8_t* xq, const float* x_scale, const int32_t* qdat
   const u32x4* qd = reinterpret_cast<const u32x4*>(qdata);
   const uint32_t* szw = reinterpret_cast<const uint32_t*>(sz);
   if (!fused) {
-    // m-tiles per workgroup: 2 from 17 rows, 4 from 33 rows on K >= 8192 (ring depth 3 / 2: a deeper ring's x stages cost the occupancy);
-    // g_fp8_int4_mt (ao_int4_set_tuning mode 960 + MT) forces a count for A/B runs
-    // (profiles/fp8_int4_mt_ab_r05.jsonl: two m-tiles win at K = 4096 -- gate_proj at M = 128 64.6 -> 45.6 us -- four on K = 14336 from 33 rows:
-    // down_proj at M = 256 118.4 -> 78.3; four m-tiles on a 3-deep ring were 5 - 12 % behind the 2-deep form everywhere; all forms give the same bits)
-    const int mt = (g_fp8_int4_mt == 1 || g_fp8_int4_mt == 2 || g_fp8_int4_mt == 4) ? g_fp8_int4_mt : (M > 32 && K >= 8192) ? 4 : (M > 16) ? 2 : 1;
-    if (mt == 4) {
-      smem *= 4;
-      grid.y = (unsigned)((M + 63) / 64);
-      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fp8_int4_mm_kernel<G, 2, 0, 4>), smem, "hipFuncSetAttribute(fp8_int4_mm_kernel)")) return rc;
-      ao::launch(fp8_int4_mm_kernel<G, 2, 0, 4>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
-    } else if (mt == 2) {
-      smem *= 2;
-      grid.y = (unsigned)((M + 31) / 32);
-      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fp8_int4_mm_kernel<G, 3, 0, 2>), smem, "hipFuncSetAttribute(fp8_int4_mm_kernel)")) return rc;
-      ao::launch(fp8_int4_mm_kernel<G, 3, 0, 2>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
-    } else {
-      ao::launch(fp8_int4_mm_kernel<G, 4, 0>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
-    }
+    // Tiles per workgroup (profiles/fp8_int4_mt_ab_r05.jsonl, fp8_int4_mt_nt_ab_r05.jsonl; cold weights, us; every form gives the same bits):
+    // two m-tiles from 17 rows (gate_proj at M = 128: 64.6 -> 46.3), and two n-tiles as well above 64 rows, or above 32 on K >= 8192
+    // (down_proj 4096 x 14336 at M = 128 / 256 / 512: 47.4 -> 33.8, 90.4 -> 67.0, 177 -> 132; qkv at M = 512 76.4 -> 73.5; at M <= 64 on
+    // K = 4096 the halved grid costs 1 us).  Four m-tiles x one n-tile (2-deep ring: the x stages of a deeper one cost the occupancy;
+    // 3-deep measured 5 - 12 % slower) lose to 2 x 2 in every cell from 64 rows and stay a tuning form; 4 x 2 spills.
+    // g_fp8_int4_mt / g_fp8_int4_nt1 (ao_int4_set_tuning modes 961 / 962 / 964, 972 / 974) force a form for A/B runs.
+    const bool forced = g_fp8_int4_mt == 1 || g_fp8_int4_mt == 2 || g_fp8_int4_mt == 4;
+    const int mt = forced ? g_fp8_int4_mt : (M > 16) ? 2 : 1;
+    const bool nt2 = (N % 32 == 0) && !g_fp8_int4_nt1 && (forced || M > 64 || (M > 32 && K >= 8192));
+    const size_t slab = (size_t)wpb * 16 * (128 + 16), redb = (size_t)wpb * 1024;
+    auto go = [&](auto kern, int mtv, int ntv) -> int {
+      const size_t sm = slab * mtv + redb * mtv * ntv;
+      dim3 g((unsigned)(N / (16 * ntv)), (unsigned)((M + 16 * mtv - 1) / (16 * mtv)));
+      if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), sm, "hipFuncSetAttribute(fp8_int4_mm_kernel)")) return rc;
+      ao::launch(kern, g, block, sm, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
+      AO_LAUNCH_CHECK("fp8_int4_mm_kernel launch");
+      return AO_OK;
+    };
+    if (mt == 4) return go(fp8_int4_mm_kernel<G, 2, 0, 4, 1>, 4, 1);  // (four m-tiles x two n-tiles do not fit 256 VGPRs without spilling)
+    if (mt == 2) return nt2 ? go(fp8_int4_mm_kernel<G, 3, 0, 2, 2>, 2, 2) : go(fp8_int4_mm_kernel<G, 3, 0, 2, 1>, 2, 1);
+    ao::launch(fp8_int4_mm_kernel<G, 4, 0>, grid, block, smem, stream, xq, x_scale, qd, szw, bias, y, (int)M, (int)N, (int)K);
   } else {
     smem += (size_t)((M * (K + 16) + 15) & ~(int64_t)15) + (size_t)(wpb * 16 + 16) * sizeof(float);
     // M == 1 with at most 16 blocks per wave: the wave-private form; else the workgroup-wide cast
@@ -328,7 +358,7 @@ int fp8_int4_check(const char* fn, int64_t M, int64_t N, int64_t K, int group_si
 }
 
 }  // namespace
-void fp8_int4_set_mt(int mt) { g_fp8_int4_mt = mt; }
+void fp8_int4_set_mt(int mt, bool nt1) { g_fp8_int4_mt = mt; g_fp8_int4_nt1 = nt1; }
 }  // namespace ao
 
 using namespace ao;

@@ -1519,11 +1519,12 @@ extern "C" int ao_int4_set_trace(unsigned long long* trace_dev) {
   return AO_OK;
 }
 
-namespace ao { void fp8_int4_set_mt(int mt); }  // fp8_int4_kernels.hip
+namespace ao { void fp8_int4_set_mt(int mt, bool nt1); }  // fp8_int4_kernels.hip
 extern "C" int ao_int4_set_tuning(int waves_per_block, int mode) {
   g_tune_wpb = waves_per_block;
   g_tune_mode = mode;
-  ao::fp8_int4_set_mt((mode == 961 || mode == 962 || mode == 964) ? mode - 960 : 0);  // fp8-act x int4: m-tiles per workgroup forced
+  // fp8-act x int4: 961 / 962 / 964 m-tiles per workgroup forced; 970 / 972 / 974: one n-tile per workgroup (0 / 2 / 4 m-tiles: 0 = by M)
+  ao::fp8_int4_set_mt((mode == 961 || mode == 962 || mode == 964) ? mode - 960 : (mode == 972 || mode == 974) ? mode - 970 : 0, mode >= 970 && mode <= 974);
   return AO_OK;
 }
 

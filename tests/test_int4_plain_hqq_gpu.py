@@ -132,11 +132,11 @@ def test_fp8_int4_kernel_matches_oracle(m, g):
         want = P.fp8_int4_linear(F8.e4m3_to_f32(xq), xs, wt.qdata.cpu().numpy(), np_from_torch_bf16(wt.scale), np_from_torch_bf16(wt.zero_point), g, bias)
         rel = _rel(y, want)
         assert rel <= 1e-3 and np.mean(y == want) > 0.9, (symmetric, rel, float(np.mean(y == want)))
-        # round 5: 1, 2 or 4 m-tiles per workgroup (a block's nibble expansion shared by up to 64 rows) -- every wave still sums the same
-        # k-run in the same order, so all three forms give the same bits
+        # round 5: 1, 2 or 4 m-tiles per workgroup (a block's nibble expansion shared by up to 64 rows), one or two n-tiles (972: one) -- every
+        # wave still sums the same k-run in the same order, so all forms give the same bits
         from ao_amd import _lib
         try:
-            for mode in (961, 962, 964):
+            for mode in (961, 962, 964, 972):
                 _lib.lib().ao_int4_set_tuning(0, mode)
                 ym = np_from_torch_bf16(ops.fp8_int4_linear(xq_t, xs_t, qdata_tp, sz, g, torch_bf16_from_f32(bias).to(DEV)))
                 assert np.array_equal(ym, y), (symmetric, m, g, mode, "m-tiles per workgroup change the result")

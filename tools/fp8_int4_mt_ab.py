@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """fp8-activation x int4-weight linear at 17 <= M <= 512: m-tiles per workgroup forced to 1 (rounds 3-4: one workgroup per 16
-rows, the weights re-read per slab), 2, 4, and the product rule (0), cold weights, Llama-3-8B shapes, g = 128.  One JSON line per (shape, M)."""
+rows, the weights re-read per slab), 2 (with one and with two n-tiles per workgroup), 4, and the product rule (0), cold weights, Llama-3-8B shapes, g = 128.  One JSON line per (shape, M)."""
 import json
 import os
 import sys
@@ -31,7 +31,7 @@ def main():
             xq, xs = ops.fp8_quantize_rowwise(torch.randn(m, k, device=dev, dtype=torch.bfloat16))
             rec = {"shape": name, "N": n, "K": k, "M": m}
             ref = None
-            for mode in (961, 962, 964, 0):
+            for mode in (961, 972, 962, 964, 0):
                 lib.ao_int4_set_tuning(0, mode)
                 try:
                     calls = [lambda q=q, sz=sz: ops.fp8_int4_linear(xq, xs, q, sz, 128) for q, sz in ws]
@@ -39,8 +39,9 @@ def main():
                     torch.cuda.synchronize()
                     if ref is None:
                         ref = y
-                    rec[f"mt{mode - 960 if mode else 'auto'}_us"] = round(graph_time(calls) * 1e6, 1)
-                    rec[f"mt{mode - 960 if mode else 'auto'}_equal"] = bool(torch.equal(y, ref))
+                    key = {961: "mt1", 972: "mt2_nt1", 962: "mt2_nt2", 964: "mt4_nt1", 0: "auto"}[mode]
+                    rec[key + "_us"] = round(graph_time(calls) * 1e6, 1)
+                    rec[key + "_equal"] = bool(torch.equal(y, ref))
                 finally:
                     lib.ao_int4_set_tuning(0, 0)
             print(json.dumps(rec), flush=True)
