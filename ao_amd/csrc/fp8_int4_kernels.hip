@@ -312,7 +312,8 @@ int launch_fp8_int4(const uint8_t* xq, const float* x_scale, const int32_t* qdat
     // g_fp8_int4_mt / g_fp8_int4_nt1 (ao_int4_set_tuning modes 961 / 962 / 964, 972 / 974) force a form for A/B runs.
     const bool forced = g_fp8_int4_mt == 1 || g_fp8_int4_mt == 2 || g_fp8_int4_mt == 4;
     const int mt = forced ? g_fp8_int4_mt : (M > 16) ? 2 : 1;
-    const bool nt2 = (N % 32 == 0) && !g_fp8_int4_nt1 && (forced || M > 64 || (M > 32 && K >= 8192));
+    // (groups of 32 / 64: two n-tiles carry 4 / 2 (scale, zero) words per n-tile and ring stage and spill 12 VGPRs -- one n-tile there)
+    const bool nt2 = (N % 32 == 0) && !g_fp8_int4_nt1 && (forced || (G >= 128 && (M > 64 || (M > 32 && K >= 8192))));
     const size_t slab = (size_t)wpb * 16 * (128 + 16), redb = (size_t)wpb * 1024;
     auto go = [&](auto kern, int mtv, int ntv) -> int {
       const size_t sm = slab * mtv + redb * mtv * ntv;
