@@ -45,6 +45,7 @@ _SIGNATURES = {
     "ao_xcd_local_state": [],
     "ao_int4_mm_kernel_name": [_I64, _I64, _I64, _INT],
     "ao_gemm8_kernel_name": [_INT, _I64, _I64, _I64],
+    "ao_fp8_int4_kernel_name": [_I64, _I64, _I64, _INT],
     "ao_int8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _P],
     "ao_int8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_int8_int_mm": [_P, _P, _P, _I64, _I64, _I64, _P],
@@ -133,6 +134,8 @@ def lib():
         l.ao_int4_mm_kernel_name.restype = ctypes.c_char_p
         if hasattr(l, "ao_gemm8_kernel_name"):
             l.ao_gemm8_kernel_name.restype = ctypes.c_char_p
+        if hasattr(l, "ao_fp8_int4_kernel_name"):
+            l.ao_fp8_int4_kernel_name.restype = ctypes.c_char_p
         l.ao_moe_padded_rows.restype = _I64
         l.ao_allreduce_flag_bytes.restype = _I64
         l.ao_allreduce_state_bytes.restype = _I64

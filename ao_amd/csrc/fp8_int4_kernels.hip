@@ -293,6 +293,13 @@ __global__ __launch_bounds__(512) void fp8_int4_mm_kernel(const uint8_t* __restr
   }
 }
 
+// product rule of the unfused form: m-tiles and n-tiles per workgroup (see launch_fp8_int4)
+int fp8_int4_m_tiles(int64_t M) { return M > 16 ? 2 : 1; }
+int fp8_int4_n_tiles(int64_t M, int64_t N, int64_t K, int group_size) {
+  // (groups of 32 / 64: two n-tiles carry 4 / 2 (scale, zero) words per n-tile and ring stage and spill 12 VGPRs -- one n-tile there)
+  return (N % 32 == 0 && group_size >= 128 && (M > 64 || (M > 32 && K >= 8192))) ? 2 : 1;
+}
+
 template <int G>
 int launch_fp8_int4(const uint8_t* xq, const float* x_scale, const int32_t* qdata, const uint16_t* sz, const uint16_t* bias, uint16_t* y,
                     int64_t M, int64_t N, int64_t K, hipStream_t stream, bool fused) {
@@ -311,9 +318,8 @@ int launch_fp8_int4(const uint8_t* xq, const float* x_scale, const int32_t* qdat
     // 3-deep measured 5 - 12 % slower) lose to 2 x 2 in every cell from 64 rows and stay a tuning form; 4 x 2 spills.
     // g_fp8_int4_mt / g_fp8_int4_nt1 (ao_int4_set_tuning modes 961 / 962 / 964, 972 / 974) force a form for A/B runs.
     const bool forced = g_fp8_int4_mt == 1 || g_fp8_int4_mt == 2 || g_fp8_int4_mt == 4;
-    const int mt = forced ? g_fp8_int4_mt : (M > 16) ? 2 : 1;
-    // (groups of 32 / 64: two n-tiles carry 4 / 2 (scale, zero) words per n-tile and ring stage and spill 12 VGPRs -- one n-tile there)
-    const bool nt2 = (N % 32 == 0) && !g_fp8_int4_nt1 && (forced || (G >= 128 && (M > 64 || (M > 32 && K >= 8192))));
+    const int mt = forced ? g_fp8_int4_mt : fp8_int4_m_tiles(M);
+    const bool nt2 = forced ? ((N % 32 == 0) && !g_fp8_int4_nt1) : (!g_fp8_int4_nt1 && fp8_int4_n_tiles(M, N, K, G) == 2);
     const size_t slab = (size_t)wpb * 16 * (128 + 16), redb = (size_t)wpb * 1024;
     auto go = [&](auto kern, int mtv, int ntv) -> int {
       const size_t sm = slab * mtv + redb * mtv * ntv;
@@ -374,6 +380,14 @@ extern "C" int ao_fp8_int4_linear(const uint8_t* xq, const float* x_scale, const
   AO_REQUIRE_PTR(x_scale);
   AO_REQUIRE_PTR(y);
   return fp8_int4_dispatch(xq, x_scale, qdata, scale_and_zero, bias, y, M, N, K, group_size, (hipStream_t)stream, false);
+}
+
+extern "C" const char* ao_fp8_int4_kernel_name(int64_t M, int64_t N, int64_t K, int group_size) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % 16 != 0 || K % 128 != 0 || !(group_size == 32 || group_size == 64 || group_size == 128 || group_size == 256) ||
+      K % group_size != 0)
+    return "invalid";
+  if (fp8_int4_m_tiles(M) == 1) return "fp8_int4_mm_kernel<1x1>";
+  return fp8_int4_n_tiles(M, N, K, group_size) == 2 ? "fp8_int4_mm_kernel<2x2>" : "fp8_int4_mm_kernel<2x1>";
 }
 
 extern "C" int ao_fp8_int4_dynamic_fits(int64_t M, int64_t N, int64_t K) {

@@ -81,3 +81,15 @@ def test_int4_dispatch_bands():
     # round 5: the 128 x 128 / 32 x 32 x 16 kernel from 129 rows on, and on wide weights (>= 64 column tiles of 128) from 65 rows
     assert name(128, 14336, 4096) == "int4_mm_w32_kernel" and name(129, 4096, 4096) == "int4_mm_w32_kernel" and name(2048, 4096, 14336) == "int4_mm_w32_kernel"
     assert name(64, 14336, 4096) == "int4_mm_rb_kernel"
+
+
+def test_fp8_int4_tile_forms():
+    """one workgroup per 16 x 16 outputs up to 16 rows; two m-tiles beyond; two n-tiles as well above 64 rows (above 32 on
+    K >= 8192) for groups of 128 / 256 when N is a multiple of 32 (profiles/fp8_int4_mt_nt_ab_r05.jsonl)."""
+    lib = _lib.lib()
+    name = lambda m, n, k, g=128: lib.ao_fp8_int4_kernel_name(m, n, k, g).decode()  # noqa: E731
+    assert [name(m, 14336, 4096) for m in (1, 16, 17, 64, 65, 512)] == ["fp8_int4_mm_kernel<1x1>"] * 2 + ["fp8_int4_mm_kernel<2x1>"] * 2 + ["fp8_int4_mm_kernel<2x2>"] * 2
+    assert [name(m, 4096, 14336) for m in (32, 33, 64)] == ["fp8_int4_mm_kernel<2x1>", "fp8_int4_mm_kernel<2x2>", "fp8_int4_mm_kernel<2x2>"]
+    assert name(128, 4096, 4096, 64) == "fp8_int4_mm_kernel<2x1>" and name(128, 4096, 4096, 256) == "fp8_int4_mm_kernel<2x2>"
+    assert name(128, 4112, 4096) == "fp8_int4_mm_kernel<2x1>"  # N % 32 != 0
+    assert name(128, 4096, 4000) == "invalid" and name(0, 4096, 4096) == "invalid" and name(8, 4096, 4096, 48) == "invalid"
