@@ -17,6 +17,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
+    # the one-process-per-GPU tests (tests/test_multigpu_gpu.py) have never met a multi-GPU node: they run LAST, so that under `-x` a
+    # surprise on the first such node cannot hide the results of the single-GPU tests behind it
+    items.sort(key=lambda item: "test_multigpu_gpu" in item.nodeid)  # (stable: everything else keeps its order)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible in this container")
