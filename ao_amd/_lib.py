@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ao_int4_mm_kernel_name": [_I64, _I64, _I64, _INT],
     "ao_gemm8_kernel_name": [_INT, _I64, _I64, _I64],
     "ao_fp8_int4_kernel_name": [_I64, _I64, _I64, _INT],
+    "ao_gemm8_plan": [_INT, _I64, _I64, _I64, _P, _P],
     "ao_int8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _P],
     "ao_int8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_int8_int_mm": [_P, _P, _P, _I64, _I64, _I64, _P],

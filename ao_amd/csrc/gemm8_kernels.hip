@@ -11,6 +11,8 @@
 // K step.  4 waves as 2x2, each 64x64 = 2x2 MFMA tiles of 32x32.
 // The epilogue applies the reference's scaling sequence in registers and stores
 // bf16 (or raw int32 for _int_mm).
+#include <string>
+
 #include "common.h"
 
 namespace ao {
@@ -25,6 +27,8 @@ int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale
 int gemm8_p8h(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
               int64_t M, int64_t N, int64_t K, hipStream_t stream);
 bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K);
+int gemm8_p8h_parts(int64_t M, int64_t N, int64_t K);
+void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bn, int* split);
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void rb8_set_wave_grid(bool two_by_four);  // rb8_kernels.hip
 void rb8_set_tuning(int bn, int split, int local_off, int ablate, int bm);
@@ -530,6 +534,22 @@ extern "C" const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int6
   if (gemm8_p8h_band(M, N, K)) return "gemm8_p8h_kernel";
   if (gemm8_p8_band(M, N, K) && gemm8_p8_fits(M, N, K)) return "gemm8_p8_kernel";
   return big >= 512 ? "gemm8_dma_kernel<256x256>" : "gemm8_dma_kernel<128x128>";
+}
+
+// The launch shape behind ao_gemm8_kernel_name: column-tile width and K parts of the product dispatch (host logic only).  rb8_kernel: the
+// cost model's pick (32 / 64 / 128 columns, 1 .. 8 parts); gemm8_p8h_kernel: 128 columns, 1 .. 4 parts; every other kernel: its tile width, one part.
+extern "C" int ao_gemm8_plan(int int8, int64_t M, int64_t N, int64_t K, int* tile_cols, int* k_parts) {
+  AO_REQUIRE_PTR(tile_cols);
+  AO_REQUIRE_PTR(k_parts);
+  const std::string name = ao_gemm8_kernel_name(int8, M, N, K);
+  AO_REQUIRE(name != "invalid", "ao_gemm8_plan: no kernel takes M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  *k_parts = 1;
+  if (name == "rb8_kernel") rb8_plan_query(M, N, K, tile_cols, k_parts);
+  else if (name == "gemm8_p8h_kernel") { *tile_cols = 128; *k_parts = gemm8_p8h_parts(M, N, K); }
+  else if (name == "gemm8_p8_kernel" || name == "gemm8_dma_kernel<256x256>") *tile_cols = 256;
+  else if (name == "gemm8_dma_kernel<128x128>" || name == "gemm8_kernel") *tile_cols = 128;
+  else *tile_cols = 16;  // the per-tile streaming kernels (dec8 / mid8 / stream8): 16-wide n-tiles, K split among the waves of a workgroup
+  return AO_OK;
 }
 
 extern "C" int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, int64_t M, int64_t N, int64_t K,

@@ -661,6 +661,7 @@ bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128);
   return M > 128 && gemm8_p8_fits(M, N, K) && ((tiles > 128 && tiles <= 256) || p8h_split_rule(M, N, K) > 1);  // (the rule: with K parts, below)
 }
+int gemm8_p8h_parts(int64_t M, int64_t N, int64_t K) { return p8h_split_rule(M, N, K); }  // (product rule; host logic only)
 void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }
 void gemm8_p8_set_split(int v) { g_p8_split = v; }
 void gemm8_p8h_set_form(int v) { g_p8h_form = v; }

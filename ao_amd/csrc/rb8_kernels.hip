@@ -1143,6 +1143,18 @@ inline Rb8Plan rb8_plan(int64_t M, int64_t N, int64_t K, int bm) {
   return best;
 }
 
+}  // namespace
+// what rb8_run picks without tuning overrides (host logic only: ao_gemm8_plan, tests/test_host_dispatch.py)
+void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bn, int* split) {
+  const int bm = (M <= 64) ? 64 : 128;
+  const Rb8Plan plan = rb8_plan(M, N, K, bm);
+  const int64_t base = ((N + plan.bn - 1) / plan.bn) * ((M + bm - 1) / bm);
+  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * plan.bn * bm) * 4 / 5;
+  *bn = plan.bn;
+  *split = (int)std::max<int64_t>(1, std::min<int64_t>(plan.split, fit));
+}
+namespace {
+
 template <int KIND>
 int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y, int64_t M,
             int64_t N, int64_t K, hipStream_t stream) {

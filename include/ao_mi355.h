@@ -149,6 +149,9 @@ const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_si
  * "stream8_kernel", "rb8_kernel" (up to 256 tiles of 128 x 128), "gemm8_p8_kernel" / "gemm8_dma_kernel<...>" / "gemm8_kernel" (tiled), or
  * "invalid".  Host logic only (no launch): bench / tests label their measurements with it.  DESIGN.md 4.4-4.5g. */
 const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int64_t K);
+/* The launch shape behind that name: column-tile width and K parts of the product dispatch for the shape (rb8_kernel: the cost model's
+ * pick; gemm8_p8h_kernel: 128 columns and 1 .. 4 parts; others: their tile width, one part).  Host logic only.  DESIGN.md 4.5h. */
+int ao_gemm8_plan(int int8, int64_t M, int64_t N, int64_t K, int* tile_cols, int* k_parts);
 /* Which form of fp8_int4_mm_kernel ao_fp8_int4_linear launches for a shape: "<m-tiles x n-tiles>" of 16 x 16 per workgroup -- "<1x1>" up to
  * 16 rows, "<2x1>" / "<2x2>" beyond (round 5: the weights stream once per 32 rows, the staged activations serve 32 columns), or "invalid".
  * Host logic only.  DESIGN.md 4.9. */

@@ -93,3 +93,38 @@ def test_fp8_int4_tile_forms():
     assert name(128, 4096, 4096, 64) == "fp8_int4_mm_kernel<2x1>" and name(128, 4096, 4096, 256) == "fp8_int4_mm_kernel<2x2>"
     assert name(128, 4112, 4096) == "fp8_int4_mm_kernel<2x1>"  # N % 32 != 0
     assert name(128, 4096, 4000) == "invalid" and name(0, 4096, 4096) == "invalid" and name(8, 4096, 4096, 48) == "invalid"
+
+
+def test_8bit_launch_plans_on_the_sweep_shapes():
+    """ao_gemm8_plan: tile width / K parts of the product dispatch on the shapes of profiles/midm_final_r05.jsonl (fp8 = int8).  The
+    weight-streaming kernel's pick comes from a cost model fitted to the round-5 sweep (rb8_plan): this table is the fit's output at the
+    time of the committed measurements -- a change of its constants has to show up here."""
+    import ctypes
+
+    lib = _lib.lib()
+    shapes = {"qkv70b": (1280, 8192), "o70b": (8192, 1024), "gate70b": (7168, 8192), "down70b": (8192, 3584),
+              "qkv8b": (6144, 4096), "o8b": (4096, 4096), "gate_up8b": (28672, 4096), "down8b": (4096, 14336)}
+    want = {  # M: (kernel, tile columns, K parts)
+        "qkv70b": {128: ("rb8", 32, 6), 256: ("rb8", 64, 4), 512: ("rb8", 64, 3), 768: ("rb8", 128, 4), 1024: ("p8h", 128, 4), 2048: ("p8h", 128, 3)},
+        "o70b": {128: ("rb8", 32, 1), 256: ("rb8", 64, 1), 512: ("rb8", 128, 1), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
+        "gate70b": {128: ("rb8", 128, 4), 256: ("rb8", 128, 2), 512: ("p8h", 128, 2), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
+        "down70b": {128: ("rb8", 64, 2), 256: ("rb8", 64, 1), 512: ("rb8", 128, 1), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
+        "qkv8b": {128: ("rb8", 128, 4), 256: ("rb8", 64, 1), 512: ("rb8", 128, 1), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
+        "o8b": {128: ("rb8", 64, 4), 256: ("rb8", 128, 4), 512: ("rb8", 64, 1), 768: ("rb8", 128, 1), 1024: ("rb8", 128, 1), 2048: ("p8h", 128, 1)},
+        "gate_up8b": {128: ("rb8", 128, 1), 256: ("p8h", 128, 1), 512: ("p8", 256, 1), 1024: ("p8", 256, 1), 2048: ("p8", 256, 1)},
+        "down8b": {128: ("rb8", 64, 4), 256: ("rb8", 128, 4), 512: ("p8h", 128, 4), 768: ("p8h", 128, 2), 1024: ("p8h", 128, 2), 2048: ("p8h", 128, 1)},
+    }
+    short = {"rb8_kernel": "rb8", "gemm8_p8h_kernel": "p8h", "gemm8_p8_kernel": "p8"}
+    for name, (n, k) in shapes.items():
+        for m, expect in want[name].items():
+            for int8 in (0, 1):
+                cols, parts = ctypes.c_int(), ctypes.c_int()
+                _lib.check(lib.ao_gemm8_plan(int8, m, n, k, ctypes.byref(cols), ctypes.byref(parts)))
+                got = (short[lib.ao_gemm8_kernel_name(int8, m, n, k).decode()], cols.value, parts.value)
+                assert got == expect, (name, m, int8, got, expect)
+    # the per-tile streaming kernels report their 16-wide n-tiles; a shape no kernel takes is an error
+    cols, parts = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.ao_gemm8_plan(0, 1, 8192, 1024, ctypes.byref(cols), ctypes.byref(parts)))
+    assert (cols.value, parts.value) == (16, 1)
+    with pytest.raises(ValueError):
+        _lib.check(lib.ao_gemm8_plan(0, 0, 64, 1024, ctypes.byref(cols), ctypes.byref(parts)))
