@@ -668,7 +668,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   constexpr int ASN = (QS == 1) ? kStages : 2, BSN = (QS == 1) ? SW : 2;          // slots per wave
   static_assert(WAVES == 4 || WAVES == 8, "mx_stream_kernel: 4 or 8 waves");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (TRACE) ts[0] = __builtin_amdgcn_s_memtime();
+  if (TRACE) { ts[0] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime(); }  // [3] / [4]: the 100 MHz clock at entry / exit
   // [3][64][128 B] a | [WAVES][SW][2 KiB] b | a scales [ASN][WAVES][ASB] | b scales [WAVES][BSN][BSB]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -994,6 +994,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   }
   if (TRACE && p.trace != nullptr && tid == 0) {
     ts[11] = ts[12] = __builtin_amdgcn_s_memtime();
+    ts[4] = __builtin_amdgcn_s_memrealtime();
     ts[15] = (unsigned long long)(g1 - g0);  // steps of this share
     unsigned long long* t = p.trace + (size_t)blockIdx.x * 16;
     for (int i = 0; i < 16; ++i) t[i] = ts[i];

@@ -123,16 +123,29 @@ def exchange(specs: Sequence[Tuple[int, int]], group, device, force_fallback: bo
     return own_t, ptrs, keep, f"coarse-grained fallback: {why}"
 
 
+def _device_ident(host, device, props=None):
+    """(host, uuid, pci domain, bus, device) of a GPU, or None when neither the UUID nor the PCI ids say which GPU it is -- a missing,
+    empty or all-zero UUID together with missing / negative PCI ids must read as "unknown", never as "the same GPU as everybody else"."""
+    try:
+        props = props if props is not None else torch.cuda.get_device_properties(device)
+    except Exception:  # noqa: BLE001
+        return None
+    uuid = str(getattr(props, "uuid", "") or "")
+    if not any(c not in "0-{} " for c in uuid.replace("GPU", "").replace("gpu", "")):
+        uuid = ""
+    pci = tuple(int(getattr(props, name, -1)) for name in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    pci_known = pci[1] >= 0 and pci[2] >= 0
+    if not uuid and not pci_known:
+        return None
+    return (host, uuid, pci if pci_known else None)
+
+
 def spans_devices(group, device) -> bool:
     """True when the ranks of `group` sit on more than one physical GPU (or that cannot be established).  Collective (one object
     all-gather): every rank names its host and the GPU's UUID / PCI bus id."""
     import socket
 
-    try:
-        props = torch.cuda.get_device_properties(device)
-        ident = (socket.gethostname(), str(getattr(props, "uuid", "")) or f"{getattr(props, 'pci_bus_id', -1)}:{getattr(props, 'pci_device_id', -1)}")
-    except Exception:  # noqa: BLE001
-        ident = None
+    ident = _device_ident(socket.gethostname(), device)
     gathered = [None] * dist.get_world_size(group)
     dist.all_gather_object(gathered, ident, group=group)
     return any(g is None for g in gathered) or len(set(gathered)) > 1

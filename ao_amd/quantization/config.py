@@ -191,16 +191,21 @@ class Float8DynamicActivationFloat8WeightConfig(AOBaseConfig):
 class Float8DynamicActivationInt4WeightConfig(AOBaseConfig):
     """float8 e4m3 rowwise dynamic activation x int4 groupwise (symmetric) weight (reference quant_api.py:630-699: group_size 128).
 
-    `int4_packing_format`: "plain" (the default HERE) or "preshuffled".  Both build the PLAIN `Int4Tensor` (reference
-    int4_tensor.py: qdata / scale / zero_point) carrying its gfx950 compute layout (tile-packed codes + stacked scale / zero, built once at
-    from_hp); its state_dict IS the reference's PLAIN format.  The REFERENCE's default is "preshuffled" (:646): an
-    `Int4PreshuffledTensor` (qdata / group_scale / row_scale, a layout pre-arranged for its H100 WGMMA kernel through un-vendored mslk
-    ops).  That tensor class and checkpoint layout are NOT produced here -- "preshuffled" is accepted so that the reference's default
-    call sites run, as an alias of "plain"; a checkpoint saved under it does not round-trip with upstream's preshuffled checkpoints
-    (ADVICE r4), which is why the default names the format that is actually written."""
+    `int4_packing_format`: "plain" (the default HERE) builds the PLAIN `Int4Tensor` (reference int4_tensor.py: qdata / scale / zero_point)
+    carrying its gfx950 compute layout (tile-packed codes + stacked scale / zero, built once at from_hp); its state_dict IS the reference's
+    PLAIN format.  The REFERENCE's default is "preshuffled" (:646): an `Int4PreshuffledTensor` (qdata / group_scale fp8 [K/g/8, 8, N] /
+    row_scale [N]: two-level scales and a byte order pre-arranged for its H100 WGMMA kernel by the un-vendored `mslk.quantize_int4_preshuffle`,
+    int4_preshuffled_tensor.py:55-66, 129-170).  Neither that arithmetic nor that byte order can be reproduced without mslk, so a checkpoint
+    written under "preshuffled" here could not be one upstream loads: the name parses (upstream JSON decodes) and `quantize_` REFUSES it with
+    the reason (round 6; rounds 4-5 accepted it as an alias of "plain", which silently produced a different checkpoint class than upstream).
+
+    Wire format (config_to_dict): the reference's class has the single field `int4_packing_format`; `group_size` -- an extension here, the
+    reference hard-codes 128 (:670) -- is written only when it is not 128, so that the default config's JSON is one upstream's
+    `config_from_dict` accepts."""
 
     int4_packing_format: Int4PackingFormat = Int4PackingFormat.PLAIN
     group_size: int = 128
+    _wire_omit_at_default = {"group_size": 128}  # (class attribute, not a field) fields the reference's class does not have
 
     def __post_init__(self):
         self.int4_packing_format = Int4PackingFormat(self.int4_packing_format)
@@ -247,8 +252,9 @@ def _encode(value):
             items = [(f.name, getattr(value, f.name)) for f in dataclasses.fields(value)]
         else:
             items = list(vars(value).items())
+        omit = getattr(type(value), "_wire_omit_at_default", {})
         return {"_type": type(value).__name__, "_version": getattr(value, "version", 1),
-                "_data": {k: _encode(v) for k, v in items if k != "version" and not k.startswith("_")}}
+                "_data": {k: _encode(v) for k, v in items if k != "version" and not k.startswith("_") and not (k in omit and v == omit[k])}}
     if isinstance(value, enum.Enum):
         return {"_type": type(value).__name__, "_data": value.name}
     if isinstance(value, torch.dtype):

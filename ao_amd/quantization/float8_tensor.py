@@ -29,6 +29,14 @@ def _require_bf16_activation(x, what):
                                   "(x.to(torch.bfloat16)) if that rounding is acceptable")
 
 
+def _tracing_now(x):
+    """fp16 / fp32 activations run raw C-ABI GEMMs that have no fake kernels: while tracing they refuse like before (NotImplementedError
+    from _require_bf16_activation) instead of failing on a FakeTensor's data_ptr."""
+    from ..torch_ops import tracing
+
+    return tracing(x)
+
+
 def _linear_other_dtype(x2, w, bias):
     """fp16 / fp32 activations (the reference supports them, float8_tensor.py:349-355 + :167-253): the cast in the activation's
     OWN dtype with the reference's op sequence -- scale = (amax / 448) in x.dtype, widened to fp32 (_choose_scale_float8); codes =
@@ -269,7 +277,7 @@ def _float8_linear(x, w, bias):
     w_tensorwise = w.scale.numel() == 1
     act0 = w.act_quant_kwargs
     if (x.dtype in (torch.float16, torch.float32) and isinstance(act0.granularity, PerRow) and not w_tensorwise and w.qdata.dim() == 2
-            and act0.hp_value_lb is None and act0.hp_value_ub is None and x2.shape[0] > 0):
+            and act0.hp_value_lb is None and act0.hp_value_ub is None and x2.shape[0] > 0 and not _tracing_now(x2)):
         return _linear_other_dtype(x2, w, bias).reshape(*x.shape[:-1], n).to(out_dtype)
     _require_bf16_activation(x, "Float8Tensor dynamic-activation linear")
     if isinstance(w.act_quant_kwargs.granularity, PerTensor) != w_tensorwise:

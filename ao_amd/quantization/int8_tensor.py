@@ -30,6 +30,14 @@ def _require_bf16_activation(x, what):
                                   "(x.to(torch.bfloat16)) if that rounding is acceptable")
 
 
+def _tracing_now(x):
+    """fp16 / fp32 activations run raw C-ABI GEMMs that have no fake kernels: while tracing they refuse like before (NotImplementedError
+    from _require_bf16_activation) instead of failing on a FakeTensor's data_ptr."""
+    from ..torch_ops import tracing
+
+    return tracing(x)
+
+
 def _linear_other_dtype(x2, w, bias):
     """fp16 / fp32 activations (the reference supports them): Int8Tensor.from_hp's arithmetic in the activation's OWN dtype as
     torch ops on the device -- choose_qparams_affine SYMMETRIC (quant_primitives.py:1534-1562: amax / 127.5, clamped at fp32 eps, fp32
@@ -192,7 +200,7 @@ def _(func, types, args, kwargs):
     x2 = x.reshape(-1, x.shape[-1]).contiguous()
     n = w.qdata.shape[0]
     if (x.dtype in (torch.float16, torch.float32) and w.act_quant_scale is None and _mapping(act.mapping_type) == MappingType.SYMMETRIC
-            and isinstance(act.granularity, PerRow) and x2.shape[0] > 0):
+            and isinstance(act.granularity, PerRow) and x2.shape[0] > 0 and not _tracing_now(x2)):
         return _linear_other_dtype(x2, w, bias).reshape(*x.shape[:-1], n).to(out_dtype)
     _require_bf16_activation(x, "Int8Tensor dynamic-activation linear")
     if x2.shape[0] == 0:

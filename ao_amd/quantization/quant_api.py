@@ -204,8 +204,8 @@ def _int4_weight_only_transform(module, config, *, parameter_name="weight"):
 @register_quantize_module_handler(Float8DynamicActivationInt4WeightConfig)
 def _float8_dynamic_activation_int4_weight_transform(module, config, *, parameter_name="weight"):
     """reference quant_api.py:660-699: Int4Tensor with activation_dtype float8_e4m3fn; shapes whose K is not a multiple of the
-    group size are left unquantized.  "preshuffled" (the reference's default) and "plain" both give the Int4Tensor that carries its
-    gfx950 compute layout -- the MI355X counterpart of the reference's H100-preshuffled tensor (config.py)."""
+    group size are left unquantized.  "plain" gives the Int4Tensor that carries its gfx950 compute layout; "preshuffled" (the reference's
+    default: Int4PreshuffledTensor, :672-676) is a checkpoint format only the un-vendored mslk can write -- refused with the reason (config.py)."""
     from .int4_plain_tensor import Int4Tensor
 
     assert hasattr(module, parameter_name), (
@@ -216,6 +216,12 @@ def _float8_dynamic_activation_int4_weight_transform(module, config, *, paramete
     assert config.int4_packing_format in (Int4PackingFormat.PRESHUFFLED, Int4PackingFormat.PLAIN), (
         f"only preshuffled and plain int4_packing_format supported right now, got: {config.int4_packing_format}"
     )
+    if config.int4_packing_format == Int4PackingFormat.PRESHUFFLED:
+        raise NotImplementedError(
+            'Float8DynamicActivationInt4WeightConfig(int4_packing_format="preshuffled") would have to write an Int4PreshuffledTensor checkpoint '
+            "(qdata / group_scale / row_scale in the byte order of mslk.quantize_int4_preshuffle, an H100 WGMMA layout); mslk is not available, so "
+            'such a checkpoint could not be one upstream torchao loads.  Use int4_packing_format="plain" (the default of this backend): the same '
+            "fp8-activation x int4-weight linear, saved in the reference's PLAIN Int4Tensor format")
     if weight.shape[-1] % config.group_size != 0:
         logger.info(f"Skipping quantizing weight of shape {weight.shape}: not compatible with group_size {config.group_size}")
         return module

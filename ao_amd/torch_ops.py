@@ -36,6 +36,11 @@ def _tracing(x) -> bool:
             or _get_current_dispatch_mode() is not None)
 
 
+def tracing(x=None) -> bool:
+    """torch.compile / export / a FakeTensor in hand: only ops with fake kernels may be called."""
+    return torch.compiler.is_compiling() or (x is not None and _tracing(x))
+
+
 def kernels(x=None):
     """Where the subclasses' F.linear implementations get their kernels: while tracing (torch.compile / export; `x` is the
     activation) the `ao_mi355::` dispatcher ops -- they have fake kernels, so FakeTensors flow through, and inductor calls

@@ -46,8 +46,8 @@ _SPECS = _roofline.get_specs("AMD Instinct MI355X")
 HBM_PEAK_GBS = _SPECS["peak_mem_bw_bytes_sec"] / 1e9   # 8000: MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = _SPECS["bf16_peak_tops"] / 1e12  # 2500: dense bf16 MFMA
 MFMA_8BIT_PEAK_TOPS = _SPECS["fp8_peak_tops"] / 1e12     # 5000: dense fp8 / int8 MFMA (fp8 ~5 PF dense, int8 ~2x the bf16 rate)
-ROUND = "r05"                    # names of the committed rocprofv3 summaries under profiles/
-PREV_ROUNDS = ("r05", "r04")     # a summary of this round when it exists, else the last round's (the source file is named beside every number)
+ROUND = "r06"                    # names of the committed rocprofv3 summaries under profiles/
+PREV_ROUNDS = ("r06", "r05")     # a summary of this round when it exists, else the last round's (the source file is named beside every number)
 
 
 def _profile_path(stem, ext):
@@ -176,6 +176,17 @@ def rocprof_avg_us(kernel_substr):
     if calls == 0:
         return None, None
     return total_ns / calls / 1e3, os.path.relpath(path, ROOT)
+
+
+def rocprof_crosscheck():
+    """profiles/int4_rocprof_crosscheck_<round>.json (scripts/rocprof_crosscheck.py), or None."""
+    path = _profile_path("int4_rocprof_crosscheck", "json")
+    if path is None:
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    d["_path"] = os.path.relpath(path, ROOT)
+    return d
 
 
 def pmc_traffic_of(config_key, workload=None):
@@ -335,9 +346,16 @@ def int4_roofline(model, batch, stream, layout="five"):
         out["algorithmic_bytes_per_launch"] = kd["algorithmic_bytes_per_launch"]
         out["traffic"], out["traffic_source"] = pmc_traffic(dom, layout)
         avg, src = rocprof_avg_us(dom + "<") if layout == "five" else (None, None)
-        if avg is not None:  # the committed rocprofv3 --kernel-trace --stats summary of this command
+        xc = rocprof_crosscheck() if layout == "five" else None
+        if xc is not None:
+            # round 6: the kernel trace of the process that printed a bench line, cut to that line's timed replays (scripts/rocprof_crosscheck.py):
+            # sum of kernel durations per step <= the profiler's wall span per step ~ that line's ms_per_step -- a figure that passes its own check
+            avg, src = xc["avg_kernel_us"], xc["_path"]
+        if avg is not None:  # the committed rocprofv3 --kernel-trace summary of this command
             out["rocprof"] = {"avg_kernel_us": avg, "achieved": kd["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9,
                               "frac": kd["algorithmic_bytes_per_launch"] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "source": src}
+            if xc is not None:
+                out["rocprof"].update({k_: xc[k_] for k_ in ("line_ms_per_step", "rocprof_span_ms_per_step", "rocprof_sum_kernel_ms_per_step", "cross_check")})
     return out
 
 
@@ -1150,6 +1168,11 @@ def main():
         flat = {"roofline_frac": (roof.get("rocprof", {}).get("frac") or roof["frac"]) if roof else None,
                 "roofline_frac_event_timed": roof["frac"] if roof else None,
                 "roofline_frac_source": (roof.get("rocprof", {}).get("source") or "HIP extension events, this run") if roof else None, "merged_tokens_per_s": other_tok_s if not merged else None,
+                # the profiled process's own figures, side by side (committed profile; this run's ms_per_step is the line's top-level key)
+                "rocprof_sum_kernel_ms_per_step": roof.get("rocprof", {}).get("rocprof_sum_kernel_ms_per_step") if roof else None,
+                "rocprof_span_ms_per_step": roof.get("rocprof", {}).get("rocprof_span_ms_per_step") if roof else None,
+                "rocprof_line_ms_per_step": roof.get("rocprof", {}).get("line_ms_per_step") if roof else None,
+                "event_sum_kernel_ms_per_step": roof.get("sum_kernel_ms_per_step") if roof else None,
                 "subclass_graph_tokens_per_s": None if not subclass else subclass.get("tokens_per_s")}
         if stats:
             for lay, st in stats.items():

@@ -1,12 +1,12 @@
 #!/bin/bash
-# The end-of-round pass (round 5): rocprofv3 stats + PMC of the headline command FIRST (five-shape layout, then the merged layout's own
+# The end-of-round pass (round 6): rocprofv3 stats + PMC of the headline command FIRST (five-shape layout, then the merged layout's own
 # PMC pass), copied into profiles/ on the box, so that the bench line that follows quotes the profile of the same build; the secondary
 # configs' PMC traffic and kernel stats; the 8-bit GEMM's MFMA-busy counters; then the full bench line, the whole GPU suite, smoke, and
 # the two multi-rank code paths a one-GPU box can exercise.  Every step under its own timeout; counters never together with a trace domain.
 #   bash scripts/gpu_final.sh [out-dir under gpurun_out, default final]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=r05
+ROUND=r06
 timeout 90 python -c "import torch; torch.zeros(1, device='cuda').add_(1).item(); print('canary ok')" || { echo "GPU canary failed"; exit 3; }
 O=$R/gpurun_out/${1:-final}
 mkdir -p $O
@@ -15,7 +15,9 @@ HEAD_CMD="python $R/bench.py --warmup 1 --no-cpu-baseline --no-second-layout --n
 echo "== rocprof stats, headline =="
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o int4 -- $HEAD_CMD --steps 10 > $O/rocprof_stats.log 2>&1
 f=$(find $O/prof_stats -name "*kernel_stats.csv" 2>/dev/null | head -1)
-if [ -n "$f" ]; then cp "$f" $O/int4_kernel_stats.csv; cp "$f" $R/profiles/int4_kernel_stats_$ROUND.csv; grep "^{" $O/rocprof_stats.log | tail -1 > $O/bench_under_rocprof.json; grep int4_mm_kernel "$f" | cut -c1-60,230-330; else echo "no kernel_stats.csv"; tail -5 $O/rocprof_stats.log; fi
+if [ -n "$f" ]; then cp "$f" $O/int4_kernel_stats.csv; cp "$f" $R/profiles/int4_kernel_stats_$ROUND.csv; grep "^{" $O/rocprof_stats.log | tail -1 > $O/bench_under_rocprof.json; cp $O/bench_under_rocprof.json $R/profiles/bench_${ROUND}_under_rocprof.json; grep int4_mm_kernel "$f" | cut -c1-60,230-330; else echo "no kernel_stats.csv"; tail -5 $O/rocprof_stats.log; fi
+# the same process's kernel trace cut to the line's timed replays: sum of kernel time per step next to the step time (round 6)
+( cd $R; timeout 300 python scripts/rocprof_crosscheck.py $O/prof_stats $O/bench_under_rocprof.json -o profiles/int4_rocprof_crosscheck_$ROUND.json | grep -E "ms_per_step|avg_kernel_us|frac_of|sum_kernel_le_span|span_over" )
 echo "== rocprof pmc, headline (separate passes), five-shape then merged layout =="
 for lay in five merged; do
   EXTRA=""; [ $lay = merged ] && EXTRA="--merged"
@@ -44,7 +46,7 @@ for c in int4_bs128 int8 mx fp8; do
   timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_cfg_${c}_write -o cfg -- $CFG_CMD --configs $c $EXTRA > $O/rocprof_cfg_${c}_write.log 2>&1
   ( cd $R; python scripts/pmc_summary.py $O/prof_cfg_${c}_fetch $O/prof_cfg_${c}_write -o $O/cfg_${c}_pmc.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --configs $c --steps 2" > /dev/null )
 done
-timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg_stats -o cfg -- $CFG_CMD --configs int4_bs128,fp8,mx --fp8-layers 8 > $O/rocprof_cfg_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg_stats -o cfg -- $CFG_CMD --configs int4_bs128,int8,fp8,mx --fp8-layers 8 > $O/rocprof_cfg_stats.log 2>&1
 f=$(find $O/prof_cfg_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/configs_kernel_stats.csv && cp "$f" $R/profiles/configs_kernel_stats_$ROUND.csv && head -8 "$f" | cut -c1-160
 O=$O R=$R ROUND=$ROUND python - <<'PY'
 import csv, glob, json, os

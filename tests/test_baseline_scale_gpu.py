@@ -59,6 +59,35 @@ def test_int4_mm_baseline_shapes_vs_oracle(n, k, m):
     assert np.mean(y == y_ref) > 0.97
 
 
+# ---- int4 at bs = 128: the BASELINE shapes through the DEFAULT dispatch, i.e. the launches bench.py's int4_bs128 config times ----
+@pytest.mark.parametrize("n,k,g,kernel", [(14336, 4096, 128, "int4_mm_w32_kernel"), (4096, 14336, 128, "int4_mm_rb_kernel"),
+                                          (4096, 4096, 128, "int4_mm_rb_kernel"), (6144, 4096, 128, "int4_mm_rb_kernel"),
+                                          (14336, 4096, 32, "int4_mm_w32_kernel"), (4096, 14336, 32, "int4_mm_rb_kernel")])
+def test_int4_mm_bs128_baseline_shapes_default_dispatch(n, k, g, kernel):
+    """int4_tile_packed_to_4d_tensor.py:243-299 at M = 128 on gate / up, down, o and qkv of Llama-3-8B: no forced mode, the kernel the
+    product dispatch picks is the one named here (and by bench.py's roofline entry), output against the C port of the reference's
+    dequant -> bf16 matmul path on a sample of columns, every row."""
+    from ao_amd import _lib
+
+    m = 128
+    assert _lib.lib().ao_int4_mm_kernel_name(m, n, k, g).decode() == kernel
+    w = _randn_bf16((n, k), n + k + g, 0.02, DEV)
+    x = _randn_bf16((m, k), n + k + g + 1, 1.0, DEV)
+    qdata, sz = ops.int4_quantize_tinygemm(w, g)
+    y = np_from_torch_bf16(ops.weight_int4pack_mm(x, qdata, g, sz))
+    # oracle on every 9th 16-row tile of the packed weight (+ the last): qdata dim 0 is N / 8 (the C port reads it in pairs: one 16-row
+    # MFMA tile = two 8-row blocks), scales dim 1 is N
+    tiles = np.unique(np.concatenate([np.arange(0, n // 16, 9), [n // 16 - 1]]))
+    blocks = (tiles[:, None] * 2 + np.arange(2)[None, :]).reshape(-1)
+    cols = (tiles[:, None] * 16 + np.arange(16)[None, :]).reshape(-1)
+    bi, ci = torch.from_numpy(blocks).to(DEV), torch.from_numpy(cols).to(DEV)
+    y_ref = bf16.from_bits(c_ref.int4_linear(_bits(x), qdata[bi].cpu().numpy(), _bits(sz[:, ci].contiguous()), len(cols), k, g))
+    ys = y[:, cols]
+    assert _rel(ys, y_ref) <= 1e-3
+    assert np.all(np.abs(ys - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -12)
+    assert np.mean(ys == y_ref) > 0.9
+
+
 # ---- MXFP8 grouped GEMM: Mixtral-8x7B expert shapes ------------------------------------------------------------------
 def _mixtral_offs(kind, rows=128, experts=8, seed=0):
     if kind == "uniform16":
@@ -124,6 +153,25 @@ def test_int8_dynamic_linear_m2048_vs_oracle(n, k):
     y_ref = c_ref.int8_dynamic_linear(_bits(x[ri]), wq[ci].cpu().numpy(), ws.flatten()[ci].cpu().numpy())
     got = _bits(y[ri][:, ci])
     assert np.array_equal(got, y_ref)  # int32 accumulation + the reference's two roundings: bit for bit
+
+
+@pytest.mark.parametrize("n,k", [(14336, 4096), (4096, 14336), (6144, 4096), (4096, 4096)])
+def test_int8_dynamic_linear_benched_chunk_vs_oracle(n, k):
+    """The launches bench.py's int8 config times: one 16384-row chunk per call (int8/kernels.py:114-144 + int8_tensor.py:305-359),
+    cast and matmul through the default dispatch; oracle on sampled rows x columns, bit for bit."""
+    m = 16384
+    x = _randn_bf16((m, k), n + 11, 1.0, DEV)
+    w = _randn_bf16((n, k), k + 13, 0.02, DEV)
+    wq, ws = ops.int8_quantize_rowwise(w)
+    xq, xs = ops.int8_quantize_rowwise(x)
+    y = ops.int8_scaled_mm(xq, xs, wq, ws)
+    rng = np.random.default_rng(n + k)
+    rows = np.unique(np.concatenate([[0, 255, 256, m - 257, m - 1], rng.integers(0, m, 40)]))
+    tiles = np.unique(np.concatenate([[0, n // 16 - 1], rng.integers(0, n // 16, 30)]))
+    cols = (tiles[:, None] * 16 + np.arange(16)[None, :]).reshape(-1)
+    ri, ci = torch.from_numpy(rows).to(DEV), torch.from_numpy(cols).to(DEV)
+    y_ref = c_ref.int8_dynamic_linear(_bits(x[ri]), wq[ci].cpu().numpy(), ws.flatten()[ci].cpu().numpy())
+    assert np.array_equal(_bits(y[ri][:, ci]), y_ref)
 
 
 @pytest.mark.parametrize("n,k", LLAMA8B + LLAMA70B_TP8)

@@ -219,3 +219,19 @@ def test_aten_overrides_opt_in_fresh_process():
     env = dict(os.environ, AO_MI355_OVERRIDE_ATEN="1")
     out = subprocess.run([sys.executable, "-c", _OVERRIDE_SCRIPT.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "override ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_torch_compile_fp16_activation_refuses_with_the_reason():
+    """fp16 / fp32 activations take an eager-only slow path (raw int32 GEMM, no fake kernel): under torch.compile the linear refuses with the
+    message that names the dtype, not with a FakeTensor data_ptr error; eager still works."""
+    from ao_amd.quantization import Int8DynamicActivationInt8WeightConfig, quantize_
+
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(512, 128, bias=False).to(torch.float16).to(DEV)
+    quantize_(lin, Int8DynamicActivationInt8WeightConfig())
+    x = torch.randn(4, 512, device=DEV, dtype=torch.float16)
+    assert lin(x).dtype == torch.float16  # eager: the slow path
+    torch._dynamo.reset()
+    with pytest.raises(Exception, match="takes bfloat16 activations"):
+        torch.compile(lin, fullgraph=True, backend="aot_eager")(x)
+    torch._dynamo.reset()

@@ -58,10 +58,12 @@ def test_hqq_only_with_tile_packed_and_plain_checks():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         quantize_(m, Float8DynamicActivationInt4WeightConfig())
     # the reference's default packing for this config is "preshuffled" (quant_api.py:646: an H100 layout whose checkpoints this backend
-    # does not write); the default HERE names the format that is written, "preshuffled" stays accepted as an alias (config.py);
-    # anything else fails with the reference's wording (:660-669)
+    # cannot write: Int4PreshuffledTensor's byte order is mslk's); the default HERE names the format that is written; "preshuffled" parses
+    # (upstream JSON decodes) and quantize_ refuses it with the reason (round 6); anything else fails with the reference's wording (:660-669)
     assert Float8DynamicActivationInt4WeightConfig().int4_packing_format == "plain"
     assert Float8DynamicActivationInt4WeightConfig(int4_packing_format="preshuffled").int4_packing_format == "preshuffled"
+    with pytest.raises(NotImplementedError, match="Int4PreshuffledTensor checkpoint"):
+        quantize_(m, Float8DynamicActivationInt4WeightConfig(int4_packing_format="preshuffled"))
     with pytest.raises(AssertionError, match="only preshuffled and plain int4_packing_format supported right now"):
         quantize_(m, Float8DynamicActivationInt4WeightConfig(int4_packing_format="tile_packed_to_4d"))
 
@@ -241,7 +243,12 @@ def test_config_json_roundtrip_and_reference_wire_format():
     assert got["int8_dyn_asym"].act_mapping_type == MappingType.ASYMMETRIC
     assert got["fp8_row"].granularity == [PerRow(), PerRow()] and got["fp8_row"].mm_config.use_fast_accum is True
     assert got["fp8_default"].granularity == [PerTensor(), PerTensor()]
-    assert got["fp8_int4"].int4_packing_format == "preshuffled"  # (accepted: an alias of "plain" here, config.py)
+    assert got["fp8_int4"].int4_packing_format == "preshuffled"  # (decodes; quantize_ refuses to write that checkpoint format: config.py)
+    # the reference's class has ONE field: this package's default config writes exactly the reference's key set (group_size, an extension,
+    # only appears when it is not the 128 the reference hard-codes)
+    assert set(config_to_dict(Float8DynamicActivationInt4WeightConfig())["_data"]) == set(ref["fp8_int4"]["_data"]) == {"int4_packing_format"}
+    assert config_to_dict(Float8DynamicActivationInt4WeightConfig(group_size=64))["_data"]["group_size"] == 64
+    assert config_from_dict(config_to_dict(Float8DynamicActivationInt4WeightConfig(group_size=64))).group_size == 64
     fqn = got["fqn"]
     assert isinstance(fqn, FqnToConfig) and fqn.fqn_to_config["lm_head"] is None
     assert fqn.fqn_to_config["re:.*q_proj"].group_size == 64 and isinstance(fqn.fqn_to_config["_default"], Float8DynamicActivationFloat8WeightConfig)
@@ -259,3 +266,22 @@ def test_config_json_roundtrip_and_reference_wire_format():
         config_from_dict({"_type": "NoSuchConfig", "_data": {}})
     with pytest.raises(NotImplementedError):
         config_to_dict(FqnToConfig({"x": Int4WeightOnlyConfig()}, version=1).__class__(fqn_to_config={"t": (1, 2)}))
+
+
+def test_peer_memory_device_identity_fails_closed():
+    """ao_amd/peer_mem.py: the guard that keeps flag polling off coarse-grained memory across GPUs must read "cannot tell which GPU" as
+    unknown (-> RCCL), not as "everybody shares one GPU" (ADVICE r5)."""
+    from types import SimpleNamespace as P
+
+    from ao_amd.peer_mem import _device_ident
+
+    assert _device_ident("h", None, P()) is None  # older torch: no uuid, no PCI ids
+    assert _device_ident("h", None, P(uuid="", pci_bus_id=-1, pci_device_id=-1)) is None
+    assert _device_ident("h", None, P(uuid="00000000-0000-0000-0000-000000000000")) is None  # a zeroed uuid is truthy and says nothing
+    a = _device_ident("h", None, P(uuid="GPU-11aa", pci_domain_id=0, pci_bus_id=5, pci_device_id=0))
+    b = _device_ident("h", None, P(uuid="GPU-22bb", pci_domain_id=0, pci_bus_id=6, pci_device_id=0))
+    assert a is not None and b is not None and a != b
+    # identical (zeroed) uuids on different PCI functions are different GPUs; the PCI domain counts
+    c = _device_ident("h", None, P(uuid="0000", pci_domain_id=0, pci_bus_id=5, pci_device_id=0))
+    d = _device_ident("h", None, P(uuid="0000", pci_domain_id=1, pci_bus_id=5, pci_device_id=0))
+    assert c is not None and d is not None and c != d

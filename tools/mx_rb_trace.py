@@ -70,6 +70,24 @@ if (t[:, 15] != 0).any():  # the stream-K kernel reports the steps of each share
     steps = float(t[:, 15].mean())
     sev = (t[:, 9] != 0) & (t[:, 2] != 0)
     print(f"  stream-K: {steps:.1f} steps per share; first 7 steps {((t[sev, 9] - t[sev, 2]) / 7).mean():.1f} ticks per step; meet + stores {int((t[:, 12] - t[:, 10]).mean())}")
+full = trace.cpu().view(-1, 16).numpy().astype(np.int64)
+if os.environ.get("AO_TRACE_DUMP"):  # raw stamps, row = workgroup id (blockIdx.x)
+    np.save(os.environ["AO_TRACE_DUMP"], full[: max(1, int(np.nonzero(full[:, 0])[0].max()) + 1)])
+if (t[:, 3] != 0).all() and (t[:, 4] != 0).all() and (t[:, 15] != 0).any():
+    # where the launch's tail comes from: a workgroup's exit time against its id (share position = slab), its XCD (id % 8), its loop rate
+    wid = np.nonzero(full[:, 0])[0]
+    ex = (t[:, 4] - t[:, 3].min()) / 100.0
+    loop = (t[:, 10] - t[:, 2]) / np.maximum(t[:, 15], 1)
+    thirds = np.array_split(np.arange(len(wid)), 6)
+    print("  exit us by sixth of the grid (share order): " + " ".join(f"{ex[i].mean():.1f}" for i in thirds) + " | loop ticks per step by sixth: " + " ".join(f"{loop[i].mean():.0f}" for i in thirds))
+    print("  exit us by XCD (id % 8): " + " ".join(f"{ex[wid % 8 == x].mean():.1f}" for x in range(8)) + " | loop ticks per step by XCD: " + " ".join(f"{loop[wid % 8 == x].mean():.0f}" for x in range(8)))
+    print(f"  loop ticks per step p10 {np.percentile(loop, 10):.0f} p50 {np.percentile(loop, 50):.0f} p90 {np.percentile(loop, 90):.0f} max {loop.max():.0f}; tail ticks p10 {np.percentile(t[:, 12] - t[:, 10], 10):.0f} p50 {np.percentile(t[:, 12] - t[:, 10], 50):.0f} p90 {np.percentile(t[:, 12] - t[:, 10], 90):.0f} max {(t[:, 12] - t[:, 10]).max()}")
+if (t[:, 3] != 0).all() and (t[:, 4] != 0).all():  # 100 MHz stamps (s_memrealtime) at entry / exit: wall time of the launch and the shader clock inside it
+    span_rt = (t[:, 4].max() - t[:, 3].min()) / 100.0
+    mhz = ((t[:, 12] - t[:, 0]) / np.maximum(t[:, 4] - t[:, 3], 1) * 100.0)
+    print(f"  realtime: launch span {span_rt:.1f} us (first entry -> last exit), workgroup life {((t[:, 4] - t[:, 3]) / 100.0).mean():.1f} us mean / {((t[:, 4] - t[:, 3]) / 100.0).max():.1f} max; "
+          f"shader clock while resident {mhz.mean():.0f} MHz (p10 {np.percentile(mhz, 10):.0f}, p90 {np.percentile(mhz, 90):.0f}); entry spread {((t[:, 3] - t[:, 3].min()) / 100.0).max():.1f} us, "
+          f"exit p10 {np.percentile(t[:, 4] - t[:, 3].min(), 10) / 100.0:.1f} p50 {np.percentile(t[:, 4] - t[:, 3].min(), 50) / 100.0:.1f} p90 {np.percentile(t[:, 4] - t[:, 3].min(), 90) / 100.0:.1f} us")
 print(f"N={n} K={k} sizes={sizes} ({act} active): {us:.1f} us eager back-to-back, {us_graph:.1f} us in a hipGraph; {len(t)} workgroups traced; "
       f"ticks (s_memtime: shader cycles): prime {int((t[:, 1] - t[:, 0]).mean())} (group found at {int((t[:, 13] - t[:, 0]).mean())}, addresses at {int((t[:, 14] - t[:, 0]).mean())}), first data {int((t[:, 2] - t[:, 1]).mean())}, "
       f"per step {d.mean():.1f} (first 7 steps), whole loop {int((t[:, 10] - t[:, 2]).mean())} = {(t[:, 10] - t[:, 2]).mean() / steps:.1f} per step, "
