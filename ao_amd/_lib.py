@@ -30,6 +30,7 @@ _SIGNATURES = {
     "ao_abi_version": [],
     "ao_prof_enable": [_INT],
     "ao_prof_collect": [_P, _INT, _P],
+    "ao_splitk_reserve": [_P, _I64],
     "ao_int4_convert_weight_to_int4pack": [_P, _P, _I64, _I64, _INT, _P],
     "ao_int4_unpack_int4pack": [_P, _P, _I64, _I64, _INT, _P],
     "ao_int4_weight_int4pack_mm": [_P, _P, _P, _P, _I64, _I64, _I64, _INT, _P],

@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "_C_mi355.so")
 OPS_LIB = os.path.join(HERE, "_C_mi355_ops.so")  # C++ dispatcher registrations (csrc_torch/binding.cpp), links against LIB
 OPS_SRC = os.path.join(HERE, "csrc_torch", "binding.cpp")
+OPS_SRC_STABLE = os.path.join(HERE, "csrc_torch", "binding_stable.cpp")  # torchao:: ops through the stable ABI (no ATen / c10 headers)
 CXX = os.environ.get("CXX", "g++")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
@@ -49,14 +50,14 @@ def _stale():
 
 def build_ops(force=False, verbose=False):
     """Compile the host-only dispatcher binding against the installed torch (no device code: plain g++)."""
-    if not force and os.path.exists(OPS_LIB) and os.path.getmtime(OPS_LIB) >= max(os.path.getmtime(OPS_SRC), os.path.getmtime(LIB)):
+    if not force and os.path.exists(OPS_LIB) and os.path.getmtime(OPS_LIB) >= max(os.path.getmtime(OPS_SRC), os.path.getmtime(OPS_SRC_STABLE), os.path.getmtime(LIB)):
         return OPS_LIB
     import torch
 
     t = os.path.dirname(torch.__file__)
     cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
-           f"-I{t}/include", f"-I{t}/include/torch/csrc/api/include", "-I/opt/rocm/include", OPS_SRC, "-o", OPS_LIB,
+           f"-I{t}/include", f"-I{t}/include/torch/csrc/api/include", "-I/opt/rocm/include", OPS_SRC, OPS_SRC_STABLE, "-o", OPS_LIB,
            f"-L{t}/lib", "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip", f"-L{HERE}", "-l:_C_mi355.so",
            "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{t}/lib"]
     if verbose:

@@ -45,6 +45,7 @@ int dec8_scaled(bool int8, const void* xq, const float* x_scale, const void* wq,
                 int64_t M, int64_t N, int64_t K, hipStream_t stream);
 void mx_rb_set_slim(bool on);          // rb8_kernels.hip
 void mx_rb_set_stream(int mode, bool quad);
+void mx_stream_set_tuning(int proto);
 int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
                    int64_t M, int64_t N, int64_t K, hipStream_t stream);
 int int8_scaled_rb(const int8_t* a, const int8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
@@ -465,7 +466,7 @@ extern "C" int ao_gemm8_set_variant(int variant) {
   mx_rb_set_slim(variant != 112);
   // MX decode groups: 113 one workgroup per tile; stream-K forms 119 (the product's, forced), 118 (4 waves x 3 stages), 114 (4 x 6); 129 / 128 = 119 / 118 with
   // the scales fetched per step instead of per 4 steps
-  mx_rb_set_stream((variant == 112 || variant == 113) ? 0 : (variant == 114) ? 2 : (variant == 118 || variant == 128) ? 3 : (variant == 119 || variant == 129) ? 4 : 1,
+  mx_rb_set_stream((variant == 112 || variant == 113) ? 0 : (variant == 114) ? 2 : (variant == 118 || variant == 128) ? 3 : (variant == 119 || variant == 129) ? 4 : (variant == 116) ? 5 : 1,
                    variant != 128 && variant != 129);
   // the straight-line decode kernel (dec8_kernels.hip): 201 / 202 / 204 / 207 / 208 force its ring depth, 290 half-line loads, 299 never
   g_dec8_mode = (variant >= 200 && variant <= 299) ? variant : 0;
@@ -480,8 +481,9 @@ extern "C" int ao_gemm8_set_variant(int variant) {
 
 namespace ao { namespace { thread_local int g_tune[16] = {0}; } }
 extern "C" int ao_gemm8_set_tuning(int key, int value) {
-  AO_REQUIRE(key >= 1 && key <= 8, "ao_gemm8_set_tuning: unknown key %d", key);
+  AO_REQUIRE(key >= 1 && key <= 9, "ao_gemm8_set_tuning: unknown key %d", key);
   g_tune[key] = value;
+  mx_stream_set_tuning(g_tune[9]);
   rb8_set_tuning(g_tune[1], g_tune[2], g_tune[3], g_tune[5], g_tune[6]);
   gemm8_p8_set_group_rows(g_tune[4]);
   gemm8_p8_set_split(g_tune[7]);

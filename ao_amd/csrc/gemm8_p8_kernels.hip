@@ -593,7 +593,7 @@ int launch_p8h(P8Args p, hipStream_t stream) {
   p.split = p8h_split(p.M, p.N, p.K);
   if (p.split > 1) {
     const int NG = (p.split + 3) / 4;
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)p.tiles_m * p.tiles_n * (p.split + NG) * 256 * 128)) return rc;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)p.tiles_m * p.tiles_n * (p.split + NG) * 256 * 128, p.split)) return rc;
   }
 #ifdef AO_LAB  // the measured-and-rejected loop forms (profiles/p8h_loop_forms_r05.jsonl) only exist in the laboratory build
   if (EPI == P8_FP8_ROWWISE && g_p8h_form == 1) {
@@ -640,7 +640,7 @@ int launch_p8(P8Args p, hipStream_t stream) {
   p.split = p8_split(p.M, p.N, p.K);
   if (p.split > 1) {
     const int NG = (p.split + 3) / 4;
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)p.tiles_m * p.tiles_n * (p.split + NG) * 256 * 256)) return rc;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)p.tiles_m * p.tiles_n * (p.split + NG) * 256 * 256, p.split)) return rc;
   }
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8_kernel<EPI>), kSmem, "hipFuncSetAttribute(gemm8_p8_kernel)")) return rc;
   ao::launch(gemm8_p8_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split)), dim3(512), kSmem, stream, p);

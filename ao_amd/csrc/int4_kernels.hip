@@ -1053,7 +1053,7 @@ int launch_mm_w32(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, u
   if (split > 1) {
     AO_REQUIRE((int64_t)grid.x * grid.y * split <= kSplitMaxTiles, "int4_mm_w32: %u x %u tiles x %d parts exceed the split-K workspace", grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets - 8, "int4_mm_w32: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * 128 * 128)) return rc;
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * 128 * 128, split)) return rc;
   }
   auto kern = int4_mm_w32_kernel<G, PROD, ABL>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_w32_kernel)")) return rc;
@@ -1083,7 +1083,7 @@ int launch_mm_rb(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, ui
     AO_REQUIRE((int64_t)grid.x * grid.y * split * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "int4_mm_rb: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets, "int4_mm_rb: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * BN * BM)) return rc;
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * BN * BM, split)) return rc;
   }
   auto kern = int4_mm_rb_kernel<G, WAVES, NT, MT, ABL, PROD>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_rb_kernel)")) return rc;
@@ -1282,7 +1282,7 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
   if (split > 1) {
     AO_REQUIRE(ntiles * mslabs <= kSplitMaxTickets && ntiles * mslabs * split * 256 <= (int64_t)kSplitSlotFloats, "int4_mm: %lld tiles x %d parts exceed the split-K workspace",
                (long long)(ntiles * mslabs), split);
-    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)(ntiles * mslabs) * split * 256)) return rc;
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)(ntiles * mslabs) * split * 256, split)) return rc;
   }
   const size_t smem = (size_t)wpb * (SLAB + 1024 * TILES);
   dim3 grid((unsigned)(ntiles / TILES), (unsigned)mslabs, (unsigned)split), block(wpb * 64);

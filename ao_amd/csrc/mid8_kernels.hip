@@ -237,7 +237,7 @@ int launch_mid8(Mid8Args p, int split, hipStream_t stream) {
   const size_t tiles = (size_t)grid.x * grid.y;
   const size_t part_floats = (split > 1) ? tiles * (split + (split + 3) / 4) * 128 * BM : 0;
   if (split > 1) {
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, part_floats)) return rc;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, part_floats, split)) return rc;
   }
   auto kern = mid8_kernel<INT8, MT, kG>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(mid8_kernel)")) return rc;

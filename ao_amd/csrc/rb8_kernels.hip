@@ -661,12 +661,15 @@ template <int WAVES, int SW, int QS, bool TRACE>
 __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   static_assert(QS == 1 || (QS == 4 && SW == 3), "mx_stream_kernel: scale fetches per step, or per 4 steps with 3 weight stages");
   constexpr int MT = 4, BM = 64, BN = 16 * WAVES, SCL = 64, kABuf = MT * 2048, NTHR = 64 * WAVES;
-  constexpr int AD = 8 / WAVES;     // activation DMAs per wave and step (8 rows each): the tile is shared by the workgroup's waves
+  constexpr int AD = (WAVES >= 8) ? 1 : 8 / WAVES;  // activation DMAs per wave and step (8 rows each): the tile is shared by the workgroup's waves (16 waves: the first 8 fetch)
   constexpr int RPW = BM / WAVES;   // activation-scale rows fetched per wave
   constexpr int LPSC = AD + 2 + (QS == 1 ? 2 : 0);  // DMAs of one stage (activations, weights; QS == 1: + the scales of both)
   constexpr int ASB = (QS == 1) ? SCL : RPW * 16, BSB = (QS == 1) ? SCL : 256;  // bytes of one scale slot (activations per wave, weights per wave)
   constexpr int ASN = (QS == 1) ? kStages : 2, BSN = (QS == 1) ? SW : 2;          // slots per wave
-  static_assert(WAVES == 4 || WAVES == 8, "mx_stream_kernel: 4 or 8 waves");
+  // 16 waves (round 6): ONE workgroup per CU over 256-column tiles -- half the activation re-reads per weight byte, and no second, younger
+  // workgroup on the CU that the instruction arbiter serves last (the round-6 traces); its activation pieces are only requested where the
+  // group has rows (QS == 4: a_cnt), so waves 8 .. 15 never issue one
+  static_assert(WAVES == 4 || WAVES == 8 || (WAVES == 16 && QS == 4), "mx_stream_kernel: 4 or 8 waves, or 16 with the scales per 4 steps");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) { ts[0] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime(); }  // [3] / [4]: the 100 MHz clock at entry / exit
   // [3][64][128 B] a | [WAVES][SW][2 KiB] b | a scales [ASN][WAVES][ASB] | b scales [WAVES][BSN][BSB]
@@ -697,12 +700,32 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   }
   const int excl = incl - ns;
   const int nslabs = __builtin_amdgcn_readlane(incl, 63);
-  const long long G = (long long)nslabs * NT * ksteps;  // < 2^31 (launcher)
-  const long long GQ = G / QS;                           // shares are cut at multiples of QS steps (ksteps % QS == 0: launcher)
-  const long long W = min((long long)gridDim.x, max(1ll, G / kStreamMinShare));
+  const int G = nslabs * NT * ksteps;  // < 2^31 (launcher)
+  const int GQ = G / QS;                // shares are cut at multiples of QS steps (ksteps % QS == 0: launcher)
+  const int W = min((int)gridDim.x, max(1, G / kStreamMinShare));
   const int w = blockIdx.x;
   if (w >= W) return;  // uniform, before any DMA or barrier
-  const int g0 = (int)(GQ * w / W) * QS, g1 = (int)(GQ * (w + 1) / W) * QS;
+  // Shares (round 6: one 32-bit division here, one per owner() -- the GQ * v / W of rounds 3 - 5 were 64-bit divisions, ~300 scalar
+  // instructions each, four to eight of them on every workgroup's way in and out): the first `sr` workgroups take sq + 1 units of QS
+  // steps, the others sq.  B(v) = where workgroup v's share begins, owner(Q) = the workgroup whose share holds unit Q.
+  const unsigned sq = (unsigned)GQ / (unsigned)W, sr = (unsigned)GQ - sq * (unsigned)W;  // sq >= 4 / QS * 4 >= 1: W <= G / 16
+  auto B = [&](int v) { return (int)((unsigned)v * sq + min((unsigned)v, sr)); };
+  auto owner = [&](int Q) {
+    const unsigned big = sr * (sq + 1);
+    return (int)(((unsigned)Q < big) ? (unsigned)Q / (sq + 1) : sr + ((unsigned)Q - big) / sq);
+  };
+  // the pieces of a tile that share boundaries cut: workgroups wf .. wf + S - 1 hold one each, parked in slot 2 v (the piece v's share
+  // BEGINS with) or 2 v + 1 (the piece it ENDS with, when that is another one) -- every piece but the tile's first begins its share
+  struct Cut { int S, wf, first_odd; };
+  auto cut_of = [&](int tile) {
+    const int T0 = tile * (ksteps / QS);
+    Cut c;
+    c.wf = owner(T0);
+    c.S = owner(T0 + ksteps / QS - 1) - c.wf + 1;
+    c.first_odd = (T0 > B(c.wf)) ? 1 : 0;
+    return c;
+  };
+  const int g0 = B(w) * QS, g1 = B(w + 1) * QS;
   if (g0 >= g1) return;
   auto find = [&](int y, int& expert, int& m0, int& m_end) {  // y-th non-empty slab; wave-uniform, registers only
     const unsigned long long hit = __ballot(incl > y);
@@ -807,13 +830,14 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     }
     return cnt;
   };
-  auto wait_upto = [&](int n) {  // s_waitcnt vmcnt(n) for a wave-uniform n in [2, AD + 4] (the immediate has to be a constant)
+  auto wait_upto = [&](int n) {  // s_waitcnt vmcnt(n) for a wave-uniform n in [2, AD + 5] (the immediate has to be a constant)
     switch (n) {
       case 2: wait_vmcnt<2>(); break;
       case 3: wait_vmcnt<3>(); break;
       case 4: wait_vmcnt<4>(); break;
       case 5: wait_vmcnt<5>(); break;
-      default: wait_vmcnt<6>(); break;
+      case 6: wait_vmcnt<6>(); break;
+      default: wait_vmcnt<7>(); break;
     }
   };
   // ---- compute cursor
@@ -853,7 +877,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   constexpr int kRegBytes = NTHR * 16, kPartBytes = MT * kRegBytes;
   const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, 0x7fffffff, 0x00020000);
   auto park = [&](const f32x4 (&v)[MT], int tile, int mth) {  // mth: m-tiles the tile's group has (only those are parked and read)
-    const int mine = (2 * w + (((long long)tile * ksteps > g0) ? 1 : 0)) * kPartBytes;  // same rule as the reader's below
+    const int mine = (2 * w + ((tile * ksteps > g0) ? 1 : 0)) * kPartBytes;  // same rule as the reader's (cut_of)
 #pragma unroll
     for (int r = 0; r < MT; ++r)
       if (r < mth) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[r]), rws, tid * 16 + r * kRegBytes, mine, kSc1);
@@ -863,6 +887,15 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   };
   bool has_head = false;
   int head_tile = 0, head_m0 = 0, head_mend = 0, head_nt = 0, head_mth = 0;
+  // round 6 (see the meeting below): the head piece's ticket is taken from the loop `head_wait` steps after it was parked (wave 1, lane 0:
+  // head_t; `lenient` = the steps whose wait lets that one returning atomic stay in flight); the tail tile's ticket word is read two steps
+  // before the share ends.  p.ablate (A/B): 1 head ticket after the loop, 2 no early read -- the round-3 protocol.
+  int head_wait = 0, lenient = 0;
+  unsigned head_t = 0u, peek = 0xffffffffu;
+  const int tile_last = (g1 - 1) / ksteps;
+  const bool tail_is_piece = !(tile_last * ksteps >= g0 && (tile_last + 1) * ksteps == g1);
+  const int g_peek = (tail_is_piece && g1 - g0 >= 3 && !(p.ablate & 2)) ? g1 - 2 : -1;
+  const __amdgpu_buffer_rsrc_t rtk = __builtin_amdgcn_make_buffer_rsrc(p.tickets, 0, 0x7fffffff, 0x00020000);
   const int pa = nl * 128 + (((kq ^ (nl >> 1)) & 7) << 4);
 
   // Issue order (SW >= 4): w(0 .. SW-4) | a(0) w(SW-3) | a(1) w(SW-2), then per step a(i+2) w(i+SW-1): when step i starts the youngest
@@ -877,9 +910,12 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   int a_prev = issue_a(1), s_prev = 0;  // QS == 4: what the step before issued besides its two weight DMAs (= all that may be in flight)
   issue_w(SW - 2);
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
+  // the share's (at most two) cut tiles, worked out while the first data is on its way: the tail needs no division
+  const Cut cut_head = (k00 != 0) ? cut_of(tile0) : Cut{1, w, 0};
+  const Cut cut_tail = tail_is_piece ? cut_of(tile_last) : Cut{1, w, 0};
   int stage = 0, wstage = 0;
   for (int g = g0; g < g1; ++g) {
-    if constexpr (QS == 4) wait_upto(a_prev + 2 + s_prev);
+    if constexpr (QS == 4) { wait_upto(a_prev + 2 + s_prev + (lenient > 0 ? 1 : 0)); lenient = max(lenient - 1, 0); }
     else if constexpr (SW >= 4) wait_vmcnt<LPSC + 3>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading the step before
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -893,6 +929,14 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     }
     a_prev = issue_a((stage == 0) ? 2 : stage - 1);
     issue_w((wstage == 0) ? SW - 1 : wstage - 1);
+    // (both behind this step's DMAs: the next wait then only asks the oldest of them to have landed one step early)
+    if (head_wait > 0 && --head_wait == 0) {  // uniform.  The park's stores of every wave have retired (two waits, two barriers since)
+      if (wave == 1) {
+        if (lane == 0) head_t = __hip_atomic_fetch_add(&p.tickets[head_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (QS == 4) lenient = 2;  // the atomic may stay in flight across the next two waits (QS == 1: they ask for it, at worst a stall)
+      }
+    }
+    if (g == g_peek && wave == 0) peek = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rtk, 0, tile_last * 4, kSc1);
     const char* A = smem + stage * kABuf;
     const char* Wt = smem + kStages * kABuf + (wave * SW + wstage) * 2048;
     const u32x4 b0 = *reinterpret_cast<const u32x4*>(Wt + pa);  // the n-tile's 16 rows are laid out like an m-tile
@@ -923,6 +967,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
       } else {  // the share began inside this tile: its piece is parked now, its ticket is taken after the loop
         park(acc, tilec, mt_have);
         has_head = true; head_tile = tilec; head_m0 = m0c; head_mend = m_endc; head_nt = ntc; head_mth = mt_have;
+        head_wait = (p.ablate & 1) ? (1 << 30) : 2;
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -930,67 +975,91 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
       set_c(++tilec);
     }
   }
-  wait_vmcnt<0>();  // the repeated fills past the end still write LDS
+  wait_vmcnt<0>();  // the repeated fills past the end still write LDS; the in-loop ticket and the peek (below) have returned
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (TRACE) ts[10] = __builtin_amdgcn_s_memtime();
 
-  // The pieces of a cut tile meet: every piece parked and written through (the loop's last wait covered the head piece), ONE
-  // ticket round for both of the share's cut tiles (wave 0 takes the tail's, wave 1 the head's), the last arriver of a tile adds
-  // its pieces in k order and stores it.
-  auto owner = [&](long long g) { return (int)(((g / QS + 1) * W - 1) / GQ); };  // the workgroup whose share holds step g
+  // The pieces of a cut tile meet: every piece parked and written through, a ticket per piece, the last arriver of a tile adds its pieces
+  // in k order and stores it.  Round 6 (the round-6 traces: the tail -- park, drain, ticket, gather, store: three dependent round trips under
+  // load -- was 7.5 k ticks at the median and 15 - 21 k for the last workgroups to leave, 3 - 10 us of a 51 us launch):
+  //  * the HEAD piece (the end of a tile the share began in) is parked from the loop, and its ticket is taken from the loop too, two steps
+  //    later: the hand-counted waits of those two steps have retired the park's stores of every wave (VMEM retires in order) and the step's
+  //    barrier has seen them all -- nothing of it is left for the tail unless it turns out to be the tile's last arriver (it is the piece
+  //    that is done a whole share before the others);
+  //  * the TAIL piece: two steps before the end the ticket word is read (sc1).  If every other piece had arrived by then, this workgroup is
+  //    the last arriver whatever happens next: it does not park, takes no ticket, adds the others' pieces and its registers in k order and
+  //    stores -- one round trip instead of three.  Otherwise the round-3 protocol: park, drain, ticket, and the last arriver gathers.
+  // v = the tile's pieces added in k order; the piece of workgroup `self` (-1: none) comes from `mine` (registers) instead of the workspace
+  auto gather = [&](f32x4 (&v)[MT], const Cut& c, int mth, int self, const f32x4 (&mine)[MT]) {
+    f32x4 sum[MT];
+#pragma unroll
+    for (int r = 0; r < MT; ++r) sum[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < c.S; q0 += 4) {  // four pieces in flight; indices past S re-read the last piece and are not added
+      f32x4 x[4][MT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = min(q0 + u, c.S - 1), vq = c.wf + q;
+        const int slot = (2 * vq + (q == 0 ? c.first_odd : 0)) * kPartBytes;
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+          x[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (vq == self) x[u][r] = mine[r];  // uniform
+          else if (r < mth) x[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, slot, kSc1));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool keep = q0 + u < c.S;
+#pragma unroll
+        for (int r = 0; r < MT; ++r) {
+          sum[r].x += keep ? x[u][r].x : 0.f; sum[r].y += keep ? x[u][r].y : 0.f;
+          sum[r].z += keep ? x[u][r].z : 0.f; sum[r].w += keep ? x[u][r].w : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < MT; ++r) v[r] = sum[r];
+  };
   const bool tail_whole = (kb == 0 && kc == ksteps);  // the share's last tile: whole (never cut) or a piece
-  if (tail_whole) store_tile(acc, m0c, m_endc, ntc);
-  else park(acc, tilec, mt_have);
-  if (!has_head && tail_whole) { /* nothing of this share meets */ }
-  else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the tickets are taken
+  bool tail_meets = false;
+  if (tail_whole) {
+    store_tile(acc, m0c, m_endc, ntc);
+  } else {
+    // ONE wave's reading decides for the workgroup (the waves issued their loads at different instants of the step: one may have seen
+    // S - 2 arrivals and its neighbour S - 1 -- the round-6 build that let every wave decide for itself stored a few torn tiles per launch)
+    unsigned* seen_lds = reinterpret_cast<unsigned*>(smem);  // (every wave is past the loop's last LDS read: the barrier above)
+    if (tid == 0) seen_lds[2] = peek;
+    __syncthreads();
+    const unsigned seen = seen_lds[2];  // 0xffffffff: not read (a share of fewer than three steps)
+    if (seen == (unsigned)(cut_tail.S - 1)) {  // everyone else's piece is parked, written through and ticketed: this one is the last arriver
+      gather(acc, cut_tail, mt_have, w, acc);
+      store_tile(acc, m0c, m_endc, ntc);
+      if (tid == 0) __hip_atomic_store(&p.tickets[tilec], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    } else {
+      park(acc, tilec, mt_have);
+      tail_meets = true;
+    }
+  }
+  const bool head_late = has_head && head_wait > 0;  // parked in the share's last two steps: its ticket is still to be taken
+  if (has_head || tail_meets) {
+    if (tail_meets || head_late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the tickets are taken
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
     if (lane == 0 && wave < 2) {
-      const bool mine = (wave == 0) ? !tail_whole : has_head;
-      const int tile = (wave == 0) ? tilec : head_tile;
       int last = 0;
-      if (mine) {
-        const long long t0 = (long long)tile * ksteps;
-        const unsigned S = (unsigned)(owner(t0 + ksteps - 1) - owner(t0) + 1);
-        const unsigned t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((wave == 0) ? tail_meets : has_head) {
+        const int tile = (wave == 0) ? tilec : head_tile;
+        unsigned t = head_t;  // (wave 1, lane 0: the ticket taken from the loop)
+        if (wave == 0 || head_late) t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned S = (unsigned)((wave == 0) ? cut_tail.S : cut_head.S);
         last = (t == S - 1);
         if (last) __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
       }
       flag[wave] = last;
     }
     __syncthreads();
-    auto gather = [&](f32x4 (&v)[MT], int tile, int mth) {
-      const long long t0 = (long long)tile * ksteps;
-      const int wf = owner(t0), S = owner(t0 + ksteps - 1) - wf + 1;
-#pragma unroll
-      for (int r = 0; r < MT; ++r) v[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int q0 = 0; q0 < S; q0 += 4) {  // four pieces in flight; indices past S re-read the last piece and are not added
-        f32x4 x[4][MT];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int vq = wf + min(q0 + u, S - 1);
-          const long long gv = GQ * vq / W * QS;  // where workgroup vq's share begins: its piece of this tile begins the share unless the tile starts later
-          const int slot = (2 * vq + ((t0 > gv) ? 1 : 0)) * kPartBytes;
-#pragma unroll
-          for (int r = 0; r < MT; ++r) {
-            x[u][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (r < mth) x[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, tid * 16 + r * kRegBytes, slot, kSc1));
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool keep = q0 + u < S;
-#pragma unroll
-          for (int r = 0; r < MT; ++r) {
-            v[r].x += keep ? x[u][r].x : 0.f; v[r].y += keep ? x[u][r].y : 0.f;
-            v[r].z += keep ? x[u][r].z : 0.f; v[r].w += keep ? x[u][r].w : 0.f;
-          }
-        }
-      }
-    };
-    if (flag[0]) { gather(acc, tilec, mt_have); store_tile(acc, m0c, m_endc, ntc); }
-    if (flag[1]) { gather(acc, head_tile, head_mth); store_tile(acc, head_m0, head_mend, head_nt); }
+    if (flag[0]) { gather(acc, cut_tail, mt_have, -1, acc); store_tile(acc, m0c, m_endc, ntc); }
+    if (flag[1]) { gather(acc, cut_head, head_mth, -1, acc); store_tile(acc, head_m0, head_mend, head_nt); }
   }
   if (TRACE && p.trace != nullptr && tid == 0) {
     ts[11] = ts[12] = __builtin_amdgcn_s_memtime();
@@ -1030,7 +1099,7 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
     AO_REQUIRE((int64_t)grid.x * grid.y * slots * BN * BM <= (int64_t)kSplitMaxTiles * 128 * 128, "rb8: %u x %u tiles x %d parts exceed the split-K workspace",
                grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y * tks <= kSplitMaxTickets - 8, "rb8: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * slots * BN * BM)) return rc;
+    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * slots * BN * BM, split)) return rc;
     // All K parts of a tile on one XCD (ids that agree mod 8; measured per device, checked per tile: splitk.h) and the parked tiles in that
     // XCD's L2.  Built and parity-clean, but OPT-IN (ao_gemm8_set_tuning(3, 2)): next to the write-through meeting it measured +- 2 % on all
     // 40 cells of profiles/midm_sweep_r05.jsonl -- the meeting's cost is its three dependent round trips (stores acknowledged -> ticket ->
@@ -1055,6 +1124,7 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
   return AO_OK;
 }
 
+thread_local int g_mx_proto = 0;  // A/B (ao_gemm8_set_tuning key 9): 1 head ticket after the loop, 2 no early read of the tail ticket (1 | 2: the round-3 meeting)
 // Launch of the stream-K form: one workgroup per resident slot of the chip.
 constexpr int kChipCUs = 256;  // MI355X
 template <int WAVES, int SW, int QS>
@@ -1062,10 +1132,11 @@ int launch_mx_stream(Rb8Args p, hipStream_t stream) {
   constexpr size_t scales = (QS == 1) ? (size_t)(kStages + SW) * WAVES * 64 : (size_t)2 * WAVES * (64 / WAVES) * 16 + (size_t)WAVES * 2 * 256;
   constexpr size_t smem = (size_t)kStages * 4 * 2048 + (size_t)WAVES * SW * 2048 + scales;
   constexpr int per_cu = (int)((160 * 1024) / smem);
-  static_assert(per_cu >= 2, "mx_stream_kernel: at least two workgroups per CU");
+  static_assert(per_cu >= 2 || (WAVES == 16 && per_cu == 1), "mx_stream_kernel: two workgroups per CU (one of 16 waves)");
   const unsigned Wg = (unsigned)(per_cu * kChipCUs);
   if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)2 * Wg * 64 * 16 * WAVES)) return rc;
   p.trace = g_fp8_rb_trace;
+  p.ablate = g_mx_proto;  // the meeting protocol's A/B bits
   auto kern = (p.trace != nullptr) ? mx_stream_kernel<WAVES, SW, QS, true> : mx_stream_kernel<WAVES, SW, QS, false>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(mx_stream_kernel)")) return rc;
   ao::launch(kern, dim3(Wg), dim3(64 * WAVES), smem, stream, p);
@@ -1084,6 +1155,7 @@ void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
 void rb8_set_wave_grid(bool two_by_four) { g_rb8_sm = two_by_four; }
 void rb8_set_tuning(int bn, int split, int local_off, int ablate, int bm) { g_rb8_bn = bn; g_rb8_split = split; g_rb8_local = local_off; g_rb8_ablate = ablate; g_rb8_bm = bm; }
 void mx_rb_set_slim(bool on) { g_mx_slim_off = !on; }
+void mx_stream_set_tuning(int proto) { g_mx_proto = proto; }
 void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = quad; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
 bool fp8_rowwise_rb_forced() { return g_fp8_rb_force >= 2; }
@@ -1221,6 +1293,7 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
     {
       // scales fetched per 4 steps when K allows (16-byte pieces of 16-byte-aligned scale rows), else per step
       const bool quad = g_mx_quad && K % 512 == 0 && ((uintptr_t)a_scale % 16 == 0) && ((uintptr_t)b_scale % 16 == 0);
+      if (g_mx_stream == 5 && quad) return launch_mx_stream<16, 3, 4>(p, stream);  // (116) one 16-wave workgroup per CU, 256-column tiles
       if (g_mx_stream == 2) return launch_mx_stream<4, 6, 1>(p, stream);
       if (g_mx_stream == 3) return quad ? launch_mx_stream<4, 3, 4>(p, stream) : launch_mx_stream<4, 3, 1>(p, stream);
       return quad ? launch_mx_stream<8, 3, 4>(p, stream) : launch_mx_stream<8, 3, 1>(p, stream);

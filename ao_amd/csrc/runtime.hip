@@ -3,6 +3,8 @@
 #include <stdio.h>
 
 #include "common.h"
+
+#include <algorithm>
 #include "splitk.h"
 
 #include <atomic>
@@ -132,7 +134,8 @@ int split_alloc(SplitWs* w, size_t floats, int dev) {
 }
 }  // namespace
 
-int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_t need_floats) {
+int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_t need_floats, int parts) {
+  AO_REQUIRE(parts >= 1 && parts <= kSplitMaxParts, "split-K: %d K parts (the ticket encoding and the two-level meeting take 1 .. %d)", parts, kSplitMaxParts);
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return hip_failed(e, "hipGetDevice");
@@ -178,6 +181,19 @@ int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_
   return AO_OK;
 }
 
+}  // namespace ao
+
+// Pre-size the calling stream's split-K workspace (outside stream capture), so that every later launch on that stream -- whatever its
+// shape -- is capture-safe without a warm-up call.  bytes <= 0: the cap (128 MiB).
+extern "C" int ao_splitk_reserve(void* stream, int64_t bytes) {
+  using namespace ao;
+  size_t floats = bytes <= 0 ? kSplitSlotFloats : std::min<size_t>(kSplitSlotFloats, ((size_t)bytes + 3) / 4);
+  float* part = nullptr;
+  unsigned* tickets = nullptr;
+  return splitk_workspace((hipStream_t)stream, &part, &tickets, floats, 1);
+}
+
+namespace ao {
 bool splitk_xcd_local_ok() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;

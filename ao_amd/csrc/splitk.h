@@ -15,7 +15,11 @@ constexpr int kSplitMaxTiles = 2048;
 constexpr int kSplitMaxTickets = 16384;
 constexpr size_t kSplitSlotFloats = (size_t)kSplitMaxTiles * 128 * 128;  // 128 MiB
 // need_floats: what this launch parks (tiles x parts x tile floats); the slot grows to the largest request seen on its stream
-int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_t need_floats);
+// Tickets count arrivals in bits 0-7 (the same-XCD form packs the XCC-id sum into 8 more bits and the sum of squares into 12: it overflows
+// beyond ~36 parts); the two-level meeting gathers <= 4 groups of <= 4.  Every launcher passes its part count here and is refused beyond
+// kSplitMaxParts -- a ticket that can never read "last" would skip the epilogue silently.
+constexpr int kSplitMaxParts = 16;
+int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_t need_floats, int parts = 1);
 // True when the current device places workgroup b of a 1-D grid on XCD b % 8 (or has ONE XCD): measured once per device by a probe
 // launch (runtime.hip; outside stream capture, with the first workspace), AO_MI355_XCD_LOCAL=0 switches it off.  Launchers that get
 // `true` may put all K parts of an output tile on one XCD (xcd_grid_decode below) and let them meet in that XCD's L2.

@@ -3,10 +3,9 @@
 // device kernels for schemas defined in Python -- csrc/cuda/mx_kernels/mxfp8_extension.cpp:425-430).  This file is that for
 // gfx950: host-only C++ over the C ABI of include/ao_mi355.h (no device code here), dispatch key CUDA (= HIP on ROCm).
 //
-//   * TORCH_LIBRARY_IMPL(torchao, CUDA): torchao::mxfp8_quantize, torchao::fused_pad_token_groups,
-//     torchao::fused_unpad_token_groups -- the reference's own op names and schemas
-//     (prototype/mx_formats/kernels.py:1022-1026, prototype/moe_training/kernels/mxfp8/quant.py:1244-1246, 1319-1321).
-//     Schemas are defined by whoever imports first: torchao's Python, or ao_amd/torch_ops.py when torchao is absent.
+//   * (round 6) torchao::mxfp8_quantize, torchao::fused_pad_token_groups, torchao::fused_unpad_token_groups -- the reference's own op
+//     names -- are registered from binding_stable.cpp through STABLE_TORCH_LIBRARY_IMPL / TORCH_BOX, as the reference does; this file
+//     keeps what needs ATen argument kinds.
 //   * TORCH_LIBRARY_IMPL(aten, CUDA), only when AO_MI355_OVERRIDE_ATEN=1 is set when the library is loaded:
 //     aten::_weight_int4pack_mm, aten::_convert_weight_to_int4pack (int4_tile_packed_to_4d_tensor.py:202,287),
 //     aten::_int_mm (int8/kernels.py:38-40,70), aten::_scaled_mm with rowwise or tensorwise scales (float8/inference.py:104-123),
@@ -127,53 +126,6 @@ Tensor scaled_mm(const Tensor& self, const Tensor& mat2, const Tensor& scale_a, 
 }
 
 // ---- MXFP8 ------------------------------------------------------------------------------------------------------
-int scaling_mode_of(const std::string& s, const char* op) {
-  if (s == "floor") return AO_MX_SCALE_FLOOR;
-  if (s == "rceil") return AO_MX_SCALE_RCEIL;
-  TORCH_CHECK(false, op, ": scaling_mode must be 'floor' or 'rceil', got: ", s);
-  return 0;
-}
-
-// torchao::mxfp8_quantize(Tensor input, bool rowwise, bool colwise, int scale_dim_x, int scale_dim_y, str fp8_format,
-//                         str scaling_mode) -> (Tensor, Tensor, Tensor, Tensor)      (mxfp8_extension.cpp:109-188)
-std::tuple<Tensor, Tensor, Tensor, Tensor> mxfp8_quantize(const Tensor& input, bool rowwise, bool colwise, int64_t scale_dim_x,
-                                                          int64_t scale_dim_y, std::string fp8_format, std::string scaling_mode) {
-  const char* op = "mxfp8_quantize";
-  check_gpu(input, op, "input");
-  TORCH_CHECK(input.is_contiguous(), op, ": input must be contiguous");
-  TORCH_CHECK(input.dim() == 2, op, ": input must be 2D");
-  TORCH_CHECK(input.scalar_type() == at::kBFloat16, op, ": input must be bfloat16 on MI355X (the float32 flavour of the reference is not on the inference path)");
-  TORCH_CHECK(rowwise || colwise, op, ": At least one of rowwise or colwise must be true");
-  TORCH_CHECK(scale_dim_x == 1 || scale_dim_x == 32, op, ": scale_dim_x must be 1 or 32, got: ", scale_dim_x);
-  TORCH_CHECK(scale_dim_y == 1 || scale_dim_y == 32, op, ": scale_dim_y must be 1 or 32, got: ", scale_dim_y);
-  TORCH_CHECK(fp8_format == "e4m3", op, ": fp8_format must be 'e4m3', got: ", fp8_format);
-  TORCH_CHECK(!rowwise || scale_dim_x == 32, op, ": rowwise output requires scale_dim_x == 32");
-  TORCH_CHECK(!colwise || scale_dim_y == 32, op, ": colwise output requires scale_dim_y == 32");
-  const int mode = scaling_mode_of(scaling_mode, op);
-  const int64_t rows = input.size(0), cols = input.size(1);
-  TORCH_CHECK(rows >= 32 && rows % 32 == 0, op, ": rows must be a multiple of 32");
-  TORCH_CHECK(cols >= 32 && cols % 32 == 0, op, ": cols must be a multiple of 32");
-  c10::DeviceGuard guard(input.device());
-  const auto o8 = input.options().dtype(at::kFloat8_e4m3fn), oe = input.options().dtype(at::kFloat8_e8m0fnu);
-  Tensor out_r = at::empty({0}, o8), out_c = at::empty({0}, o8), sc_r = at::empty({0}, oe), sc_c = at::empty({0}, oe);
-  const uint16_t* x = reinterpret_cast<const uint16_t*>(input.data_ptr());
-  if (rowwise) {
-    out_r = at::empty({rows, cols}, o8);
-    sc_r = at::empty({rows, cols / 32}, oe);
-    check_rc(ao_mxfp8_quantize_rowwise(x, reinterpret_cast<uint8_t*>(out_r.data_ptr()), reinterpret_cast<uint8_t*>(sc_r.data_ptr()), rows, cols,
-                                       mode, current_stream(input)), op);
-  }
-  if (colwise) {
-    // column-major data {rows, cols} with strides {1, rows}; scales {cols, rows/32} with strides {1, cols}
-    Tensor dt = at::empty({cols, rows}, o8), st = at::empty({rows / 32, cols}, oe);
-    check_rc(ao_mxfp8_quantize_colwise(x, reinterpret_cast<uint8_t*>(dt.data_ptr()), reinterpret_cast<uint8_t*>(st.data_ptr()), rows, cols, mode,
-                                       current_stream(input)), op);
-    out_c = dt.t();
-    sc_c = st.t();
-  }
-  return std::make_tuple(out_r, out_c, sc_r, sc_c);
-}
-
 // aten::_scaled_grouped_mm(self, mat2, scale_a, scale_b, offs?, bias?, scale_result?, out_dtype?, use_fast_accum)
 // MXFP8 2d-3d form (mxfp8_grouped_mm.py:541): self e4m3 [M, K]; mat2 e4m3 [E, K, N] whose experts are K-major (the
 // transpose of [E, N, K]); scale_a e8m0 [M, K/32]; scale_b e8m0 [E, N, K/32] -- plain row-major scales: CDNA4's scaled
@@ -205,49 +157,6 @@ Tensor scaled_grouped_mm(const Tensor& self, const Tensor& mat2, const Tensor& s
   return y;
 }
 
-// ---- MoE token-group padding ----------------------------------------------------------------------------------------
-int elem_bytes_of(const Tensor& t, const char* op) {
-  TORCH_CHECK(t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kFloat, op, ": inputs must be bfloat16 or float32");
-  return t.scalar_type() == at::kFloat ? 4 : 2;
-}
-
-// torchao::fused_pad_token_groups(Tensor inputs, Tensor group_offsets, int alignment_size) -> (Tensor, Tensor, Tensor)
-std::tuple<Tensor, Tensor, Tensor> fused_pad_token_groups(const Tensor& inputs, const Tensor& offsets, int64_t alignment_size) {
-  const char* op = "fused_pad_token_groups";
-  check_gpu(inputs, op, "inputs"); check_gpu(offsets, op, "group_offsets");
-  TORCH_CHECK(inputs.dim() == 2 && inputs.is_contiguous(), op, ": inputs must be a contiguous 2-D tensor");
-  TORCH_CHECK(offsets.dim() == 1 && offsets.scalar_type() == at::kInt && offsets.is_contiguous(), op, ": group_offsets must be int32 [num_groups]");
-  const int eb = elem_bytes_of(inputs, op);
-  const int64_t T = inputs.size(0), D = inputs.size(1), G = offsets.size(0);
-  const int64_t rows = ao_moe_padded_rows(T, G, (int)alignment_size);
-  TORCH_CHECK(rows >= 0, op, ": ", ao_last_error());
-  c10::DeviceGuard guard(inputs.device());
-  Tensor padded = at::empty({rows, D}, inputs.options());
-  Tensor starts = at::empty({G}, offsets.options()), ends = at::empty({G}, offsets.options());
-  check_rc(ao_moe_pad_token_groups(inputs.data_ptr(), offsets.data_ptr<int32_t>(), padded.data_ptr(), starts.data_ptr<int32_t>(),
-                                   ends.data_ptr<int32_t>(), T, D, eb, G, (int)alignment_size, current_stream(inputs)), op);
-  return std::make_tuple(padded, starts, ends);
-}
-
-// torchao::fused_unpad_token_groups(Tensor padded, Tensor group_offsets, Tensor padded_group_start_offsets, int num_tokens,
-//                                   int alignment_size) -> Tensor
-Tensor fused_unpad_token_groups(const Tensor& padded, const Tensor& offsets, const Tensor& padded_starts, int64_t num_tokens,
-                                int64_t alignment_size) {
-  const char* op = "fused_unpad_token_groups";
-  (void)alignment_size;
-  check_gpu(padded, op, "inputs"); check_gpu(offsets, op, "group_offsets"); check_gpu(padded_starts, op, "padded_group_start_offsets");
-  TORCH_CHECK(padded.dim() == 2 && padded.is_contiguous(), op, ": inputs must be a contiguous 2-D tensor");
-  TORCH_CHECK(offsets.scalar_type() == at::kInt && padded_starts.scalar_type() == at::kInt && offsets.sizes() == padded_starts.sizes(),
-              op, ": offsets must be int32 tensors of the same shape");
-  TORCH_CHECK(num_tokens >= 0, op, ": num_tokens must be non-negative");
-  const int eb = elem_bytes_of(padded, op);
-  c10::DeviceGuard guard(padded.device());
-  Tensor out = at::empty({num_tokens, padded.size(1)}, padded.options());
-  check_rc(ao_moe_unpad_token_groups(padded.data_ptr(), offsets.contiguous().data_ptr<int32_t>(), padded_starts.contiguous().data_ptr<int32_t>(),
-                                     out.data_ptr(), num_tokens, padded.size(1), eb, offsets.size(0), current_stream(padded)), op);
-  return out;
-}
-
 bool override_aten() {
   const char* e = std::getenv("AO_MI355_OVERRIDE_ATEN");
   return e != nullptr && e[0] != '\0' && e[0] != '0';
@@ -255,12 +164,7 @@ bool override_aten() {
 
 }  // namespace
 
-// The reference's own op names (schemas live in Python: torchao's, or ao_amd/torch_ops.py when torchao is not imported).
-TORCH_LIBRARY_IMPL(torchao, CUDA, m) {
-  m.impl("mxfp8_quantize", &mxfp8_quantize);
-  m.impl("fused_pad_token_groups", &fused_pad_token_groups);
-  m.impl("fused_unpad_token_groups", &fused_unpad_token_groups);
-}
+// (torchao::mxfp8_quantize / fused_pad_token_groups / fused_unpad_token_groups: binding_stable.cpp, through the stable ABI like the reference)
 
 // Own namespace: always there, same functions (tests / opcheck / explicit use without touching aten).
 TORCH_LIBRARY(ao_mi355_c, m) {

@@ -50,6 +50,12 @@ extern "C" {
 int ao_abi_version(void);
 const char* ao_last_error(void);
 
+/* Pre-size the split-K scratch buffer of `stream` (see "Library state" above) outside stream capture: afterwards every op on that stream is
+ * capture-safe whatever its shape, without a warm-up call per shape.  bytes <= 0 reserves the cap (128 MiB); smaller requests are rounded up
+ * to the next power of two >= 8 MiB.  The reference's ops own no workspace (SURVEY 8(b) "stateless"); its split-K lives inside hipBLASLt /
+ * cuBLAS, which pre-allocate theirs per handle the same way (ATen's cublas workspace, CUDABlas / CublasHandlePool). */
+int ao_splitk_reserve(void* stream, int64_t bytes);
+
 /* Per-launch kernel timing for benchmarks: after ao_prof_enable(n) the next n
  * kernel launches of this library are bracketed with HIP extension events that
  * timestamp the dispatch itself (begin/end of the kernel, no launch gaps).

@@ -29,7 +29,9 @@ def test_ops_library_is_loaded_and_registers_reference_names():
     for name in ("mxfp8_quantize", "fused_pad_token_groups", "fused_unpad_token_groups"):
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f"torchao::{name}", "CUDA"), name
         dump = torch._C._dispatch_dump(f"torchao::{name}")
-        assert "binding.cpp" in dump, dump  # the CUDA-key kernel is the C++ one inside the .so, not a Python lambda
+        # the CUDA-key kernel is the C++ one inside the .so (round 6: a BOXED kernel registered through the stable ABI, like the
+        # reference's STABLE_TORCH_LIBRARY_IMPL(torchao, CUDA) in mxfp8_extension.cpp:425-430), not a Python lambda
+        assert "binding_stable.cpp" in dump and "[ boxed ]" in dump.split("CUDA:")[1].splitlines()[0], dump
     assert not torch.ops.ao_mi355_c.aten_overrides_active()  # opt-in only
 
 
@@ -227,11 +229,12 @@ def test_torch_compile_fp16_activation_refuses_with_the_reason():
     from ao_amd.quantization import Int8DynamicActivationInt8WeightConfig, quantize_
 
     torch.manual_seed(0)
-    lin = torch.nn.Linear(512, 128, bias=False).to(torch.float16).to(DEV)
+    lin = torch.nn.Linear(512, 128, bias=False).to(torch.bfloat16).to(DEV)
     quantize_(lin, Int8DynamicActivationInt8WeightConfig())
+    w = lin.weight
     x = torch.randn(4, 512, device=DEV, dtype=torch.float16)
-    assert lin(x).dtype == torch.float16  # eager: the slow path
+    assert torch.nn.functional.linear(x, w).dtype == torch.float16  # eager: the slow path
     torch._dynamo.reset()
     with pytest.raises(Exception, match="takes bfloat16 activations"):
-        torch.compile(lin, fullgraph=True, backend="aot_eager")(x)
+        torch.compile(lambda a: torch.nn.functional.linear(a, w), fullgraph=True, backend="aot_eager")(x)
     torch._dynamo.reset()

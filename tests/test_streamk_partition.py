@@ -8,13 +8,19 @@ import random
 
 
 def shares(G, W_grid, QS, min_share=16):
+    """Round 6: the first sr workgroups take sq + 1 units of QS steps, the others sq (one division; rounds 3 - 5: GQ * v // W per boundary)."""
     GQ = G // QS
     W = min(W_grid, max(1, G // min_share))
-    return W, GQ, [((GQ * w // W) * QS, (GQ * (w + 1) // W) * QS) for w in range(W)]
+    sq, sr = divmod(GQ, W)
+    B = lambda v: v * sq + min(v, sr)  # noqa: E731
+    return W, GQ, (sq, sr), [(B(w) * QS, B(w + 1) * QS) for w in range(W)]
 
 
-def owner(g, W, GQ, QS):
-    return ((g // QS + 1) * W - 1) // GQ
+def owner(g, W, GQ, QS, wts):
+    """The kernel's owner(): one division."""
+    sq, sr = wts
+    Q, big = g // QS, sr * (sq + 1)
+    return Q // (sq + 1) if Q < big else sr + (Q - big) // sq
 
 
 def test_stream_k_partition_invariants():
@@ -24,10 +30,10 @@ def test_stream_k_partition_invariants():
         ksteps = rng.choice([3, 4, 16, 32, 112]) * (QS if QS == 4 else 1)
         if QS == 4 and ksteps % 4:
             ksteps *= 4
-        tiles = rng.randint(1, 300)
-        W_grid = rng.choice([512, 768, 7, 64])
+        tiles = rng.randint(1, 1200)
+        W_grid = rng.choice([512, 768, 7, 64, 512, 512])
         G = tiles * ksteps
-        W, GQ, sh = shares(G, W_grid, QS)
+        W, GQ, wts, sh = shares(G, W_grid, QS)
         # contiguous cover, cut at multiples of QS, no empty share among the first W
         assert sh[0][0] == 0 and sh[-1][1] == G
         for (a0, a1), (b0, b1) in zip(sh, sh[1:]):
@@ -36,7 +42,7 @@ def test_stream_k_partition_invariants():
             assert g0 % QS == 0 and g1 % QS == 0 and g1 > g0
         # owner() inverts the shares
         for g in [0, G - 1] + [rng.randrange(G) for _ in range(50)]:
-            v = owner(g, W, GQ, QS)
+            v = owner(g, W, GQ, QS, wts)
             assert sh[v][0] <= g < sh[v][1]
         # pieces: writer side (per workgroup) vs reader side (per tile)
         written = {}
@@ -56,14 +62,14 @@ def test_stream_k_partition_invariants():
                 written[slot] = t
         for t in range(tiles):
             t0 = t * ksteps
-            wf, wl = owner(t0, W, GQ, QS), owner(t0 + ksteps - 1, W, GQ, QS)
+            wf, wl = owner(t0, W, GQ, QS, wts), owner(t0 + ksteps - 1, W, GQ, QS, wts)
             if wf == wl:
                 continue  # whole tile inside one share: stored from the loop, nothing parked
+            first_odd = 1 if t0 > sh[wf][0] else 0  # the kernel's cut_of(): only the tile's FIRST piece can be the END of a share
             for vq in range(wf, wl + 1):
-                gv = (GQ * vq // W) * QS
-                slot = 2 * vq + (1 if t0 > gv else 0)  # the kernel's gather()
+                slot = 2 * vq + (first_odd if vq == wf else 0)  # the kernel's gather()
                 assert written.get(slot) == t, (t, vq, slot)
         # every parked piece is read by exactly one tile's gather
         assert sorted(written.values()) == sorted(t for t in range(tiles)
-                                                  for _ in range(owner(t * ksteps, W, GQ, QS), owner(t * ksteps + ksteps - 1, W, GQ, QS) + 1)
-                                                  if owner(t * ksteps, W, GQ, QS) != owner(t * ksteps + ksteps - 1, W, GQ, QS))
+                                                  for _ in range(owner(t * ksteps, W, GQ, QS, wts), owner(t * ksteps + ksteps - 1, W, GQ, QS, wts) + 1)
+                                                  if owner(t * ksteps, W, GQ, QS, wts) != owner(t * ksteps + ksteps - 1, W, GQ, QS, wts))

@@ -19,6 +19,9 @@ from ao_amd import ops  # noqa: E402
 lib = _lib.lib()
 if len(sys.argv) > 5:
     lib.ao_gemm8_set_variant(int(sys.argv[5]))  # e.g. 120: weights through the LDS ring
+for kv in filter(None, os.environ.get("AO_GEMM8_TUNE", "").split(",")):  # e.g. AO_GEMM8_TUNE=9=101,10=3 (equal shares, the round-3 meeting)
+    key, val = kv.split("=")
+    _lib.check(lib.ao_gemm8_set_tuning(int(key), int(val)))
 n, k = int(sys.argv[1]), int(sys.argv[2])
 sizes = [int(s) for s in sys.argv[3].split(",")]
 E, rows = len(sizes), sum(sizes)
