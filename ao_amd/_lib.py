@@ -58,6 +58,11 @@ _SIGNATURES = {
     "ao_mxfp8_quantize_colwise_3d": [_P, _P, _P, _I64, _I64, _I64, _INT, _P],
     "ao_fp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "ao_mxfp8_grouped_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
+    "ao_mxfp8_grouped_mm_dyn": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P],
+    "ao_mxfp8_grouped_mm_dyn_fits": [_I64, _I64, _I64, _I64],
+    "ao_mxfp8_grouped_mm_pair_fits": [_I64, _I64, _I64, _I64],
+    "ao_mxfp8_grouped_mm_dyn_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _INT, _P],
+    "ao_mxfp8_grouped_mm_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P],
     "ao_dyn_linear_fits": [_I64, _I64, _I64],
     "ao_int8_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_fp8_dynamic_linear": [_P, _P, _P, _P, _P, _I64, _I64, _I64, _P],

@@ -286,67 +286,9 @@ __global__ __launch_bounds__(kThreads) void mxfp8_quant_kernel(const uint16_t* _
   if (blk >= total_blocks) return;  // whole 4-lane groups exit together
   const int part = threadIdx.x & 3;
   const u32x4 v = reinterpret_cast<const u32x4*>(x + blk * 32)[part];
-  bool has_nan = false;
-  float m = amax8(v, has_nan);
-  m = fmaxf(m, __shfl_xor(m, 1));
-  m = fmaxf(m, __shfl_xor(m, 2));
-  uint32_t nanbits = has_nan ? 1u : 0u;
-  nanbits |= __shfl_xor(nanbits, 1);
-  nanbits |= __shfl_xor(nanbits, 2);
-  const bool finite = (nanbits == 0u) && (m < INFINITY);
   uint32_t e;  // biased E8M0 exponent
-  if (MODE == AO_MX_SCALE_RCEIL) {
-    // descale = amax * (1/448) in fp32; round its value up to a power of two
-    const uint32_t bits = f32_to_bits(m * (1.0f / 448.0f));
-    const uint32_t be = (bits >> 23) & 0xffu, mant = bits & 0x7fffffu;
-    const bool up = (be == 0) ? (mant > 0x400000u) : (mant != 0);
-    e = be + (up ? 1u : 0u);
-  } else {
-    // floor(log2(amax)) - 8, clamped to [-127, 128], biased
-    const int ex = (int)((f32_to_bits(m) >> 23) & 0xffu) - 127 - 8;
-    e = (uint32_t)(min(max(ex, -127), 128) + 127);
-  }
-  if (!finite) e = 255u;
-  // reciprocal scale 2^(127 - e) built from the E8M0 byte 254 - e (mx_tensor.py:132-158)
-  const uint32_t re = (254u - e) & 0xffu;
-  uint32_t rbits = re << 23;
-  if (re == 0u) rbits = 0x00400000u;    // 2^-127 as an fp32 subnormal
-  if (re == 255u) rbits = 0x7F800001u;  // NaN
-  const float r = bits_to_f32(rbits);
-  float f[8] = {bf16_lo_to_f32(v.x), bf16_hi_to_f32(v.x), bf16_lo_to_f32(v.y), bf16_hi_to_f32(v.y),
-                bf16_lo_to_f32(v.z), bf16_hi_to_f32(v.z), bf16_lo_to_f32(v.w), bf16_hi_to_f32(v.w)};
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    f[j] *= r;
-    if (MODE == AO_MX_SCALE_FLOOR) f[j] = clamp448(f[j]);  // eager saturation (torch < 2.13), :361-373
-  }
-  reinterpret_cast<u32x2*>(q + blk * 32)[part] =
-      u32x2{cvt4_e4m3(f[0], f[1], f[2], f[3]), cvt4_e4m3(f[4], f[5], f[6], f[7])};
+  reinterpret_cast<u32x2*>(q + blk * 32)[part] = mx_cast8<MODE>(v, e);  // quant_math.h: shared with the grouped GEMM's fused cast
   if (part == 0) scale[blk] = (uint8_t)e;
-}
-
-// E8M0 scale exponent of one 32-block from its amax (to_mx, mx_tensor.py:255-330) and the reciprocal 2^(127 - e) built from the
-// E8M0 byte 254 - e (mx_tensor.py:132-158)
-template <int MODE>
-__device__ __forceinline__ uint32_t mx_block_exponent(float m, bool finite) {
-  uint32_t e;
-  if (MODE == AO_MX_SCALE_RCEIL) {
-    const uint32_t bits = f32_to_bits(m * (1.0f / 448.0f));
-    const uint32_t be = (bits >> 23) & 0xffu, mant = bits & 0x7fffffu;
-    const bool up = (be == 0) ? (mant > 0x400000u) : (mant != 0);
-    e = be + (up ? 1u : 0u);
-  } else {
-    const int ex = (int)((f32_to_bits(m) >> 23) & 0xffu) - 127 - 8;
-    e = (uint32_t)(min(max(ex, -127), 128) + 127);
-  }
-  return finite ? e : 255u;
-}
-__device__ __forceinline__ float mx_reciprocal(uint32_t e) {
-  const uint32_t re = (254u - e) & 0xffu;
-  uint32_t rbits = re << 23;
-  if (re == 0u) rbits = 0x00400000u;
-  if (re == 255u) rbits = 0x7F800001u;
-  return bits_to_f32(rbits);
 }
 
 // ---- MXFP8 colwise: one E8M0 scale per 32 elements along the ROWS (32 x 1 blocks), data written column-major -------------

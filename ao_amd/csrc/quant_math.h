@@ -75,4 +75,55 @@ __device__ __forceinline__ u32x2 fp8_quant8(const u32x4& v, float s) {
   return u32x2{cvt4_e4m3(f[0], f[1], f[2], f[3]), cvt4_e4m3(f[4], f[5], f[6], f[7])};
 }
 
+
+// ---- MXFP8 (to_mx, prototype/mx_formats/mx_tensor.py:228-409) --------------------------------------------------------------------
+// E8M0 scale exponent of one 32-block from its amax (:255-330; RCEIL :111-129, :161-225) and the reciprocal 2^(127 - e) built from the
+// E8M0 byte 254 - e (:132-158).  MODE: AO_MX_SCALE_FLOOR (0) / AO_MX_SCALE_RCEIL (1).
+template <int MODE>
+__device__ __forceinline__ uint32_t mx_block_exponent(float m, bool finite) {
+  uint32_t e;
+  if (MODE == 1) {
+    // descale = amax * (1/448) in fp32; its value rounded up to a power of two
+    const uint32_t bits = f32_to_bits(m * (1.0f / 448.0f));
+    const uint32_t be = (bits >> 23) & 0xffu, mant = bits & 0x7fffffu;
+    const bool up = (be == 0) ? (mant > 0x400000u) : (mant != 0);
+    e = be + (up ? 1u : 0u);
+  } else {
+    // floor(log2(amax)) - 8, clamped to [-127, 128], biased
+    const int ex = (int)((f32_to_bits(m) >> 23) & 0xffu) - 127 - 8;
+    e = (uint32_t)(min(max(ex, -127), 128) + 127);
+  }
+  return finite ? e : 255u;
+}
+__device__ __forceinline__ float mx_reciprocal(uint32_t e) {
+  const uint32_t re = (254u - e) & 0xffu;
+  uint32_t rbits = re << 23;
+  if (re == 0u) rbits = 0x00400000u;    // 2^-127 as an fp32 subnormal
+  if (re == 255u) rbits = 0x7F800001u;  // NaN
+  return bits_to_f32(rbits);
+}
+// The 1 x 32 cast of one block by FOUR ADJACENT LANES (lane & 3 = the block's quarter: 8 bf16 each): block amax across the four lanes,
+// the E8M0 exponent (returned in e, the same in all four), 8 e4m3 codes of this lane's quarter.  One definition for the stand-alone cast
+// (quant_kernels.hip: mxfp8_quant_kernel) and the cast fused into the grouped GEMM's A-fill (rb8_kernels.hip): the same bits by construction.
+template <int MODE>
+__device__ __forceinline__ u32x2 mx_cast8(const u32x4& v, uint32_t& e) {
+  bool has_nan = false;
+  float m = amax8(v, has_nan);
+  m = fmaxf(m, __shfl_xor(m, 1));
+  m = fmaxf(m, __shfl_xor(m, 2));
+  uint32_t nanbits = has_nan ? 1u : 0u;
+  nanbits |= __shfl_xor(nanbits, 1);
+  nanbits |= __shfl_xor(nanbits, 2);
+  e = mx_block_exponent<MODE>(m, (nanbits == 0u) && (m < INFINITY));
+  const float r = mx_reciprocal(e);
+  float f[8] = {bf16_lo_to_f32(v.x), bf16_hi_to_f32(v.x), bf16_lo_to_f32(v.y), bf16_hi_to_f32(v.y),
+                bf16_lo_to_f32(v.z), bf16_hi_to_f32(v.z), bf16_lo_to_f32(v.w), bf16_hi_to_f32(v.w)};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f[j] *= r;
+    if (MODE == 0) f[j] = clamp448(f[j]);  // eager saturation (torch < 2.13), :361-373
+  }
+  return u32x2{cvt4_e4m3(f[0], f[1], f[2], f[3]), cvt4_e4m3(f[4], f[5], f[6], f[7])};
+}
+
 }  // namespace ao

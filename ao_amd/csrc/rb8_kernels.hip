@@ -17,6 +17,7 @@
 // parts meet through the fence-free split-K workspace (splitk.h), the last arriver applies the scales.
 #include "common.h"
 #include "lds_dma.h"
+#include "quant_math.h"
 #include "splitk.h"
 
 #include <algorithm>
@@ -54,6 +55,11 @@ struct Rb8Args {
   const uint8_t* a_mx;    // MX: [M][K/32] e8m0
   const uint8_t* b_mx;    // MX: [E][N][K/32] e8m0
   const int32_t* offs;    // MX: [E] cumulative group ends (null: one group)
+  // MX stream-K, round 6: a SECOND weight tensor of the same shape multiplied by the same activations in the same launch (an MoE layer's
+  // w1 and w3: x @ w1, x @ w3) -- its column tiles follow the first's in every slab; null: one product
+  const uint8_t* b2;
+  const uint8_t* b2_mx;
+  uint16_t* y2;
   int slabs, E;           // MX: 128-row slabs per group the grid provides (grid.y = E * slabs)
   float* ws;
   unsigned* tickets;
@@ -657,10 +663,22 @@ constexpr int kStreamMinShare = 16;  // k steps: fewer would not pay for priming
 // steps (K % 512 == 0, 3 weight stages).  The dword DMAs moved 1 % of the bytes and cost a quarter of the kernel: with them switched
 // off (timing probe, profiles/mx_rb_trace_r03.txt session F) w1 went 65.9 -> 49.3 us and w2 64.7 -> 44.9 -- the LDS-DMA path is
 // bound by instructions, not bytes (fetching the activation tile through ONE line per DMA instead of eight: -4 %).
-template <int WAVES, int SW, int QS, bool TRACE>
+// CAST (round 6, SURVEY 8 f1 for the MX format): 0 -- p.a / p.a_mx are e4m3 codes and E8M0 scales (the caller cast the activations);
+// 1 + mode -- p.a is the BF16 activation matrix and the 1 x 32 cast (to_mx, mode = AO_MX_SCALE_FLOOR / RCEIL) happens in the A-fill:
+// the 16 waves fetch the step's [64 rows][128 k] bf16 tile (16 KiB: one 1 KiB LDS-DMA each, four rows per wave) ONE step ahead into a
+// two-stage raw ring, and during step i every thread reads back the 16 bytes its own lane fetched for step i + 1 (no barrier: the
+// wave's own vmcnt covers them), casts them with the stand-alone cast's function (quant_math.h: mx_cast8 -- four lanes per 32-block)
+// and writes 8 codes into the swizzled operand tile of step i + 1 and the block's exponent byte into its scale slot; the step's barrier
+// publishes both.  No cast kernel, no e4m3 copy of the activations in HBM, the same bits.
+template <int WAVES, int SW, int QS, bool TRACE, int CAST = 0>
 __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   static_assert(QS == 1 || (QS == 4 && SW == 3), "mx_stream_kernel: scale fetches per step, or per 4 steps with 3 weight stages");
+  constexpr bool kCast = CAST != 0;
+  static_assert(!kCast || (WAVES == 16 && QS == 4), "mx_stream_kernel: the fused cast is built on the 16-wave form");
   constexpr int MT = 4, BM = 64, BN = 16 * WAVES, SCL = 64, kABuf = MT * 2048, NTHR = 64 * WAVES;
+  constexpr int KA = kCast ? 2 : kStages;        // stages of the e4m3 operand ring of the activations
+  constexpr int kRaw = kCast ? BM * 256 : 0;     // one stage of the raw bf16 ring (two stages)
+  constexpr int kWOff = KA * kABuf + 2 * kRaw;   // where the weight rings begin
   constexpr int AD = (WAVES >= 8) ? 1 : 8 / WAVES;  // activation DMAs per wave and step (8 rows each): the tile is shared by the workgroup's waves (16 waves: the first 8 fetch)
   constexpr int RPW = BM / WAVES;   // activation-scale rows fetched per wave
   constexpr int LPSC = AD + 2 + (QS == 1 ? 2 : 0);  // DMAs of one stage (activations, weights; QS == 1: + the scales of both)
@@ -672,13 +690,13 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   static_assert(WAVES == 4 || WAVES == 8 || (WAVES == 16 && QS == 4), "mx_stream_kernel: 4 or 8 waves, or 16 with the scales per 4 steps");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) { ts[0] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime(); }  // [3] / [4]: the 100 MHz clock at entry / exit
-  // [3][64][128 B] a | [WAVES][SW][2 KiB] b | a scales [ASN][WAVES][ASB] | b scales [WAVES][BSN][BSB]
+  // [KA][64][128 B] a | CAST: [2][64][256 B] raw bf16 | [WAVES][SW][2 KiB] b | a scales [ASN][WAVES][ASB] (CAST: [2][64 rows][4 B]) | b scales [WAVES][BSN][BSB]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
-  const int ksteps = p.K >> 7, NT = (p.N + BN - 1) / BN, n16 = p.N >> 4;
+  const int ksteps = p.K >> 7, NT1 = (p.N + BN - 1) / BN, NT = (p.b2 != nullptr) ? 2 * NT1 : NT1, n16 = p.N >> 4;  // NT: column tiles of one slab (both products)
   const uint32_t kb32 = (uint32_t)(p.K >> 5);
 
   // group table: lane e holds expert e's rows [lo, hi), its slab count and the running slab count
@@ -701,31 +719,36 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   const int excl = incl - ns;
   const int nslabs = __builtin_amdgcn_readlane(incl, 63);
   const int G = nslabs * NT * ksteps;  // < 2^31 (launcher)
-  const int GQ = G / QS;                // shares are cut at multiples of QS steps (ksteps % QS == 0: launcher)
   const int W = min((int)gridDim.x, max(1, G / kStreamMinShare));
   const int w = blockIdx.x;
   if (w >= W) return;  // uniform, before any DMA or barrier
-  // Shares (round 6: one 32-bit division here, one per owner() -- the GQ * v / W of rounds 3 - 5 were 64-bit divisions, ~300 scalar
-  // instructions each, four to eight of them on every workgroup's way in and out): the first `sr` workgroups take sq + 1 units of QS
-  // steps, the others sq.  B(v) = where workgroup v's share begins, owner(Q) = the workgroup whose share holds unit Q.
-  const unsigned sq = (unsigned)GQ / (unsigned)W, sr = (unsigned)GQ - sq * (unsigned)W;  // sq >= 4 / QS * 4 >= 1: W <= G / 16
+  // Shares (round 6): cut at single steps (rounds 3 - 5: at multiples of QS -- at 21 steps a share that meant 24 steps for a quarter of
+  // the workgroups and 20 for the rest; the scales' 4-step blocks stay aligned to the TILE, a share that begins inside one fetches it
+  // whole: gv below); the first `sr` workgroups take sq + 1 steps, the others sq: ONE 32-bit division here and one per owner() (the
+  // GQ * v / W of rounds 3 - 5 were 64-bit divisions, ~300 scalar instructions each, four to eight of them on every workgroup's way in
+  // and out).  B(v) = where workgroup v's share begins, owner(g) = the workgroup whose share holds step g.
+  // (Measured and not kept, profiles/mx_stream_ab_r06.txt: shares of equal COST -- a 64-row slab's step takes 1.10 - 1.14 x a 32-row
+  // slab's -- level the workgroups' exit times and leave the launch where it was: the loop runs at the memory system's rate, and a
+  // workgroup that leaves early leaves its bandwidth to the others.  The same for shares weighted by dispatch order on the two-per-CU form.)
+  const unsigned sq = (unsigned)G / (unsigned)W, sr = (unsigned)G - sq * (unsigned)W;  // sq >= 16: W <= G / 16
   auto B = [&](int v) { return (int)((unsigned)v * sq + min((unsigned)v, sr)); };
-  auto owner = [&](int Q) {
+  auto owner = [&](int g) {
     const unsigned big = sr * (sq + 1);
-    return (int)(((unsigned)Q < big) ? (unsigned)Q / (sq + 1) : sr + ((unsigned)Q - big) / sq);
+    return (int)(((unsigned)g < big) ? (unsigned)g / (sq + 1) : sr + ((unsigned)g - big) / sq);
   };
+  const int g0 = B(w), g1 = B(w + 1);
   // the pieces of a tile that share boundaries cut: workgroups wf .. wf + S - 1 hold one each, parked in slot 2 v (the piece v's share
-  // BEGINS with) or 2 v + 1 (the piece it ENDS with, when that is another one) -- every piece but the tile's first begins its share
+  // BEGINS with) or 2 v + 1 (the piece it ENDS with, when that is another one) -- every piece but the tile's first begins its share.
+  // Of one of THIS share's cut tiles, the end that lies inside the share is this workgroup's (no division for it).
   struct Cut { int S, wf, first_odd; };
   auto cut_of = [&](int tile) {
-    const int T0 = tile * (ksteps / QS);
+    const int T0 = tile * ksteps;
     Cut c;
-    c.wf = owner(T0);
-    c.S = owner(T0 + ksteps / QS - 1) - c.wf + 1;
+    c.wf = (T0 >= g0) ? w : owner(T0);
+    c.S = ((T0 + ksteps <= g1) ? w : owner(T0 + ksteps - 1)) - c.wf + 1;
     c.first_odd = (T0 > B(c.wf)) ? 1 : 0;
     return c;
   };
-  const int g0 = B(w) * QS, g1 = B(w + 1) * QS;
   if (g0 >= g1) return;
   auto find = [&](int y, int& expert, int& m0, int& m_end) {  // y-th non-empty slab; wave-uniform, registers only
     const unsigned long long hit = __ballot(incl > y);
@@ -737,8 +760,8 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   if (TRACE) ts[13] = __builtin_amdgcn_s_memtime();
 
   const uint32_t a_lds = lds_offset(smem);
-  const uint32_t w_lds = a_lds + kStages * kABuf + wave * (SW * 2048);
-  const uint32_t as_lds = a_lds + kStages * kABuf + WAVES * (SW * 2048);
+  const uint32_t w_lds = a_lds + kWOff + wave * (SW * 2048);
+  const uint32_t as_lds = a_lds + kWOff + WAVES * (SW * 2048);
   const uint32_t bs_lds = as_lds + ASN * WAVES * ASB + wave * (BSN * BSB);
   const int tile0 = g0 / ksteps, k00 = g0 - tile0 * ksteps;
 
@@ -757,9 +780,10 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     const int slab = tile / NT, nt = tile - slab * NT;
     int e, m0, m_end;
     find(slab, e, m0, m_end);
-    const int t16 = min(nt * WAVES + wave, n16 - 1);  // tiles past N alias the last one; never stored
-    brows = p.b + ((size_t)e * p.N + (size_t)t16 * 16) * p.K;
-    bsrows = p.b_mx + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
+    const bool second = nt >= NT1;  // (the second product's tiles)
+    const int t16 = min((second ? nt - NT1 : nt) * WAVES + wave, n16 - 1);  // tiles past N alias the last one; never stored
+    brows = (second ? p.b2 : p.b) + ((size_t)e * p.N + (size_t)t16 * 16) * p.K;
+    bsrows = (second ? p.b2_mx : p.b_mx) + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
   };
   auto issue_w = [&](int stage) {  // the cursor's step into `stage`, then on to the next step (the last step repeats past the end)
     dma_b128_nt_s(brows + (size_t)kw * 128, boff[0], w_lds + stage * 2048);
@@ -789,12 +813,21 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     }
     asoff = (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32;
     if constexpr (QS == 4) a_cnt = __builtin_amdgcn_readfirstlane(max(0, min(AD, (min(m_end - m0, BM) - 8 * AD * wave + 7) >> 3)));
+    if constexpr (kCast) {  // the raw bf16 tile: wave w fetches rows 4 w .. 4 w + 3 (lane: row 4 w + lane / 16, 16-byte chunk lane % 16 of its 256 B)
+      const int row = 4 * wave + (lane >> 4);
+      aoff[0] = (uint32_t)min(m0 + row, m_end - 1) * (uint32_t)p.K * 2u + ((lane & 15) << 4);
+      a_cnt = __builtin_amdgcn_readfirstlane((4 * wave < min(m_end - m0, BM)) ? 1 : 0);
+    }
   };
   auto issue_a = [&](int stage) -> int {  // returns the DMAs issued
     const int cnt = a_cnt;
+    if constexpr (kCast) {  // (stage: the RAW ring's)
+      if (cnt) dma_b128_s(p.a + (size_t)ka * 256, aoff[0], a_lds + KA * kABuf + stage * kRaw + wave * 1024);
+    } else {
 #pragma unroll
     for (int i = 0; i < AD; ++i)
       if (QS == 1 || i < cnt) dma_b128_s(p.a + (size_t)ka * 128, aoff[i], a_lds + stage * kABuf + (AD * wave + i) * 1024);
+    }
     if constexpr (QS == 1) {
       if (lane < RPW) dma_b32_s(p.a_mx + (size_t)ka * 4, asoff, as_lds + (stage * WAVES + wave) * SCL);
     }
@@ -808,15 +841,17 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   uint32_t asoff4 = 0;
   bool as_have = true;  // this wave's activation-scale rows exist in the cursor's slab
   const uint8_t* bsrows4 = nullptr;
-  int gs = g0, ks4 = k00, tiles4 = tile0;
+  const int gv = g0 - (k00 & 3);  // QS == 4: the step the share's first 4-step scale block begins with (tiles begin at multiples of 4)
+  int gs = gv, ks4 = k00 & ~3, tiles4 = tile0;
   auto set_s = [&](int tile) {
     const int slab = tile / NT, nt = tile - slab * NT;
     int e, m0, m_end;
     find(slab, e, m0, m_end);
-    const int t16 = min(nt * WAVES + wave, n16 - 1);
-    bsrows4 = p.b_mx + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
+    const bool second = nt >= NT1;
+    const int t16 = min((second ? nt - NT1 : nt) * WAVES + wave, n16 - 1);
+    bsrows4 = (second ? p.b2_mx : p.b_mx) + ((size_t)e * p.N + (size_t)t16 * 16) * kb32;
     asoff4 = (uint32_t)min(m0 + RPW * wave + (lane % RPW), m_end - 1) * kb32;
-    as_have = RPW * wave < m_end - m0;
+    as_have = !kCast && RPW * wave < m_end - m0;  // (CAST: the activation scales are computed here, not fetched)
   };
   auto issue_s = [&](int slot) -> int {  // (the last block repeats past the end, like the tiles); returns the DMAs issued
     const int cnt = as_have ? 2 : 1;
@@ -854,10 +889,11 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   set_c(tile0);
   if constexpr (QS == 4) set_s(tile0);
 
-  uint16_t* __restrict__ y = p.y;
   auto store_tile = [&](const f32x4 (&v)[MT], int m0, int m_end, int nt) {  // scales were applied by the MFMA: out = bf16(acc)
-    const int t16 = nt * WAVES + wave;
+    const bool second = nt >= NT1;
+    const int t16 = (second ? nt - NT1 : nt) * WAVES + wave;
     if (t16 >= n16) return;
+    uint16_t* __restrict__ y = second ? p.y2 : p.y;
     const int n = t16 * 16 + nl;  // D layout: lane (col = nl, kq) holds rows 4 kq + {0..3} of each 16 x 16 tile
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -903,32 +939,59 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   // a(1) w(1), per step a(i+2) w(i+2): one stage may be in flight.  (The stores of a tile finished inside the loop are younger
   // than what the next two waits need and VMEM retires in order: those waits only become stricter, never wrong.)
   if (TRACE) ts[14] = __builtin_amdgcn_s_memtime();
-  if constexpr (QS == 4) issue_s(0);  // QS == 4: scales of steps 0..3 first; of steps 4 j + 4 .. + 7 at the head of step 4 j + 1 (below)
+  // QS == 4: the scales of the block the share begins in first; of each next block at the second step of the one before (below) -- a share
+  // that begins at the third or fourth step of its block is past that point: its second block goes out here too
+  if constexpr (QS == 4) {
+    issue_s(0);
+    if ((k00 & 3) >= 2) issue_s(1);
+  }
 #pragma unroll
   for (int i = 0; i < SW - 3; ++i) issue_w(i);
-  issue_a(0); issue_w(SW - 3);
+  [[maybe_unused]] const int a_first = issue_a(0);
+  issue_w(SW - 3);
   int a_prev = issue_a(1), s_prev = 0;  // QS == 4: what the step before issued besides its two weight DMAs (= all that may be in flight)
   issue_w(SW - 2);
+  // CAST: this thread's 16 bytes of raw stage `rs` (fetched by its own lane) -> 8 codes in operand stage `os` + the block's exponent byte
+  [[maybe_unused]] auto convert = [&](int rs, int os) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + KA * kABuf + rs * kRaw + wave * 1024 + lane * 16);
+    uint32_t e;
+    const u32x2 q = mx_cast8<(CAST > 0 ? CAST - 1 : 0)>(v, e);
+    const int row = 4 * wave + (lane >> 4), c = lane & 15, r = row & 15;  // c: which 8 of the step's 128 k
+    *reinterpret_cast<u32x2*>(smem + os * kABuf + (row >> 4) * 2048 + r * 128 + ((((c >> 1) ^ (r >> 1)) & 7) << 4) + (c & 1) * 8) = q;
+    if ((lane & 3) == 0) *reinterpret_cast<uint8_t*>(smem + kWOff + WAVES * (SW * 2048) + os * 256 + row * 4 + (c >> 2)) = (uint8_t)e;
+  };
+  if constexpr (kCast) {
+    // raw(0) has to be cast before the first barrier: everything up to it has landed when at most raw(1) and the two weight stages behind
+    // it are in flight
+    wait_upto(4 + a_prev);
+    if (a_first) convert(0, 0);
+  }
   if (TRACE) ts[1] = __builtin_amdgcn_s_memtime();
-  // the share's (at most two) cut tiles, worked out while the first data is on its way: the tail needs no division
-  const Cut cut_head = (k00 != 0) ? cut_of(tile0) : Cut{1, w, 0};
-  const Cut cut_tail = tail_is_piece ? cut_of(tile_last) : Cut{1, w, 0};
+  // (the share's cut tiles are worked out where they are needed: the tail's at the step that reads its ticket word, the head's by the one
+  // lane that holds its ticket -- ahead of the loop they cost every workgroup 2 - 4 k cycles between priming and the first step)
+  Cut cut_tail{1, w, 0};
   int stage = 0, wstage = 0;
   for (int g = g0; g < g1; ++g) {
-    if constexpr (QS == 4) { wait_upto(a_prev + 2 + s_prev + (lenient > 0 ? 1 : 0)); lenient = max(lenient - 1, 0); }
+    // (CAST: raw(i + 1), requested first in the step before, has to be in: only that step's two weight DMAs may still be in flight)
+    if constexpr (kCast) { wait_upto(2 + (lenient > 0 ? 1 : 0)); lenient = max(lenient - 1, 0); }
+    else if constexpr (QS == 4) { wait_upto(a_prev + 2 + s_prev + (lenient > 0 ? 1 : 0)); lenient = max(lenient - 1, 0); }
     else if constexpr (SW >= 4) wait_vmcnt<LPSC + 3>(); else wait_vmcnt<LPSC>();
     // everyone's share of the activation tile has landed, and everyone has finished reading the step before
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (TRACE && g == g0) ts[2] = __builtin_amdgcn_s_memtime();  // static indices: the stamps stay in SGPRs
     if (TRACE && g == g0 + 7) ts[9] = __builtin_amdgcn_s_memtime();
     if constexpr (QS == 4) {
-      // step i of the share (i = g - g0; shares and tiles begin at multiples of 4): the next block's scales go out at i % 4 == 1 into
+      // step i counted from the share's first scale block (i = g - gv; tiles begin at multiples of 4): the next block's scales go out at i % 4 == 1 into
       // the slot the block before this one used (last read at step i - 2); they are older than a(i + 2), w(i + 2), whose wait at
       // step i + 2 therefore covers them, and at that wait -- only there -- two more requests are younger than what it needs
-      s_prev = (((g - g0) & 3) == 1) ? issue_s((((g - g0) >> 2) + 1) & 1) : 0;
+      s_prev = (((g - gv) & 3) == 1) ? issue_s((((g - gv) >> 2) + 1) & 1) : 0;
     }
-    a_prev = issue_a((stage == 0) ? 2 : stage - 1);
+    [[maybe_unused]] const int a_landed = a_prev;  // CAST: whether this wave fetched rows of step i + 1's tile (requested a step ago)
+    a_prev = issue_a(kCast ? stage : (stage == 0) ? 2 : stage - 1);  // (CAST: raw(i + 2) into the raw stage cast a step ago)
     issue_w((wstage == 0) ? SW - 1 : wstage - 1);
+    if constexpr (kCast) {
+      if (a_landed) convert(stage ^ 1, stage ^ 1);
+    }
     // (both behind this step's DMAs: the next wait then only asks the oldest of them to have landed one step early)
     if (head_wait > 0 && --head_wait == 0) {  // uniform.  The park's stores of every wave have retired (two waits, two barriers since)
       if (wave == 1) {
@@ -936,16 +999,19 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
         if constexpr (QS == 4) lenient = 2;  // the atomic may stay in flight across the next two waits (QS == 1: they ask for it, at worst a stall)
       }
     }
-    if (g == g_peek && wave == 0) peek = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rtk, 0, tile_last * 4, kSc1);
+    if (g == g_peek) {
+      if (wave == 0) peek = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rtk, 0, tile_last * 4, kSc1);
+      cut_tail = cut_of(tile_last);
+    }
     const char* A = smem + stage * kABuf;
-    const char* Wt = smem + kStages * kABuf + (wave * SW + wstage) * 2048;
+    const char* Wt = smem + kWOff + (wave * SW + wstage) * 2048;
     const u32x4 b0 = *reinterpret_cast<const u32x4*>(Wt + pa);  // the n-tile's 16 rows are laid out like an m-tile
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(Wt + (pa ^ 64));
     const i32x8 bf = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
     // the scale byte of lane group kq is that of 32-k block kq of the step (operand layout probed on gfx950, stream8_kernels.hip)
-    const int blk = ((g - g0) >> 2) & 1, ph = (g - g0) & 3;  // QS == 4: slot and position of this step's scale dword
-    const char* AS = smem + kStages * kABuf + WAVES * (SW * 2048) + ((QS == 1) ? stage : blk) * WAVES * ASB + ((QS == 1) ? 0 : ph * 4);
-    const char* BS = smem + kStages * kABuf + WAVES * (SW * 2048) + ASN * WAVES * ASB + (wave * BSN + ((QS == 1) ? wstage : blk)) * BSB;
+    const int blk = ((g - gv) >> 2) & 1, ph = (g - gv) & 3;  // QS == 4: slot and position of this step's scale dword
+    const char* AS = smem + kWOff + WAVES * (SW * 2048) + (kCast ? stage * 256 : ((QS == 1) ? stage : blk) * WAVES * ASB + ((QS == 1) ? 0 : ph * 4));
+    const char* BS = smem + kWOff + WAVES * (SW * 2048) + ASN * WAVES * ASB + (wave * BSN + ((QS == 1) ? wstage : blk)) * BSB;
     const int sb = (int)(*reinterpret_cast<const uint32_t*>(BS + ((QS == 1) ? nl * 4 : nl * 16 + ph * 4)) >> (8 * kq)) & 0xff;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -953,12 +1019,12 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
         const u32x4 a0 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + pa);
         const u32x4 a1 = *reinterpret_cast<const u32x4*>(A + mt * 2048 + (pa ^ 64));
         const i32x8 af = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-        const int row = mt * 16 + nl;  // its scales sit in the slot of wave row / RPW
-        const int sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (row / RPW) * ASB + (row % RPW) * ((QS == 1) ? 4 : 16)) >> (8 * kq)) & 0xff;
+        const int row = mt * 16 + nl;  // its scales sit in the slot of wave row / RPW (CAST: [row][4 B])
+        const int sa = (int)(*reinterpret_cast<const uint32_t*>(AS + (kCast ? row * 4 : (row / RPW) * ASB + (row % RPW) * ((QS == 1) ? 4 : 16))) >> (8 * kq)) & 0xff;
         acc[mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf, acc[mt], 0, 0, 0, sa, 0, sb);
       }
     }
-    stage = (stage == 2) ? 0 : stage + 1;
+    stage = (stage == KA - 1) ? 0 : stage + 1;
     wstage = (wstage == SW - 1) ? 0 : wstage + 1;
     ++kc;
     if (kc == ksteps && g + 1 < g1) {  // a tile ends inside the share
@@ -1022,6 +1088,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   };
   const bool tail_whole = (kb == 0 && kc == ksteps);  // the share's last tile: whole (never cut) or a piece
   bool tail_meets = false;
+  if (!tail_whole && g_peek < 0) cut_tail = cut_of(tile_last);  // (a share of fewer than three steps, or the round-3 protocol: not worked out in the loop)
   if (tail_whole) {
     store_tile(acc, m0c, m_endc, ntc);
   } else {
@@ -1051,7 +1118,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
         const int tile = (wave == 0) ? tilec : head_tile;
         unsigned t = head_t;  // (wave 1, lane 0: the ticket taken from the loop)
         if (wave == 0 || head_late) t = __hip_atomic_fetch_add(&p.tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned S = (unsigned)((wave == 0) ? cut_tail.S : cut_head.S);
+        const unsigned S = (unsigned)((wave == 0) ? cut_tail.S : cut_of(head_tile).S);
         last = (t == S - 1);
         if (last) __hip_atomic_store(&p.tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
       }
@@ -1059,7 +1126,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     }
     __syncthreads();
     if (flag[0]) { gather(acc, cut_tail, mt_have, -1, acc); store_tile(acc, m0c, m_endc, ntc); }
-    if (flag[1]) { gather(acc, cut_head, head_mth, -1, acc); store_tile(acc, head_m0, head_mend, head_nt); }
+    if (flag[1]) { gather(acc, cut_of(head_tile), head_mth, -1, acc); store_tile(acc, head_m0, head_mend, head_nt); }
   }
   if (TRACE && p.trace != nullptr && tid == 0) {
     ts[11] = ts[12] = __builtin_amdgcn_s_memtime();
@@ -1127,17 +1194,18 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
 thread_local int g_mx_proto = 0;  // A/B (ao_gemm8_set_tuning key 9): 1 head ticket after the loop, 2 no early read of the tail ticket (1 | 2: the round-3 meeting)
 // Launch of the stream-K form: one workgroup per resident slot of the chip.
 constexpr int kChipCUs = 256;  // MI355X
-template <int WAVES, int SW, int QS>
+template <int WAVES, int SW, int QS, int CAST = 0>
 int launch_mx_stream(Rb8Args p, hipStream_t stream) {
   constexpr size_t scales = (QS == 1) ? (size_t)(kStages + SW) * WAVES * 64 : (size_t)2 * WAVES * (64 / WAVES) * 16 + (size_t)WAVES * 2 * 256;
-  constexpr size_t smem = (size_t)kStages * 4 * 2048 + (size_t)WAVES * SW * 2048 + scales;
+  constexpr size_t smem = (CAST ? (size_t)2 * 4 * 2048 + (size_t)2 * 64 * 256 : (size_t)kStages * 4 * 2048) + (size_t)WAVES * SW * 2048 + scales;
+  static_assert(smem <= 160 * 1024, "mx_stream_kernel: LDS");
   constexpr int per_cu = (int)((160 * 1024) / smem);
   static_assert(per_cu >= 2 || (WAVES == 16 && per_cu == 1), "mx_stream_kernel: two workgroups per CU (one of 16 waves)");
   const unsigned Wg = (unsigned)(per_cu * kChipCUs);
   if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)2 * Wg * 64 * 16 * WAVES)) return rc;
   p.trace = g_fp8_rb_trace;
   p.ablate = g_mx_proto;  // the meeting protocol's A/B bits
-  auto kern = (p.trace != nullptr) ? mx_stream_kernel<WAVES, SW, QS, true> : mx_stream_kernel<WAVES, SW, QS, false>;
+  auto kern = (p.trace != nullptr) ? mx_stream_kernel<WAVES, SW, QS, true, CAST> : mx_stream_kernel<WAVES, SW, QS, false, CAST>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(mx_stream_kernel)")) return rc;
   ao::launch(kern, dim3(Wg), dim3(64 * WAVES), smem, stream, p);
   AO_LAUNCH_CHECK("mx_stream_kernel launch");
@@ -1293,7 +1361,9 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
     {
       // scales fetched per 4 steps when K allows (16-byte pieces of 16-byte-aligned scale rows), else per step
       const bool quad = g_mx_quad && K % 512 == 0 && ((uintptr_t)a_scale % 16 == 0) && ((uintptr_t)b_scale % 16 == 0);
-      if (g_mx_stream == 5 && quad) return launch_mx_stream<16, 3, 4>(p, stream);  // (116) one 16-wave workgroup per CU, 256-column tiles
+      // round 6: ONE 16-wave workgroup per CU over 256-column tiles where the scales can be fetched per 4 steps (119 forces the 8-wave form,
+      // two workgroups per CU over 128-column tiles: rounds 3 - 5's product)
+      if ((g_mx_stream == 1 || g_mx_stream == 5) && quad) return launch_mx_stream<16, 3, 4>(p, stream);
       if (g_mx_stream == 2) return launch_mx_stream<4, 6, 1>(p, stream);
       if (g_mx_stream == 3) return quad ? launch_mx_stream<4, 3, 4>(p, stream) : launch_mx_stream<4, 3, 1>(p, stream);
       return quad ? launch_mx_stream<8, 3, 4>(p, stream) : launch_mx_stream<8, 3, 1>(p, stream);
@@ -1307,6 +1377,30 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
   }
   if (((N + 127) / 128) * groups * p.slabs < 400) return quad ? launch_rb8<4, RB8_MX, 8, false, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 8>(p, 1, stream);
   return quad ? launch_rb8<8, RB8_MX, 8, false, 4>(p, 1, stream) : launch_rb8<8, RB8_MX, 8>(p, 1, stream);
+}
+
+// The same with the activations' 1 x 32 cast fused into the A-fill (reference call order mxfp8_grouped_mm.py:330-371: to_mx(A)
+// then the grouped mm): `a` is the BF16 [M_total, K] matrix.  Decode-size groups on the 16-wave stream-K kernel only: mx_dyn_fits says
+// whether a shape is taken (callers cast + multiply otherwise).
+// (products: 1, or 2 for the pair forms -- two weight tensors of one shape against the same activations in one launch)
+bool mxfp8_grouped_dyn_fits(int64_t M_total, int64_t N, int64_t K, int64_t E, bool have_offs, int products) {
+  const int64_t groups = have_offs ? E : 1;
+  if (M_total <= 0 || M_total > 48 * groups || groups > 64 || K % 512 != 0 || N % 16 != 0) return false;
+  if (M_total * K >= (1ll << 31) || N * K >= (1ll << 32)) return false;
+  const int64_t tiles = ((M_total + 63) / 64 + groups) * ((N + 63) / 64) * products;
+  return tiles <= kSplitMaxTickets && tiles * (K >> 7) < (1ll << 31);
+}
+// a: BF16 activations (scaling_mode 0 / 1: the cast fused into the A-fill) or, with a_scale != nullptr, their e4m3 codes.  b2 / b2_scale /
+// out2: the second product of the pair forms, or null.
+int mxfp8_grouped_stream16(const void* a, const uint8_t* a_scale, const uint8_t* b, const uint8_t* b_scale, const uint8_t* b2, const uint8_t* b2_scale,
+                           const int32_t* offs, uint16_t* out, uint16_t* out2, int64_t M_total, int64_t N, int64_t K, int64_t E, int scaling_mode,
+                           hipStream_t stream) {
+  Rb8Args p{};
+  p.a = reinterpret_cast<const uint8_t*>(a); p.b = b; p.y = out; p.a_mx = a_scale; p.b_mx = b_scale; p.offs = offs;
+  p.b2 = b2; p.b2_mx = b2_scale; p.y2 = out2;
+  p.M = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
+  if (a_scale != nullptr) return launch_mx_stream<16, 3, 4>(p, stream);
+  return scaling_mode == 1 ? launch_mx_stream<16, 3, 4, 2>(p, stream) : launch_mx_stream<16, 3, 4, 1>(p, stream);
 }
 
 // Float8Tensor's _grouped_mm, rowwise (float8_tensor.py:1085-1122 -> scaled_grouped_mm with RowWise scales):

@@ -21,6 +21,10 @@ int fp8_rowwise_grouped_rb(const uint8_t* a, const uint8_t* b, const float* scal
                            int64_t M_total, int64_t N, int64_t K, int64_t E, hipStream_t stream);  // rb8_kernels.hip
 int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b, const uint8_t* b_scale, const int32_t* offs, uint16_t* out,
                      int64_t M_total, int64_t N, int64_t K, int64_t E, int64_t rows_hint, hipStream_t stream);
+bool mxfp8_grouped_dyn_fits(int64_t M_total, int64_t N, int64_t K, int64_t E, bool have_offs, int products);
+int mxfp8_grouped_stream16(const void* a, const uint8_t* a_scale, const uint8_t* b, const uint8_t* b_scale, const uint8_t* b2, const uint8_t* b2_scale,
+                           const int32_t* offs, uint16_t* out, uint16_t* out2, int64_t M_total, int64_t N, int64_t K, int64_t E, int scaling_mode,
+                           hipStream_t stream);
 thread_local int g_mx_variant = 0;  // profiling / A-B tests (ao_gemm8_set_variant 110 / 111): 0 by shape, 1 always the LDS-staged kernel, 2 never
 namespace {
 
@@ -464,4 +468,62 @@ extern "C" int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale, con
   }
   // other K: the per-tile kernel, m-tiling for the worst case (a group cannot exceed M_total rows)
   return launch_stream8<S8_MX>(p, (int)M_total, (hipStream_t)stream);
+}
+
+// Host-only: whether ao_mxfp8_grouped_mm_dyn (products = 1) / the pair forms (products = 2) take the shape: decode-size groups
+// (M_total <= 48 per group, <= 64 groups), K % 512 == 0, N % 16 == 0.
+extern "C" int ao_mxfp8_grouped_mm_dyn_fits(int64_t M_total, int64_t N, int64_t K, int64_t E) {
+  return mxfp8_grouped_dyn_fits(M_total, N, K, E, true, 1) ? 1 : 0;
+}
+extern "C" int ao_mxfp8_grouped_mm_pair_fits(int64_t M_total, int64_t N, int64_t K, int64_t E) {
+  return mxfp8_grouped_dyn_fits(M_total, N, K, E, true, 2) ? 1 : 0;
+}
+
+namespace {
+int mx_stream16_entry(const char* fn, const void* a, const uint8_t* a_scale, const uint8_t* b, const uint8_t* b_scale, const uint8_t* b2,
+                      const uint8_t* b2_scale, const int32_t* offs, uint16_t* out, uint16_t* out2, int64_t M_total, int64_t N, int64_t K, int64_t E,
+                      int scaling_mode, bool pair, void* stream) {
+  AO_REQUIRE(a_scale != nullptr || scaling_mode == 0 || scaling_mode == 1, "%s: scaling_mode must be AO_MX_SCALE_FLOOR or AO_MX_SCALE_RCEIL, got %d", fn, scaling_mode);
+  AO_REQUIRE(M_total >= 0 && N > 0 && K > 0 && E > 0, "%s: bad shape M_total=%lld N=%lld K=%lld E=%lld", fn, (long long)M_total, (long long)N, (long long)K, (long long)E);
+  if (M_total == 0) return AO_OK;
+  AO_REQUIRE_PTR(a);
+  AO_REQUIRE_PTR(b);
+  AO_REQUIRE_PTR(b_scale);
+  AO_REQUIRE_PTR(offs);
+  AO_REQUIRE_PTR(out);
+  if (pair) {
+    AO_REQUIRE_PTR(b2);
+    AO_REQUIRE_PTR(b2_scale);
+    AO_REQUIRE_PTR(out2);
+  }
+  const bool aligned = ((uintptr_t)b_scale % 16 == 0) && ((uintptr_t)a % 16 == 0) && (a_scale == nullptr || (uintptr_t)a_scale % 16 == 0) &&
+                       (!pair || (uintptr_t)b2_scale % 16 == 0);
+  AO_REQUIRE(mxfp8_grouped_dyn_fits(M_total, N, K, E, true, pair ? 2 : 1) && aligned,
+             "%s: shape M_total=%lld N=%lld K=%lld E=%lld is not a decode-size grouped product (ao_mxfp8_grouped_mm_dyn_fits / _pair_fits; scales and "
+             "activations 16-byte aligned): cast with ao_mxfp8_quantize_rowwise and call ao_mxfp8_grouped_mm per weight", fn, (long long)M_total, (long long)N,
+             (long long)K, (long long)E);
+  return mxfp8_grouped_stream16(a, a_scale, b, b_scale, pair ? b2 : nullptr, pair ? b2_scale : nullptr, offs, out, pair ? out2 : nullptr, M_total, N, K, E,
+                                scaling_mode, (hipStream_t)stream);
+}
+}  // namespace
+
+// _to_mxfp8_then_scaled_grouped_mm's forward in ONE launch (mxfp8_grouped_mm.py:330-371: to_mx(A, block 32, scaling_mode) then the 2d-3d
+// grouped mm): a is the BF16 activation matrix, the cast happens in the kernel's A-fill with the stand-alone cast's arithmetic.
+extern "C" int ao_mxfp8_grouped_mm_dyn(const uint16_t* a, const uint8_t* b, const uint8_t* b_scale, const int32_t* offs, uint16_t* out,
+                                       int64_t M_total, int64_t N, int64_t K, int64_t E, int scaling_mode, void* stream) {
+  return mx_stream16_entry(__func__, a, nullptr, b, b_scale, nullptr, nullptr, offs, out, nullptr, M_total, N, K, E, scaling_mode, false, stream);
+}
+// Two expert-weight tensors of ONE shape against the same activations in one launch -- an MoE layer's w1 and w3 (x @ w1, x @ w3: the
+// reference calls _to_mxfp8_then_scaled_grouped_mm once per weight, casting x twice): out1 / out3 are bit-identical to two single calls.
+extern "C" int ao_mxfp8_grouped_mm_dyn_pair(const uint16_t* a, const uint8_t* b1, const uint8_t* b1_scale, const uint8_t* b3, const uint8_t* b3_scale,
+                                            const int32_t* offs, uint16_t* out1, uint16_t* out3, int64_t M_total, int64_t N, int64_t K, int64_t E,
+                                            int scaling_mode, void* stream) {
+  return mx_stream16_entry(__func__, a, nullptr, b1, b1_scale, b3, b3_scale, offs, out1, out3, M_total, N, K, E, scaling_mode, true, stream);
+}
+// The same with activations the caller cast already (e4m3 codes + E8M0 scales: the output of the EP dispatch, or a cast shared with other consumers).
+extern "C" int ao_mxfp8_grouped_mm_pair(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b1, const uint8_t* b1_scale, const uint8_t* b3,
+                                        const uint8_t* b3_scale, const int32_t* offs, uint16_t* out1, uint16_t* out3, int64_t M_total, int64_t N,
+                                        int64_t K, int64_t E, void* stream) {
+  AO_REQUIRE_PTR(a_scale);
+  return mx_stream16_entry(__func__, a, a_scale, b1, b1_scale, b3, b3_scale, offs, out1, out3, M_total, N, K, E, 0, true, stream);
 }

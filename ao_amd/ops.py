@@ -764,6 +764,82 @@ def mxfp8_grouped_mm(a, a_scale, b, b_scale, offs):
     return out
 
 
+def _mx_mode(scaling_mode) -> int:
+    mode = MX_SCALE_MODES.get(str(getattr(scaling_mode, "value", scaling_mode)).lower())
+    if mode is None:
+        raise RuntimeError(f"unsupported MX scaling mode {scaling_mode!r} (floor | rceil)")
+    return mode
+
+
+def mxfp8_grouped_mm_dyn_fits(m, n, k, e) -> bool:
+    """Whether mxfp8_grouped_mm_dyn takes the shape (host logic: decode-size groups, K % 512 == 0)."""
+    return bool(_lib.lib().ao_mxfp8_grouped_mm_dyn_fits(int(m), int(n), int(k), int(e)))
+
+
+def mxfp8_grouped_mm_dyn(a, b, b_scale, offs, scaling_mode="rceil"):
+    """to_mx(a) + the MXFP8 grouped mm in ONE launch (mxfp8_grouped_mm.py:330-371; SURVEY 8 f1): a bf16 [M, K]; b e4m3 [E, N, K];
+    b_scale e8m0 [E, N, K/32]; offs int32 [E] -> bf16 [M, N], bit-identical to mxfp8_quantize(a) followed by mxfp8_grouped_mm.  Rows past
+    offs[-1] are left unwritten (torch._scaled_grouped_mm's contract; mxfp8_grouped_mm zero-fills them)."""
+    dev = _require_gpu("mxfp8_grouped_mm_dyn", a, b, b_scale, offs)
+    if a.dtype != torch.bfloat16 or a.dim() != 2:
+        raise RuntimeError(f"mxfp8_grouped_mm_dyn: a must be a 2-D bfloat16 tensor, got {a.dtype} {tuple(a.shape)}")
+    a = a.contiguous()
+    b = _fp8_bytes("mxfp8_grouped_mm_dyn", b).contiguous()
+    b_scale = b_scale.view(torch.uint8).contiguous()
+    if b.dim() != 3 or a.shape[1] != b.shape[2]:
+        raise RuntimeError(f"mxfp8_grouped_mm_dyn: A must be [M, K] and B [E, N, K], got {tuple(a.shape)} {tuple(b.shape)}")
+    m, k = a.shape
+    e, n, _ = b.shape
+    if tuple(b_scale.shape) != (e, n, k // 32):
+        raise RuntimeError("mxfp8_grouped_mm_dyn: b_scale must be [E, N, K/32]")
+    if offs.dtype != torch.int32 or offs.numel() != e:
+        raise RuntimeError("mxfp8_grouped_mm_dyn: offs must be int32 [E]")
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        _lib.check(_lib.lib().ao_mxfp8_grouped_mm_dyn(_ptr(a), _ptr(b), _ptr(b_scale), _ptr(offs.contiguous()), _ptr(out), m, n, k, e,
+                                                      _mx_mode(scaling_mode), _stream()))
+    return out
+
+
+def mxfp8_grouped_mm_pair_fits(m, n, k, e) -> bool:
+    """Whether the pair forms take the shape (host logic: the mxfp8_grouped_mm_dyn conditions with twice the tiles)."""
+    return bool(_lib.lib().ao_mxfp8_grouped_mm_pair_fits(int(m), int(n), int(k), int(e)))
+
+
+def mxfp8_grouped_mm_pair(a, b1, b1_scale, b3, b3_scale, offs, scaling_mode="rceil", a_scale=None):
+    """x @ w1 and x @ w3 of an MoE layer in ONE launch: two expert-weight tensors of one shape [E, N, K] (e4m3 + E8M0 [E, N, K/32]) against
+    the same activations.  a bf16 [M, K] (the 1 x 32 cast fused into the kernel, as mxfp8_grouped_mm_dyn) or, with a_scale, its e4m3 codes.
+    -> (y1, y3) bf16 [M, N], bit-identical to two single products.  Rows past offs[-1] are left unwritten."""
+    dev = _require_gpu("mxfp8_grouped_mm_pair", a, b1, b1_scale, b3, b3_scale, offs)
+    b1 = _fp8_bytes("mxfp8_grouped_mm_pair", b1).contiguous()
+    b3 = _fp8_bytes("mxfp8_grouped_mm_pair", b3).contiguous()
+    b1_scale, b3_scale = b1_scale.view(torch.uint8).contiguous(), b3_scale.view(torch.uint8).contiguous()
+    if a.dim() != 2 or b1.dim() != 3 or b1.shape != b3.shape or a.shape[1] != b1.shape[2]:
+        raise RuntimeError(f"mxfp8_grouped_mm_pair: A must be [M, K] and both B [E, N, K], got {tuple(a.shape)} {tuple(b1.shape)} {tuple(b3.shape)}")
+    m, k = a.shape
+    e, n, _ = b1.shape
+    if tuple(b1_scale.shape) != (e, n, k // 32) or tuple(b3_scale.shape) != (e, n, k // 32):
+        raise RuntimeError("mxfp8_grouped_mm_pair: weight scales must be [E, N, K/32]")
+    if offs.dtype != torch.int32 or offs.numel() != e:
+        raise RuntimeError("mxfp8_grouped_mm_pair: offs must be int32 [E]")
+    y1 = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    y3 = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+    with _on(dev):
+        if a_scale is None:
+            if a.dtype != torch.bfloat16:
+                raise RuntimeError(f"mxfp8_grouped_mm_pair: a must be bfloat16 (or e4m3 codes with a_scale), got {a.dtype}")
+            _lib.check(_lib.lib().ao_mxfp8_grouped_mm_dyn_pair(_ptr(a.contiguous()), _ptr(b1), _ptr(b1_scale), _ptr(b3), _ptr(b3_scale), _ptr(offs.contiguous()),
+                                                               _ptr(y1), _ptr(y3), m, n, k, e, _mx_mode(scaling_mode), _stream()))
+        else:
+            aq = _fp8_bytes("mxfp8_grouped_mm_pair", a).contiguous()
+            asc = a_scale.view(torch.uint8).contiguous()
+            if tuple(asc.shape) != (m, k // 32):
+                raise RuntimeError("mxfp8_grouped_mm_pair: a_scale must be [M, K/32]")
+            _lib.check(_lib.lib().ao_mxfp8_grouped_mm_pair(_ptr(aq), _ptr(asc), _ptr(b1), _ptr(b1_scale), _ptr(b3), _ptr(b3_scale), _ptr(offs.contiguous()),
+                                                           _ptr(y1), _ptr(y3), m, n, k, e, _stream()))
+    return y1, y3
+
+
 def _check_token_groups(name, inputs, offsets):
     if inputs.dim() != 2:
         raise AssertionError("input activations must be 2d")

@@ -101,6 +101,9 @@ def _cached_expert_weights(B_t, mode):
     return cast
 
 
+FUSE_ACTIVATION_CAST = True  # (A/B and tests: False = the two-launch path)
+
+
 def _to_mxfp8_then_scaled_grouped_mm(
     A: torch.Tensor,
     B_t,
@@ -131,18 +134,49 @@ def _to_mxfp8_then_scaled_grouped_mm(
         assert block_size == BLOCK, "Only block_size=32 is supported"
         assert offs is not None, "offs must be provided for 2d-2d and 2d-3d grouped mm"
         assert A.dtype == torch.bfloat16 and A.shape[-1] == B_t.shape[-2], f"shape {A.shape} and {B_t.shape} are not compatible"
-        a_q, a_s = ops.mxfp8_quantize(A.contiguous(), scale_calculation_mode)
-        return ops.mxfp8_grouped_mm(a_q, a_s, B_t.data, B_t.scale, offs.to(torch.int32))
+        return _cast_then_grouped_mm(A, B_t, offs, scale_calculation_mode)
     assert B_t.ndim == 3, "B must be 3D"
     assert block_size == BLOCK, "Only block_size=32 is supported"
     assert offs is not None, "offs must be provided for 2d-2d and 2d-3d grouped mm"
     assert out_dtype == torch.bfloat16, "Only bfloat16 out_dtype is supported"
     assert A.dtype == torch.bfloat16 and B_t.dtype == torch.bfloat16, "A and B_t must be bfloat16"
     assert A.shape[-1] == B_t.shape[-2], f"shape {A.shape} and {B_t.shape} are not compatible for _scaled_grouped_mm"
-    a_q, a_s = ops.mxfp8_quantize(A.contiguous(), scale_calculation_mode)
     # weights: 1x32 blocks along K of the [E, N, K] tensor (the reference quantises B_t.transpose(-2, -1))
     w = _cached_expert_weights(B_t, scale_calculation_mode) if cache_weights else MXFP8ExpertWeights.from_hp(B_t, scale_calculation_mode)
-    return ops.mxfp8_grouped_mm(a_q, a_s, w.data, w.scale, offs.to(torch.int32))
+    return _cast_then_grouped_mm(A, w, offs, scale_calculation_mode)
+
+
+def _to_mxfp8_then_scaled_grouped_mm_pair(A: torch.Tensor, B1_t, B3_t, offs: torch.Tensor, scale_calculation_mode: ScaleCalculationMode = ScaleCalculationMode.RCEIL,
+                                          cache_weights: bool = False):
+    """(A @ w1, A @ w3) of an MoE layer's experts -- the reference computes them by two calls of _to_mxfp8_then_scaled_grouped_mm
+    (mxfp8_grouped_mm.py:56-239), casting A twice; here decode-size groups take ONE launch for both products with the cast fused in
+    (ops.mxfp8_grouped_mm_pair), other shapes two calls.  Same bits either way.  B1_t / B3_t: bf16 [E, K, N] views or MXFP8ExpertWeights."""
+    assert A.ndim == 2 and A.dtype == torch.bfloat16 and offs is not None
+    ws = []
+    for B_t in (B1_t, B3_t):
+        if isinstance(B_t, MXFP8ExpertWeights):
+            ws.append(B_t)
+        else:
+            assert B_t.ndim == 3 and B_t.dtype == torch.bfloat16, "B must be a 3-D bfloat16 tensor or MXFP8ExpertWeights"
+            ws.append(_cached_expert_weights(B_t, scale_calculation_mode) if cache_weights else MXFP8ExpertWeights.from_hp(B_t, scale_calculation_mode))
+    w1, w3 = ws
+    assert w1.data.shape == w3.data.shape and A.shape[-1] == w1.data.shape[-1], f"shapes {A.shape}, {w1.data.shape}, {w3.data.shape} are not compatible"
+    E, N, K = w1.data.shape
+    offs = offs.to(torch.int32)
+    if FUSE_ACTIVATION_CAST and A.is_cuda and ops.mxfp8_grouped_mm_pair_fits(A.shape[0], N, K, E):
+        return ops.mxfp8_grouped_mm_pair(A, w1.data, w1.scale, w3.data, w3.scale, offs, scale_calculation_mode)
+    return _cast_then_grouped_mm(A, w1, offs, scale_calculation_mode), _cast_then_grouped_mm(A, w3, offs, scale_calculation_mode)
+
+
+def _cast_then_grouped_mm(A, w, offs, scale_calculation_mode):
+    """to_mx(A) then the grouped mm (mxfp8_grouped_mm.py:330-371).  Decode-size groups take ONE launch with the cast fused into the kernel's
+    A-fill (round 6, SURVEY 8 f1: ops.mxfp8_grouped_mm_dyn, bit-identical); other shapes the cast kernel and the GEMM."""
+    E, N, K = w.data.shape
+    offs = offs.to(torch.int32)
+    if FUSE_ACTIVATION_CAST and A.is_cuda and ops.mxfp8_grouped_mm_dyn_fits(A.shape[0], N, K, E):
+        return ops.mxfp8_grouped_mm_dyn(A, w.data, w.scale, offs, scale_calculation_mode)
+    a_q, a_s = ops.mxfp8_quantize(A.contiguous(), scale_calculation_mode)
+    return ops.mxfp8_grouped_mm(a_q, a_s, w.data, w.scale, offs)
 
 
 def pad_token_groups(input_act: torch.Tensor, group_end_offsets: torch.Tensor, alignment_size: int = 32):

@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--configs", default="int4_bs128,int8,fp8,mx,tp", help="comma list of secondary configs to run")
+    ap.add_argument("--mx-two-launch", action="store_true", help="config mx: time the cast kernel + GEMM form as the config's value (A/B)")
+    ap.add_argument("--mx-no-pair", action="store_true", help="config mx: one launch per product (w1 and w3 apart) as the config's value (A/B)")
     ap.add_argument("--wpb", type=int, default=0, help="tuning: waves per workgroup override")
     ap.add_argument("--mode", type=int, default=0, help="tuning: kernel ablation / depth variant (profiling only)")
     ap.add_argument("--force-tp", action="store_true", help="run the TP-linear config even with one rank (exercises the RCCL path on a 1-GPU box)")
@@ -837,10 +839,26 @@ def config_mx(stream, device, args):
             wts.append((name, n, k) + ops.mxfp8_quantize(w, "rceil"))  # expert weights are cast ONCE (weight prep)
             del w
     xs = {k: torch.randn(rows, k, device=device, dtype=torch.bfloat16, generator=gen) for k in (4096, 14336)}
-    def step():
+    # the product path of _to_mxfp8_then_scaled_grouped_mm (ao_amd/prototype/mx.py): decode-size groups take ONE launch with the activations'
+    # 1 x 32 cast fused into the kernel's A-fill (round 6); the two-launch form (cast kernel, then the GEMM) is timed beside it
+    fused = all(ops.mxfp8_grouped_mm_dyn_fits(rows, n, k, E) for _, n, k, _, _ in wts[:3]) and not args.mx_two_launch
+    def step_two():
         for name, n, k, wq, wsc in wts:
             aq, asc = ops.mxfp8_quantize(xs[k], "rceil")  # activations: dynamic cast every forward
             ops.mxfp8_grouped_mm(aq, asc, wq, wsc, offs)
+    def step_fused():
+        for name, n, k, wq, wsc in wts:
+            ops.mxfp8_grouped_mm_dyn(xs[k], wq, wsc, offs, "rceil")
+    # one launch for an expert layer's w1 and w3 (x @ w1, x @ w3: same activations, same shape; ops.mxfp8_grouped_mm_pair), one for w2
+    pair = fused and not args.mx_no_pair and ops.mxfp8_grouped_mm_pair_fits(rows, MIXTRAL[0][1], MIXTRAL[0][2], E)
+    def layer_pairs(w, x, o):
+        for i in range(0, len(w), 3):
+            (_, n1, k1, w1q, w1s), (_, _, _, w3q, w3s), (_, n2, k2, w2q, w2s) = w[i], w[i + 1], w[i + 2]
+            ops.mxfp8_grouped_mm_pair(x[k1], w1q, w1s, w3q, w3s, o, "rceil")
+            ops.mxfp8_grouped_mm_dyn(x[k2], w2q, w2s, o, "rceil")
+    def step_pair():
+        layer_pairs(wts, xs, offs)
+    step = step_pair if pair else step_fused if fused else step_two
     # SURVEY 8(d)'s second workload: 16 tokens on EVERY expert, each group padded to the 32-row alignment of the grouped GEMM
     # (fused_pad_token_groups semantics: 8 x 32 = 256 rows, half of them zero padding) -- all 8 experts' weights are read: 484 MB per w1
     rows_u = 32 * E
@@ -850,13 +868,21 @@ def config_mx(stream, device, args):
         t = torch.zeros(rows_u, k, device=device, dtype=torch.bfloat16)
         t.view(E, 32, k)[:, :16] = torch.randn(E, 16, k, device=device, dtype=torch.bfloat16, generator=gen)
         xs_u[k] = t
-    def step_u():
+    def step_u_two():
         for name, n, k, wq, wsc in wts:
             aq, asc = ops.mxfp8_quantize(xs_u[k], "rceil")
             ops.mxfp8_grouped_mm(aq, asc, wq, wsc, offs_u)
+    def step_u_fused():
+        for name, n, k, wq, wsc in wts:
+            ops.mxfp8_grouped_mm_dyn(xs_u[k], wq, wsc, offs_u, "rceil")
+    def step_u_pair():
+        layer_pairs(wts, xs_u, offs_u)
+    step_u = step_u_pair if pair else step_u_fused if fused else step_u_two
     with torch.cuda.stream(stream):
         t, graphed = _graph_time(step, stream, device, steps=5)
         tu, _ = _graph_time(step_u, stream, device, steps=5)
+        t_two, tu_two = (_graph_time(step_two, stream, device, steps=5)[0], _graph_time(step_u_two, stream, device, steps=5)[0]) if fused else (None, None)
+        t_one, tu_one = (_graph_time(step_fused, stream, device, steps=5)[0], _graph_time(step_u_fused, stream, device, steps=5)[0]) if pair else (None, None)
     used = int((sizes > 0).sum())
     bts = sum(used * n * k * (1 + 1 / 32) + rows * k * 2 + rows * k * (1 + 1 / 32) + rows * n * 2 for _, n, k, _, _ in wts)
     bts_u = sum(E * n * k * (1 + 1 / 32) + rows_u * k * 2 + rows_u * k * (1 + 1 / 32) + rows_u * n * 2 for _, n, k, _, _ in wts)
@@ -865,7 +891,7 @@ def config_mx(stream, device, args):
                        f"64 tokens x top-2 = 128 rows, group sizes {sizes.tolist()} (32 x multinomial, seed 0), 32 layers",
            "value": 64 / t, "unit": "tokens/s", "ms_per_step": t * 1e3, "dtype": "e4m3 x e4m3 with E8M0 1x32 block scales, bf16 out",
            "launch": "hipGraph replay" if graphed else "eager",
-           "roofline": {"kernel": "mx_stream_kernel<8, 3, 4> (stream-K, decode-size groups)", "bound": "hbm", "achieved": bts / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "roofline": {"kernel": "mx_stream_kernel (stream-K, decode-size groups; 16 waves / 256-column tiles, one workgroup per CU)", "bound": "hbm", "achieved": bts / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": bts / t / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_of("mx")[0], "traffic_source": pmc_traffic_of("mx")[1],
                         "timing": "hipGraph replay wall time of the whole step (activation casts included)",
                         "bytes_note": "weights of the experts that received tokens only", "TFLOPs": flops / t / 1e12},
@@ -875,6 +901,15 @@ def config_mx(stream, device, args):
                          "roofline": {"bound": "hbm", "achieved": bts_u / tu / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bts_u / tu / 1e9 / HBM_PEAK_GBS,
                                       "traffic": pmc_traffic_of("mx", "uniform16")[0], "traffic_source": pmc_traffic_of("mx", "uniform16")[1],
                                       "algorithmic_bytes_per_step": bts_u, "timing": "hipGraph replay wall time of the whole step (activation casts included)"}}}
+    out["launches_per_step"] = (len(wts) // 3 * 2) if pair else (1 if fused else 2) * len(wts)
+    out["w1_w3"] = "one launch for both products (ao_mxfp8_grouped_mm_dyn_pair)" if pair else "one launch each"
+    if pair:  # one launch per product, cast fused (what a caller of the reference's per-weight interface gets)
+        out["one_launch_per_product"] = {"value": 64 / t_one, "ms_per_step": t_one * 1e3, "frac": bts / t_one / 1e9 / HBM_PEAK_GBS,
+                                         "uniform16_value": 64 / tu_one, "uniform16_ms_per_step": tu_one * 1e3, "uniform16_frac": bts_u / tu_one / 1e9 / HBM_PEAK_GBS}
+    out["activation_cast"] = "fused into the grouped GEMM's A-fill (ao_mxfp8_grouped_mm_dyn)" if fused else "its own kernel (ao_mxfp8_quantize_rowwise) before every GEMM"
+    if fused:  # the A/B the round-5 verdict asked for: the same 96 products as cast kernel + GEMM (two launches each), same process, same weights
+        out["two_launch"] = {"value": 64 / t_two, "ms_per_step": t_two * 1e3, "frac": bts / t_two / 1e9 / HBM_PEAK_GBS,
+                             "uniform16_value": 64 / tu_two, "uniform16_ms_per_step": tu_two * 1e3, "uniform16_frac": bts_u / tu_two / 1e9 / HBM_PEAK_GBS}
     if not args.no_cpu_baseline:
         from oracle import c_ref
         rng = np.random.default_rng(3)
@@ -1043,6 +1078,9 @@ def main():
         lib.ao_int4_set_tuning(args.wpb, args.mode)
     if args.gemm_variant:
         lib.ao_gemm8_set_variant(args.gemm_variant)
+    for kv in filter(None, os.environ.get("AO_GEMM8_TUNE", "").split(",")):  # A/B runs of the tools: key=value pairs of ao_gemm8_set_tuning
+        key, val = kv.split("=")
+        _lib.check(lib.ao_gemm8_set_tuning(int(key), int(val)))
 
     merged = args.merged and not args.unmerged
     shapes = LLAMA3_8B_MERGED if merged else LLAMA3_8B_UNMERGED

@@ -298,6 +298,29 @@ int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale,
                         const int32_t* offs, uint16_t* out, int64_t M_total,
                         int64_t N, int64_t K, int64_t E, void* stream);
 
+/* _to_mxfp8_then_scaled_grouped_mm's forward in ONE launch (torchao/prototype/moe_training/mxfp8_grouped_mm.py:330-371, 552-594: to_mx(A, 32,
+ * scaling_mode) followed by the grouped mm above; SURVEY.md 8 f1 for the MX format; native analogue of the cast: torchao/csrc/cuda/mx_kernels/
+ * mxfp8_quantize.cuh:460-820).  a is the BF16 activation matrix [M_total][K]; the 1 x 32 cast runs inside the kernel's A-fill with the
+ * arithmetic of ao_mxfp8_quantize_rowwise (same codes, same scales, so out is bit-identical to cast + ao_mxfp8_grouped_mm).
+ * Decode-size groups only: ao_mxfp8_grouped_mm_dyn_fits(M_total, N, K, E) (host logic, no launch) is 1 when M_total <= 48 E, E <= 64,
+ * K % 512 == 0, N % 16 == 0; other shapes return AO_ERR_INVALID_ARGUMENT -- cast and call ao_mxfp8_grouped_mm.  a and b_scale 16-byte aligned. */
+int ao_mxfp8_grouped_mm_dyn_fits(int64_t M_total, int64_t N, int64_t K, int64_t E);
+int ao_mxfp8_grouped_mm_dyn(const uint16_t* a, const uint8_t* b, const uint8_t* b_scale, const int32_t* offs, uint16_t* out,
+                            int64_t M_total, int64_t N, int64_t K, int64_t E, int scaling_mode, void* stream);
+
+/* Two expert-weight tensors of ONE shape [E][N][K] against the same activations in ONE launch: an MoE layer's w1 and w3 (the reference's
+ * experts compute x @ w1 and x @ w3 by two calls of _to_mxfp8_then_scaled_grouped_mm, mxfp8_grouped_mm.py:56-239, casting x twice).
+ * out1 / out3 bf16 [M_total][N] are bit-identical to two single calls.  _dyn_pair: a is BF16, cast fused (as ao_mxfp8_grouped_mm_dyn);
+ * _pair: a / a_scale are the caller's e4m3 codes / E8M0 scales.  Shapes: ao_mxfp8_grouped_mm_pair_fits (host logic; the _dyn conditions
+ * with twice the tiles). */
+int ao_mxfp8_grouped_mm_pair_fits(int64_t M_total, int64_t N, int64_t K, int64_t E);
+int ao_mxfp8_grouped_mm_dyn_pair(const uint16_t* a, const uint8_t* b1, const uint8_t* b1_scale, const uint8_t* b3, const uint8_t* b3_scale,
+                                 const int32_t* offs, uint16_t* out1, uint16_t* out3, int64_t M_total, int64_t N, int64_t K, int64_t E,
+                                 int scaling_mode, void* stream);
+int ao_mxfp8_grouped_mm_pair(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b1, const uint8_t* b1_scale, const uint8_t* b3,
+                             const uint8_t* b3_scale, const int32_t* offs, uint16_t* out1, uint16_t* out3, int64_t M_total, int64_t N,
+                             int64_t K, int64_t E, void* stream);
+
 /* Float8Tensor's aten::_grouped_mm with rowwise scales (float8_tensor.py:1085-1122 -> scaled_grouped_mm, RowWise recipes):
  *   out[offs[e-1]:offs[e]] = bf16( (a_rows @ b[e]^T)_f32 * scale_a[m] * scale_b[e][n] )
  *   a e4m3 [M_total][K]; scale_a fp32 [M_total]; b e4m3 [E][N][K]; scale_b fp32 [E][N]; offs int32 [E]; out bf16 [M_total][N].

@@ -470,7 +470,7 @@ def test_mxfp8_grouped_mm_lds_staged_kernel(sizes, n, k):
     assert _rel(np_from_torch_bf16(y_other), yn) <= 1e-3
 
 
-@pytest.mark.parametrize("variant", [119, 118, 129, 128, 114])
+@pytest.mark.parametrize("variant", [119, 116, 118, 129, 128, 114])
 @pytest.mark.parametrize(
     "sizes,n,k",
     [([16, 16, 16, 16], 256, 4096),          # 16 tiles x 32 steps over 32 shares: every tile cut in two
@@ -482,7 +482,8 @@ def test_mxfp8_grouped_mm_lds_staged_kernel(sizes, n, k):
      ([32, 0, 0, 0, 32, 64, 0, 0], 1024, 4096)],  # BASELINE config 5's routing
 )
 def test_mxfp8_grouped_mm_stream_k_kernel(sizes, n, k, variant):
-    """mx_stream_kernel (decode-size groups; variant 119 = the product's form, forced for every N: 8 waves / 128-column tiles, 3 weight stages, two workgroups per CU;
+    """mx_stream_kernel (decode-size groups; variant 119: 8 waves / 128-column tiles, 3 weight stages, two workgroups per CU; 116 (round 6): 16 waves / 256-column
+    tiles, ONE workgroup per CU, where K % 512 == 0;
     118: 4 waves / 64 columns, three per CU; both fetch the block scales per 4 k steps when K % 512 == 0 (129 / 128: per step, as every K % 512 != 0
     does); 114: 4 waves, 6 stages, two per CU):
     shares of the (slab, tile, k step) space that cross tile and expert boundaries, pieces of cut tiles meeting through the
@@ -517,6 +518,106 @@ def test_mxfp8_grouped_mm_stream_k_kernel(sizes, n, k, variant):
     yt = np_from_torch_bf16(y_tile)  # the one-workgroup-per-tile kernel (scales per 4 steps when K % 512 == 0) against the oracle too
     assert _rel(yt, yn) <= 1e-3
     assert np.all(np.abs(yt - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + mag * 2.0 ** -16)
+
+
+@pytest.mark.parametrize("mode", ["rceil", "floor"])
+@pytest.mark.parametrize(
+    "sizes,n,k",
+    [([16, 16, 16, 16], 256, 4096),            # every tile cut in two
+     ([40, 0, 5, 27], 80, 512),                # one workgroup walks tiles of three experts; N not a multiple of the 256-column tile
+     ([1, 17, 33, 49, 0, 64, 65, 0], 80, 512),  # every m-tile count, a group of two slabs (rows the waves do not fetch)
+     ([2] * 64, 48, 1024),                     # 64 experts
+     ([3, 0, 0, 1], 64, 14336),                # 112-step tiles in many pieces
+     ([32, 0, 0, 0, 32, 64, 0, 0], 1024, 4096),  # BASELINE config 5's routing
+     ([32, 0, 0, 0, 32, 64, 0, 0], 3584, 4096)],  # ... on a width that is not a multiple of 256 x 8
+)
+def test_mxfp8_grouped_mm_fused_activation_cast(sizes, n, k, mode):
+    """SURVEY 8 f1 for the MX format (round 6): ao_mxfp8_grouped_mm_dyn casts the bf16 activations 1 x 32 inside the grouped GEMM's A-fill
+    (reference call order mxfp8_grouped_mm.py:330-371: to_mx(A) then the grouped mm).  Bit for bit the two-launch path (same cast function,
+    same kernel, same k order), against the oracle, same bits on repeated launches; inf / NaN / zero blocks go through the cast as they do
+    stand-alone; shapes it does not take are refused."""
+    E, M = len(sizes), sum(sizes)
+    a = _randn_bf16((M, k), 71 + n, 3.0)
+    a[0, :32] = 0.0
+    a[min(1, M - 1), 40] = float("inf")
+    if M > 2:
+        a[2, 70] = float("nan")
+    w = _randn_bf16((E, n, k), 72 + k, 0.1)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32).to(DEV)
+    w_d, w_s = ops.mxfp8_quantize(w.to(DEV), "rceil")
+    ad = a.to(DEV)
+    assert ops.mxfp8_grouped_mm_dyn_fits(M, n, k, E)
+    y = ops.mxfp8_grouped_mm_dyn(ad, w_d, w_s, offs, mode)
+    for _ in range(3):
+        assert torch.equal(ops.mxfp8_grouped_mm_dyn(ad, w_d, w_s, offs, mode).view(torch.int16), y.view(torch.int16))
+    a_d, a_s = ops.mxfp8_quantize(ad, mode)
+    y2 = ops.mxfp8_grouped_mm(a_d, a_s, w_d, w_s, offs)
+    rows = int(offs[-1])
+    assert torch.equal(y[:rows].view(torch.int16), y2[:rows].view(torch.int16))  # (NaN rows included: compared as bits)
+    # and the two-launch path is the oracle's (on the finite rows)
+    y_ref, mag = MX.grouped_mm(a_d.view(torch.uint8).cpu().numpy(), a_s.view(torch.uint8).cpu().numpy(), w_d.view(torch.uint8).cpu().numpy(),
+                               w_s.view(torch.uint8).cpu().numpy(), offs.cpu().numpy(), return_abs=True)
+    yn = np_from_torch_bf16(y)[:rows]
+    fin = np.isfinite(y_ref[:rows]).all(axis=1) & np.isfinite(yn).all(axis=1)
+    assert fin.sum() >= rows - 3
+    assert np.all(np.abs(yn[fin] - y_ref[:rows][fin]) <= np.abs(y_ref[:rows][fin]) * 2.0 ** -7 + mag[:rows][fin] * 2.0 ** -16)
+
+
+@pytest.mark.parametrize("sizes,n,k", [([16, 16, 16, 16], 256, 4096), ([1, 17, 33, 49, 0, 64, 65, 0], 80, 512), ([32, 0, 0, 0, 32, 64, 0, 0], 3584, 4096),
+                                       ([3, 0, 0, 1], 64, 14336)])
+def test_mxfp8_grouped_mm_pair_is_two_single_products(sizes, n, k):
+    """ao_mxfp8_grouped_mm_dyn_pair / _pair: an MoE layer's x @ w1 and x @ w3 in ONE launch (the second weight tensor's column tiles follow the
+    first's in every slab of the stream-K space): both outputs bit for bit the single-product launches, fused cast and pre-cast activations,
+    repeated launches, and through the mirror (_to_mxfp8_then_scaled_grouped_mm_pair)."""
+    from ao_amd.prototype import mx as MXP
+
+    E, M = len(sizes), sum(sizes)
+    a = _randn_bf16((M, k), 81 + n, 2.0).to(DEV)
+    w1 = _randn_bf16((E, n, k), 82 + k, 0.1).to(DEV)
+    w3 = _randn_bf16((E, n, k), 83 + k, 0.1).to(DEV)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32).to(DEV)
+    rows = int(offs[-1])
+    w1d, w1s = ops.mxfp8_quantize(w1, "rceil")
+    w3d, w3s = ops.mxfp8_quantize(w3, "rceil")
+    assert ops.mxfp8_grouped_mm_pair_fits(M, n, k, E)
+    want1 = ops.mxfp8_grouped_mm_dyn(a, w1d, w1s, offs)[:rows]
+    want3 = ops.mxfp8_grouped_mm_dyn(a, w3d, w3s, offs)[:rows]
+    for _ in range(3):
+        y1, y3 = ops.mxfp8_grouped_mm_pair(a, w1d, w1s, w3d, w3s, offs)
+        assert torch.equal(y1[:rows], want1) and torch.equal(y3[:rows], want3)
+    aq, asc = ops.mxfp8_quantize(a, "rceil")
+    y1, y3 = ops.mxfp8_grouped_mm_pair(aq, w1d, w1s, w3d, w3s, offs, a_scale=asc)
+    assert torch.equal(y1[:rows], want1) and torch.equal(y3[:rows], want3)
+    m1, m3 = MXP._to_mxfp8_then_scaled_grouped_mm_pair(a, w1.transpose(-2, -1), w3.transpose(-2, -1), offs)
+    assert torch.equal(m1[:rows], want1) and torch.equal(m3[:rows], want3)
+    assert torch.equal(MXP._to_mxfp8_then_scaled_grouped_mm(a, w1.transpose(-2, -1), offs)[:rows], want1)
+
+
+def test_mxfp8_grouped_mm_fused_cast_refuses_other_shapes_and_the_mirror_falls_back():
+    from ao_amd.prototype import mx as MXP
+
+    assert not ops.mxfp8_grouped_mm_dyn_fits(128, 256, 384, 4)      # K % 512 != 0
+    assert not ops.mxfp8_grouped_mm_dyn_fits(4 * 49, 256, 512, 4)   # groups beyond decode size
+    assert not ops.mxfp8_grouped_mm_dyn_fits(64, 256, 512, 65)      # more experts than the group table holds
+    a = _randn_bf16((64, 384), 5).to(DEV)
+    w = _randn_bf16((2, 64, 384), 6, 0.1).to(DEV)
+    w_d, w_s = ops.mxfp8_quantize(w, "rceil")
+    offs = torch.tensor([32, 64], dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError, match="not a decode-size grouped product"):
+        ops.mxfp8_grouped_mm_dyn(a, w_d, w_s, offs)
+    # the mirror (_to_mxfp8_then_scaled_grouped_mm) takes the fused launch where it fits and the two launches elsewhere: same bits either way
+    for k in (384, 1024):
+        a = _randn_bf16((64, k), 7).to(DEV)
+        b_t = _randn_bf16((2, 128, k), 8, 0.1).to(DEV).transpose(-2, -1)
+        want = None
+        for fuse in (False, True):
+            MXP.FUSE_ACTIVATION_CAST = fuse
+            try:
+                got = MXP._to_mxfp8_then_scaled_grouped_mm(a, b_t, offs)
+            finally:
+                MXP.FUSE_ACTIVATION_CAST = True
+            want = got if want is None else want
+            assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("m,n,k,bias", [(128, 1024, 8192, False), (128, 7168, 8192, True), (200, 8192, 1024, True), (2048, 1024, 1024, False),
