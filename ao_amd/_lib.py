@@ -43,7 +43,6 @@ _SIGNATURES = {
     "ao_int4_set_trace": [_P],
     "ao_gemm8_set_variant": [_INT],
     "ao_gemm8_set_tuning": [_INT, _INT],
-    "ao_xcd_local_state": [],
     "ao_int4_mm_kernel_name": [_I64, _I64, _I64, _INT],
     "ao_gemm8_kernel_name": [_INT, _I64, _I64, _I64],
     "ao_fp8_int4_kernel_name": [_I64, _I64, _I64, _INT],

@@ -31,7 +31,7 @@ int gemm8_p8h_parts(int64_t M, int64_t N, int64_t K);
 void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bn, int* split);
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void rb8_set_wave_grid(bool two_by_four);  // rb8_kernels.hip
-void rb8_set_tuning(int bn, int split, int local_off, int ablate, int bm);
+void rb8_set_tuning(int bn, int split, int ablate);
 void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
 extern thread_local int g_mx_variant;  // stream8_kernels.hip
@@ -43,7 +43,6 @@ int mid8_scaled(bool int8, const void* a, const float* scale_a, const void* b, c
 bool dec8_takes(int64_t M, int64_t N, int64_t K);
 int dec8_scaled(bool int8, const void* xq, const float* x_scale, const void* wq, const float* w_scale, const uint16_t* bias, uint16_t* y,
                 int64_t M, int64_t N, int64_t K, hipStream_t stream);
-void mx_rb_set_slim(bool on);          // rb8_kernels.hip
 void mx_rb_set_stream(int mode, bool quad);
 void mx_stream_set_tuning(int proto);
 int fp8_rowwise_rb(const uint8_t* a, const uint8_t* b, const float* scale_a, const float* scale_b, const uint16_t* bias, uint16_t* y,
@@ -463,11 +462,9 @@ extern "C" int ao_gemm8_set_variant(int variant) {
   g_gemm8_force_regstage = (variant == 1);
   g_gemm8_tiled_only = (variant == 100);
   g_mx_variant = (variant == 110) ? 1 : (variant == 111) ? 2 : 0;
-  mx_rb_set_slim(variant != 112);
-  // MX decode groups: 113 one workgroup per tile; stream-K forms 119 (the product's, forced), 118 (4 waves x 3 stages), 114 (4 x 6); 129 / 128 = 119 / 118 with
-  // the scales fetched per step instead of per 4 steps
-  mx_rb_set_stream((variant == 112 || variant == 113) ? 0 : (variant == 114) ? 2 : (variant == 118 || variant == 128) ? 3 : (variant == 119 || variant == 129) ? 4 : (variant == 116) ? 5 : 1,
-                   variant != 128 && variant != 129);
+  // MX decode groups: 113 one workgroup per tile (the form of larger groups); 129 the stream-K kernel's per-step-scales form (8 waves, two per CU:
+  // what K % 512 != 0 takes) on every K
+  mx_rb_set_stream(variant == 113 ? 0 : 1, variant != 129);
   // the straight-line decode kernel (dec8_kernels.hip): 201 / 202 / 204 / 207 / 208 force its ring depth, 290 half-line loads, 299 never
   g_dec8_mode = (variant >= 200 && variant <= 299) ? variant : 0;
   // the register-ring mid-M kernel (mid8_kernels.hip): 300 never, 301 wherever the shape allows, 310 + S: S K-parts forced
@@ -484,7 +481,7 @@ extern "C" int ao_gemm8_set_tuning(int key, int value) {
   AO_REQUIRE(key >= 1 && key <= 9, "ao_gemm8_set_tuning: unknown key %d", key);
   g_tune[key] = value;
   mx_stream_set_tuning(g_tune[9]);
-  rb8_set_tuning(g_tune[1], g_tune[2], g_tune[3], g_tune[5], g_tune[6]);
+  rb8_set_tuning(g_tune[1], g_tune[2], g_tune[5]);
   gemm8_p8_set_group_rows(g_tune[4]);
   gemm8_p8_set_split(g_tune[7]);
   gemm8_p8h_set_form(g_tune[8]);

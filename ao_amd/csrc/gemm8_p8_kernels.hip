@@ -68,19 +68,15 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
   int wg = blockIdx.x;
   const int nwg = gridDim.x;
   if ((nwg & 7) == 0) wg = (wg & 7) * (nwg >> 3) + (wg >> 3);
-  // K parts: the S parts of a tile are consecutive work items (of one XCD when the grid is a multiple of 8)
-  const int S = p.split;
-  const int ks = wg % S;
-  wg /= S;
+  // (K parts -- built in round 5 for this tile shape too, never dispatched: a 256 x 256 fp32 partial is 256 KiB, the meeting cost what the
+  // shorter loop saved, profiles/p8_split_sweep_r05.jsonl -- live on in the 256 x 128 form below only)
   const int GR = p.group_rows;
   const int group = GR * p.tiles_n;
   const int g0 = (wg / group) * GR;
   const int gsz = min(GR, p.tiles_m - g0);
   const int tm = g0 + (wg % group) % gsz, tn = (wg % group) / gsz;
   const int m0 = tm * 256, n0 = tn * 256;
-  const int ktiles_all = p.K >> 7;
-  const int kb = (int)((int64_t)ks * ktiles_all / S);                      // this part's first K tile
-  const int ktiles = (int)((int64_t)(ks + 1) * ktiles_all / S) - kb;       // >= 1: launchers keep S <= K / 128
+  const int kb = 0, ktiles = p.K >> 7;
 
   // DMA sources.  Half tile rows 16 w + 8 i + (lane >> 3), i = 0, 1; lane lands at chunk position lane & 7.
   uint32_t aoff[2][2], boff[2][2];  // [half][i]: byte offset from the tile's first row, k = 0
@@ -225,13 +221,6 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (S > 1) {
-    // the K parts meet (csrc/splitk.h): parked through to memory in part order, the last arriver of the tile sums them in part order
-    // -- the result does not depend on who arrives when -- and goes on to the epilogue
-    if (!split_k_meet2<32, 512, IS_INT, 2, false, 8>(reinterpret_cast<f32x4(&)[32]>(acc), p.ws, p.tickets, tm * p.tiles_n + tn, S, ks, tid,
-                                                       reinterpret_cast<int*>(smem)))
-      return;
-  }
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------
   // D layout of the 16 x 16 MFMA: lane (col = nl, kq) holds rows 4 kq + {0..3}
@@ -506,7 +495,7 @@ __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
   if constexpr (!IS_INT) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // asm MFMA results -> VALU / VMEM readers (see gemm8_p8_kernel)
   __builtin_amdgcn_sched_barrier(0);
   if (S > 1) {  // the K parts meet: 128 KiB per part, summed in part order by the last arriver, which goes on to the epilogue
-    if (!split_k_meet2<16, 512, IS_INT, 2, false, 8>(reinterpret_cast<f32x4(&)[16]>(acc), p.ws, p.tickets, tm * p.tiles_n + tn, S, ks, tid,
+    if (!split_k_meet2<16, 512, IS_INT, 2, 8>(reinterpret_cast<f32x4(&)[16]>(acc), p.ws, p.tickets, tm * p.tiles_n + tn, S, ks, tid,
                                                        reinterpret_cast<int*>(smem)))
       return;
   }
@@ -618,18 +607,6 @@ int launch_p8h(P8Args p, hipStream_t stream) {
   return AO_OK;
 }
 
-// K parts of a launch (ao_gemm8_set_tuning key 7; the product launches ONE part): a 256 x 256 fp32 partial tile is 256 KiB, so S parts move
-// S x 512 KiB per tile through memory at the meeting -- 1024 x 7168 x 8192 with 2 parts: 112 MB, ~25 us, on top of a 38 us k loop (77 us
-// unsplit, 66 split, hipBLASLt 64; profiles/p8_split_sweep_r05.jsonl).  Ahead of the product dispatch only on the Llama-3-8B down_proj
-// (K = 14336) at 768 - 2048 rows before the 256 x 128 form below took those shapes; kept as a measured tuning form.
-int p8_split(int64_t M, int64_t N, int64_t K) {
-  const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256), ktiles = K / 128;
-  const int64_t fit = std::min<int64_t>({256 / tiles, ktiles, 16, (int64_t)(kSplitSlotFloats / ((size_t)tiles * 256 * 256)) * 4 / 5,
-                                         (int64_t)kSplitMaxTickets / (tiles * 5)});
-  if (g_p8_split > 0) return (int)std::max<int64_t>(1, std::min<int64_t>(g_p8_split, fit));
-  return 1;
-}
-
 template <int EPI>
 int launch_p8(P8Args p, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
@@ -637,13 +614,9 @@ int launch_p8(P8Args p, hipStream_t stream) {
   // round 5 sweep (profiles/p8_group_rows_r05.jsonl): 4 tile rows per group measured 0 .. 7 % ahead of 8 on the Llama-3-8B int8 shapes at
   // M = 16384 (an XCD's L2 then holds 4 MB of A panels, its size, instead of 8 MB) and level elsewhere
   p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
-  p.split = p8_split(p.M, p.N, p.K);
-  if (p.split > 1) {
-    const int NG = (p.split + 3) / 4;
-    if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)p.tiles_m * p.tiles_n * (p.split + NG) * 256 * 256, p.split)) return rc;
-  }
+  p.split = 1;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8_kernel<EPI>), kSmem, "hipFuncSetAttribute(gemm8_p8_kernel)")) return rc;
-  ao::launch(gemm8_p8_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n * p.split)), dim3(512), kSmem, stream, p);
+  ao::launch(gemm8_p8_kernel<EPI>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), kSmem, stream, p);
   AO_LAUNCH_CHECK("gemm8_p8_kernel launch");
   return AO_OK;
 }

@@ -158,57 +158,39 @@ struct XRegs {
   uint32_t v[kDwords];
 };
 
-// SCHED: instruction order of a block's dequant + products.
-//   0  word by word (dequantise one packed word, multiply, next word) -- MFMA and VALU work of a wave never overlap
-//   1  stage by stage over the block's four words, the 4x4x4 "add" MFMAs issued between the cvt_pk of earlier results
-//   3  profiling only: no dequant at all
-//   2  as 1, and software-pipelined across blocks: the four products of block b-1 are issued between the mask / convert /
-//      multiply VALU work of block b (x slab double-buffered so that block b-1's A fragments are still in LDS)
-// TILES (round 3 A/B): a workgroup walks TILES consecutive n-tiles with the register ring carried across them (each wave's run per
-//   tile is exactly DEPTH blocks, so one pass of the unrolled ring = one tile): wide weights at small K give a wave 4 blocks per
-//   workgroup otherwise.
-// grid.z = S > 1 (round 3 A/B): cross-workgroup split-K -- part ks owns k-blocks [kblocks ks / S, kblocks (ks + 1) / S); the parts'
-//   fp32 tiles meet in the split-K workspace (sc1 stores / loads, one ticket per output tile), the last arriver adds them in part
-//   order and stores the tile.
-// STRAIGHT: every wave of the workgroup owns exactly DEPTH blocks per tile (K = 128 DEPTH waves): prologue, one pass of the ring, done --
+// A block is consumed word by word (dequantise one packed word, multiply, next word).  Rounds 2 - 3 also built, measured and dropped
+// (profiles/int4_modes_r03.jsonl, dequant_lab_r02.txt; removed from the source in round 6): stage-by-stage and software-pipelined
+// instruction orders of the dequant, several n-tiles per workgroup, and cross-workgroup K parts at M = 1.
+// STRAIGHT: every wave of the workgroup owns exactly DEPTH blocks (K = 128 DEPTH waves): prologue, one pass of the ring, done --
 //   no steady-state / drain loops, fewer live registers (64 VGPRs: four 8-wave workgroups per CU instead of three)
-template <int G, int MAXM, int DEPTH, int SCHED = 0, int TILES = 1, bool SPLITK = false, bool STRAIGHT = (TILES > 1)>
+template <int G, int MAXM, int DEPTH, bool STRAIGHT = false>
 __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata,
-    const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets) {
+    const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M, int N, int K, float* __restrict__ /* unused */, unsigned* __restrict__ /* unused */) {
+  // (the two trailing arguments carried the M = 1 split-K workspace of round 3; the form is gone, the kernarg layout stays: removing them
+  // re-allocates the prologue's scalar registers, and every measurement of this kernel since round 3 was taken on this layout)
   constexpr int NG = (G >= 128) ? 1 : (128 / G);              // groups per 128-k block
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;          // bytes, padded vs bank conflicts
-  constexpr int NSLAB = (SCHED == 2) ? 2 : 1;                 // x slabs per wave (rows 0..MAXM-1 each) + one shared zero row
-  constexpr int SLAB = (NSLAB * MAXM + 1) * ROWSTRIDE;        // per-wave x staging
+  constexpr int SLAB = (MAXM + 1) * ROWSTRIDE;                // per-wave x staging: rows 0 .. MAXM - 1 + one zero row
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
-  const int ntile = blockIdx.x * TILES;
+  const int ntile = blockIdx.x;
   const int m0 = blockIdx.y * 16;
   const int rows = min(16, M - m0);
   const int kblocks = K >> 7;
-  const int S = SPLITK ? (int)gridDim.z : 1, ks = SPLITK ? (int)blockIdx.z : 0;
-  const int pb0 = SPLITK ? (int)(((long long)kblocks * ks) / S) : 0;  // this part's k-blocks
-  const int pbn = SPLITK ? (int)(((long long)kblocks * (ks + 1)) / S) - pb0 : kblocks;
   // straight-line form: every wave owns exactly DEPTH blocks (the host checked K = 128 DEPTH waves) -- no division by the runtime wave count
-  constexpr bool kFixedRun = STRAIGHT && !SPLITK && TILES == 1;
-  const int kb0 = kFixedRun ? wave * DEPTH : pb0 + (pbn * wave) / nwaves;
-  const int kb1 = kFixedRun ? kb0 + DEPTH : pb0 + (pbn * (wave + 1)) / nwaves;
+  constexpr bool kFixedRun = STRAIGHT;
+  const int kb0 = kFixedRun ? wave * DEPTH : (kblocks * wave) / nwaves;
+  const int kb1 = kFixedRun ? kb0 + DEPTH : (kblocks * (wave + 1)) / nwaves;
 
   char* slab = smem + wave * SLAB;
   float* red = reinterpret_cast<float*>(smem + nwaves * SLAB);
 
   // zero row (last row) of this wave's slab: 256 B
-  *reinterpret_cast<uint32_t*>(slab + NSLAB * MAXM * ROWSTRIDE + lane * 4) = 0u;
-  if constexpr (SCHED == 2) {
-    // the first iteration multiplies "block -1" (zero weights) by whatever slab 1 holds: make that finite
-#pragma unroll
-    for (int r = 0; r < MAXM; ++r)
-#pragma unroll
-      for (int i = 0; i < ROWSTRIDE / 256; ++i) *reinterpret_cast<uint32_t*>(slab + (MAXM + r) * ROWSTRIDE + i * 256 + lane * 4) = 0u;
-  }
+  *reinterpret_cast<uint32_t*>(slab + MAXM * ROWSTRIDE + lane * 4) = 0u;
 
   const int n = ntile * 16 + (lane & 15);
   const int kq = lane >> 4;
@@ -224,8 +206,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   // LDS addresses
   const int mrow = lane & 15;
   const bool a_zero = !(mrow < rows);
-  const char* a_base = slab + (a_zero ? NSLAB * MAXM : mrow) * ROWSTRIDE + kq * 64;
-  const int a_step = a_zero ? 0 : MAXM * ROWSTRIDE;  // slab 0 -> slab 1 (SCHED 2)
+  const char* a_base = slab + (a_zero ? MAXM : mrow) * ROWSTRIDE + kq * 64;
   int st_off;  // byte offset (within a row) this lane stores its x piece at
   if (MAXM <= 4) {
     // dword = k = 2*lane, 2*lane+1
@@ -247,7 +228,7 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   // LDS copy of such a row is never read) so that the steady-state loop is
   // straight-line code and the compiler can use counted s_waitcnt vmcnt(N).
   const int last_row = rows - 1;
-  auto issue = [&](Stage& s, int kb, int t = 0) {
+  auto issue = [&](Stage& s, int kb) {
     const int kg0 = (G >= 128) ? ((kb * 128) / G) : (kb * NG);
     if constexpr (kFixedRun && MAXM == 1) {
       // measured (profiles/int4_addr_ab_r04.txt, three alternating processes on one box): weights through the descriptor 812 -> 818 tok/s;
@@ -258,9 +239,9 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
       s.xr.v[0] = *reinterpret_cast<const uint32_t*>(xrow0 + (size_t)kb * 128 + lane * 2);
       return;
     }
-    s.w = __builtin_nontemporal_load(wp + ((size_t)t * kblocks + kb) * 64);
+    s.w = __builtin_nontemporal_load(wp + (size_t)kb * 64);
 #pragma unroll
-    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n + 16 * t];
+    for (int i = 0; i < NG; ++i) s.sz[i] = sz[(size_t)(kg0 + i) * N + n];
     if (MAXM <= 4) {
 #pragma unroll
       for (int r = 0; r < MAXM; ++r) {
@@ -280,13 +261,6 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const s16x4 ident = identity_fragment(lane);
-
-  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-  uint32_t prev[4][4];  // SCHED 2: the previous block's dequantised words
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) prev[j][i] = 0u;
 
   auto stage_x = [&](const Stage& s, char* dst) {
     // stage x (wave-private: DS ops of one wave execute in order, no barrier)
@@ -309,80 +283,20 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
   };
 
-  // PAR: which x slab this block uses (SCHED 2; compile-time: consecutive blocks alternate)
-  auto consume = [&](const Stage& s, auto par_c) {
-    constexpr int PAR = decltype(par_c)::value;
+  auto consume = [&](const Stage& s) {
     const uint32_t wds[4] = {s.w.x, s.w.y, s.w.z, s.w.w};
-    if constexpr (SCHED == 3) {
-      // profiling only: no dequant (the packed words go to the MFMA as they are) -- what the launch structure, the
-      // weight stream and the x staging cost without the VALU work
-      stage_x(s, slab);
-      u32x4 a[4];
+    stage_x(s, slab);
+    u32x4 a[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
-      const uint32_t b[4] = {wds[0] ^ s.sz[0], wds[1], wds[2], wds[3]};
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mma(a[j], b, acc);
-    } else if constexpr (SCHED == 0) {
-      stage_x(s, slab);
-      u32x4 a[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int gi = (G >= 128) ? 0 : ((j * 32) / G);
-        const float sc = bf16_lo_to_f32(s.sz[gi]);
-        const float zp = bf16_hi_to_f32(s.sz[gi]);
-        uint32_t b[4];
-        dequant_word_mfma(wds[j], sc, -8.0f * sc, zp, ident, b);
-        mma(a[j], b, acc);
-      }
-    } else {
-      float sc[4], n8s[4], zp[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int gi = (G >= 128) ? 0 : ((j * 32) / G);
-        sc[j] = bf16_lo_to_f32(s.sz[gi]); zp[j] = bf16_hi_to_f32(s.sz[gi]); n8s[j] = -8.0f * sc[j];
-      }
-      DequantPipe d[4];
-      u32x4 a[4];
-      if constexpr (SCHED == 1) {
-        stage_x(s, slab);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_base + j * 16);
-      } else {
-        // this block's x into slab PAR; the previous block's A fragments out of slab PAR ^ 1
-        stage_x(s, slab + PAR * MAXM * ROWSTRIDE);
-        const char* ab = a_base + (PAR ^ 1) * a_step;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(ab + j * 16);
-        mma(a[0], prev[0], acc); mma(a[1], prev[1], acc2); mma(a[2], prev[2], acc); mma(a[3], prev[3], acc2);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dequant_stage<0>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dequant_stage<1>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dequant_stage<2>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dequant_stage<3>(d[j], wds[j], sc[j], n8s[j], zp[j], ident);
-      if constexpr (SCHED == 1) {
-        mma(a[0], d[0].out, acc); mma(a[1], d[1].out, acc2); mma(a[2], d[2].out, acc); mma(a[3], d[3].out, acc2);
-        __builtin_amdgcn_sched_group_barrier(0x2, 64, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) prev[j][i] = d[j].out[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 16, 0); }
-      }
-      // 4x4x4 "add" MFMAs with the cvt_pk of the results two MFMAs back in their shadow
-      __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x2, 2, 0); __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
-      __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
-      if constexpr (SCHED == 1) __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+    for (int j = 0; j < 4; ++j) {
+      const int gi = (G >= 128) ? 0 : ((j * 32) / G);
+      const float sc = bf16_lo_to_f32(s.sz[gi]);
+      const float zp = bf16_hi_to_f32(s.sz[gi]);
+      uint32_t b[4];
+      dequant_word_mfma(wds[j], sc, -8.0f * sc, zp, ident, b);
+      mma(a[j], b, acc);
     }
   };
 
@@ -392,33 +306,26 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue(st[d], kFixedRun ? kb0 + d : min(kb0 + d, kb_last));
 
-  // ring slots as compile-time indices (the slot's parity picks the x slab under SCHED 2)
+  // ring slots as compile-time indices
   auto for_slots = [&](auto&& f) {
     [&]<int... D>(std::integer_sequence<int, D...>) { (f(std::integral_constant<int, D>{}), ...); }(std::make_integer_sequence<int, DEPTH>{});
   };
   if constexpr (STRAIGHT) {
-    // the host guarantees kb1 - kb0 == DEPTH for every wave: one pass of the ring per tile, refilled with the next tile's blocks
-    static_assert(SCHED == 0, "TILES > 1 is built on the word-by-word schedule");
-    [&]<int... T>(std::integer_sequence<int, T...>) {
-      (([&] {
-         for_slots([&](auto dc) {
-           constexpr int d = decltype(dc)::value;
-           consume(st[d], std::integral_constant<int, (d & 1)>{});
-           if constexpr (T + 1 < TILES) issue(st[d], kb0 + d, T + 1);
-         });
-         float* r = red + (T * nwaves + wave) * 256 + (kq * 4) * 16 + (lane & 15);
-         r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
-         acc = f32x4{0.f, 0.f, 0.f, 0.f};
-       }()),
-       ...);
-    }(std::make_integer_sequence<int, TILES>{});
+    // the host guarantees kb1 - kb0 == DEPTH for every wave: one pass of the ring
+    for_slots([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      consume(st[d]);
+    });
+    float* r = red + wave * 256 + (kq * 4) * 16 + (lane & 15);
+    r[0] = acc.x; r[16] = acc.y; r[32] = acc.z; r[48] = acc.w;
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
   } else {
   int kb = kb0;
   // steady state: every consumed stage is refilled, no branches in the body
   for (; kb + 2 * DEPTH <= kb1; kb += DEPTH) {
     for_slots([&](auto dc) {
       constexpr int d = decltype(dc)::value;
-      consume(st[d], std::integral_constant<int, (d & 1)>{});
+      consume(st[d]);
       issue(st[d], kb + d + DEPTH);
     });
   }
@@ -426,28 +333,16 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   for_slots([&](auto dc) {
     constexpr int d = decltype(dc)::value;
     if (kb + d < kb1) {
-      consume(st[d], std::integral_constant<int, (d & 1)>{});
+      consume(st[d]);
       if (kb + d + DEPTH < kb1) issue(st[d], kb + d + DEPTH);
     }
   });
   kb += DEPTH;
   for_slots([&](auto dc) {
     constexpr int d = decltype(dc)::value;
-    if (kb + d < kb1) consume(st[d], std::integral_constant<int, (d & 1)>{});
+    if (kb + d < kb1) consume(st[d]);
   });
-  if constexpr (SCHED == 2) {
-    // the last block's products (its x sits in slab (count - 1) & 1; DEPTH is even, so ring slot parity = block parity)
-    static_assert(DEPTH % 2 == 0, "SCHED 2 alternates x slabs by ring slot");
-    if (kb1 > kb0) {
-      const char* ab = a_base + ((kb1 - kb0 - 1) & 1) * a_step;
-      u32x4 a[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const u32x4*>(ab + j * 16);
-      mma(a[0], prev[0], acc); mma(a[1], prev[1], acc2); mma(a[2], prev[2], acc); mma(a[3], prev[3], acc2);
-    }
   }
-  }
-  acc += acc2;
 
   // cross-wave reduction: red[tile][wave][row][col]
   if constexpr (!STRAIGHT) {
@@ -457,38 +352,9 @@ __global__ __launch_bounds__((MAXM > 4) ? 512 : 1024) void int4_mm_kernel(
   __syncthreads();
   const int tid = threadIdx.x;
   const int row = tid >> 4, col = tid & 15;
-  if (!SPLITK || S == 1) {
-    if (tid < 256 && row < rows) {
-#pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        float sum = 0.f;
-        for (int w = 0; w < nwaves; ++w) sum += red[(t * nwaves + w) * 256 + tid];
-        y[(size_t)(m0 + row) * N + (ntile + t) * 16 + col] = f32_to_bf16_bits(sum);
-      }
-    }
-    return;
-  }
-  // split-K meeting (TILES == 1): 256 fp32 per part and output tile
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-  float* mine = ws + ((size_t)tile * S + ks) * 256;
   if (tid < 256 && row < rows) {
     float sum = 0.f;
     for (int w = 0; w < nwaves; ++w) sum += red[w * 256 + tid];
-    __hip_atomic_store(mine + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: written through
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int* flag = reinterpret_cast<int*>(smem);
-  if (tid == 0) {
-    const unsigned t = __hip_atomic_fetch_add(&tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag = (t == (unsigned)S - 1);
-    if (t == (unsigned)S - 1) __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!*flag) return;
-  if (tid < 256 && row < rows) {
-    float sum = 0.f;
-    for (int p = 0; p < S; ++p) sum += __hip_atomic_load(ws + ((size_t)tile * S + p) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     y[(size_t)(m0 + row) * N + ntile * 16 + col] = f32_to_bf16_bits(sum);
   }
 }
@@ -1255,53 +1121,38 @@ __global__ __launch_bounds__(64) void int4_quantize_kernel(const uint16_t* __res
 
 thread_local int g_tune_mode = 0;  // profiling only (ao_int4_set_tuning): 95-99 small-M A/B builds, 600-699 batched kernel (parts, ablation / trace builds)
 
-template <int G, int MAXM, int DEPTH = 4, int SCHED = 0, int TILES = 1>
+template <int G, int MAXM, int DEPTH = 4>
 int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M,
-              int64_t N, int64_t K, hipStream_t stream, int split = 1, bool straight = false) {
+              int64_t N, int64_t K, hipStream_t stream, bool straight = false) {
   constexpr int ROWSTRIDE = (MAXM <= 4) ? 256 : 272;
-  constexpr int SLAB = (((SCHED == 2) ? 2 : 1) * MAXM + 1) * ROWSTRIDE;
+  constexpr int SLAB = (MAXM + 1) * ROWSTRIDE;
   const int kblocks = (int)(K >> 7);
   const int64_t ntiles = N >> 4;
   const int64_t mslabs = (M + 15) / 16;
-  split = std::max(1, std::min(split, kblocks));
-  const int kpart = kblocks / split;  // k-blocks of the smallest part
   // waves per workgroup: 8 once a wave still gets >= 2 weight blocks (measured at M = 1 on the Llama-3-8B shapes:
   // 4 waves 800, 8 waves 868, 16 waves 705 tok/s), else 4 (>= 256 threads for the epilogue)
-  int wpb = (kpart >= 16) ? 8 : 4;
+  int wpb = (kblocks >= 16) ? 8 : 4;
   if (ntiles * mslabs >= 2048 && wpb > 4 && MAXM > 1) wpb /= 2;
   if (g_tune_wpb >= 4 && g_tune_wpb <= 16) wpb = g_tune_wpb;
   if (straight && kblocks % DEPTH == 0 && kblocks / DEPTH >= 4 && kblocks / DEPTH <= 16) wpb = kblocks / DEPTH;  // straight-line form
   if (MAXM > 4 && wpb > 8) wpb = 8;  // 16-row variant is built for <= 512 threads
-  if (wpb > kpart) wpb = kpart < 4 ? 4 : kpart;
-  if (TILES > 1) {
-    // the multi-tile form needs every wave's run to be exactly the ring depth; anything else takes the plain kernel
-    if (kblocks != wpb * DEPTH || ntiles % TILES != 0 || split != 1) return launch_mm<G, MAXM, DEPTH, SCHED, 1>(x, qdata, sz, y, M, N, K, stream, split);
-  }
-  float* ws = nullptr;
-  unsigned* tickets = nullptr;
-  if (split > 1) {
-    AO_REQUIRE(ntiles * mslabs <= kSplitMaxTickets && ntiles * mslabs * split * 256 <= (int64_t)kSplitSlotFloats, "int4_mm: %lld tiles x %d parts exceed the split-K workspace",
-               (long long)(ntiles * mslabs), split);
-    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)(ntiles * mslabs) * split * 256, split)) return rc;
-  }
-  const size_t smem = (size_t)wpb * (SLAB + 1024 * TILES);
-  dim3 grid((unsigned)(ntiles / TILES), (unsigned)mslabs, (unsigned)split), block(wpb * 64);
+  if (wpb > kblocks) wpb = kblocks < 4 ? 4 : kblocks;
+  const size_t smem = (size_t)wpb * (SLAB + 1024);
+  dim3 grid((unsigned)ntiles, (unsigned)mslabs), block(wpb * 64);
   auto go = [&](auto kern) {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_kernel)")) return rc;
     ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y,
-               (int)M, (int)N, (int)K, ws, tickets);
+               (int)M, (int)N, (int)K, (float*)nullptr, (unsigned*)nullptr);
     return (int)AO_OK;
   };
-  if constexpr (MAXM == 1 && DEPTH != 4 && (DEPTH == 7 || DEPTH == 14 || DEPTH == 2) && SCHED == 0 && TILES == 1) {
-    AO_REQUIRE(split == 1 && straight && kblocks == wpb * DEPTH && wpb <= 16, "int4_mm: the %d-deep form is straight-line only", DEPTH);
-    if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false, true>)) return rc;
-  } else if constexpr (MAXM == 1 && DEPTH == 4 && SCHED == 0 && TILES == 1) {
-    if (split > 1) { if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, true>)) return rc; }
-    else if (straight && kblocks == wpb * DEPTH) { if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false, true>)) return rc; }
-    else if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false>)) return rc;
+  if constexpr (MAXM == 1 && DEPTH != 4 && (DEPTH == 7 || DEPTH == 14 || DEPTH == 2)) {
+    AO_REQUIRE(straight && kblocks == wpb * DEPTH && wpb <= 16, "int4_mm: the %d-deep form is straight-line only", DEPTH);
+    if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, true>)) return rc;
+  } else if constexpr (MAXM == 1 && DEPTH == 4) {
+    if (straight && kblocks == wpb * DEPTH) { if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, true>)) return rc; }
+    else if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, false>)) return rc;
   } else {
-    AO_REQUIRE(split == 1, "int4_mm: split-K is built for the single-row kernel only");
-    if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, SCHED, TILES, false>)) return rc;
+    if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, false>)) return rc;
   }
   AO_LAUNCH_CHECK("int4_mm_kernel launch");
   return AO_OK;
@@ -1317,44 +1168,11 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   // for the narrow projections, 1.5x the M = 1 time on wide ones -- weights of >= 1024 n-tiles (merged gate_up_proj, lm_head) take
   // the batched kernel below with 16-row slabs, where 4 n-tiles share one staged x tile (gate_up_proj at M = 16: 32 -> 21.8 us).
   // (At M <= 4 the same switch measured 16.2 vs 17.4 us on one box and 19.7 vs 14.2 us on another: not taken.)
-  // Modes 94-99: A/B builds for profiling (94 never / 93 always the batched kernel on wide weights at M <= 16, 95 / 96 ring depth
-  // 6 / 8, 98 the 4-row build at M = 1, 99 the 16-row build at any M).
+  // Modes 93-99: A/B builds for profiling (94 never / 93 always the batched kernel on wide weights at M <= 16, 97 the ring kernel at M = 1
+  // whatever K, 98 the 4-row build at M = 1, 99 the 16-row build at any M).
   const bool wide = (N >> 4) >= 1024 && g_tune_mode != 94;
-#ifdef AO_LAB  // wrong-result ablation builds exist only in the laboratory library (python -m ao_amd.build --lab -> tools/bin/_C_mi355_lab.so)
-  if (M == 1 && g_tune_mode == 90) return launch_mm<G, 1, 4, 3>(x, qdata, sz, y, M, N, K, stream);
-#endif
-  if (M == 1 && g_tune_mode == 91) return launch_mm<G, 1, 4, 1>(x, qdata, sz, y, M, N, K, stream);
-  if (M == 1 && g_tune_mode == 92) return launch_mm<G, 1, 4, 2>(x, qdata, sz, y, M, N, K, stream);
-  if (M == 1 && g_tune_mode == 89) return launch_mm<G, 1, 6, 2>(x, qdata, sz, y, M, N, K, stream);
   if (M == 1 && g_tune_mode == 98) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
-  if (M == 1 && g_tune_mode == 96) return launch_mm<G, 1, 8>(x, qdata, sz, y, M, N, K, stream);
-  if (M == 1 && g_tune_mode == 95) return launch_mm<G, 1, 6>(x, qdata, sz, y, M, N, K, stream);
   if (g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
-  // round-3 A/Bs at M = 1 (profiles/int4_modes_r03.jsonl): 20S = cross-workgroup split-K, S parts, for weights of < 512 n-tiles
-  // (o, qkv, down); 21T = T n-tiles per workgroup for weights of >= 512 n-tiles (gate, up); 22x = both (S = 2, T = x)
-  if (M == 1 && g_tune_mode >= 200 && g_tune_mode < 230) {
-    const int kind = (g_tune_mode - 200) / 10, v = g_tune_mode % 10;
-    const bool narrow = (N >> 4) < 512;
-    const int sp = narrow ? (kind == 0 ? v : kind == 2 ? 2 : 1) : 1;
-    const int tl = narrow ? 1 : (kind == 1 || kind == 2 ? v : 1);
-    if (tl == 2) return launch_mm<G, 1, 4, 0, 2>(x, qdata, sz, y, M, N, K, stream);
-    if (tl == 4) return launch_mm<G, 1, 4, 0, 4>(x, qdata, sz, y, M, N, K, stream);
-    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, sp);
-  }
-  if (M == 1 && g_tune_mode == 230) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);  // straight-line form where K = 128 * 4 * waves
-  if (M == 1 && g_tune_mode == 231) {  // ... and K = 128 * 7 * 16 (down_proj): 16 waves, every block of the weight in flight at once
-    if ((K >> 7) == 112) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, 1, true);
-    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);
-  }
-  if (M == 1 && g_tune_mode == 232) {  // down_proj: 8 waves x 14 blocks, all in flight
-    if ((K >> 7) == 112) return launch_mm<G, 1, 14>(x, qdata, sz, y, M, N, K, stream, 1, true);
-    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);
-  }
-  if (M == 1 && g_tune_mode == 233) {  // 231 + narrow K = 4096 weights (o, qkv) as 16 waves x 2 blocks
-    if ((K >> 7) == 112) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, 1, true);
-    if ((K >> 7) == 32 && (N >> 4) < 512) return launch_mm<G, 1, 2>(x, qdata, sz, y, M, N, K, stream, 1, true);
-    return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream, 1, true);
-  }
   if (M <= 16 && g_tune_mode < 600 && !(wide && (M > 4 || g_tune_mode == 93))) {
     if (M == 1 && g_tune_mode != 97) {
       // round 3: when the weight's K divides into (waves <= 16) x (2 | 4 | 7 | 14 blocks), every block of the tile is requested in the
@@ -1362,10 +1180,10 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
       // resident at once; down_proj as 16 waves x 7 blocks has its whole weight in flight).  Llama-3-8B, same run, five shapes /
       // merged: 765 -> 818 / 846 -> 906 tok/s (profiles/int4_modes_r03.jsonl); mode 97 = the ring kernel everywhere
       const int64_t kbl = K >> 7;
-      if (kbl % 4 == 0 && kbl / 4 >= 4 && kbl / 4 <= 16) return launch_mm<G, 1, 4>(x, qdata, sz, y, M, N, K, stream, 1, true);
-      if (kbl % 7 == 0 && kbl / 7 >= 4 && kbl / 7 <= 16) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, 1, true);
-      if (kbl % 14 == 0 && kbl / 14 >= 4 && kbl / 14 <= 16) return launch_mm<G, 1, 14>(x, qdata, sz, y, M, N, K, stream, 1, true);
-      if (kbl % 2 == 0 && kbl / 2 >= 4 && kbl / 2 <= 16) return launch_mm<G, 1, 2>(x, qdata, sz, y, M, N, K, stream, 1, true);
+      if (kbl % 4 == 0 && kbl / 4 >= 4 && kbl / 4 <= 16) return launch_mm<G, 1, 4>(x, qdata, sz, y, M, N, K, stream, true);
+      if (kbl % 7 == 0 && kbl / 7 >= 4 && kbl / 7 <= 16) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, true);
+      if (kbl % 14 == 0 && kbl / 14 >= 4 && kbl / 14 <= 16) return launch_mm<G, 1, 14>(x, qdata, sz, y, M, N, K, stream, true);
+      if (kbl % 2 == 0 && kbl / 2 >= 4 && kbl / 2 <= 16) return launch_mm<G, 1, 2>(x, qdata, sz, y, M, N, K, stream, true);
     }
     if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
     if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);

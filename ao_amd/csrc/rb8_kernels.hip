@@ -33,7 +33,7 @@ constexpr int kStages = 3;   // activation ring (shared), filled 2 steps ahead
 // 8-wave MX form, whose scale rings would otherwise push the workgroup past 160 KiB of LDS
 // (also 5 for the 64-row MX slab, which then fits two workgroups per CU)
 constexpr int w_stages(int waves, int kind, int mt, bool slim = false) {
-  return slim ? 3 : (kind == 2 && (waves == 8 || mt == 4)) ? 5 : ((kind == 0 || kind == 1) && mt == 16 && waves == 8) ? 3 : 6;
+  return slim ? 3 : (kind == 2 && (waves == 8 || mt == 4)) ? 5 : 6;
 }
 // Activation ring: 3 stages (2 steps ahead).  Round 5 measured 5 / 4 stages for the rowwise kinds (the ring's depth looked like the
 // loop's bound: 1100 cycles per step for every tile width, ~ half an LDS-DMA round trip): the step time did not move -- it is the sum
@@ -64,9 +64,6 @@ struct Rb8Args {
   float* ws;
   unsigned* tickets;
   unsigned long long* trace;  // profiling build only
-  // round 5, rowwise kinds with K parts: xcd = 1 -- a 1-D grid of 8 * split * ceil(gx * gy / 8) workgroups in which the `split` parts of
-  // an output tile have ids that agree mod 8 (splitk.h: xcd_grid_decode), so that they run on ONE XCD and meet in its L2
-  int xcd, gx, gy, split;
   int ablate;  // profiling build (TRACE) only: 1 no MFMAs, 2 no fragment reads, 4 no weight DMAs, 8 no activation DMAs -- wrong results, timing probes
 };
 
@@ -82,7 +79,7 @@ struct Rb8Args {
 // on a loop that is bound by the LDS reads (144 KiB per step and workgroup at 128 B / clk against 512 cycles of MFMA per SIMD).
 template <int WAVES, int KIND, int MT = 8, bool TRACE = false, bool SLIM = false, int QS = 1, bool SM = false>
 __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
-  static_assert(!SM || (WAVES == 8 && (MT == 8 || MT == 16) && (KIND == RB8_FP8 || KIND == RB8_INT8)), "rb8_kernel: the 2 x 4 wave arrangement is built for 8 waves x 128 / 256 rows, rowwise kinds");
+  static_assert(!SM || (WAVES == 8 && MT == 8 && (KIND == RB8_FP8 || KIND == RB8_INT8)), "rb8_kernel: the 2 x 4 wave arrangement is built for 8 waves x 128 rows, rowwise kinds");
   constexpr int MH = MT / 2;  // SM: m-tiles per wave (wave (wm, wn): m-tiles MH wm .. + MH - 1, n-tiles 2 wn, 2 wn + 1; acc[2 i + j])
   constexpr int SCL = SLIM ? 64 : 256;  // bytes of one scale slot (one dword per row: 16 rows -> 64 B; unmasked DMAs write 256)
   static_assert(QS == 1 || (QS == 4 && KIND == RB8_MX && !SLIM), "rb8_kernel: 4-step scale fetches are an MX form");
@@ -105,18 +102,8 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nl = lane & 15, kq = lane >> 4;
   const int ntiles = p.N >> 4;
-  // (bx, by): the workgroup's column tile and slab; ks of S: its K part.  Three-dimensional grid, or the XCD-aware one-dimensional one
-  int bx = blockIdx.x, by = blockIdx.y, ks = blockIdx.z, S = gridDim.z, gx = gridDim.x;
-  if constexpr (!GROUPED_KIND(KIND)) {
-    if (p.xcd) {
-      int t;
-      S = p.split; gx = p.gx;
-      xcd_grid_decode(blockIdx.x, S, t, ks);
-      if (t >= p.gx * p.gy) return;  // uniform, before any DMA or barrier
-      by = t / gx; bx = t - by * gx;
-    }
-  }
-  const bool local = !GROUPED_KIND(KIND) && p.xcd != 0;
+  // (bx, by): the workgroup's column tile and slab; ks of S: its K part
+  const int bx = blockIdx.x, by = blockIdx.y, ks = blockIdx.z, S = gridDim.z, gx = gridDim.x;
   const int tile = bx * WAVES + wave;
   const int tile_c = min(tile, ntiles - 1);  // tiles past N alias the last one; never stored
   const int ksteps = p.K >> 7;
@@ -485,7 +472,7 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
   auto dump = [&] {
     if (TRACE && p.trace != nullptr && tid == 0) {
       ts[12] = __builtin_amdgcn_s_memtime();
-      unsigned long long* t = p.trace + (p.xcd ? (size_t)blockIdx.x : ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)) * 16;
+      unsigned long long* t = p.trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16;
       for (int i = 0; i < 16; ++i) t[i] = ts[i];
     }
   };
@@ -497,11 +484,8 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
     const int otile = by * gx + bx;
     int* flag = reinterpret_cast<int*>(smem);
     if constexpr (!GROUPED) {
-      // round 5: all parts on one XCD (p.xcd): the parked tiles stay in that XCD's L2 (splitk.h, LOCAL)
-      if (local) go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8, (MT >= 16 ? 2 : 4), true>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
-                                 : split_k_meet<MT, 64 * WAVES, INT8, true>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
-      else go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8, (MT >= 16 ? 2 : 4)>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
-                           : split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
+      go_on = (S > 4) ? split_k_meet2<MT, 64 * WAVES, INT8, 4>(acc, p.ws, p.tickets, otile, S, ks, tid, flag)
+                      : split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
     } else {
       go_on = split_k_meet<MT, 64 * WAVES, INT8>(acc, p.ws, p.tickets, otile, S, ks, tid, flag);
     }
@@ -687,7 +671,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
   // 16 waves (round 6): ONE workgroup per CU over 256-column tiles -- half the activation re-reads per weight byte, and no second, younger
   // workgroup on the CU that the instruction arbiter serves last (the round-6 traces); its activation pieces are only requested where the
   // group has rows (QS == 4: a_cnt), so waves 8 .. 15 never issue one
-  static_assert(WAVES == 4 || WAVES == 8 || (WAVES == 16 && QS == 4), "mx_stream_kernel: 4 or 8 waves, or 16 with the scales per 4 steps");
+  static_assert((WAVES == 8 && QS == 1) || (WAVES == 16 && QS == 4), "mx_stream_kernel: 8 waves with the scales per step, or 16 with the scales per 4 steps");
   unsigned long long ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (TRACE) { ts[0] = __builtin_amdgcn_s_memtime(); ts[3] = __builtin_amdgcn_s_memrealtime(); }  // [3] / [4]: the 100 MHz clock at entry / exit
   // [KA][64][128 B] a | CAST: [2][64][256 B] raw bf16 | [WAVES][SW][2 KiB] b | a scales [ASN][WAVES][ASB] (CAST: [2][64 rows][4 B]) | b scales [WAVES][BSN][BSB]
@@ -1139,7 +1123,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 // A/B knobs of the rowwise weight-streaming kernel (ao_gemm8_set_tuning; 0 = product rule): column-tile width, K parts, same-XCD meeting
-thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_local = 0, g_rb8_ablate = 0, g_rb8_bm = 0;  // local: 0 product (off), 1 off, 2 on where the device allows
+thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_ablate = 0;
 thread_local bool g_rb8_sm = true;  // rb8_kernel's 2 x 4 wave arrangement where it is built (ao_gemm8_set_variant 103: off)
 
 template <int WAVES, int KIND, int MT = 8, bool SLIM = false, int QS = 1>
@@ -1167,23 +1151,13 @@ int launch_rb8(Rb8Args p, int split, hipStream_t stream) {
                grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y * tks <= kSplitMaxTickets - 8, "rb8: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
     if (int rc = splitk_workspace(stream, &p.ws, &p.tickets, (size_t)grid.x * grid.y * slots * BN * BM, split)) return rc;
-    // All K parts of a tile on one XCD (ids that agree mod 8; measured per device, checked per tile: splitk.h) and the parked tiles in that
-    // XCD's L2.  Built and parity-clean, but OPT-IN (ao_gemm8_set_tuning(3, 2)): next to the write-through meeting it measured +- 2 % on all
-    // 40 cells of profiles/midm_sweep_r05.jsonl -- the meeting's cost is its three dependent round trips (stores acknowledged -> ticket ->
-    // gather), each ~1 us under load whether it ends in the XCD's L2 or at the fabric -- so the product keeps the protocol that depends on
-    // no placement at all.
-    if (!kGrouped && g_rb8_local == 2 && splitk_xcd_local_ok()) {
-      p.xcd = 1; p.gx = (int)grid.x; p.gy = (int)grid.y; p.split = split;
-      const unsigned tiles = grid.x * grid.y;
-      grid = dim3(8u * (unsigned)split * ((tiles + 7u) / 8u));
-    }
   }
   p.trace = g_fp8_rb_trace;
   p.ablate = g_rb8_ablate;
   auto kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS>;
-  if constexpr (WAVES == 8 && (MT == 8 || MT == 16) && (KIND == RB8_FP8 || KIND == RB8_INT8) && !SLIM && QS == 1) {
+  if constexpr (WAVES == 8 && MT == 8 && (KIND == RB8_FP8 || KIND == RB8_INT8) && !SLIM && QS == 1) {
     // the 2 x 4 wave arrangement (fewer operand fragments per MFMA); ao_gemm8_set_variant(103): the 1 x 8 form, for A/B
-    if (g_rb8_sm || MT == 16) kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS, true> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS, true>;
+    if (g_rb8_sm) kern = (p.trace != nullptr) ? rb8_kernel<WAVES, KIND, MT, true, SLIM, QS, true> : rb8_kernel<WAVES, KIND, MT, false, SLIM, QS, true>;
   }
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(rb8_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, p);
@@ -1212,27 +1186,22 @@ int launch_mx_stream(Rb8Args p, hipStream_t stream) {
   return AO_OK;
 }
 
-thread_local bool g_mx_quad = true;  // (ao_gemm8_set_variant 12x: off) scales per 4 steps
-thread_local int g_mx_stream = 1;  // (ao_gemm8_set_variant) 1 product: stream-K (8 waves x 3 weight stages) by shape; 4: always (119); 2: always, 4 waves x 6 (114); 3: always, 4 waves x 3 (118); 0 never (113)
-thread_local bool g_mx_slim_off = false;  // profiling (ao_gemm8_set_variant 112): the two-workgroups-per-CU form of the MX decode kernel
+thread_local bool g_mx_quad = true;  // (ao_gemm8_set_variant 129: off) block scales fetched per 4 k steps where K % 512 == 0
+thread_local int g_mx_stream = 1;  // (ao_gemm8_set_variant) 1 product: the stream-K kernel for decode-size groups; 0 never (113: one workgroup per tile, the form of larger groups)
 thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 never, 2 always, 3 always + 64-column tiles, two workgroups per CU
 
 }  // namespace
 
 void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
 void rb8_set_wave_grid(bool two_by_four) { g_rb8_sm = two_by_four; }
-void rb8_set_tuning(int bn, int split, int local_off, int ablate, int bm) { g_rb8_bn = bn; g_rb8_split = split; g_rb8_local = local_off; g_rb8_ablate = ablate; g_rb8_bm = bm; }
-void mx_rb_set_slim(bool on) { g_mx_slim_off = !on; }
+void rb8_set_tuning(int bn, int split, int ablate) { g_rb8_bn = bn; g_rb8_split = split; g_rb8_ablate = ablate; }
 void mx_stream_set_tuning(int proto) { g_mx_proto = proto; }
 void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = quad; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
 bool fp8_rowwise_rb_forced() { return g_fp8_rb_force >= 2; }
 
-// 256-row slabs (round 5; ao_gemm8_set_tuning key 6): where 128-row slabs would need a second round of the chip and 256-row ones do not they
-// measured ahead of the tile kernels (M = 1024: o 8192 x 1024 20.1 -> 18.6 us, gate_up 7168 x 8192 78.9 -> 71.2, down 41.6 -> 38.3, qkv
-// 6144 x 4096 45.9 -> 40.5; profiles/midm_sweep_r05.jsonl, midm_forms_r05.jsonl) -- and behind the phase-interleaved 256 x 128 GEMM built
-// later in the round (gemm8_p8h_kernel: 14.7 / 56.0 / 30.6 / 31.3 on the same four), which takes exactly these shapes
-// (gemm8_p8h_band: more than 128 and at most 256 tiles of 256 x 128).  The slab form stays as a tuning form.
+// (Round 5 also built 256-row slabs: ahead of the tile kernels where 128-row slabs needed a second round of the chip, behind the 256 x 128
+// phase-interleaved GEMM built later that round, which takes exactly those shapes -- removed in round 6; profiles/midm_forms_r05.jsonl.)
 bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K);  // gemm8_p8_kernels.hip
 
 // True when this kernel is the better choice: the 128 x 128 GEMM grid would leave most of the chip idle (same rule for int8).
@@ -1267,10 +1236,9 @@ inline Rb8Plan rb8_plan(int64_t M, int64_t N, int64_t K, int bm) {
   Rb8Plan best{128, 1};
   double best_t = 1e30;
   for (int bn : {128, 64, 32}) {
-    if (bm == 256 && bn == 32) continue;  // (256-row slabs are built with 64- and 128-column tiles)
     const int64_t tiles = ((N + bn - 1) / bn) * slabs;
     const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (tiles * bn * bm) * 4 / 5;  // (x 4 / 5: the two-level meeting parks S + S / 4 tiles)
-    const double c = (bn == 32 ? 0.333 : bn == 64 ? 0.35 : 0.52) * (bm == 256 ? 1.6 : 1.0);
+    const double c = (bn == 32 ? 0.333 : bn == 64 ? 0.35 : 0.52);
     for (int S : {1, 2, 3, 4, 6, 8}) {
       if (S > 1 && (S > fit || S > std::max<int64_t>(1, ksteps / 4))) continue;
       const int64_t wgs = tiles * S, rounds = (wgs + 255) / 256, steps = (ksteps + S - 1) / S;
@@ -1302,21 +1270,16 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   Rb8Args p{};
   p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.y = y;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  // slabs of 64 rows for M <= 64, else 128; (round 5) 256 rows where 128-row slabs would need a second round of the chip and 256-row
-  // ones do not (897 .. 1024 rows -- what was measured -- on the 70B / TP8 shards: a step's fixed cost -- the barrier, the waits, ~430 cycles whatever the tile -- is
-  // then spread over twice the MFMAs: o 8192 x 1024 20.1 -> 18.6 us, gate_up 78.9 -> 71.2, down 41.6 -> 38.3).  g_rb8_bm forces 128 / 256.
-  const int bm = (M <= 64) ? 64 : (g_rb8_bm == 128) ? 128 : (g_rb8_bm == 256) ? 256 : 128;
+  const int bm = (M <= 64) ? 64 : 128;  // slabs of 64 rows for M <= 64, else 128
   const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
   Rb8Plan plan = rb8_plan(M, N, K, bm);
   if (g_fp8_rb_force == 3) plan.bn = 64;
   int bn = (g_rb8_bn == 32 || g_rb8_bn == 64 || g_rb8_bn == 128) ? g_rb8_bn : plan.bn;
-  if (bm == 256 && bn == 32) bn = 64;
   const int64_t base = ((N + bn - 1) / bn) * slabs;
   const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * bm) * 4 / 5;
   int split = (bn == plan.bn) ? plan.split : (int)std::max<int64_t>(1, std::min<int64_t>({256 / base, fit, 16, ksteps / 4}));
   if (g_rb8_split > 0) split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)g_rb8_split, fit, 16, ksteps}));
   split = (int)std::max<int64_t>(1, std::min<int64_t>(split, fit));
-  if (bm == 256) return (bn == 128) ? launch_rb8<8, KIND, 16>(p, split, stream) : launch_rb8<4, KIND, 16>(p, split, stream);
   if (bn == 32) return (bm == 64) ? launch_rb8<2, KIND, 4>(p, split, stream) : launch_rb8<2, KIND, 8>(p, split, stream);
   if (bm == 64) return bn == 64 ? launch_rb8<4, KIND, 4>(p, split, stream) : launch_rb8<8, KIND, 4>(p, split, stream);
   return bn == 64 ? launch_rb8<4, KIND, 8>(p, split, stream) : launch_rb8<8, KIND, 8>(p, split, stream);
@@ -1361,18 +1324,15 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
     {
       // scales fetched per 4 steps when K allows (16-byte pieces of 16-byte-aligned scale rows), else per step
       const bool quad = g_mx_quad && K % 512 == 0 && ((uintptr_t)a_scale % 16 == 0) && ((uintptr_t)b_scale % 16 == 0);
-      // round 6: ONE 16-wave workgroup per CU over 256-column tiles where the scales can be fetched per 4 steps (119 forces the 8-wave form,
-      // two workgroups per CU over 128-column tiles: rounds 3 - 5's product)
-      if ((g_mx_stream == 1 || g_mx_stream == 5) && quad) return launch_mx_stream<16, 3, 4>(p, stream);
-      if (g_mx_stream == 2) return launch_mx_stream<4, 6, 1>(p, stream);
-      if (g_mx_stream == 3) return quad ? launch_mx_stream<4, 3, 4>(p, stream) : launch_mx_stream<4, 3, 1>(p, stream);
-      return quad ? launch_mx_stream<8, 3, 4>(p, stream) : launch_mx_stream<8, 3, 1>(p, stream);
+      // round 6: ONE 16-wave workgroup per CU over 256-column tiles where the scales can be fetched per 4 steps; other K (and variant 129,
+      // which tests that form on every shape) the 8-wave form of rounds 3 - 5 with the scales fetched per step, two workgroups per CU
+      if (quad) return launch_mx_stream<16, 3, 4>(p, stream);
+      return launch_mx_stream<8, 3, 1>(p, stream);
     }
   }
   // larger groups (and more than 64 experts): one workgroup per (slab, tile); scales per 4 steps when K allows
   const bool quad = g_mx_quad && K % 512 == 0 && ((uintptr_t)a_scale % 16 == 0) && ((uintptr_t)b_scale % 16 == 0);
   if (bm == 64) {
-    if (g_mx_slim_off) return launch_rb8<4, RB8_MX, 4>(p, 1, stream);  // (112: the round-2 form)
     return quad ? launch_rb8<4, RB8_MX, 4, false, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 4, true>(p, 1, stream);
   }
   if (((N + 127) / 128) * groups * p.slabs < 400) return quad ? launch_rb8<4, RB8_MX, 8, false, 4>(p, 1, stream) : launch_rb8<4, RB8_MX, 8>(p, 1, stream);

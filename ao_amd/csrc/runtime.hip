@@ -92,39 +92,12 @@ unsigned long long g_split_clock = 0;
 std::vector<char*> g_split_retired;  // outgrown buffers, kept alive for graphs captured before the growth
 constexpr size_t kSplitMinFloats = (size_t)2 << 20;  // 8 MiB
 
-// ---- workgroup -> XCD placement, measured (splitk.h: splitk_xcd_local_ok) -------------------------------------------------------------
-// The same-XCD split-K meeting wants the K parts of a tile on one XCD.  HIP promises no placement; the dispatcher of MI355X has been
-// observed to put workgroup b of a grid on XCD b % 8 (MI355X_MICROARCH.md).  One probe launch per device records hwreg(XCC_ID) of 256
-// workgroups: the fast meeting is allowed on the device only if ids that agree mod 8 ran on the same XCD (also true of a one-XCD
-// partition).  The kernels check it again on every tile (xcc_ticket_check) and trap rather than sum wrongly.
-__global__ void xcc_probe_kernel(unsigned* out) {
-  if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
-}
-std::atomic<int> g_xcd_local[64];  // per device: 0 not measured, 1 ids agree mod 8 -> same XCD, -1 they do not
-
-void xcc_probe(int dev, unsigned* scratch /* >= 256 words of device memory */) {
-  if (g_xcd_local[dev].load() != 0) return;
-  constexpr int kBlocks = 256;
-  unsigned host[kBlocks];
-  hipLaunchKernelGGL(xcc_probe_kernel, dim3(kBlocks), dim3(64), 0, nullptr, scratch);
-  if (hipGetLastError() != hipSuccess || hipMemcpy(host, scratch, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) {
-    g_xcd_local[dev].store(-1);
-    return;
-  }
-  bool ok = true;
-  for (int b = 8; b < kBlocks; ++b) ok = ok && host[b] == host[b & 7];
-  const char* env = getenv("AO_MI355_XCD_LOCAL");
-  if (env != nullptr && env[0] == '0') ok = false;
-  g_xcd_local[dev].store(ok ? 1 : -1);
-}
-
 int split_alloc(SplitWs* w, size_t floats, int dev) {
   char* p = nullptr;
   hipError_t e = hipMalloc(&p, floats * sizeof(float) + kSplitMaxTickets * sizeof(unsigned));
   if (e != hipSuccess)
     return hip_failed(e, "hipMalloc(split-K workspace); call the op with this shape once on this stream outside stream capture "
                          "before capturing it into a graph");
-  xcc_probe(dev, reinterpret_cast<unsigned*>(p + floats * sizeof(float)));  // (the ticket area is zeroed next)
   e = hipMemset(p + floats * sizeof(float), 0, kSplitMaxTickets * sizeof(unsigned));
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) { (void)hipFree(p); return hip_failed(e, "hipMemset(split-K tickets)"); }
@@ -194,12 +167,6 @@ extern "C" int ao_splitk_reserve(void* stream, int64_t bytes) {
 }
 
 namespace ao {
-bool splitk_xcd_local_ok() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  return g_xcd_local[dev].load() == 1;
-}
-
 // ---- collectives: wait bound shared by the one-shot all-reduce and the all-to-all-v (peer_sync.h) --------------------------------
 namespace {
 std::atomic<int> g_collective_timeout_ms{5000};
@@ -269,11 +236,6 @@ extern "C" int ao_peer_close(void* imported_ptr) {
   return AO_OK;
 }
 
-extern "C" int ao_xcd_local_state(void) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  return ao::g_xcd_local[dev].load();
-}
 extern "C" int ao_abi_version(void) { return AO_MI355_ABI_VERSION; }
 extern "C" const char* ao_last_error(void) { return ao::g_err; }
 

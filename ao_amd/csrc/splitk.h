@@ -15,38 +15,10 @@ constexpr int kSplitMaxTiles = 2048;
 constexpr int kSplitMaxTickets = 16384;
 constexpr size_t kSplitSlotFloats = (size_t)kSplitMaxTiles * 128 * 128;  // 128 MiB
 // need_floats: what this launch parks (tiles x parts x tile floats); the slot grows to the largest request seen on its stream
-// Tickets count arrivals in bits 0-7 (the same-XCD form packs the XCC-id sum into 8 more bits and the sum of squares into 12: it overflows
-// beyond ~36 parts); the two-level meeting gathers <= 4 groups of <= 4.  Every launcher passes its part count here and is refused beyond
+// The two-level meeting gathers <= 4 groups of <= 4 parts.  Every launcher passes its part count here and is refused beyond
 // kSplitMaxParts -- a ticket that can never read "last" would skip the epilogue silently.
 constexpr int kSplitMaxParts = 16;
 int splitk_workspace(hipStream_t stream, float** part, unsigned** tickets, size_t need_floats, int parts = 1);
-// True when the current device places workgroup b of a 1-D grid on XCD b % 8 (or has ONE XCD): measured once per device by a probe
-// launch (runtime.hip; outside stream capture, with the first workspace), AO_MI355_XCD_LOCAL=0 switches it off.  Launchers that get
-// `true` may put all K parts of an output tile on one XCD (xcd_grid_decode below) and let them meet in that XCD's L2.
-bool splitk_xcd_local_ok();
-
-// XCC_ID of the executing wave: 0 .. 7 on MI355X (s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4))
-__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }
-// What a part adds to its tile's ticket when the parts meet in ONE XCD's L2 (LOCAL below): arrival count in bits 0-7, the sum of the
-// arrivers' XCC ids in bits 8-15, the sum of their squares in bits 16-27.  The last arriver checks sum == S x own id and
-// sum of squares == S x own id^2 -- both hold only if every part ran on its XCD (zero variance) -- and TRAPS otherwise: the placement
-// b -> XCD b % 8 is an observed property of the dispatcher, not a contract, so it is checked on every tile of every launch and a
-// violation is a loud kernel abort (hipErrorLaunchFailure at the next synchronise), never a wrong sum.  The tickets themselves are
-// device-scope atomics: the COUNT is right under any placement.
-__device__ __forceinline__ unsigned xcc_ticket_increment(unsigned x) { return 1u + (x << 8) + ((x * x) << 16); }
-__device__ __forceinline__ void xcc_ticket_check(unsigned total_before, unsigned own_increment, int S) {
-  const unsigned total = total_before + own_increment, x = (own_increment >> 8) & 0xffu;
-  if (((total >> 8) & 0xffu) != (unsigned)S * x || (total >> 16) != (unsigned)S * x * x) __builtin_trap();
-}
-// Workgroup id -> (tile, K part) such that all S parts of a tile have ids that agree mod 8: id = 8 j + c runs the j-th work item of
-// XCD c, item j = (c-th residue class' tile j / S, part j % S).  Grid: 8 * S * ceil(tiles / 8) workgroups; tile >= tiles: exit.
-__device__ __forceinline__ void xcd_grid_decode(unsigned id, int S, int& tile, int& ks) {
-  const int c = (int)(id & 7u), j = (int)(id >> 3);
-  const int q = j / S;
-  tile = c + 8 * q;
-  ks = j - q * S;
-}
-
 // ---------------------------------------------------------------------------
 // Split-K meeting: every part parks its fp32 tile in the workspace
 // ([tile][part][reg][thread], 16 B per thread and register: coalesced), takes a ticket, and the last one
@@ -56,16 +28,14 @@ __device__ __forceinline__ void xcd_grid_decode(unsigned id, int S, int& tile, i
 // the whole L2 and cost ~60 us per launch.  `flag` is any LDS word no wave is still using.
 // ---------------------------------------------------------------------------
 // INT: the registers hold int32 partial sums (exact integer adds) instead of fp32.
-// LOCAL (round 5): every part of the tile runs on ONE XCD (xcd_grid_decode): the parked tiles are PLAIN stores -- they stay, dirty, in
-// that XCD's L2, which all its CUs share -- and the last arriver reads them with sc1 loads (sc1 on a load only bypasses the reading CU's
-// L1; the L2 serves it): no write-through to memory and no fabric round trip on the way back (MI355X_MICROARCH.md: same-XCD hand-off
-// reads 104-122 GB/s per workgroup against 62-70 cross-XCD; a 64 KB write-through publish costs ~3 us).  The placement is CHECKED per tile
-// (xcc_ticket_check), not assumed.
-template <int NREG, int NTHR, bool INT = false, bool LOCAL = false>
+// (Round 5 built a same-XCD form -- all parts of a tile on one XCD, parked with plain stores in its L2, the placement checked per tile by
+// the ticket -- and measured it at +- 2 % of this one on 40 cells, profiles/midm_sweep_r05.jsonl: the meeting costs its three dependent
+// round trips whether they end in the XCD's L2 or at the fabric.  Removed in round 6; git history has it.)
+template <int NREG, int NTHR, bool INT = false>
 __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag,
                                              bool active = true) {
   constexpr int kSc1 = 16;  // cache-policy bit 4 = sc1 on gfx950
-  constexpr int kPark = LOCAL ? 0 : kSc1;
+  constexpr int kPark = kSc1;
   constexpr int kRegBytes = NTHR * 16;
   constexpr int kPartBytes = NREG * kRegBytes;
   const __amdgpu_buffer_rsrc_t rws =
@@ -85,7 +55,7 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
     for (int r = 0; r < NREG; ++r)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, parked[r]), rws, tid * 16 + r * kRegBytes, ks * kPartBytes, kPark);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through (LOCAL: acknowledged by the L2) before the ticket is taken
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
 #pragma unroll
   for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(parked[r]));
   // The accumulators stay LIVE until the stores have completed.  Round 3: hipcc re-used a data register of a just-issued
@@ -97,13 +67,12 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
   for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(acc[r]));
   __syncthreads();
   if (tid == 0) {
-    const unsigned inc = LOCAL ? xcc_ticket_increment(xcc_id()) : 1u;
+    const unsigned inc = 1u;
     const unsigned t = __hip_atomic_fetch_add(&tickets[tile], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = ((t & 0xffu) == (unsigned)S - 1);
+    const bool last = (t == (unsigned)S - 1);
     *flag = last;
     // everyone has arrived: leave the ticket ready for the next launch
     if (last) {
-      if constexpr (LOCAL) xcc_ticket_check(t, inc, S);
       __hip_atomic_store(&tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -153,10 +122,10 @@ __device__ __forceinline__ bool split_k_meet(f32x4 (&acc)[NREG], float* ws, unsi
 // UMAX: parts gathered per round trip (4 x NREG x 4 VGPRs: callers that run four waves per SIMD pass 2 for 8-register tiles)
 // RC (round 5): registers per batch.  A 256 x 256 tile on 512 threads is 32 registers of 4 floats per thread (128 VGPRs): parked and gathered
 // in batches of RC registers so that neither the pinned store copies nor the gather's landing registers double the tile.
-template <int NREG, int NTHR, bool INT = false, int UMAX = 4, bool LOCAL = false, int RC = NREG>
+template <int NREG, int NTHR, bool INT = false, int UMAX = 4, int RC = NREG>
 __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, unsigned* tickets, int tile, int S, int ks, int tid, int* flag) {
   constexpr int kSc1 = 16;
-  constexpr int kPark = LOCAL ? 0 : kSc1;  // LOCAL: see split_k_meet
+  constexpr int kPark = kSc1;
   constexpr int kRegBytes = NTHR * 16;
   constexpr int kPartBytes = NREG * kRegBytes;
   const int NG = (S + 3) >> 2;          // groups
@@ -176,7 +145,7 @@ __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, uns
 #pragma unroll
       for (int r = 0; r < NREG; ++r)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, parked[r]), rws, tid * 16 + r * kRegBytes, slot * kPartBytes, kPark);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through (LOCAL: acknowledged by the L2) before the ticket is taken
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // written through before the ticket is taken
 #pragma unroll
       for (int r = 0; r < NREG; ++r) asm volatile("" ::"v"(parked[r]));  // the data registers stay untouched until the stores are out
     } else {
@@ -203,12 +172,11 @@ __device__ __forceinline__ bool split_k_meet2(f32x4 (&acc)[NREG], float* ws, uns
   };
   auto last_of = [&](unsigned* t, int n) {
     if (tid == 0) {
-      const unsigned inc = LOCAL ? xcc_ticket_increment(xcc_id()) : 1u;
+      const unsigned inc = 1u;
       const unsigned v = __hip_atomic_fetch_add(t, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool last = ((v & 0xffu) == (unsigned)n - 1);
+      const bool last = (v == (unsigned)n - 1);
       *flag = last;
       if (last) {
-        if constexpr (LOCAL) xcc_ticket_check(v, inc, n);
         __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
       }
     }

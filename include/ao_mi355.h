@@ -126,28 +126,24 @@ int ao_int4_set_tuning(int waves_per_block, int mode);
 /* Profiling only: 0 = product dispatch of the 8-bit GEMMs (LDS-DMA staged kernel when K % 128 == 0),
  * 1 = force the register-staged kernel, 2 / 4 / 8 = force the LDS-DMA kernel with 128x128, 256x128 (4 waves), 256x256 (8 waves) tiles,
  * 32 = the phase-interleaved 256x256 kernel, 33 = its 256x128 form (gemm8_p8h_kernel); 100 / 101 / 102 = the fp8 weight-streaming kernel never / always / always with 64-column tiles; 103 = its round-3 wave arrangement (1 x 8);
- * MXFP8 grouped mm: 110 always the LDS-staged kernels, 111 never (A-stationary / per-tile kernels); decode-size groups: 119 stream-K
- * (the product's form, forced), 118 / 114 / 129 / 128 its other shapes, 113 one workgroup per tile, 112 the round-2 form
- * (ao_amd/csrc/rb8_kernels.hip, DESIGN.md 4.5b).  Thread-local, like ao_int4_set_tuning. */
+ * MXFP8 grouped mm: 110 always the LDS-staged kernels, 111 never (A-stationary / per-tile kernels); decode-size groups: 113 one workgroup
+ * per tile instead of the stream-K kernel, 129 the stream-K kernel's per-step-scales form (what K % 512 != 0 takes) on every K
+ * (ao_amd/csrc/rb8_kernels.hip, DESIGN.md 4.5).  Thread-local, like ao_int4_set_tuning. */
 int ao_gemm8_set_variant(int variant);
 /* Profiling only, key / value (every setting computes the SAME result as the product; 0 = product rule; thread-local):
  *   key 1  column-tile width of the rowwise weight-streaming kernel (rb8_kernel): 32, 64 or 128
  *   key 2  its K parts (1 .. 16)
- *   key 3  2 = the same-XCD split-K meeting where the device's workgroup placement allows it (opt-in; 0 / 1: the write-through,
- *          placement-independent one)
+ *   key 3  (unused since round 6: the same-XCD split-K meeting was removed)
  *   key 4  tile rows an XCD's workgroups of gemm8_p8_kernel walk together (product: 4)
  *   key 5  timing probes of the TRACED build of rb8_kernel only (ao_int4_set_trace set; results are wrong): bit 0 no MFMAs, 1 no fragment
  *          reads, 2 no weight DMAs, 3 no activation DMAs -- the product build ignores it
- *   key 6  slab height of rb8_kernel above 64 rows: 128 or 256
- *   key 7  K parts of gemm8_p8_kernel (1 .. 16, clamped to what fits one round of the chip and the split-K workspace)
+ *   key 6  (unused since round 6: the 256-row slabs of rb8_kernel were removed)
+ *   key 7  K parts of gemm8_p8h_kernel (1 .. 16, clamped to what fits one round of the chip and the split-K workspace)
  *   key 8  loop form of gemm8_p8h_kernel, laboratory build only (the product build ignores it)
+ *   key 9  the MXFP8 stream-K kernel's meeting, A/B: bit 0 the head piece's ticket after the loop, bit 1 no early read of the tail ticket
+ *          (3 = the round-3 protocol)
  * An unknown key is an error.  DESIGN.md 4.5h. */
 int ao_gemm8_set_tuning(int key, int value);
-/* 1 when the current device was measured to place workgroup b of a grid on XCD b % 8 (or has one XCD) -- the split-K kernels then put
- * the K parts of an output tile on one XCD and let them meet in its L2 (checked again per tile on the device; a violation traps);
- * -1 when it was measured not to, or AO_MI355_XCD_LOCAL=0; 0 before the first split-K launch of the process on the device (the probe
- * runs with the first workspace allocation).  ao_amd/csrc/splitk.h, DESIGN.md 4.5h. */
-int ao_xcd_local_state(void);
 /* Name of the kernel ao_int4_weight_int4pack_mm launches for this problem (product dispatch, no
  * tuning override): what a profiler's kernel table should be matched against.  Static string. */
 const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size);
