@@ -19,6 +19,8 @@ namespace ao {
 bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K);  // gemm8_p8_kernels.hip (epi numbering = enum Epilogue)
 void gemm8_p8_set_group_rows(int v);
 void gemm8_p8_set_split(int v);
+void gemm8_p8_set_persistent(int v);
+bool gemm8_p8_persistent_shape(int64_t M, int64_t N, int64_t K);  // the persistent form's product rule (shape part; 16-byte-aligned scales assumed)
 void gemm8_p8h_set_form(int v);
 int gemm8_p8(int epi, const uint8_t* a, const uint8_t* b, const float* row_scale, const float* col_scale, const uint16_t* bias, void* out,
              int64_t M, int64_t N, int64_t K, hipStream_t stream);
@@ -484,6 +486,7 @@ extern "C" int ao_gemm8_set_tuning(int key, int value) {
   rb8_set_tuning(g_tune[1], g_tune[2], g_tune[5]);
   gemm8_p8_set_group_rows(g_tune[4]);
   gemm8_p8_set_split(g_tune[7]);
+  gemm8_p8_set_persistent(g_tune[6]);
   gemm8_p8h_set_form(g_tune[8]);
   return AO_OK;
 }
@@ -531,7 +534,7 @@ extern "C" const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int6
   if (K % BK != 0) return "gemm8_kernel";  // register-staged tiles (K % 128 != 0)
   const int64_t big = ((N + 255) / 256) * ((M + 255) / 256);
   if (gemm8_p8h_band(M, N, K)) return "gemm8_p8h_kernel";
-  if (gemm8_p8_band(M, N, K) && gemm8_p8_fits(M, N, K)) return "gemm8_p8_kernel";
+  if (gemm8_p8_band(M, N, K) && gemm8_p8_fits(M, N, K)) return gemm8_p8_persistent_shape(M, N, K) ? "gemm8_p8p_kernel" : "gemm8_p8_kernel";
   return big >= 512 ? "gemm8_dma_kernel<256x256>" : "gemm8_dma_kernel<128x128>";
 }
 
@@ -545,7 +548,7 @@ extern "C" int ao_gemm8_plan(int int8, int64_t M, int64_t N, int64_t K, int* til
   *k_parts = 1;
   if (name == "rb8_kernel") rb8_plan_query(M, N, K, tile_cols, k_parts);
   else if (name == "gemm8_p8h_kernel") { *tile_cols = 128; *k_parts = gemm8_p8h_parts(M, N, K); }
-  else if (name == "gemm8_p8_kernel" || name == "gemm8_dma_kernel<256x256>") *tile_cols = 256;
+  else if (name == "gemm8_p8_kernel" || name == "gemm8_p8p_kernel" || name == "gemm8_dma_kernel<256x256>") *tile_cols = 256;
   else if (name == "gemm8_dma_kernel<128x128>" || name == "gemm8_kernel") *tile_cols = 128;
   else *tile_cols = 16;  // the per-tile streaming kernels (dec8 / mid8 / stream8): 16-wide n-tiles, K split among the waves of a workgroup
   return AO_OK;

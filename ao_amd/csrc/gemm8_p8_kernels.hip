@@ -277,6 +277,297 @@ __global__ __launch_bounds__(512) void gemm8_p8_kernel(P8Args p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// gemm8_p8p_kernel (round 6): the PERSISTENT form of gemm8_p8_kernel for problems with more 256 x 256 tiles than CUs (BASELINE config 3:
+// 1024 - 3584 tiles per launch).  One workgroup per CU walks its XCD's share of the tile list; what changes against one workgroup per tile:
+//   * the K-tile stream never drains: the half-tile fetches of K tiles t + 1 / t + 2 run on into the NEXT output tile (K tile 0 / 1 of
+//     tile j + 1 are in flight while tile j's last K tile multiplies), so no tile but the first pays the ring's priming, and no workgroup
+//     dispatch, address set-up or kernarg load stands between two tiles;
+//   * the MFMAs are issued with the operands SWAPPED (weights as the A operand): lane (nl, kq) of a 16 x 16 result then holds four
+//     consecutive COLUMNS n = 4 kq + {0..3} of ONE row m = nl, not a 4-row column strip -- a row scale per lane and tile, packed bf16 pairs
+//     straight out of v_cvt_pk_bf16_f32, and two v_permlane32_swap / v_permlane16_swap pairs per two tiles leave every lane with 16
+//     contiguous output bytes: the epilogue touches NO LDS (the old one transposed the tile through all 144 KiB of it, so nothing could be
+//     fetched under it) and issues ~half the VALU instructions;
+//   * row / column scales and the bias of tile j arrive by LDS-DMA during tile j's first K tile (parity-double-buffered 2.5 KiB slots behind
+//     the K-tile buffers): no compiler-visible global load whose wait would be a vmcnt(0) on the running DMA queue;
+//   * the first K tile of an output tile multiplies into C = 0 (a wave-uniform branch), so no accumulator is ever cleared by hand.
+// The epilogue's 16 global stores per wave are younger than every fetch the next vmcnt(4) needs (loads retire in order among loads, so "at
+// most 4 outstanding" still means all but the 4 youngest fetches have landed; the stores only make that wait stricter).
+// Full tiles only (M, N multiples of 256), K >= 256, scale pointers 16-byte aligned: everything else keeps gemm8_p8_kernel.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+constexpr int kPScale = 2 * kBuf;             // the scale slots sit behind the two K-tile buffers
+constexpr int kPSlot = 2560;                  // row scales 1 KiB | column scales 1 KiB | bias 512 B
+constexpr int kPSmem = kPScale + 2 * kPSlot;  // 136192 B
+
+// a, b: one dword per lane of two 16 x 16 result tiles in the swapped-operand layout (lane row q = lane >> 4 holds columns 4 q .. 4 q + 3).
+// Afterwards a / b hold what lane rows (0, 1) resp. (2, 3) of tile a held, if this lane's row is 0 or 1, and the same of tile b otherwise:
+// lane row q then owns columns 8 q .. 8 q + 7 of the 32 columns of the pair (a = the first four of them, b = the second four).
+__device__ __forceinline__ void lane_rows_pair_up(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);        // a: [a0 a1 b0 b1], b: [a2 a3 b2 b3]   (lane rows of a | b)
+  const auto s = __builtin_amdgcn_permlane16_swap(r[0], r[1], false, false);  // a: [a0 a2 b0 b2], b: [a1 a3 b1 b3]
+  a = s[0];
+  b = s[1];
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8_p8p_kernel(P8Args p) {
+  constexpr bool IS_INT = (EPI == P8_INT8_SCALED || EPI == P8_INT32);
+  constexpr bool SCALED = (EPI == P8_INT8_SCALED || EPI == P8_FP8_ROWWISE);
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nl = lane & 15, kq = lane >> 4;
+
+  // this workgroup's tiles: XCD x (= id % 8) owns the contiguous range [x T / 8, (x + 1) T / 8) of the tile order (groups of GR tile rows
+  // walking N together, as in gemm8_p8_kernel), its workgroups walk it side by side
+  const int per = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  const int T = p.tiles_m * p.tiles_n;
+  const int lo = (int)(((int64_t)xcd * T) >> 3), hi = (int)(((int64_t)(xcd + 1) * T) >> 3);
+  if (hi - lo <= slot) return;
+  const int mine = (hi - lo - slot + per - 1) / per;
+  const int ktiles = p.K >> 7;
+  const int GR = p.group_rows, group = GR * p.tiles_n;
+  auto origin = [&](int j, int& m0, int& n0) {
+    const int id = lo + slot + j * per;
+    const int g0 = (id / group) * GR;
+    const int gsz = min(GR, p.tiles_m - g0);
+    m0 = (g0 + (id % group) % gsz) * 256;
+    n0 = ((id % group) / gsz) * 256;
+  };
+
+  // DMA sources (full tiles: the same offsets for A and B, both have row pitch K): half-tile rows 16 w + 8 i + (lane >> 3)
+  uint32_t off[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 16 * wave + 8 * i + (lane >> 3);
+      off[h][i] = (uint32_t)(h * 128 + row) * (uint32_t)p.K + ((uint32_t)(((lane & 7) ^ (row >> 1)) & 7) << 4);
+    }
+  const uint32_t lds0 = lds_offset(smem);
+  auto issue = [&](const uint8_t* asrc, const uint8_t* bsrc, int buf, int which) {  // which: 0 A-lo, 1 B-hi, 2 B-lo, 3 A-hi
+    const bool is_a = (which == 0 || which == 3);
+    const int half = (which == 1 || which == 3) ? 1 : 0;
+    const uint32_t dst = lds0 + buf * kBuf + ((is_a ? 0 : 2) + half) * kHalf + wave * 2048;
+    const uint8_t* src = is_a ? asrc : bsrc;
+    dma_b128_s(src, off[half][0], dst);
+    dma_b128_s(src, off[half][1], dst + 1024);
+  };
+  // the epilogue operands of a tile: waves 0 / 1 fetch the 256 row / column scales, waves 2 / 3 the two halves of the bias
+  const uint32_t lane16 = (uint32_t)lane << 4, lane4 = (uint32_t)lane << 2;
+  auto issue_scales = [&](int m0, int n0, int par) {
+    if constexpr (SCALED) {
+      const uint32_t dst = lds0 + kPScale + par * kPSlot;
+      if (wave == 0) dma_b128_s(p.row_scale + m0, lane16, dst);
+      if (wave == 1) dma_b128_s(p.col_scale + n0, lane16, dst + 1024);
+      if (p.bias != nullptr && (wave == 2 || wave == 3)) dma_b32_s(p.bias + n0 + (wave - 2) * 128, lane4, dst + 2048 + (wave - 2) * 256);
+    }
+  };
+
+  const int pos_lo = ((kq ^ (nl >> 1)) & 7) << 4;
+  const int a_frag = wr * kHalf + nl * 128 + pos_lo;
+  const int b_frag = (2 + (wc >> 1)) * kHalf + ((wc & 1) * 64 + nl) * 128 + pos_lo;
+
+  f32x4 acc[8][4];
+  u32x4 af[4][2], bf[4][2];
+  auto load_a = [&](const char* buf, int mi) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int o = a_frag + (mi * 64 + mt * 16) * 128;
+      af[mt][0] = *reinterpret_cast<const u32x4*>(buf + o);
+      af[mt][1] = *reinterpret_cast<const u32x4*>(buf + (o ^ 64));
+    }
+  };
+  auto load_b = [&](const char* buf) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int o = b_frag + (nt * 16) * 128;
+      bf[nt][0] = *reinterpret_cast<const u32x4*>(buf + o);
+      bf[nt][1] = *reinterpret_cast<const u32x4*>(buf + (o ^ 64));
+    }
+  };
+  const int unit_scale = 127;  // E8M0 1.0
+  // operands swapped (weights first): D[i = 4 kq + r][j = nl] = column n = 16 nt + i of row m = 16 mt + j
+  auto multiply = [&](int mi, int nj, bool first) {
+    if (first) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int nt = nj * 2 + n2;
+          f32x4& c = acc[mi * 4 + mt][nt];
+          if constexpr (IS_INT) {
+            c = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bf[nt][0]), __builtin_bit_cast(i32x4, af[mt][0]),
+                                                                               i32x4{0, 0, 0, 0}, 0, 0, 0));
+          } else {
+            const i32x8 av = {(int)af[mt][0].x, (int)af[mt][0].y, (int)af[mt][0].z, (int)af[mt][0].w,
+                              (int)af[mt][1].x, (int)af[mt][1].y, (int)af[mt][1].z, (int)af[mt][1].w};
+            const i32x8 bv = {(int)bf[nt][0].x, (int)bf[nt][0].y, (int)bf[nt][0].z, (int)bf[nt][0].w,
+                              (int)bf[nt][1].x, (int)bf[nt][1].y, (int)bf[nt][1].z, (int)bf[nt][1].w};
+            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&v"(c) : "v"(bv), "v"(av), "v"(unit_scale));
+          }
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int nt = nj * 2 + n2;
+          f32x4& c = acc[mi * 4 + mt][nt];
+          if constexpr (IS_INT) {
+            c = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bf[nt][0]), __builtin_bit_cast(i32x4, af[mt][0]),
+                                                                               __builtin_bit_cast(i32x4, c), 0, 0, 0));
+          } else {
+            const i32x8 av = {(int)af[mt][0].x, (int)af[mt][0].y, (int)af[mt][0].z, (int)af[mt][0].w,
+                              (int)af[mt][1].x, (int)af[mt][1].y, (int)af[mt][1].z, (int)af[mt][1].w};
+            const i32x8 bv = {(int)bf[nt][0].x, (int)bf[nt][0].y, (int)bf[nt][0].z, (int)bf[nt][0].w,
+                              (int)bf[nt][1].x, (int)bf[nt][1].y, (int)bf[nt][1].z, (int)bf[nt][1].w};
+            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bv), "v"(av), "v"(unit_scale));
+          }
+        }
+    }
+    if constexpr (IS_INT) {  // the second k half of every tile in a second sweep (back-to-back MFMAs on one accumulator would wait for each other)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int nt = nj * 2 + n2;
+          f32x4& c = acc[mi * 4 + mt][nt];
+          c = __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bf[nt][1]), __builtin_bit_cast(i32x4, af[mt][1]),
+                                                                             __builtin_bit_cast(i32x4, c), 0, 0, 0));
+        }
+    }
+  };
+  auto seam = [&] {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  int m0, n0, m1 = 0, n1 = 0;
+  origin(0, m0, n0);
+  if (mine > 1) origin(1, m1, n1);
+  const uint8_t* acur = p.a + (size_t)m0 * p.K;
+  const uint8_t* bcur = p.b + (size_t)n0 * p.K;
+  const uint8_t* anext = p.a + (size_t)m1 * p.K;
+  const uint8_t* bnext = p.b + (size_t)n1 * p.K;
+
+  // prologue: K tile 0 entirely and the B halves of K tile 1 (as if issued in q2 / q3 of a tile -1); wait for tile 0
+  issue(acur, bcur, 0, 0); issue(acur, bcur, 0, 3); issue(acur, bcur, 0, 2); issue(acur, bcur, 0, 1);
+  issue(acur + 128, bcur + 128, 1, 2); issue(acur + 128, bcur + 128, 1, 1);
+  wait_vmcnt<4>();
+  asm volatile("s_barrier" ::: "memory");
+  if (wr == 1) asm volatile("s_barrier" ::: "memory");  // the stagger: wave row 1 runs one barrier behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  int gpar = 0;  // parity of the stream position (j ktiles + t): which buffer holds it
+  for (int j = 0; j < mine; ++j) {
+    const bool has_next = j + 1 < mine;
+    for (int t = 0; t < ktiles; ++t, gpar ^= 1) {
+      const char* buf = smem + gpar * kBuf;
+      const bool first = (t == 0);
+      // the sources of stream positions + 1 and + 2: this tile's next K tiles, or the next output tile's first ones
+      const bool in1 = t + 1 < ktiles, in2 = t + 2 < ktiles;
+      const bool ok1 = in1 || has_next, ok2 = in2 || has_next;
+      const uint8_t* a1 = in1 ? acur + (size_t)(t + 1) * 128 : anext + (size_t)(t + 1 - ktiles) * 128;
+      const uint8_t* b1 = in1 ? bcur + (size_t)(t + 1) * 128 : bnext + (size_t)(t + 1 - ktiles) * 128;
+      const uint8_t* a2 = in2 ? acur + (size_t)(t + 2) * 128 : anext + (size_t)(t + 2 - ktiles) * 128;
+      const uint8_t* b2 = in2 ? bcur + (size_t)(t + 2) * 128 : bnext + (size_t)(t + 2 - ktiles) * 128;
+      // ---- q0: m-lo x n-lo ------------------------------------------------------------------------------------------------------------
+      load_b(buf); __builtin_amdgcn_sched_barrier(0); load_a(buf, 0);
+      if (first) issue_scales(m0, n0, j & 1);  // older than the fetches below: the q3 wait of this K tile covers them
+      if (ok1) issue(a1, b1, gpar ^ 1, 0);
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(0, 0, first); __builtin_amdgcn_s_setprio(0);
+      seam();
+      // ---- q1: m-lo x n-hi ------------------------------------------------------------------------------------------------------------
+      if (ok1) issue(a1, b1, gpar ^ 1, 3);
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(0, 1, first); __builtin_amdgcn_s_setprio(0);
+      seam();
+      // ---- q2: m-hi x n-hi ------------------------------------------------------------------------------------------------------------
+      load_a(buf, 1);
+      if (ok2) issue(a2, b2, gpar, 2);
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(1, 1, first); __builtin_amdgcn_s_setprio(0);
+      seam();
+      // ---- q3: m-hi x n-lo; stream position + 1 must have landed before the next phase reads it --------------------------------------------
+      if (ok2) { issue(a2, b2, gpar, 1); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+      seam();
+      __builtin_amdgcn_s_setprio(1); multiply(1, 0, first); __builtin_amdgcn_s_setprio(0);
+      seam();
+    }
+    if (!has_next && wr == 0) asm volatile("s_barrier" ::: "memory");  // the last tile: wave row 1's final barrier must not wait for this row's epilogue
+    if constexpr (!IS_INT) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // asm MFMA results -> VALU readers (see gemm8_p8_kernel)
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue of tile j (no LDS but the scale slot, no barrier: the other wave row multiplies on) -------------------------------------------
+    {
+      const int rbase = m0 + wr * 128, cbase = n0 + wc * 64;
+      if constexpr (!SCALED) {
+        uint32_t* out = reinterpret_cast<uint32_t*>(p.out);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            *reinterpret_cast<u32x4*>(out + (size_t)(rbase + mt * 16 + nl) * p.N + cbase + nt * 16 + kq * 4) = __builtin_bit_cast(u32x4, acc[mt][nt]);
+      } else {
+        const char* sl = smem + kPScale + (j & 1) * kPSlot;
+        uint16_t* out = reinterpret_cast<uint16_t*>(p.out);
+        auto scaled = [&](auto with_bias) {
+          constexpr bool BIAS = decltype(with_bias)::value;
+          f32x4 cs[4], bs[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            cs[nt] = *reinterpret_cast<const f32x4*>(sl + 1024 + (wc * 64 + nt * 16 + kq * 4) * 4);
+            if constexpr (BIAS) {
+              const u32x2 b = *reinterpret_cast<const u32x2*>(sl + 2048 + (wc * 64 + nt * 16 + kq * 4) * 2);
+              bs[nt] = f32x4{bf16_lo_to_f32(b.x), bf16_hi_to_f32(b.x), bf16_lo_to_f32(b.y), bf16_hi_to_f32(b.y)};
+            }
+          }
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {
+            const float rs = *reinterpret_cast<const float*>(sl + (wr * 128 + mt * 16 + nl) * 4);
+            uint32_t d[4][2];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if constexpr (EPI == P8_INT8_SCALED) {
+                  // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+                  v[r] = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt][nt])[r] * rs) * cs[nt][r];
+                } else {
+                  v[r] = acc[mt][nt][r] * rs * cs[nt][r];
+                }
+                if constexpr (BIAS) v[r] += bs[nt][r];
+              }
+              d[nt][0] = pack_bf16x2(v[0], v[1]);
+              d[nt][1] = pack_bf16x2(v[2], v[3]);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              lane_rows_pair_up(d[2 * pr][0], d[2 * pr + 1][0]);
+              lane_rows_pair_up(d[2 * pr][1], d[2 * pr + 1][1]);
+              const u32x4 o = {d[2 * pr][0], d[2 * pr][1], d[2 * pr + 1][0], d[2 * pr + 1][1]};
+              *reinterpret_cast<u32x4*>(out + (size_t)(rbase + mt * 16 + nl) * p.N + cbase + pr * 32 + kq * 8) = o;
+            }
+          }
+        };
+        if (p.bias != nullptr) scaled(std::true_type{}); else scaled(std::false_type{});
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    m0 = m1; n0 = n1; acur = anext; bcur = bnext;
+    if (j + 2 < mine) {
+      origin(j + 2, m1, n1);
+      anext = p.a + (size_t)m1 * p.K;
+      bnext = p.b + (size_t)n1 * p.K;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
 // gemm8_p8h_kernel (round 5): the same phase-interleaved scheme on a 256 (M) x 128 (N) tile, for problems whose 256 x 256 tiles would leave
 // half the chip idle (M <= 1024 on the TP shards: 28 .. 128 such tiles) while 256 x 128 tiles fill one round of it.
 //   * 8 waves = 4 (m) x 2 (n): wave 4 g + s owns rows 64 s .. 64 s + 63 and columns 64 g .. 64 g + 63 (4 x 4 MFMA tiles, 64 accumulator
@@ -607,10 +898,40 @@ int launch_p8h(P8Args p, hipStream_t stream) {
   return AO_OK;
 }
 
+thread_local int g_p8_persist = 0;  // (ao_gemm8_set_tuning key 6) 0 product rule, 1 never, 2 wherever the shape allows
+constexpr int kP8ChipCUs = 256;     // MI355X: one persistent workgroup per CU, 32 per XCD
+
+// The persistent form takes full tiles when there are more tiles than CUs, and any tile count at K < 4096, where its register-only epilogue and
+// DMA-fetched scales are worth 2 - 7 % even with one tile per workgroup (profiles/p8_persist_ab_r06.jsonl, same process, alternating, cold weights:
+// int8 at M = 16384 qkv 347 -> 331 us, o 222 -> 220, gate / up 784 -> 759, down 705 -> 707; fp8 K = 3584 / 4096 + 5 - 12 %, K = 1024 + 24 %;
+// at <= 256 tiles and K >= 4096 the two are level, +- 1 %).  A loop form that dealt the 24 fragment reads of a K tile 8 / 4 / 8 / 4 over the
+// four phases (the n-lo B fragments prefetched a K tile ahead) instead of 16 / 0 / 8 / 0 was 3 - 13 % SLOWER in every cell of that file
+// ("balanced") and left the tree.
+bool p8_persistent_shape(int64_t M, int64_t N, int64_t K) {
+  return M % 256 == 0 && N % 256 == 0 && K >= 256 && K % 128 == 0 && ((M / 256) * (N / 256) > kP8ChipCUs || K < 4096);
+}
+bool p8_persistent_takes(const P8Args& p) {
+  if (g_p8_persist == 1) return false;
+  const bool fits = p.M % 256 == 0 && p.N % 256 == 0 && p.K >= 256 && (reinterpret_cast<uintptr_t>(p.row_scale) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(p.col_scale) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.bias) & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+  return fits && (g_p8_persist == 2 || p8_persistent_shape(p.M, p.N, p.K));
+}
+
 template <int EPI>
 int launch_p8(P8Args p, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
+  if (p8_persistent_takes(p)) {
+    p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
+    p.split = 1;
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
+    const unsigned grid = (unsigned)std::min<int64_t>(kP8ChipCUs, (tiles + 7) / 8 * 8);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm8_p8p_kernel<EPI>), kPSmem, "hipFuncSetAttribute(gemm8_p8p_kernel)")) return rc;
+    ao::launch(gemm8_p8p_kernel<EPI>, dim3(grid), dim3(512), kPSmem, stream, p);
+    AO_LAUNCH_CHECK("gemm8_p8p_kernel launch");
+    return AO_OK;
+  }
   // round 5 sweep (profiles/p8_group_rows_r05.jsonl): 4 tile rows per group measured 0 .. 7 % ahead of 8 on the Llama-3-8B int8 shapes at
   // M = 16384 (an XCD's L2 then holds 4 MB of A panels, its size, instead of 8 MB) and level elsewhere
   p.group_rows = (g_p8_group_rows >= 1 && g_p8_group_rows <= 64) ? g_p8_group_rows : 4;
@@ -637,6 +958,8 @@ bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K) {
 int gemm8_p8h_parts(int64_t M, int64_t N, int64_t K) { return p8h_split_rule(M, N, K); }  // (product rule; host logic only)
 void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }
 void gemm8_p8_set_split(int v) { g_p8_split = v; }
+void gemm8_p8_set_persistent(int v) { g_p8_persist = v; }
+bool gemm8_p8_persistent_shape(int64_t M, int64_t N, int64_t K) { return p8_persistent_shape(M, N, K); }
 void gemm8_p8h_set_form(int v) { g_p8h_form = v; }
 
 // the 256 x 128 form (same epi numbering and shape limits)

@@ -710,7 +710,7 @@ def config_int8(stream, device, args):
                        "1 of 32 layers timed (x32 = one forward; every layer does the same work)",
            "value": M / (t * N_LAYERS), "unit": "tokens/s", "ms_per_layer": t * 1e3, "dtype": "int8 x int8 -> int32, bf16 out",
            "launch": "hipGraph replay" if graphed else "eager", "launches_per_layer": 2 * nchunk * len(ws),
-           "roofline": {"kernel": "gemm8_p8_kernel<int8> (256x256 phase-interleaved; gemm8_dma_kernel below 160 tiles)", "bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_8BIT_PEAK_TOPS,
+           "roofline": {"kernel": "gemm8_p8p_kernel<int8> (256x256 phase-interleaved, persistent: one workgroup per CU walks 4 - 14 tiles)", "bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_8BIT_PEAK_TOPS,
                         "unit": "TOP/s", "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_8BIT_PEAK_TOPS, "traffic": pmc_traffic_of("int8")[0], "traffic_source": pmc_traffic_of("int8")[1],
                         "measured_mfma_ceiling": _SPECS["int8_measured_mfma_tops"] / 1e12, "frac_of_measured_ceiling": flops / (gemm_ms * 1e-3) / _SPECS["int8_measured_mfma_tops"],
                         "timing": "HIP extension events, one eager layer", "gemm_ms_per_layer": gemm_ms, "act_cast_ms_per_layer": cast_ms,
@@ -798,7 +798,7 @@ def config_fp8_shards(stream, device, args):
                        "(qkv 1280x8192, o 8192x1024, gate_up 7168x8192, down 8192x3584), 80 layers, activation cast + scaled mm per linear",
            "value": res["M2048"]["tokens_per_s"], "unit": "tokens/s (per GPU, M = 2048, before the all-reduce)", "dtype": "e4m3 x e4m3 -> fp32, bf16 out",
            "by_M": res,
-           "roofline": {"kernel": "gemm8_p8_kernel<fp8> (o, gate_up, down shards) / gemm8_p8h_kernel<fp8> with 3 K parts (qkv shard) at M = 2048", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
+           "roofline": {"kernel": "gemm8_p8p_kernel<fp8> (o, down shards) / gemm8_p8_kernel<fp8> (gate_up shard) / gemm8_p8h_kernel<fp8> with 3 K parts (qkv shard) at M = 2048", "bound": "mfma", "achieved": res["M2048"]["TFLOPs"], "peak": MFMA_8BIT_PEAK_TOPS, "unit": "TFLOP/s",
                         "frac": res["M2048"]["frac"], "traffic": pmc_traffic_of("fp8")[0], "traffic_source": pmc_traffic_of("fp8")[1],
                         "measured_mfma_ceiling": _SPECS["fp8_measured_mfma_tops"] / 1e12, "frac_of_measured_ceiling": res["M2048"]["TFLOPs"] * 1e12 / _SPECS["fp8_measured_mfma_tops"],
                         "timing": "hipGraph replay wall time of the whole step (casts included)"}}

@@ -51,7 +51,7 @@ f=$(find $O/prof_cfg_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && 
 O=$O R=$R ROUND=$ROUND python - <<'PY'
 import csv, glob, json, os
 O, R, ROUND = os.environ["O"], os.environ["R"], os.environ["ROUND"]
-dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8_kernel", "mx": "mx_stream_kernel", "fp8": "gemm8_p8_kernel"}
+dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8p_kernel", "mx": "mx_stream_kernel", "fp8": "gemm8_p8_kernel"}
 out = {"source": "scripts/gpu_final.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes per config; FETCH x1024 x2 (gfx950), WRITE x1024 (uncalibrated); "
                  "mean over the dispatches of the config's dominant kernel (int4_bs128: int4_mm_rb_kernel serves qkv / o / down, int4_mm_w32_kernel gate / up -- both listed)", "configs": {}}
 for c, k in dom.items():

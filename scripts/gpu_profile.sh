@@ -46,7 +46,7 @@ f=$(find $O/prof_cfg_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && 
 O=$O python - <<'PY'
 import json, os
 O = os.environ["O"]
-dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8_kernel", "mx": "mx_stream_kernel", "fp8": "gemm8_p8_kernel"}
+dom = {"int4_bs128": "int4_mm_rb_kernel", "int8": "gemm8_p8p_kernel", "mx": "mx_stream_kernel", "fp8": "gemm8_p8_kernel"}
 out = {"source": "scripts/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes per config; FETCH x1024 x2 (gfx950), WRITE x1024 (uncalibrated); "
                  "mean over the dispatches of the config's dominant kernel", "configs": {}}
 for c, k in dom.items():
@@ -108,8 +108,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O + "/prof_gemm_pmc/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f, newline="")):
         n = row["Kernel_Name"]
-        if "gemm8_p8_kernel" in n:
-            k = "gemm8_p8_kernel<" + ("int8" if "<0>" in n or "<1>" in n else "fp8") + ">"
+        if "gemm8_p8_kernel" in n or "gemm8_p8p_kernel" in n:
+            k = ("gemm8_p8p_kernel<" if "gemm8_p8p_kernel" in n else "gemm8_p8_kernel<") + ("int8" if "<0>" in n or "<1>" in n else "fp8") + ">"
         elif "gemm8_dma_kernel" in n:
             k = "gemm8_dma_kernel"
         else:

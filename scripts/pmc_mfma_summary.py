@@ -16,6 +16,8 @@ import json
 def label(n):
     if "gemm8_p8h_kernel" in n:
         return "gemm8_p8h_kernel<" + ("int8" if "<0," in n or "<1," in n else "fp8") + ">"
+    if "gemm8_p8p_kernel" in n:
+        return "gemm8_p8p_kernel<" + ("int8" if "<0>" in n or "<1>" in n else "fp8") + ">"
     if "gemm8_p8_kernel" in n:
         return "gemm8_p8_kernel<" + ("int8" if "<0>" in n or "<1>" in n else "fp8") + ">"
     if "gemm8_dma_kernel" in n:

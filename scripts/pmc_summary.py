@@ -16,7 +16,7 @@ import json
 import os
 from collections import defaultdict
 
-KERNELS = ["int4_mm_kernel", "int4_mm_rb_kernel", "int4_mm_w32_kernel", "int4_quantize_kernel", "gemm8_p8_kernel", "gemm8_p8h_kernel", "gemm8_dma_kernel", "rb8_kernel", "mx_stream_kernel",
+KERNELS = ["int4_mm_kernel", "int4_mm_rb_kernel", "int4_mm_w32_kernel", "int4_quantize_kernel", "gemm8_p8_kernel", "gemm8_p8p_kernel", "gemm8_p8h_kernel", "gemm8_dma_kernel", "rb8_kernel", "mx_stream_kernel",
            "stream8_kernel", "dyn8_kernel", "fp8_int4_mm_kernel", "quant_rowwise_reg_kernel", "mxfp8_quant_rowwise_kernel"]
 
 

@@ -711,6 +711,46 @@ def test_gemm8_phase_interleaved_kernel_race_screen(m, n, k, variant):
         assert _rel(np_from_torch_bf16((raw * fs * hs.t()).to(torch.bfloat16)), np_from_torch_bf16(want_f)) <= 2e-3
 
 
+@pytest.mark.parametrize("m,n,k,bias", [(2048, 4096, 4096, False), (4096, 5120, 1024, True), (8192, 6144, 384, False), (256, 256, 256, True),
+                                        (16384, 4096, 4096, True), (2304, 14336, 256, False)])
+def test_gemm8_persistent_form_equals_one_workgroup_per_tile(m, n, k, bias):
+    """gemm8_p8p_kernel (round 6): one workgroup per CU walks its XCD's share of the 256 x 256 tiles with the K-tile stream running across
+    tile boundaries, swapped MFMA operands and a register-only epilogue (v_permlane32_swap / v_permlane16_swap instead of the LDS transposition).
+    Against gemm8_p8_kernel (one workgroup per tile) on fresh operands: int32 and the scaled bf16 output of the int8 GEMM bit for bit (the
+    epilogue's rounding sequence is the same), fp8 within accumulation order; 1, 2 and 3+ tiles per workgroup, odd K-tile counts (the buffer
+    parity then flips from tile to tile), a grid with idle workgroups, with and without bias."""
+    from ao_amd import _lib
+
+    lib = _lib.lib()
+    for run in range(3):
+        g = torch.Generator(device=DEV).manual_seed(77 * run + m + k)
+        a = torch.randint(-128, 128, (m, k), device=DEV, dtype=torch.int8, generator=g)
+        b = torch.randint(-128, 128, (n, k), device=DEV, dtype=torch.int8, generator=g)
+        sa = torch.rand(m, 1, device=DEV, generator=g) * 0.01 + 1e-3
+        sb = torch.rand(n, 1, device=DEV, generator=g) * 0.01 + 1e-3
+        bv = (torch.randn(n, device=DEV, generator=g)).to(torch.bfloat16) if bias else None
+        f = torch.randn(m, k, device=DEV, generator=g).to(torch.bfloat16)
+        h = (torch.randn(n, k, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+        fq, fs = ops.fp8_quantize_rowwise(f)
+        hq, hs = ops.fp8_quantize_rowwise(h)
+        out = {}
+        try:
+            lib.ao_gemm8_set_variant(32)
+            for form in (1, 2):  # 1: never persistent, 2: persistent wherever the shape allows
+                lib.ao_gemm8_set_tuning(6, form)
+                out[form] = (ops.int_mm(a, b.t()), ops.int8_scaled_mm(a, sa, b, sb, bv), ops.fp8_scaled_mm(fq, hq.t(), fs, hs.t(), bv),
+                             ops.fp8_mm_f32(fq, hq.t()))
+        finally:
+            lib.ao_gemm8_set_tuning(6, 0)
+            lib.ao_gemm8_set_variant(0)
+        for form in (2,):
+            assert torch.equal(out[1][0], out[form][0]), (run, form, int((out[1][0] != out[form][0]).sum()))
+            assert torch.equal(out[1][1].view(torch.int16), out[form][1].view(torch.int16)), (run, form)
+            assert _rel(np_from_torch_bf16(out[form][2]), np_from_torch_bf16(out[1][2])) <= 1e-3
+            assert _rel(out[form][3].cpu().numpy(), out[1][3].cpu().numpy()) <= 1e-5
+    assert lib.ao_gemm8_set_variant(0) == 0
+
+
 # ---- round 5: the same-XCD split-K meeting, the LDS-transposed epilogue, the 32-column tiles ------------------------------------------------
 @pytest.mark.parametrize("kind", ["int8", "fp8"])
 @pytest.mark.parametrize("m,n,k,bias", [(128, 1280, 8192, False), (200, 1296, 2048, True), (33, 8192, 1024, False), (128, 4096, 4096, True),

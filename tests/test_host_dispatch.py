@@ -44,13 +44,15 @@ TABLE = [
     ((256, 7168, 8192), "rb8_kernel"),
     ((128, 28672, 4096), "rb8_kernel"),          # 128 rows: never
     # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on (from 128 at short K / > 512 small tiles)
-    ((1024, 28672, 4096), "gemm8_p8_kernel"),
+    ((1024, 28672, 4096), "gemm8_p8p_kernel"),  # 448 full tiles: the persistent form (round 6)
     ((2048, 8192, 4096), "gemm8_p8_kernel"),   # 256 tiles of 256 x 256
     ((512, 16512, 4096), "gemm8_p8_kernel"),   # 130 tiles of 256 x 256 and K <= 4096 (round 4); 258 tiles of 256 x 128 would need a second round
     ((1280, 7168, 8192), "gemm8_p8_kernel"),   # 140 such tiles, but 560 of 128 x 128: a second round of the chip otherwise
     ((2048, 7168, 8192), "gemm8_p8_kernel"),
-    ((16384, 14336, 4096), "gemm8_p8_kernel"),
-    ((16384, 4096, 14336), "gemm8_p8_kernel"),
+    ((16384, 14336, 4096), "gemm8_p8p_kernel"),
+    ((16384, 4096, 14336), "gemm8_p8p_kernel"),
+    ((2048, 8192, 1024), "gemm8_p8p_kernel"),   # 256 tiles, K < 4096: one tile per workgroup, the register-only epilogue still pays
+    ((2048, 8192, 3584), "gemm8_p8p_kernel"),
     # K not a multiple of 128: the register-staged tile kernel
     ((2048, 4096, 4000), "gemm8_kernel"),
     ((0, 64, 1024), "invalid"),
@@ -114,7 +116,7 @@ def test_8bit_launch_plans_on_the_sweep_shapes():
         "gate_up8b": {128: ("rb8", 128, 1), 256: ("p8h", 128, 1), 512: ("p8", 256, 1), 1024: ("p8", 256, 1), 2048: ("p8", 256, 1)},
         "down8b": {128: ("rb8", 64, 4), 256: ("rb8", 128, 4), 512: ("p8h", 128, 4), 768: ("p8h", 128, 2), 1024: ("p8h", 128, 2), 2048: ("p8h", 128, 1)},
     }
-    short = {"rb8_kernel": "rb8", "gemm8_p8h_kernel": "p8h", "gemm8_p8_kernel": "p8"}
+    short = {"rb8_kernel": "rb8", "gemm8_p8h_kernel": "p8h", "gemm8_p8_kernel": "p8", "gemm8_p8p_kernel": "p8"}
     for name, (n, k) in shapes.items():
         for m, expect in want[name].items():
             for int8 in (0, 1):

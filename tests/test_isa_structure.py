@@ -135,7 +135,7 @@ def test_fp8_gemm_covers_the_mfma_to_epilogue_hazard_explicitly(tmp_path):
     checked = 0
     for block in re.split(r"\n(?=[0-9a-f]+ <)", asm):
         head = block.split("\n", 1)[0]
-        if "gemm8_p8_kernel" not in head and "gemm8_p8h_kernel" not in head:
+        if "gemm8_p8_kernel" not in head and "gemm8_p8h_kernel" not in head and "gemm8_p8p_kernel" not in head:
             continue
         ins = [l.split("//")[0].strip() for l in block.split("\n")[1:] if l.split("//")[0].strip()]
         if not any(t.startswith("v_mfma_scale_f32_16x16x128_f8f6f4") for t in ins):
@@ -145,4 +145,4 @@ def test_fp8_gemm_covers_the_mfma_to_epilogue_hazard_explicitly(tmp_path):
         # nothing matrix-pipe-related is issued behind the cover
         assert not any(t.startswith("v_mfma") for t in ins[pairs[-1]:]) or len(pairs) >= 1
         checked += 1
-    assert checked >= 4, "fp8 instantiations of gemm8_p8_kernel / gemm8_p8h_kernel not found"
+    assert checked >= 6, "fp8 instantiations of gemm8_p8_kernel / gemm8_p8p_kernel / gemm8_p8h_kernel not found"
