@@ -29,7 +29,7 @@
 #include <type_traits>
 
 namespace ao {
-thread_local int g_dec8_mode = 0;  // ao_gemm8_set_variant 200 + d: force ring depth d; 290: half-line loads (no LDS transposition); 299: never this kernel
+thread_local int g_dec8_mode = 0;  // ao_gemm8_set_variant 200 + d: force ring depth d; 290: half-line loads (no LDS transposition); 291 / 292: 8-row tiles never / always; 299: never this kernel
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -58,9 +58,13 @@ constexpr int kXV = 4;                      // 16-byte activation vectors a thre
 // LOOP: any K % 128 == 0 -- a wave's run is ceil / floor (K / 128 / waves) steps, walked with the DEPTH-deep ring refilled slot by slot
 // (steady state branch-free, so the compiler still counts its vmcnt waits; the drain has uniform branches).  K of the popular models
 // that do not factor into <= 16 waves x {8, 7, 4, 2, 1} steps take it: Llama-2-7B's 11008 (86 steps), Llama-3-70B's unsharded 28672.
-template <bool INT8, bool DYN, int DEPTH, bool XFAST, bool HALF, bool LOOP = false>
+// ROWS8 (round 6): the tile is 8 weight rows, not 16 -- one full-line load per step; columns 8 .. 15 of the MFMA repeat columns 0 .. 7 and are
+// not stored.  For weights with so few rows that N / 16 workgroups leave most CUs without work (the 70B / TP8 qkv shard: 80 workgroups).
+template <bool INT8, bool DYN, int DEPTH, bool XFAST, bool HALF, bool LOOP = false, bool ROWS8 = false>
 __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
   static_assert(!(LOOP && XFAST), "the loop form casts / copies the activation workgroup-wide");
+  static_assert(!(ROWS8 && (HALF || LOOP)), "8-row tiles: the straight-line full-line form only");
+  constexpr int TR = ROWS8 ? 8 : 16;  // weight rows per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,12 +88,12 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
   Stage st[DEPTH];
   // lane l: HALF -- row l & 15, pieces kq and 4 + kq of the step (the operand layout);  else row (l >> 3) of the tile's rows 0..7 (b0) /
   // 8..15 (b1), chunk l & 7 of the step's 128 bytes: full lines
-  const uint8_t* brow = (HALF ? p.b + ((size_t)ntile * 16 + nl) * p.K + kq * 16 : p.b + ((size_t)ntile * 16 + (lane >> 3)) * p.K + (lane & 7) * 16) +
+  const uint8_t* brow = (HALF ? p.b + ((size_t)ntile * 16 + nl) * p.K + kq * 16 : p.b + ((size_t)ntile * TR + (lane >> 3)) * p.K + (lane & 7) * 16) +
                         (size_t)ks0 * 128;  // the wave's first step; steps are addressed relative to it (straight-line form: immediates)
   const size_t b1off = HALF ? (size_t)64 : (size_t)8 * p.K;
   auto issue_step = [&](Stage& s, int rel) {
     s.b0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + rel * 128));
-    s.b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + b1off + rel * 128));
+    if constexpr (!ROWS8) s.b1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(brow + b1off + rel * 128));
     __builtin_amdgcn_sched_barrier(0);  // request order = consumption order (VMEM returns in order)
   };
   auto issue_ring = [&]() {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
   // rows >= M of the A operand alias row 0: they only reach output rows that are never stored
   const char* arow = xq + (nl < p.M ? nl : 0) * stride + kq * 16 + ks0 * 128;  // relative steps, like the weights
   char* wr0 = slab + (lane >> 3) * kSlabStride + (lane & 7) * 16;  // this lane's piece of rows 0..7; rows 8..15: + 8 rows
-  const char* rd = slab + nl * kSlabStride + kq * 16;
+  const char* rd = slab + (ROWS8 ? (nl & 7) : nl) * kSlabStride + kq * 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};  // int8: int32 bit patterns
   auto consume = [&](const Stage& sg, int rel) {
     u32x4 b0, b1;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
       b0 = sg.b0; b1 = sg.b1;
     } else {
       *reinterpret_cast<u32x4*>(wr0) = sg.b0;
-      *reinterpret_cast<u32x4*>(wr0 + 8 * kSlabStride) = sg.b1;
+      if constexpr (!ROWS8) *reinterpret_cast<u32x4*>(wr0 + 8 * kSlabStride) = sg.b1;
       b0 = *reinterpret_cast<const u32x4*>(rd);
       b1 = *reinterpret_cast<const u32x4*>(rd + 64);
     }
@@ -253,7 +257,8 @@ __global__ __launch_bounds__(1024) void dec8_kernel(Dec8Args p) {
   lds_barrier();
   for (int idx = tid; idx < p.M * 16; idx += nthreads) {  // (workgroups of 1 .. 3 waves have fewer threads than outputs)
     const int row = idx >> 4, col = idx & 15;
-    const int gn = ntile * 16 + col;
+    if (ROWS8 && col >= 8) continue;
+    const int gn = ntile * TR + col;
     const float sx = DYN ? rs[row] : p.row_scale[row];
     float v;
     if constexpr (INT8) {
@@ -302,9 +307,20 @@ size_t dec8_lds(int64_t M, int64_t K, int waves) {
   return (size_t)((M * (K + 16) + 15) & ~(int64_t)15) + (size_t)waves * kSlab + (size_t)(waves * 256 + waves * 16 + 16) * sizeof(float);
 }
 
+// 8-row tiles where 16-row tiles would leave more than half of the chip's CUs without a workgroup (N / 16 < 128) -- the straight-line
+// form with more than one wave only (a one-wave workgroup streams 1 KiB per step as it is)
+bool dec8_rows8(int64_t N, int waves) { return g_dec8_mode != 291 && (g_dec8_mode == 292 || N / 16 < 128) && N % 8 == 0 && waves >= 2; }
+
 template <bool INT8, bool DYN, int DEPTH, bool XFAST>
 int launch_dec8_h(const Dec8Args& p, int waves, bool half, hipStream_t stream) {
   const size_t smem = dec8_lds(p.M, p.K, waves);
+  if (!half && dec8_rows8(p.N, waves)) {
+    auto kern = dec8_kernel<INT8, DYN, DEPTH, XFAST, false, false, true>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(dec8_kernel)")) return rc;
+    ao::launch(kern, dim3((unsigned)(p.N / 8)), dim3(waves * 64), smem, stream, p);
+    AO_LAUNCH_CHECK("dec8_kernel launch");
+    return AO_OK;
+  }
   const void* kern = half ? reinterpret_cast<const void*>(dec8_kernel<INT8, DYN, DEPTH, XFAST, true>)
                           : reinterpret_cast<const void*>(dec8_kernel<INT8, DYN, DEPTH, XFAST, false>);
   if (int rc = ensure_dynamic_lds(kern, smem, "hipFuncSetAttribute(dec8_kernel)")) return rc;

@@ -165,7 +165,7 @@ def test_decode_kernel_every_form(kind, m, n, k, bias):
         xq, xs = ops.fp8_quantize_rowwise(xd)
         y_ref = F.linear(x.float().numpy(), w.float().numpy(), bn)
     ran = 0
-    for variant in (0, 299, 290, 201, 202, 204, 207, 208):
+    for variant in (0, 299, 290, 291, 292, 201, 202, 204, 207, 208):  # (291 / 292: 8-row tiles never / wherever the form allows, round 6)
         lib.ao_gemm8_set_variant(variant)
         try:
             if kind == "int8":
@@ -182,7 +182,7 @@ def test_decode_kernel_every_form(kind, m, n, k, bias):
             assert np.array_equal(np_from_torch_bf16(two), y_ref), variant
         else:
             assert _rel(two.float().cpu().numpy(), np.asarray(y_ref, dtype=np.float32)) <= 1e-3, variant
-    assert ran == 8
+    assert ran == 10
 
 
 @pytest.mark.parametrize("kind", ["int8", "fp8"])
