@@ -95,7 +95,7 @@ print({c: (round(v.get("hbm_bytes_per_launch") or 0) if isinstance(v, dict) else
 PY
 echo "== rocprof 8-bit GEMM: MFMA-busy pmc =="
 timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/prof_gemm_pmc -o gemm8 -- python $R/tools/bench_8bit.py --which int8,fp8l --m 8192 --iters 3 > $O/rocprof_gemm_pmc.log 2>&1
-( cd $R; python scripts/pmc_mfma_summary.py $O/prof_gemm_pmc -o profiles/gemm8_p8_pmc_mfma_$ROUND.json --source "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ... -- tools/bench_8bit.py --which int8,fp8l --m 8192 (round 5: tile-group height 4)" )
+( cd $R; python scripts/pmc_mfma_summary.py $O/prof_gemm_pmc -o profiles/gemm8_p8_pmc_mfma_$ROUND.json --source "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ... -- tools/bench_8bit.py --which int8,fp8l --m 8192 (round 6: the persistent 256 x 256 form takes these shapes)" )
 find $O -name "*counter_collection.csv" -size +4M -delete 2>/dev/null; find $O -name "*kernel_trace.csv" -size +4M -delete 2>/dev/null
 cd $R
 echo "== full bench ==" ; ( time timeout 1200 python bench.py ) 2>$O/bench.err > $O/bench.json; tail -4 $O/bench.err; cut -c1-300 $O/bench.json; cp $O/bench.json $R/profiles/bench_$ROUND.json
