@@ -662,6 +662,11 @@ __global__ __launch_bounds__(64 * WAVES * (PROD ? 2 : 1), (WAVES == 4 && !PROD) 
 
 thread_local unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
 thread_local int g_tune_wpb = 0;
+// 128 x 256 tiles (64-column wave tiles) of the batched kernel: M >= 512 and tiles that fill >= 7/8 of every round of the 256 CUs
+inline bool int4_mm_w32_tiles64(int64_t M, int64_t N) {
+  const int64_t tiles = ((N + 255) / 256) * ((M + 127) / 128), rounds = (tiles + 255) / 256;
+  return M >= 512 && tiles >= 200 && tiles * 8 >= rounds * 256 * 7;
+}
 
 // ---------------------------------------------------------------------------
 // Round 5: int4_mm_w32_kernel -- the batched kernel on 128 x 128 tiles with v_mfma_f32_32x32x16_bf16.
@@ -680,11 +685,14 @@ thread_local int g_tune_wpb = 0;
 //     layouts, same swizzle, same waits); narrow weights cut K and meet through splitk.h.
 // Same products, fp32 accumulation in a different order than the 16 x 16 kernel: <= 1e-3 of the oracle like it.
 // ---------------------------------------------------------------------------
-template <int G, bool PROD, int ABL = 0>
+template <int G, bool PROD, int ABL = 0, int CG = 1>
 __global__ __launch_bounds__(PROD ? 512 : 256) void int4_mm_w32_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ qdata, const uint32_t* __restrict__ sz, uint16_t* __restrict__ y, int M,
     int N, int K, float* __restrict__ ws, unsigned* __restrict__ tickets, unsigned long long* __restrict__ trace) {
-  constexpr int WAVES = 4, NT = 2;
+  // CG (round 6): 32-column groups per wave.  2: a wave owns 64 columns -- every A fragment feeds TWO MFMAs (one per group): half the LDS
+  // fragment reads per MFMA, 128 accumulator registers, a 128 x 256 workgroup tile (G >= 128 only: the weight rings of four 16-column tiles
+  // per wave and the 96 KiB x ring fill the LDS)
+  constexpr int WAVES = 4, NT = 2 * CG;
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
   constexpr int WBLK = 1024 + NG * 256;
   constexpr int WST = NT * WBLK;
@@ -764,78 +772,93 @@ __global__ __launch_bounds__(PROD ? 512 : 256) void int4_mm_w32_kernel(
     wait_vmcnt<0>();
     asm volatile("s_barrier" ::: "memory");
     if (S > 1) {
-      f32x4 none[16];
-      (void)split_k_meet<16, 64 * WAVES>(none, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem), false);
+      f32x4 none[16 * CG];
+      (void)split_k_meet<16 * CG, 64 * WAVES>(none, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem), false);
     }
     return;
   }
 
-  f32x16 acc[4];
+  f32x16 acc[4 * CG];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4 * CG; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   // A fragment of step s, m-tile mt: chunk 2 s + g of row 32 mt + (lane & 31), at position chunk ^ (row & 15) = chunk ^ nl
   const int arow = (lane & 31) * 256;
   // the lane's packed words: 16 bytes of packed lanes (nl, 2 g) and (nl, 2 g + 1) of tile lt
-  const int wbase = lt * WBLK + ((2 * g) * 16 + nl) * 16;
+  const int wbase = lt * WBLK + ((2 * g) * 16 + nl) * 16;  // (+ 2 c WBLK for column group c)
 
   auto kblock = [&](int stage, int refill, int kb) {
     const char* A = smem + stage * ABUF;
     const char* Wst = smem + 3 * ABUF + (wave * KW + stage) * WST;
-    const u32x4 pa = *reinterpret_cast<const u32x4*>(Wst + wbase);
-    const u32x4 pb = *reinterpret_cast<const u32x4*>(Wst + wbase + 256);
-    float sc[NG], zp[NG];
+    u32x4 pa[CG], pb[CG];
+    float sc[CG][NG], zp[CG][NG];
 #pragma unroll
-    for (int q = 0; q < NG; ++q) {
-      const uint32_t z = *reinterpret_cast<const uint32_t*>(Wst + lt * WBLK + 1024 + q * 256 + nl * 4);
-      sc[q] = bf16_lo_to_f32(z); zp[q] = bf16_hi_to_f32(z);
+    for (int c = 0; c < CG; ++c) {
+      pa[c] = *reinterpret_cast<const u32x4*>(Wst + 2 * c * WBLK + wbase);
+      pb[c] = *reinterpret_cast<const u32x4*>(Wst + 2 * c * WBLK + wbase + 256);
+#pragma unroll
+      for (int q = 0; q < NG; ++q) {
+        const uint32_t z = *reinterpret_cast<const uint32_t*>(Wst + (2 * c + lt) * WBLK + 1024 + q * 256 + nl * 4);
+        sc[c][q] = bf16_lo_to_f32(z); zp[c][q] = bf16_hi_to_f32(z);
+      }
     }
-    const uint32_t word[4][2] = {{pa.x, pb.x}, {pa.y, pb.y}, {pa.z, pb.z}, {pa.w, pb.w}};  // [j][which packed lane]
     constexpr auto group_of = [](int j) constexpr { return (G >= 128) ? 0 : (G == 64) ? (j >> 1) : j; };
-    DequantPipe dq[2][2];  // [j & 1][which]: word j is dequantised while word j - 1 multiplies
+    DequantPipe dq[CG][2][2];  // [column group][j & 1][which]: word j is dequantised while word j - 1 multiplies
     // ABL (laboratory builds only, wrong results): 1 no 32 x 32 x 16 MFMAs, 2 no dequant, 3 no A-fragment reads; 5 = product + s_memtime stamps
-    auto stage_of = [&](auto st_c, auto j_c, auto which_c) {  // (compile-time indices: everything stays in registers)
-      constexpr int j = decltype(j_c)::value, which = decltype(which_c)::value, q = group_of(j);
+    auto word_of = [&](int c, int j, int which) -> uint32_t {
+      const u32x4& v = which ? pb[c] : pa[c];
+      return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+    };
+    auto stage_of = [&](auto st_c, auto j_c, auto which_c, auto c_c) {  // (compile-time indices: everything stays in registers)
+      constexpr int j = decltype(j_c)::value, which = decltype(which_c)::value, q = group_of(j), c = decltype(c_c)::value;
       if (ABL == 2) {
-        if constexpr (decltype(st_c)::value == 3) { DequantPipe& d = dq[j & 1][which]; d.out[0] = word[j][which]; d.out[1] = d.out[0] + 1; d.out[2] = d.out[0] ^ 5; d.out[3] = d.out[0] + 7; }
+        if constexpr (decltype(st_c)::value == 3) { DequantPipe& d = dq[c][j & 1][which]; d.out[0] = word_of(c, j, which); d.out[1] = d.out[0] + 1; d.out[2] = d.out[0] ^ 5; d.out[3] = d.out[0] + 7; }
         return;
       }
-      dequant_stage<decltype(st_c)::value>(dq[j & 1][which], word[j][which], sc[q], -8.0f * sc[q], zp[q], ident);
+      dequant_stage<decltype(st_c)::value>(dq[c][j & 1][which], word_of(c, j, which), sc[c][q], -8.0f * sc[c][q], zp[c][q], ident);
     };
     auto read_a = [&](int s, int mt) {
-      if (ABL == 3) return u32x4{(uint32_t)s, (uint32_t)mt, pa.x, pb.y};
+      if (ABL == 3) return u32x4{(uint32_t)s, (uint32_t)mt, pa[0].x, pb[0].y};
       return *reinterpret_cast<const u32x4*>(A + mt * (32 * 256) + arow + ((((2 * s + g) ^ nl) & 15) << 4));
     };
     // word 0 first (nothing to hide it behind: its data landed with this k-block's barrier)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    stage_of(I0{}, I0{}, I0{}); stage_of(I1{}, I0{}, I0{}); stage_of(std::integral_constant<int, 2>{}, I0{}, I0{}); stage_of(std::integral_constant<int, 3>{}, I0{}, I0{});
-    stage_of(I0{}, I0{}, I1{}); stage_of(I1{}, I0{}, I1{}); stage_of(std::integral_constant<int, 2>{}, I0{}, I1{}); stage_of(std::integral_constant<int, 3>{}, I0{}, I1{});
-    // A fragments are requested AHD slots ahead (an LDS round trip is ~100 cycles, an MFMA 32): a ring of AHD + 1 registers quads
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    [&]<int... C>(std::integer_sequence<int, C...>) {
+      ((stage_of(I0{}, I0{}, I0{}, std::integral_constant<int, C>{}), stage_of(I1{}, I0{}, I0{}, std::integral_constant<int, C>{}),
+        stage_of(I2{}, I0{}, I0{}, std::integral_constant<int, C>{}), stage_of(I3{}, I0{}, I0{}, std::integral_constant<int, C>{}),
+        stage_of(I0{}, I0{}, I1{}, std::integral_constant<int, C>{}), stage_of(I1{}, I0{}, I1{}, std::integral_constant<int, C>{}),
+        stage_of(I2{}, I0{}, I1{}, std::integral_constant<int, C>{}), stage_of(I3{}, I0{}, I1{}, std::integral_constant<int, C>{})),
+       ...);
+    }(std::make_integer_sequence<int, CG>{});
+    // A fragments are requested AHD fragments ahead (an LDS round trip is ~100 cycles, an MFMA 32): a ring of AHD + 1 register quads
     constexpr int AHD = 3;
     u32x4 aq[AHD + 1];
 #pragma unroll
     for (int i = 0; i < AHD; ++i) aq[i] = read_a(i >> 2, i & 3);
     [&]<int... SL>(std::integer_sequence<int, SL...>) {
       (([&] {
-         constexpr int sl = SL, s = sl >> 2, mt = sl & 3, j = s >> 1, h = s & 1;  // slot = (step s, m-tile mt)
+         // slot = (fragment f = (step s, m-tile mt), column group c): a fragment is read once and multiplies CG times
+         constexpr int sl = SL, f = sl / CG, c = sl % CG, s = f >> 2, mt = f & 3, j = s >> 1, h = s & 1;
          __builtin_amdgcn_sched_barrier(0);
-         if constexpr (sl + AHD < 32) aq[(sl + AHD) % (AHD + 1)] = read_a((sl + AHD) >> 2, (sl + AHD) & 3);
-         const u32x4 a_cur = aq[sl % (AHD + 1)];
+         if constexpr (c == 0 && f + AHD < 32) aq[(f + AHD) % (AHD + 1)] = read_a((f + AHD) >> 2, (f + AHD) & 3);
+         const u32x4 a_cur = aq[f % (AHD + 1)];
          if constexpr (!PROD && sl < LPS) issue_one(std::integral_constant<int, sl>{}, refill, kb + 2, refill, kb + 2);
-         if constexpr (j < 3) {  // the 8 slots of word j carry the 8 stage calls of word j + 1: slot (h, mt) -> which = h, stage = mt
-           stage_of(std::integral_constant<int, mt>{}, std::integral_constant<int, (j < 3 ? j + 1 : 3)>{}, std::integral_constant<int, h>{});
+         if constexpr (j < 3) {  // the 8 CG slots of word j carry the 8 CG stage calls of word j + 1: slot (h, mt, c) -> group c, which = h, stage = mt
+           stage_of(std::integral_constant<int, mt>{}, std::integral_constant<int, (j < 3 ? j + 1 : 3)>{}, std::integral_constant<int, h>{}, std::integral_constant<int, c>{});
          }
-         const DequantPipe& d0 = dq[j & 1][0];
-         const DequantPipe& d1 = dq[j & 1][1];
+         const DequantPipe& d0 = dq[c][j & 1][0];
+         const DequantPipe& d1 = dq[c][j & 1][1];
          const u32x4 bv = {d0.out[2 * h], d0.out[2 * h + 1], d1.out[2 * h], d1.out[2 * h + 1]};
-         if (ABL == 1) acc[mt][0] += bits_to_f32(a_cur.x ^ bv.x ^ a_cur.y ^ a_cur.z ^ a_cur.w ^ bv.y ^ bv.z ^ bv.w);
-         else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur), __builtin_bit_cast(bf16x8, bv), acc[mt], 0, 0, 0);
+         if (ABL == 1) acc[c * 4 + mt][0] += bits_to_f32(a_cur.x ^ bv.x ^ a_cur.y ^ a_cur.z ^ a_cur.w ^ bv.y ^ bv.z ^ bv.w);
+         else acc[c * 4 + mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur), __builtin_bit_cast(bf16x8, bv), acc[c * 4 + mt], 0, 0, 0);
        }()),
        ...);
-    }(std::make_integer_sequence<int, 32>{});
+    }(std::make_integer_sequence<int, 32 * CG>{});
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -865,15 +888,15 @@ __global__ __launch_bounds__(PROD ? 512 : 256) void int4_mm_w32_kernel(
   };
 
   if (S > 1) {
-    f32x4 part[16];
+    f32x4 part[16 * CG];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) part[i] = f32x4{acc[i >> 2][4 * (i & 3)], acc[i >> 2][4 * (i & 3) + 1], acc[i >> 2][4 * (i & 3) + 2], acc[i >> 2][4 * (i & 3) + 3]};
-    if (!split_k_meet<16, 64 * WAVES>(part, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
+    for (int i = 0; i < 16 * CG; ++i) part[i] = f32x4{acc[i >> 2][4 * (i & 3)], acc[i >> 2][4 * (i & 3) + 1], acc[i >> 2][4 * (i & 3) + 2], acc[i >> 2][4 * (i & 3) + 3]};
+    if (!split_k_meet<16 * CG, 64 * WAVES>(part, ws, tickets, blockIdx.y * gridDim.x + blockIdx.x, S, ks, tid, reinterpret_cast<int*>(smem))) {
       dump();
       return;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 16 * CG; ++i) {
       acc[i >> 2][4 * (i & 3)] = part[i].x; acc[i >> 2][4 * (i & 3) + 1] = part[i].y;
       acc[i >> 2][4 * (i & 3) + 2] = part[i].z; acc[i >> 2][4 * (i & 3) + 3] = part[i].w;
     }
@@ -883,23 +906,27 @@ __global__ __launch_bounds__(PROD ? 512 : 256) void int4_mm_w32_kernel(
   // D layout of the 32 x 32 tile: lane (col = lane & 31, g) holds rows (r & 3) + 8 (r >> 2) + 4 g, r = 0 .. 15.  Through the idle LDS
   // and out as 16-byte row pieces (the direct form would be 64 two-byte stores per lane).
   {
-    constexpr int RS = 128 * 2 + 16;  // staging row stride in bytes
-    const int col = wave * 32 + (lane & 31);
+    constexpr int BN = 128 * CG;      // columns of the workgroup tile
+    constexpr int RS = BN * 2 + 16;   // staging row stride in bytes
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int c = 0; c < CG; ++c) {
+      const int col = wave * (32 * CG) + c * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
-        *reinterpret_cast<uint16_t*>(smem + row * RS + col * 2) = f32_to_bf16_bits(acc[mt][r]);
-      }
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
+          *reinterpret_cast<uint16_t*>(smem + row * RS + col * 2) = f32_to_bf16_bits(acc[c * 4 + mt][r]);
+        }
+    }
     // (only the consumer waves are here: the producers left after the loop's last barrier)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // NOTE: see the launch: the barrier counts the waves still alive
 #pragma unroll
-    for (int it = 0; it < (128 * 16) / 256; ++it) {
-      const int c = it * 256 + tid;
-      const int row = c >> 4, piece = c & 15;
-      const int m = m0 + row, n = blockIdx.x * 128 + piece * 8;
+    for (int it = 0; it < (128 * (BN / 8)) / 256; ++it) {
+      const int cc = it * 256 + tid;
+      const int row = cc / (BN / 8), piece = cc % (BN / 8);
+      const int m = m0 + row, n = blockIdx.x * BN + piece * 8;
       if (m < M && n + 8 <= N)
         *reinterpret_cast<u32x4*>(y + (size_t)m * N + n) = *reinterpret_cast<const u32x4*>(smem + row * RS + piece * 16);
     }
@@ -907,21 +934,23 @@ __global__ __launch_bounds__(PROD ? 512 : 256) void int4_mm_w32_kernel(
   dump();
 }
 
-template <int G, bool PROD, int ABL = 0>
+template <int G, bool PROD, int ABL = 0, int CG = 1>
 int launch_mm_w32(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint16_t* y, int64_t M, int64_t N, int64_t K, int split,
                   hipStream_t stream) {
   constexpr int NG = (G >= 128) ? 1 : (128 / G);
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)split), block(PROD ? 512 : 256);
-  constexpr size_t smem = (size_t)3 * 128 * 256 + (size_t)4 * 3 * 2 * (1024 + NG * 256);
+  constexpr int BN = 128 * CG;
+  dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + 127) / 128), (unsigned)split), block(PROD ? 512 : 256);
+  constexpr size_t smem = (size_t)3 * 128 * 256 + (size_t)4 * 3 * 2 * CG * (1024 + NG * 256);
   static_assert(smem <= 160 * 1024, "int4_mm_w32_kernel: LDS");
+  static_assert((size_t)128 * (BN * 2 + 16) <= smem, "int4_mm_w32_kernel: the epilogue's staging tile");
   float* ws = nullptr;
   unsigned* tickets = nullptr;
   if (split > 1) {
-    AO_REQUIRE((int64_t)grid.x * grid.y * split <= kSplitMaxTiles, "int4_mm_w32: %u x %u tiles x %d parts exceed the split-K workspace", grid.x, grid.y, split);
+    AO_REQUIRE((int64_t)grid.x * grid.y * split * CG <= kSplitMaxTiles, "int4_mm_w32: %u x %u tiles x %d parts exceed the split-K workspace", grid.x, grid.y, split);
     AO_REQUIRE((int64_t)grid.x * grid.y <= kSplitMaxTickets - 8, "int4_mm_w32: %u x %u output tiles exceed the split-K tickets", grid.x, grid.y);
-    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * 128 * 128, split)) return rc;
+    if (int rc = splitk_workspace(stream, &ws, &tickets, (size_t)grid.x * grid.y * split * 128 * BN, split)) return rc;
   }
-  auto kern = int4_mm_w32_kernel<G, PROD, ABL>;
+  auto kern = int4_mm_w32_kernel<G, PROD, ABL, CG>;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, "hipFuncSetAttribute(int4_mm_w32_kernel)")) return rc;
   ao::launch(kern, grid, block, smem, stream, x, reinterpret_cast<const u32x4*>(qdata), reinterpret_cast<const uint32_t*>(sz), y, (int)M,
              (int)N, (int)K, ws, tickets, g_mm_trace);
@@ -1251,6 +1280,17 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     const int sp = (int)std::max<int64_t>(1, s_req == 0 ? std::min<int64_t>({256 / base8, fit8, 8, kblocks / 4}) : std::min<int64_t>({(int64_t)s_req, kblocks, fit8}));
     if (g_tune_mode < 930) return launch_mm_w32<G, false>(x, qdata, sz, y, M, N, K, sp, stream);
     return launch_mm_w32<G, true>(x, qdata, sz, y, M, N, K, sp, stream);
+  } else if (g_tune_mode >= 950 && g_tune_mode < 960 && M > 64 && G >= 128) {
+    // round 6: 64-column wave tiles (128 x 256 workgroup tiles, every A fragment feeds two MFMAs), producer form; 95S: S K parts (0: fill ~256 workgroups).
+    // (The form in which the consumers fetch for themselves -- 4 waves, 424 registers, no spills -- was 5 - 25 % behind this one in every cell of
+    // profiles/int4_w64_ab_r06.jsonl (modes 96S there) and left the tree.)
+    if constexpr (G >= 128) {
+      const int s_req = g_tune_mode % 10;
+      const int64_t base8 = ((N + 255) / 256) * ((M + 127) / 128);
+      const int64_t fit8 = (int64_t)kSplitMaxTiles / (2 * base8);
+      const int sp = (int)std::max<int64_t>(1, s_req == 0 ? std::min<int64_t>({256 / base8, fit8, 8, kblocks / 4}) : std::min<int64_t>({(int64_t)s_req, kblocks, fit8}));
+      return launch_mm_w32<G, true, 0, 2>(x, qdata, sz, y, M, N, K, sp, stream);
+    }
   } else if (g_tune_mode >= 940 && g_tune_mode < 950 && M > 64) {
     // profiling: 945 = the producer form with s_memtime stamps; 941 / 942 / 943 (laboratory library only: wrong results) = without the
     // 32 x 32 x 16 MFMAs / the dequant / the A-fragment reads.  One K part.
@@ -1273,7 +1313,14 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   // o 21.6 -> 21.5, gate 49.2 -> 37.9, down 56.1 -> 44.2; M = 2048 gate 320 -> 281, down 301 -> 267; M = 128 gate 29.0 -> 28.2 (qkv, o, down
   // stay: 48 / 32 column tiles need 5 - 8 K parts of 64 KiB partial tiles to fill the chip, 20.4 / 15.0 / 31.7 vs 22.0 / 21.7 / 34.1).
   // Mode 911: never (the round-4 dispatch, for A/B).
-  if (g_tune_mode != 911 && g_tune_mode < 600 && forced_split == 0 && waves == 0 && M > 64 && (M > 128 || (N + 127) / 128 >= 64)) {
+  if (g_tune_mode != 911 && (g_tune_mode < 600 || g_tune_mode == 912) && forced_split == 0 && waves == 0 && M > 64 && (M > 128 || (N + 127) / 128 >= 64)) {
+    // Round 6: 64-column wave tiles (128 x 256 workgroup tiles) where one K part of them fills whole rounds of the chip -- the tile is twice as
+    // large, so the last round has to be >= 7/8 full -- from 512 rows, group sizes >= 128 (int4_mm_w32_tiles64).  profiles/int4_w64_ab_r06.jsonl,
+    // cold, us: M = 512 gate 70.7 -> 64.1; M = 2048 o 79.7 -> 72.8, down 262 -> 238, gate 278 -> 266; qkv at M = 2048 (384 tiles = 1.5 rounds)
+    // 117 -> 121 and every shape below 200 tiles (K parts of a 128 KiB partial tile) 1.3 - 4 x slower: those keep the 128 x 128 tile.  Mode 912: never.
+    if constexpr (G >= 128) {
+      if (g_tune_mode != 912 && int4_mm_w32_tiles64(M, N)) return launch_mm_w32<G, true, 0, 2>(x, qdata, sz, y, M, N, K, 1, stream);
+    }
     const int64_t base8 = ((N + 127) / 128) * ((M + 127) / 128);
     const int64_t fit8 = (int64_t)kSplitMaxTiles / base8;
     const int sp = (int)std::max<int64_t>(1, std::min<int64_t>({256 / base8, fit8, 8, kblocks / 4}));
@@ -1324,9 +1371,9 @@ int check_int4_shape(const char* fn, int64_t N, int64_t K, int group_size) {
 using namespace ao;
 
 extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, int group_size) {
-  (void)group_size;
   (void)K;
-  if (M > 64 && (M > 128 || (N + 127) / 128 >= 64)) return "int4_mm_w32_kernel";  // round 5: 128 x 128 tiles, 32 x 32 x 16 MFMAs
+  if (M > 64 && (M > 128 || (N + 127) / 128 >= 64))  // round 5: 128 x 128 tiles, 32 x 32 x 16 MFMAs; round 6: 128 x 256 where they fill whole rounds
+    return (group_size >= 128 && int4_mm_w32_tiles64(M, N)) ? "int4_mm_w32_kernel<128x256>" : "int4_mm_w32_kernel";
   if (M > 16 || (M > 4 && (N >> 4) >= 1024)) return "int4_mm_rb_kernel";
   return "int4_mm_kernel";
 }

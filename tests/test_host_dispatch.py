@@ -74,14 +74,19 @@ def test_fp8_needs_n_multiple_of_16_int8_does_not():
 
 def test_int4_dispatch_bands():
     lib = _lib.lib()
-    name = lambda m, n, k: lib.ao_int4_mm_kernel_name(m, n, k, 128).decode()  # noqa: E731
+    name = lambda m, n, k, g=128: lib.ao_int4_mm_kernel_name(m, n, k, g).decode()  # noqa: E731
     # per-tile kernel (1-, 4-, 8- and 16-row builds) up to 16 rows; wide weights (>= 1024 n-tiles) switch to the batched kernel from 5 rows
     assert [name(m, 14336, 4096) for m in (1, 4, 5, 8, 16)] == ["int4_mm_kernel"] * 5
     assert [name(m, 28672, 4096) for m in (1, 4)] == ["int4_mm_kernel"] * 2
     assert [name(m, 28672, 4096) for m in (5, 16)] == ["int4_mm_rb_kernel"] * 2
     assert name(17, 4096, 4096) == "int4_mm_rb_kernel" and name(128, 6144, 4096) == "int4_mm_rb_kernel"
     # round 5: the 128 x 128 / 32 x 32 x 16 kernel from 129 rows on, and on wide weights (>= 64 column tiles of 128) from 65 rows
-    assert name(128, 14336, 4096) == "int4_mm_w32_kernel" and name(129, 4096, 4096) == "int4_mm_w32_kernel" and name(2048, 4096, 14336) == "int4_mm_w32_kernel"
+    assert name(128, 14336, 4096) == "int4_mm_w32_kernel" and name(129, 4096, 4096) == "int4_mm_w32_kernel" and name(2048, 6144, 4096) == "int4_mm_w32_kernel"
+    # round 6: 128 x 256 tiles (64-column wave tiles) from 512 rows where one K part of them fills >= 7/8 of every round of the chip, g >= 128
+    big = "int4_mm_w32_kernel<128x256>"
+    assert name(2048, 4096, 14336) == big and name(2048, 4096, 4096) == big and name(512, 14336, 4096) == big and name(2048, 14336, 4096) == big
+    assert name(512, 4096, 14336) == "int4_mm_w32_kernel" and name(256, 14336, 4096) == "int4_mm_w32_kernel"  # 64 / 112 such tiles: K parts would be needed
+    assert name(2048, 4096, 4096, 32) == "int4_mm_w32_kernel" and name(2048, 4096, 4096, 256) == big  # the weight rings of groups of 32 / 64 do not fit
     assert name(64, 14336, 4096) == "int4_mm_rb_kernel"
 
 

@@ -172,7 +172,9 @@ def test_mm_tiled_batched(m, n, k, g):
 # the batched kernel's tuning variants: 8 / 4 waves per workgroup, with and without split-K, the two-tiles-per-wave
 # build, every group size, ragged M / N
 # (round 5) 92S / 93S: the 128 x 128 tile / 32 x 32 x 16 kernel, fused and with DMA-producer waves, S K parts (0: as the product would cut)
-@pytest.mark.parametrize("wpb,mode", [(8, 601), (8, 604), (4, 601), (4, 603), (8, 662), (0, 920), (0, 921), (0, 923), (0, 930), (0, 932), (0, 911)])
+# (round 6) 95S: 64-column wave tiles (128 x 256 workgroup tiles, producer waves), S K parts; 912: never those tiles
+@pytest.mark.parametrize("wpb,mode", [(8, 601), (8, 604), (4, 601), (4, 603), (8, 662), (0, 920), (0, 921), (0, 923), (0, 930), (0, 932), (0, 911),
+                                      (0, 950), (0, 952), (0, 953), (0, 912)])
 @pytest.mark.parametrize(
     "m,n,k,g", [(128, 256, 1024, 128), (17, 64, 1024, 32), (200, 208, 2048, 64), (129, 4096, 2048, 128), (64, 48, 2560, 256), (100, 6144, 512, 128)]
 )
