@@ -906,7 +906,9 @@ constexpr int kP8ChipCUs = 256;     // MI355X: one persistent workgroup per CU, 
 // int8 at M = 16384 qkv 347 -> 331 us, o 222 -> 220, gate / up 784 -> 759, down 705 -> 707; fp8 K = 3584 / 4096 + 5 - 12 %, K = 1024 + 24 %;
 // at <= 256 tiles and K >= 4096 the two are level, +- 1 %).  A loop form that dealt the 24 fragment reads of a K tile 8 / 4 / 8 / 4 over the
 // four phases (the n-lo B fragments prefetched a K tile ahead) instead of 16 / 0 / 8 / 0 was 3 - 13 % SLOWER in every cell of that file
-// ("balanced") and left the tree.
+// ("balanced") and left the tree; so did a form that read the A fragments of the next phase under the wave's OWN MFMAs (a second fragment
+// register set; no load phase but q0 then waits for an LDS round trip): int8 15 - 20 % slower, fp8 4 - 7 % (profiles/p8_persist_form1_ab_r06.jsonl) --
+// the phase structure's premise, one wave row reads while the other multiplies, is where this loop is fastest.
 bool p8_persistent_shape(int64_t M, int64_t N, int64_t K) {
   return M % 256 == 0 && N % 256 == 0 && K >= 256 && K % 128 == 0 && ((M / 256) * (N / 256) > kP8ChipCUs || K < 4096);
 }
