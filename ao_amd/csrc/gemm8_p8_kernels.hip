@@ -516,40 +516,43 @@ __global__ __launch_bounds__(512) void gemm8_p8p_kernel(P8Args p) {
         uint16_t* out = reinterpret_cast<uint16_t*>(p.out);
         auto scaled = [&](auto with_bias) {
           constexpr bool BIAS = decltype(with_bias)::value;
-          f32x4 cs[4], bs[4];
+          // column pair by column pair (two 16-column tiles = the 32 columns one store covers): 8 + 8 scale / bias registers live at a time
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            cs[nt] = *reinterpret_cast<const f32x4*>(sl + 1024 + (wc * 64 + nt * 16 + kq * 4) * 4);
-            if constexpr (BIAS) {
-              const u32x2 b = *reinterpret_cast<const u32x2*>(sl + 2048 + (wc * 64 + nt * 16 + kq * 4) * 2);
-              bs[nt] = f32x4{bf16_lo_to_f32(b.x), bf16_hi_to_f32(b.x), bf16_lo_to_f32(b.y), bf16_hi_to_f32(b.y)};
-            }
-          }
+          for (int pr = 0; pr < 2; ++pr) {
+            f32x4 cs[2], bs[2];
 #pragma unroll
-          for (int mt = 0; mt < 8; ++mt) {
-            const float rs = *reinterpret_cast<const float*>(sl + (wr * 128 + mt * 16 + nl) * 4);
-            uint32_t d[4][2];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              float v[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                if constexpr (EPI == P8_INT8_SCALED) {
-                  // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
-                  v[r] = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt][nt])[r] * rs) * cs[nt][r];
-                } else {
-                  v[r] = acc[mt][nt][r] * rs * cs[nt][r];
-                }
-                if constexpr (BIAS) v[r] += bs[nt][r];
+            for (int n2 = 0; n2 < 2; ++n2) {
+              const int nt = 2 * pr + n2;
+              cs[n2] = *reinterpret_cast<const f32x4*>(sl + 1024 + (wc * 64 + nt * 16 + kq * 4) * 4);
+              if constexpr (BIAS) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(sl + 2048 + (wc * 64 + nt * 16 + kq * 4) * 2);
+                bs[n2] = f32x4{bf16_lo_to_f32(b.x), bf16_hi_to_f32(b.x), bf16_lo_to_f32(b.y), bf16_hi_to_f32(b.y)};
               }
-              d[nt][0] = pack_bf16x2(v[0], v[1]);
-              d[nt][1] = pack_bf16x2(v[2], v[3]);
             }
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-              lane_rows_pair_up(d[2 * pr][0], d[2 * pr + 1][0]);
-              lane_rows_pair_up(d[2 * pr][1], d[2 * pr + 1][1]);
-              const u32x4 o = {d[2 * pr][0], d[2 * pr][1], d[2 * pr + 1][0], d[2 * pr + 1][1]};
+            for (int mt = 0; mt < 8; ++mt) {
+              const float rs = *reinterpret_cast<const float*>(sl + (wr * 128 + mt * 16 + nl) * 4);
+              uint32_t d[2][2];
+#pragma unroll
+              for (int n2 = 0; n2 < 2; ++n2) {
+                const int nt = 2 * pr + n2;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  if constexpr (EPI == P8_INT8_SCALED) {
+                    // t = bf16(f32(c) * sx[m]);  y = bf16(f32(t) * sw[n] (+ bias))   (int8_tensor.py:315-359)
+                    v[r] = round_bf16((float)__builtin_bit_cast(i32x4, acc[mt][nt])[r] * rs) * cs[n2][r];
+                  } else {
+                    v[r] = acc[mt][nt][r] * rs * cs[n2][r];
+                  }
+                  if constexpr (BIAS) v[r] += bs[n2][r];
+                }
+                d[n2][0] = pack_bf16x2(v[0], v[1]);
+                d[n2][1] = pack_bf16x2(v[2], v[3]);
+              }
+              lane_rows_pair_up(d[0][0], d[1][0]);
+              lane_rows_pair_up(d[0][1], d[1][1]);
+              const u32x4 o = {d[0][0], d[0][1], d[1][0], d[1][1]};
               *reinterpret_cast<u32x4*>(out + (size_t)(rbase + mt * 16 + nl) * p.N + cbase + pr * 32 + kq * 8) = o;
             }
           }
