@@ -980,7 +980,15 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
     if (head_wait > 0 && --head_wait == 0) {  // uniform.  The park's stores of every wave have retired (two waits, two barriers since)
       if (wave == 1) {
         if (lane == 0) head_t = __hip_atomic_fetch_add(&p.tickets[head_tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if constexpr (QS == 4) lenient = 2;  // the atomic may stay in flight across the next two waits (QS == 1: they ask for it, at worst a stall)
+        // The atomic may stay in flight across the waits in which it is YOUNGER than what the wait needs, or sits between what it needs and
+        // what it allows (QS == 1: the static waits ask for it, at worst a stall).  Without the cast that is two waits: step i + 1 needs the
+        // stage requested in step i - 1 (everything of step i + the atomic may fly), step i + 2 needs step i's (older than the atomic: with
+        // step i + 1's requests AND the atomic allowed, everything older than the atomic has still landed).  With the cast only ONE: step
+        // i + 2 needs raw(i + 3), requested in step i + 1 -- YOUNGER than the atomic; with three in flight allowed its two weight DMAs and
+        // raw(i + 3) itself could be the three.  Round 6 shipped 2 there: wave 1 then cast rows 4 .. 7 of a tile from a raw stage that had
+        // not landed in ~1 % of the launches whose shares begin inside a tile (tools/fuzz_long.py, tools/stress_mx_pair.py;
+        // profiles/mx_pair_race_r06.jsonl), one k step of garbage in 4 rows x 256 columns.
+        if constexpr (QS == 4) lenient = kCast ? 1 : 2;
       }
     }
     if (g == g_peek) {

@@ -809,7 +809,9 @@ def mxfp8_grouped_mm_pair_fits(m, n, k, e) -> bool:
 def mxfp8_grouped_mm_pair(a, b1, b1_scale, b3, b3_scale, offs, scaling_mode="rceil", a_scale=None):
     """x @ w1 and x @ w3 of an MoE layer in ONE launch: two expert-weight tensors of one shape [E, N, K] (e4m3 + E8M0 [E, N, K/32]) against
     the same activations.  a bf16 [M, K] (the 1 x 32 cast fused into the kernel, as mxfp8_grouped_mm_dyn) or, with a_scale, its e4m3 codes.
-    -> (y1, y3) bf16 [M, N], bit-identical to two single products.  Rows past offs[-1] are left unwritten."""
+    -> (y1, y3) bf16 [M, N]: the two single products' values -- bit for bit where the stream-K shares cut the tiles at the same k steps as the
+    single launches do, else up to the fp32 summation order of a cut tile's pieces (single elements one bf16 ulp apart; reproducible from
+    launch to launch).  Rows past offs[-1] are left unwritten."""
     dev = _require_gpu("mxfp8_grouped_mm_pair", a, b1, b1_scale, b3, b3_scale, offs)
     b1 = _fp8_bytes("mxfp8_grouped_mm_pair", b1).contiguous()
     b3 = _fp8_bytes("mxfp8_grouped_mm_pair", b3).contiguous()

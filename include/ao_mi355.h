@@ -306,7 +306,9 @@ int ao_mxfp8_grouped_mm_dyn(const uint16_t* a, const uint8_t* b, const uint8_t* 
 
 /* Two expert-weight tensors of ONE shape [E][N][K] against the same activations in ONE launch: an MoE layer's w1 and w3 (the reference's
  * experts compute x @ w1 and x @ w3 by two calls of _to_mxfp8_then_scaled_grouped_mm, mxfp8_grouped_mm.py:56-239, casting x twice).
- * out1 / out3 bf16 [M_total][N] are bit-identical to two single calls.  _dyn_pair: a is BF16, cast fused (as ao_mxfp8_grouped_mm_dyn);
+ * out1 / out3 bf16 [M_total][N] hold the values of two single calls: the same bits where the stream-K shares cut the tiles at the same k steps
+ * (a cut tile's pieces are added in k order; another cut is another fp32 summation order -- single elements one bf16 ulp apart, the same from
+ * launch to launch).  _dyn_pair: a is BF16, cast fused (as ao_mxfp8_grouped_mm_dyn);
  * _pair: a / a_scale are the caller's e4m3 codes / E8M0 scales.  Shapes: ao_mxfp8_grouped_mm_pair_fits (host logic; the _dyn conditions
  * with twice the tiles). */
 int ao_mxfp8_grouped_mm_pair_fits(int64_t M_total, int64_t N, int64_t K, int64_t E);

@@ -565,7 +565,8 @@ def test_mxfp8_grouped_mm_fused_activation_cast(sizes, n, k, mode):
                                        ([3, 0, 0, 1], 64, 14336)])
 def test_mxfp8_grouped_mm_pair_is_two_single_products(sizes, n, k):
     """ao_mxfp8_grouped_mm_dyn_pair / _pair: an MoE layer's x @ w1 and x @ w3 in ONE launch (the second weight tensor's column tiles follow the
-    first's in every slab of the stream-K space): both outputs bit for bit the single-product launches, fused cast and pre-cast activations,
+    first's in every slab of the stream-K space): both outputs bit for bit the single-product launches (these shapes' shares cut the tiles at the
+    same k steps in both forms; where they do not, single elements round the other way: the race screen below), fused cast and pre-cast activations,
     repeated launches, and through the mirror (_to_mxfp8_then_scaled_grouped_mm_pair)."""
     from ao_amd.prototype import mx as MXP
 
@@ -589,6 +590,43 @@ def test_mxfp8_grouped_mm_pair_is_two_single_products(sizes, n, k):
     m1, m3 = MXP._to_mxfp8_then_scaled_grouped_mm_pair(a, w1.transpose(-2, -1), w3.transpose(-2, -1), offs)
     assert torch.equal(m1[:rows], want1) and torch.equal(m3[:rows], want3)
     assert torch.equal(MXP._to_mxfp8_then_scaled_grouped_mm(a, w1.transpose(-2, -1), offs)[:rows], want1)
+
+
+def test_mxfp8_grouped_mm_pair_shares_that_begin_inside_a_tile_race_screen():
+    """Round-6 regression (found by tools/fuzz_long.py): with the cast fused and a share that BEGINS inside a tile, wave 1 takes the head piece's
+    ticket from inside the k loop, and the two waits after it allowed one request too many in flight -- in ~1 % of such launches wave 1 cast
+    rows 4 .. 7 of one k step's tile from a raw stage that had not landed (4 rows x 256 columns of garbage, not reproducible).  E = 8,
+    N = K = 4096 as a pair launch has 28- / 20- / 12-step shares against 32-step tiles: every launch has head pieces.  480 launches: every one
+    gives the bits of the first for its routing, and the single-product launches' values up to the summation order of the cut tiles."""
+    E, n, k = 8, 4096, 4096
+    w1 = _randn_bf16((E, n, k), 91, 0.1).to(DEV)
+    w3 = _randn_bf16((E, n, k), 92, 0.1).to(DEV)
+    w1d, w1s = ops.mxfp8_quantize(w1, "rceil")
+    w3d, w3s = ops.mxfp8_quantize(w3, "rceil")
+    del w1, w3
+    rng = np.random.default_rng(6)
+    for draw in range(60):
+        sizes = [int(v) for v in rng.choice([0, 0, 1, 5, 16, 31, 33, 48], size=E)]
+        if sum(sizes) == 0:
+            sizes[0] = 3
+        M = sum(sizes)
+        a = _randn_bf16((M, k), 1000 + draw, 2.0).to(DEV)
+        offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32).to(DEV)
+        assert ops.mxfp8_grouped_mm_pair_fits(M, n, k, E)
+        aq, asc = ops.mxfp8_quantize(a, "rceil")
+        want = [ops.mxfp8_grouped_mm(aq, asc, w1d, w1s, offs)[:M].float(), ops.mxfp8_grouped_mm(aq, asc, w3d, w3s, offs)[:M].float()]
+        first = None
+        for rep in range(8):
+            got = [t[:M] for t in ops.mxfp8_grouped_mm_pair(a, w1d, w1s, w3d, w3s, offs)]
+            if first is None:
+                first = got
+                for y, ref in zip(got, want):  # another cut of the tiles: single elements may round the other way, nothing more
+                    ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+                    off = (y.float() - ref).abs() > 2 * ulp  # (2: a flip across a power of two is one ulp of the upper binade)
+                    assert int(off.sum()) == 0, (draw, sizes, int(off.sum()), off.nonzero()[:4].tolist())
+                    assert int((y.float() != ref).sum()) <= 8, (draw, sizes, int((y.float() != ref).sum()))
+            else:
+                assert torch.equal(got[0], first[0]) and torch.equal(got[1], first[1]), (draw, rep, sizes)
 
 
 def test_mxfp8_grouped_mm_fused_cast_refuses_other_shapes_and_the_mirror_falls_back():

@@ -26,7 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--kinds", default="int4,int8,fp8,mx")
+    ap.add_argument("--kinds", default="int4,int8,fp8,mx,dyn,mxdyn")
     args = ap.parse_args()
     lib = _lib.lib()
     rng = np.random.default_rng(args.seed)
@@ -85,12 +85,66 @@ def main():
                     # fp32 reference + 2e-5 of slack for the summation order.
                     if m * n < 4096 and r > 1e-3:
                         err = (y.float() - ref).abs()
-                        bound = ref.abs() * (2.0 ** -9 + 2e-5) + 1e-30
+                        half_ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 8)  # half a bf16 ulp of the reference value
+                        bound = half_ulp + ref.abs() * 2e-5 + 1e-30
                         close = bool((err <= bound).all())
                     else:
                         close = r <= 1e-3
                     ok = close and torch.equal(again, y)
                     info = {"bias": b is not None, "rel": r, "reproducible": bool(torch.equal(again, y))}
+            elif kind == "dyn":
+                # the fused cast + linear entry points (one launch at M <= 16) against cast, then scaled mm: same bits
+                x = torch.randn(m, k, device=DEV, generator=gen).to(torch.bfloat16)
+                w = (torch.randn(n, k, device=DEV, generator=gen) * 0.05).to(torch.bfloat16)
+                b = torch.randn(n, device=DEV, generator=gen).to(torch.bfloat16) if rng.integers(2) else None
+                wq8, ws8 = ops.int8_quantize_rowwise(w)
+                wqf, wsf = ops.fp8_quantize_rowwise(w)
+                xq8, xs8 = ops.int8_quantize_rowwise(x)
+                xqf, xsf = ops.fp8_quantize_rowwise(x)
+                y8, yf = ops.int8_linear(x, wq8, ws8, b), ops.fp8_linear(x, wqf, wsf, b)
+                r8, rf = ops.int8_scaled_mm(xq8, xs8, wq8, ws8, b), ops.fp8_scaled_mm(xqf, wqf.t(), xsf, wsf.t(), b)
+                ok8 = torch.equal(y8, r8)
+                okf = torch.equal(yf, rf)  # (the fused form runs the same kernel with the cast in its prologue: same bits, as tests/test_fuzz_gpu.py asserts)
+                ok = ok8 and okf
+                info = {"bias": b is not None, "int8_equal": bool(ok8), "fp8_rel": rel(yf, rf)}
+            elif kind == "mxdyn":
+                e = int(rng.choice([1, 2, 8]))
+                sizes = [int(s) for s in rng.choice([0, 0, 1, 5, 16, 31, 33, 48], size=e)]
+                if sum(sizes) == 0:
+                    sizes[0] = 3
+                n = min(n, 4096)
+                k = max(512, (min(k, 4096) // 512) * 512)
+                mtot = sum(sizes)
+                m = mtot
+                a = torch.randn(mtot, k, device=DEV, generator=gen).to(torch.bfloat16)
+                w1 = (torch.randn(e, n, k, device=DEV, generator=gen) * 0.1).to(torch.bfloat16)
+                w3 = (torch.randn(e, n, k, device=DEV, generator=gen) * 0.1).to(torch.bfloat16)
+                offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device=DEV)
+                mode = "rceil" if rng.integers(2) else "floor"
+                aq, a_s = ops.mxfp8_quantize(a, mode)
+                w1q, w1s = ops.mxfp8_quantize(w1, "rceil")
+                w3q, w3s = ops.mxfp8_quantize(w3, "rceil")
+                y1 = ops.mxfp8_grouped_mm(aq, a_s, w1q, w1s, offs)
+                y3 = ops.mxfp8_grouped_mm(aq, a_s, w3q, w3s, offs)
+                ok, info = True, {"sizes": sizes, "mode": mode}
+                if ops.mxfp8_grouped_mm_dyn_fits(mtot, n, k, e):
+                    d1 = ops.mxfp8_grouped_mm_dyn(a, w1q, w1s, offs, mode)
+                    ok = ok and torch.equal(d1[:mtot], y1[:mtot])
+                    info["dyn_equal"] = bool(torch.equal(d1[:mtot], y1[:mtot]))
+                if ops.mxfp8_grouped_mm_pair_fits(mtot, n, k, e):
+                    p1, p3 = ops.mxfp8_grouped_mm_pair(a, w1q, w1s, w3q, w3s, offs, mode)
+                    # (the pair launch cuts the tiles into other shares than the single launches: a cut tile's pieces are added in k order, so
+                    # single elements may round the other way -- at most a bf16 ulp, a handful of elements; anything more is a bug:
+                    # profiles/mx_pair_race_r06.jsonl)
+                    eq = True
+                    for pp, yy in ((p1[:mtot], y1[:mtot]), (p3[:mtot], y3[:mtot])):
+                        ulp = torch.exp2(torch.floor(torch.log2(yy.float().abs().clamp_min(1e-30))) - 7)
+                        d = (pp.float() - yy.float()).abs()
+                        eq = eq and bool((d <= 2 * ulp).all()) and int((pp != yy).sum()) <= 8
+                    again1, again3 = ops.mxfp8_grouped_mm_pair(a, w1q, w1s, w3q, w3s, offs, mode)
+                    eq = eq and torch.equal(again1[:mtot], p1[:mtot]) and torch.equal(again3[:mtot], p3[:mtot])
+                    ok = ok and eq
+                    info["pair_ok"] = bool(eq)
             else:
                 e = int(rng.choice([1, 2, 3, 8, 16]))
                 sizes = [int(s) for s in rng.choice([0, 0, 1, 5, 16, 31, 33, 64, 70, 140, 300], size=e)]

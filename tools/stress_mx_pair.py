@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""tools/fuzz_long.py saw ao_mxfp8_grouped_mm_pair differ from the two single-product launches in ~0.6 % of its E = 8, N = 4096, K >= 2560
+cases while tools/mx_pair_diff.py finds them bit-equal: so the difference depends on the data or on what ran before.  This loop replays that
+corner (sizes drawn like the fuzzer's, fresh random data, other launches in between), and on a mismatch says which output deviates: every
+form is launched twice (run-to-run reproducibility) and compared with the per-tile kernel (variant 113), a different program."""
+import argparse, json, os, sys
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ao_amd import _lib, ops
+
+DEV = "cuda"
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=3000)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--n", type=int, default=4096)
+ap.add_argument("--k", type=int, default=4096)
+ap.add_argument("--noise", type=int, default=1, help="1: other shapes are launched between the cases, like the fuzzer does")
+args = ap.parse_args()
+lib = _lib.lib()
+rng = np.random.default_rng(args.seed)
+
+
+def ulps(a, b):
+    u = torch.exp2(torch.floor(torch.log2(b.float().abs().clamp_min(1e-30))) - 7)
+    return (a.float() - b.float()).abs() / u
+
+
+bad = 0
+for it in range(args.iters):
+    e = 8
+    sizes = [int(s) for s in rng.choice([0, 0, 1, 5, 16, 31, 33, 48], size=e)]
+    if sum(sizes) == 0:
+        sizes[0] = 3
+    n, k, m = args.n, args.k, sum(sizes)
+    g = torch.Generator(device=DEV).manual_seed(int(rng.integers(1 << 30)))
+    if args.noise:
+        # something else on the stream first: another grouped shape and a rowwise GEMM with K parts (they share the split-K workspace)
+        e2 = int(rng.choice([1, 2, 8]))
+        s2 = [int(s) for s in rng.choice([1, 5, 16, 33], size=e2)]
+        a2 = torch.randn(sum(s2), 1024, device=DEV, generator=g).to(torch.bfloat16)
+        w2 = (torch.randn(e2, 256, 1024, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+        w2q, w2s = ops.mxfp8_quantize(w2, "rceil")
+        ops.mxfp8_grouped_mm_dyn(a2, w2q, w2s, torch.tensor(np.cumsum(s2), dtype=torch.int32, device=DEV))
+        x = torch.randn(int(rng.integers(17, 200)), 4096, device=DEV, generator=g).to(torch.bfloat16)
+        wq, ws = ops.fp8_quantize_rowwise((torch.randn(1280, 4096, device=DEV, generator=g) * 0.05).to(torch.bfloat16))
+        ops.fp8_linear(x, wq, ws)
+    a = torch.randn(m, k, device=DEV, generator=g).to(torch.bfloat16)
+    w1 = (torch.randn(e, n, k, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    w3 = (torch.randn(e, n, k, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    offs = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device=DEV)
+    mode = "rceil" if rng.integers(2) else "floor"
+    aq, a_s = ops.mxfp8_quantize(a, mode)
+    w1q, w1s = ops.mxfp8_quantize(w1, "rceil")
+    w3q, w3s = ops.mxfp8_quantize(w3, "rceil")
+    outs = {}
+    for rep in range(2):
+        outs[f"single1_{rep}"] = ops.mxfp8_grouped_mm(aq, a_s, w1q, w1s, offs)[:m]
+        outs[f"single3_{rep}"] = ops.mxfp8_grouped_mm(aq, a_s, w3q, w3s, offs)[:m]
+        outs[f"dyn1_{rep}"] = ops.mxfp8_grouped_mm_dyn(a, w1q, w1s, offs, mode)[:m]
+        p1, p3 = ops.mxfp8_grouped_mm_pair(a, w1q, w1s, w3q, w3s, offs, mode)
+        outs[f"pair1_{rep}"], outs[f"pair3_{rep}"] = p1[:m], p3[:m]
+    try:
+        lib.ao_gemm8_set_variant(113)
+        old1 = ops.mxfp8_grouped_mm(aq, a_s, w1q, w1s, offs)[:m]
+        old3 = ops.mxfp8_grouped_mm(aq, a_s, w3q, w3s, offs)[:m]
+    finally:
+        lib.ao_gemm8_set_variant(0)
+    torch.cuda.synchronize()
+    base = {"1": outs["single1_0"], "3": outs["single3_0"]}
+    rows = {}
+    for name, t in outs.items():
+        which = "1" if "1_" in name else "3"
+        if not torch.equal(t, base[which]):
+            idx = (t != base[which]).nonzero()
+            old = old1 if which == "1" else old3
+            rows[name] = {"differ": int(idx.shape[0]), "rows": sorted(set(idx[:, 0].tolist()))[:10], "cols": [int(idx[:, 1].min()), int(idx[:, 1].max())],
+                          "max_ulps_vs_single": float(ulps(t, base[which]).max()),
+                          "this_vs_tile_kernel_max_ulps_on_differing": float(ulps(t, old)[idx[:, 0], idx[:, 1]].max()),
+                          "single_vs_tile_kernel_max_ulps_on_differing": float(ulps(base[which], old)[idx[:, 0], idx[:, 1]].max())}
+    if rows:
+        bad += 1
+        print(json.dumps({"iter": it, "sizes": sizes, "mode": mode, "mismatch": rows}), flush=True)
+print(json.dumps({"summary": "stress_mx_pair", "iters": args.iters, "n": args.n, "k": args.k, "noise": args.noise, "cases_with_a_mismatch": bad}), flush=True)
