@@ -132,3 +132,74 @@ def test_split_k_meeting_is_reproducible_from_a_cold_process(shape):
     assert "int8 mismatches 0, fp8 mismatches 0" in out.stdout, out.stdout[-2000:]
     first = [l for l in out.stdout.splitlines() if l.startswith("first launch vs tiled kernel")][0]
     assert float(first.split("rel")[1]) <= 1e-3, first
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_cast_shape_sweep(chunk):
+    """int8 / fp8 per-row casts and the MXFP8 1 x 32 cast against the oracles on row lengths the fixed cases do not visit: every register
+    depth of the one-sweep kernels (K / 8 vectors over 256 threads: 1, 2, 4, 8 per thread, ragged last vector), the two-sweep kernels beyond
+    16384, rows of very different magnitude, an all-zero row, one huge element.  Bit-exact."""
+    from ao_amd import ops
+    from oracle import fp8_ref as F8, int8_ref as I8, mx_ref as MX
+
+    rng = np.random.default_rng(400 + chunk)
+    ks = [8, 24, 32, 96, 1000, 2040, 2048, 2056, 4104, 8184, 12320, 16376, 16384, 16392, 20000, 40000]
+    for _ in range(8):
+        m = int(rng.choice([1, 2, 3, 17, 64, 130]))
+        k = int(rng.choice(ks))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn(m, k, generator=g) * torch.exp2(torch.randint(-20, 20, (m, 1), generator=g).float())
+        x[m // 2] = 0
+        if m > 1:
+            x[0, int(rng.integers(k))] = 3.0e38
+        x = x.to(torch.bfloat16)
+        xn = x.float().numpy()
+        xd = x.to(DEV)
+        q, s = ops.int8_quantize_rowwise(xd)
+        qo, so = I8.quantize_rowwise(xn)
+        assert np.array_equal(s.flatten().cpu().numpy(), so), ("int8 scale", m, k)
+        assert np.array_equal(q.cpu().numpy(), qo), ("int8 codes", m, k)
+        q, s = ops.fp8_quantize_rowwise(xd)
+        qo, so = F8.quantize_rowwise(xn)
+        assert np.array_equal(s.flatten().cpu().numpy(), so), ("fp8 scale", m, k)
+        got, exp = q.view(torch.uint8).cpu().numpy(), qo
+        nan_e, nan_g = (exp & 0x7F) == 0x7F, (got & 0x7F) == 0x7F  # (the all-zero row: 0 / 0 -> NaN codes, sign as it falls)
+        assert np.array_equal(nan_e, nan_g) and np.array_equal(got[~nan_g], exp[~nan_e]), ("fp8 codes", m, k)
+        if k % 32 == 0:
+            for name, mode in (("rceil", MX.RCEIL), ("floor", MX.FLOOR)):
+                q, s = ops.mxfp8_quantize(xd, name)
+                qo, so = MX.to_mx(xn, mode)
+                assert np.array_equal(s.view(torch.uint8).cpu().numpy(), so), ("mx scale", name, m, k)
+                got, exp = q.view(torch.uint8).cpu().numpy(), qo
+                nan_e, nan_g = (exp & 0x7F) == 0x7F, (got & 0x7F) == 0x7F
+                assert np.array_equal(nan_e, nan_g) and np.array_equal(got[~nan_g], exp[~nan_e]), ("mx codes", name, m, k)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_int4_weight_prep_shape_sweep(chunk):
+    """The fused int4 quantizer (qparams + codes + tile pack + scale / zero pack) against the oracle on weight shapes off the model grid:
+    N any multiple of 16, K any multiple of 128, every group size, weights of very different magnitude per row, constant and zero groups.
+    Bit-exact, and the dequantised weight as well."""
+    from ao_amd import ops
+    from conftest import np_from_torch_bf16
+    from oracle import int4_ref as R
+
+    rng = np.random.default_rng(500 + chunk)
+    for _ in range(6):
+        n = int(rng.choice([16, 48, 80, 208, 1040, 2064]))
+        k = int(rng.choice([128, 384, 1152, 2560, 4224]))
+        g = int(rng.choice([g for g in (32, 64, 128, 256) if k % g == 0]))
+        gen = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        w = torch.randn(n, k, generator=gen) * torch.exp2(torch.randint(-12, 6, (n, 1), generator=gen).float())
+        w[1, :g] = 0.5      # a constant group
+        w[2, :] = 0         # a zero row
+        w[3, g:2 * g] = -w[3, g:2 * g].abs() if k >= 2 * g else w[3, :g]  # an all-negative group
+        w = w.to(torch.bfloat16)
+        wn = w.float().numpy()
+        s, z = R.choose_qparams_tinygemm(wn, g)
+        q = R.quantize_tinygemm(wn, s, z, g)
+        qdata, sz = ops.int4_quantize_tinygemm(w.to(DEV), g)
+        assert np.array_equal(np_from_torch_bf16(sz), R.pack_scales_and_zeros(s, z)), (n, k, g)
+        assert np.array_equal(qdata.cpu().numpy(), R.convert_weight_to_int4pack(R.nibble_pack(q))), (n, k, g)
+        dq = ops.int4_dequantize(qdata, sz, g)
+        assert np.array_equal(np_from_torch_bf16(dq), R.dequantize_tinygemm(q, R.pack_scales_and_zeros(s, z), g)), (n, k, g)
