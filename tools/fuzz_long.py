@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--kinds", default="int4,int8,fp8,mx,dyn,mxdyn,fp8g,f3")
+    ap.add_argument("--hog", type=int, default=0, help="1: a second stream copies 512 MiB buffers back and forth the whole time -- memory latencies "
+                    "stretch and move, which is what a hand-counted wait that is one request too lenient needs to show itself")
     args = ap.parse_args()
     lib = _lib.lib()
     rng = np.random.default_rng(args.seed)
@@ -35,7 +37,19 @@ def main():
     n_run = {k: 0 for k in kinds}
     fails = []
     names = {}
+    hog_stream = hog_evt = hog_a = hog_b = None
+    if args.hog:
+        hog_stream = torch.cuda.Stream()
+        hog_a = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+        hog_b = torch.empty_like(hog_a)
     while time.time() - t0 < args.seconds:
+        if args.hog and (hog_evt is None or hog_evt.query()):
+            with torch.cuda.stream(hog_stream):
+                for _ in range(6):
+                    hog_b.copy_(hog_a, non_blocking=True)
+                    hog_a.copy_(hog_b, non_blocking=True)
+                hog_evt = torch.cuda.Event()
+                hog_evt.record(hog_stream)
         kind = kinds[int(rng.integers(len(kinds)))]
         # M: decode, mid, ragged large
         m = int(rng.choice([int(rng.integers(1, 18)), int(rng.integers(17, 300)), int(rng.integers(300, 5000)), int(rng.choice([512, 1024, 2048, 4096]))]))
@@ -230,7 +244,7 @@ def main():
             row = {"fail": kind, "M": m, "N": n, "K": k, **info}
             fails.append(row)
             print(json.dumps(row), flush=True)
-    print(json.dumps({"summary": "fuzz_long", "seed": args.seed, "seconds": round(time.time() - t0, 1), "cases": n_run, "failures": len(fails)}), flush=True)
+    print(json.dumps({"summary": "fuzz_long", "hog": args.hog, "seed": args.seed, "seconds": round(time.time() - t0, 1), "cases": n_run, "failures": len(fails)}), flush=True)
     return 1 if fails else 0
 
 

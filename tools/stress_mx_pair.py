@@ -17,6 +17,7 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--n", type=int, default=4096)
 ap.add_argument("--k", type=int, default=4096)
 ap.add_argument("--noise", type=int, default=1, help="1: other shapes are launched between the cases, like the fuzzer does")
+ap.add_argument("--hog", type=int, default=0, help="1: a second stream copies 512 MiB buffers back and forth the whole time")
 args = ap.parse_args()
 lib = _lib.lib()
 rng = np.random.default_rng(args.seed)
@@ -28,7 +29,19 @@ def ulps(a, b):
 
 
 bad = 0
+hog_stream = hog_evt = hog_a = hog_b = None
+if args.hog:
+    hog_stream = torch.cuda.Stream()
+    hog_a = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+    hog_b = torch.empty_like(hog_a)
 for it in range(args.iters):
+    if args.hog and (hog_evt is None or hog_evt.query()):
+        with torch.cuda.stream(hog_stream):
+            for _ in range(6):
+                hog_b.copy_(hog_a, non_blocking=True)
+                hog_a.copy_(hog_b, non_blocking=True)
+            hog_evt = torch.cuda.Event()
+            hog_evt.record(hog_stream)
     e = 8
     sizes = [int(s) for s in rng.choice([0, 0, 1, 5, 16, 31, 33, 48], size=e)]
     if sum(sizes) == 0:
