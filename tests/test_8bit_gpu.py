@@ -885,3 +885,50 @@ def test_gemm8_p8_split_k_every_part_count(m, n, k, bias, variant):
         assert _rel(np_from_torch_bf16(d), yf_ref) <= 1e-3, f"fp8 off at {split} parts"
         assert float((e - raw).abs().max()) <= 1e-4 * float(raw.abs().max()), f"fp8 raw sums off at {split} parts"
     assert np.array_equal(np_from_torch_bf16(y8), y8_ref)
+
+
+def test_empty_inputs_empty_groups_and_malformed_offsets():
+    """The edges the reference's tests visit: zero rows through every cast and linear, grouped products whose groups are all empty or end before
+    M_total (the rows past offs[-1]: zero-filled by the two-launch entry points), and offsets a router would never send -- decreasing, past
+    M_total, negative -- which must not fault (the kernels clamp them into [0, M_total] and make them monotone)."""
+    n, k, E = 64, 256, 4
+    w = _randn_bf16((n, k), 1, 0.05).to(DEV)
+    wq8, ws8 = ops.int8_quantize_rowwise(w)
+    wqf, wsf = ops.fp8_quantize_rowwise(w)
+    x0 = torch.zeros(0, k, dtype=torch.bfloat16, device=DEV)
+    assert [tuple(v.shape) for v in ops.int8_quantize_rowwise(x0)] == [(0, k), (0, 1)]
+    assert [tuple(v.shape) for v in ops.fp8_quantize_rowwise(x0)] == [(0, k), (0, 1)]
+    assert [tuple(v.shape) for v in ops.mxfp8_quantize(x0, "rceil")] == [(0, k), (0, k // 32)]
+    assert tuple(ops.int8_linear(x0, wq8, ws8).shape) == (0, n) and tuple(ops.fp8_linear(x0, wqf, wsf).shape) == (0, n)
+    xq, xs = ops.int8_quantize_rowwise(_randn_bf16((3, k), 2).to(DEV))
+    fq, fs = ops.fp8_quantize_rowwise(_randn_bf16((3, k), 3).to(DEV))
+    assert tuple(ops.int8_scaled_mm(xq[:0], xs[:0], wq8, ws8).shape) == (0, n)
+    assert tuple(ops.fp8_scaled_mm(fq[:0], wqf.t(), fs[:0], wsf.t()).shape) == (0, n)
+    zeros = torch.zeros(E, dtype=torch.int32, device=DEV)
+    we = _randn_bf16((E, n, k), 4, 0.1).to(DEV)
+    weq, wes = ops.mxfp8_quantize(we, "rceil")
+    a = _randn_bf16((8, k), 5).to(DEV)
+    aq, asc = ops.mxfp8_quantize(a, "rceil")
+    assert tuple(ops.mxfp8_grouped_mm(aq[:0], asc[:0], weq, wes, zeros).shape) == (0, n)
+    assert float(ops.mxfp8_grouped_mm(aq, asc, weq, wes, zeros).abs().max()) == 0.0
+    short = ops.mxfp8_grouped_mm(aq, asc, weq, wes, torch.tensor([2, 2, 5, 5], dtype=torch.int32, device=DEV))
+    assert float(short[5:].abs().max()) == 0.0 and float(short[:5].abs().max()) > 0.0
+    k2 = 512
+    we2 = _randn_bf16((E, n, k2), 6, 0.1).to(DEV)
+    we2q, we2s = ops.mxfp8_quantize(we2, "rceil")
+    a2 = _randn_bf16((8, k2), 7).to(DEV)
+    assert tuple(ops.mxfp8_grouped_mm_dyn(a2, we2q, we2s, zeros).shape) == (8, n)
+    assert tuple(ops.mxfp8_grouped_mm_dyn(a2[:0], we2q, we2s, zeros).shape) == (0, n)
+    assert [tuple(v.shape) for v in ops.mxfp8_grouped_mm_pair(a2, we2q, we2s, we2q, we2s, zeros)] == [(8, n), (8, n)]
+    wgq, wgs = ops.fp8_quantize_rowwise(we.reshape(E * n, k))
+    assert float(ops.fp8_grouped_mm(fq, fs, wgq.reshape(E, n, k), wgs.reshape(E, n), zeros).abs().max()) == 0.0
+    assert tuple(ops.fp8_grouped_mm(fq[:0], fs[:0], wgq.reshape(E, n, k), wgs.reshape(E, n), zeros).shape) == (0, n)
+    for bad in ([5, 2, 8, 8], [2, 4, 6, 100], [-3, 4, 6, 8]):
+        offs = torch.tensor(bad, dtype=torch.int32, device=DEV)
+        assert tuple(ops.mxfp8_grouped_mm(aq, asc, weq, wes, offs).shape) == (8, n)
+        assert tuple(ops.mxfp8_grouped_mm_dyn(a2, we2q, we2s, offs).shape) == (8, n)
+        torch.cuda.synchronize()  # a fault would surface here
+    with pytest.raises(ValueError, match="multiple of 8"):
+        ops.int8_quantize_rowwise(_randn_bf16((2, 100), 8).to(DEV))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.int8_quantize_rowwise(_randn_bf16((2, 128), 9))
