@@ -150,7 +150,8 @@ def _to_mxfp8_then_scaled_grouped_mm_pair(A: torch.Tensor, B1_t, B3_t, offs: tor
                                           cache_weights: bool = False):
     """(A @ w1, A @ w3) of an MoE layer's experts -- the reference computes them by two calls of _to_mxfp8_then_scaled_grouped_mm
     (mxfp8_grouped_mm.py:56-239), casting A twice; here decode-size groups take ONE launch for both products with the cast fused in
-    (ops.mxfp8_grouped_mm_pair), other shapes two calls.  Same bits either way.  B1_t / B3_t: bf16 [E, K, N] views or MXFP8ExpertWeights."""
+    (ops.mxfp8_grouped_mm_pair), other shapes two calls.  Same values either way (the same bits unless the pair launch's stream-K shares cut a tile at other k steps than
+    the single launches: then single elements may round the other way -- include/ao_mi355.h).  B1_t / B3_t: bf16 [E, K, N] views or MXFP8ExpertWeights."""
     assert A.ndim == 2 and A.dtype == torch.bfloat16 and offs is not None
     ws = []
     for B_t in (B1_t, B3_t):
