@@ -47,6 +47,7 @@ _SIGNATURES = {
     "ao_gemm8_kernel_name": [_INT, _I64, _I64, _I64],
     "ao_fp8_int4_kernel_name": [_I64, _I64, _I64, _INT],
     "ao_gemm8_plan": [_INT, _I64, _I64, _I64, _P, _P],
+    "ao_gemm8_plan_rows": [_INT, _I64, _I64, _I64, _P],
     "ao_int8_quantize_rowwise": [_P, _P, _P, _I64, _I64, _P],
     "ao_int8_scaled_mm": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _P],
     "ao_int8_int_mm": [_P, _P, _P, _I64, _I64, _I64, _P],
@@ -78,6 +79,9 @@ _SIGNATURES = {
     "ao_moe_padded_rows": [_I64, _I64, _INT],
     "ao_moe_pad_token_groups": [_P, _P, _P, _P, _P, _I64, _I64, _INT, _I64, _INT, _P],
     "ao_moe_unpad_token_groups": [_P, _P, _P, _P, _I64, _I64, _INT, _I64, _P],
+    "ao_mx_blocked_rows": [_I64, _I64],
+    "ao_mx_block_rearrange_2d_m_groups": [_P, _P, _P, _I64, _I64, _I64, _P],
+    "ao_mx_to_blocked": [_P, _P, _I64, _I64, _P],
     "ao_allreduce_flag_bytes": [],
     "ao_allreduce_state_bytes": [],
     "ao_allreduce_oneshot": [_P, _P, _P, _P, _P, _I64, _INT, _I64, _INT, _INT, _P],
@@ -143,6 +147,7 @@ def lib():
         if hasattr(l, "ao_fp8_int4_kernel_name"):
             l.ao_fp8_int4_kernel_name.restype = ctypes.c_char_p
         l.ao_moe_padded_rows.restype = _I64
+        l.ao_mx_blocked_rows.restype = _I64
         l.ao_allreduce_flag_bytes.restype = _I64
         l.ao_allreduce_state_bytes.restype = _I64
         if hasattr(l, "ao_moe_a2a_flag_bytes"):

@@ -30,10 +30,11 @@ int gemm8_p8h(int epi, const uint8_t* a, const uint8_t* b, const float* row_scal
               int64_t M, int64_t N, int64_t K, hipStream_t stream);
 bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K);
 int gemm8_p8h_parts(int64_t M, int64_t N, int64_t K);
-void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bn, int* split);
+void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bm, int* bn, int* split);
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
 void rb8_set_wave_grid(bool two_by_four);  // rb8_kernels.hip
 void rb8_set_tuning(int bn, int split, int ablate);
+void rb8_set_slab_rows(int rows);
 void fp8_rowwise_rb_set_mode(int mode);
 bool fp8_rowwise_rb_forced();
 extern thread_local int g_mx_variant;  // stream8_kernels.hip
@@ -484,6 +485,7 @@ extern "C" int ao_gemm8_set_tuning(int key, int value) {
   g_tune[key] = value;
   mx_stream_set_tuning(g_tune[9]);
   rb8_set_tuning(g_tune[1], g_tune[2], g_tune[5]);
+  rb8_set_slab_rows(g_tune[3]);
   gemm8_p8_set_group_rows(g_tune[4]);
   gemm8_p8_set_split(g_tune[7]);
   gemm8_p8_set_persistent(g_tune[6]);
@@ -538,20 +540,31 @@ extern "C" const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int6
   return big >= 512 ? "gemm8_dma_kernel<256x256>" : "gemm8_dma_kernel<128x128>";
 }
 
-// The launch shape behind ao_gemm8_kernel_name: column-tile width and K parts of the product dispatch (host logic only).  rb8_kernel: the
-// cost model's pick (32 / 64 / 128 columns, 1 .. 8 parts); gemm8_p8h_kernel: 128 columns, 1 .. 4 parts; every other kernel: its tile width, one part.
-extern "C" int ao_gemm8_plan(int int8, int64_t M, int64_t N, int64_t K, int* tile_cols, int* k_parts) {
-  AO_REQUIRE_PTR(tile_cols);
-  AO_REQUIRE_PTR(k_parts);
+// The launch shape behind ao_gemm8_kernel_name: tile rows, column-tile width and K parts of the product dispatch (host logic only).
+// rb8_kernel: the cost model's pick (64- / 128-row slabs, 32 / 64 / 128 columns, 1 .. 8 parts); gemm8_p8h_kernel: 256 x 128, 1 .. 4 parts;
+// every other kernel: its tile, one part.
+static int gemm8_plan3(int int8, int64_t M, int64_t N, int64_t K, int* tile_rows, int* tile_cols, int* k_parts) {
   const std::string name = ao_gemm8_kernel_name(int8, M, N, K);
   AO_REQUIRE(name != "invalid", "ao_gemm8_plan: no kernel takes M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   *k_parts = 1;
-  if (name == "rb8_kernel") rb8_plan_query(M, N, K, tile_cols, k_parts);
-  else if (name == "gemm8_p8h_kernel") { *tile_cols = 128; *k_parts = gemm8_p8h_parts(M, N, K); }
-  else if (name == "gemm8_p8_kernel" || name == "gemm8_p8p_kernel" || name == "gemm8_dma_kernel<256x256>") *tile_cols = 256;
-  else if (name == "gemm8_dma_kernel<128x128>" || name == "gemm8_kernel") *tile_cols = 128;
-  else *tile_cols = 16;  // the per-tile streaming kernels (dec8 / mid8 / stream8): 16-wide n-tiles, K split among the waves of a workgroup
+  if (name == "rb8_kernel") rb8_plan_query(M, N, K, tile_rows, tile_cols, k_parts);
+  else if (name == "gemm8_p8h_kernel") { *tile_rows = 256; *tile_cols = 128; *k_parts = gemm8_p8h_parts(M, N, K); }
+  else if (name == "gemm8_p8_kernel" || name == "gemm8_p8p_kernel" || name == "gemm8_dma_kernel<256x256>") *tile_rows = *tile_cols = 256;
+  else if (name == "gemm8_dma_kernel<128x128>" || name == "gemm8_kernel") *tile_rows = *tile_cols = 128;
+  else { *tile_rows = 16; *tile_cols = 16; }  // the per-tile streaming kernels (dec8 / mid8 / stream8): 16-wide n-tiles, K split among the waves of a workgroup
   return AO_OK;
+}
+extern "C" int ao_gemm8_plan(int int8, int64_t M, int64_t N, int64_t K, int* tile_cols, int* k_parts) {
+  AO_REQUIRE_PTR(tile_cols);
+  AO_REQUIRE_PTR(k_parts);
+  int rows = 0;
+  return gemm8_plan3(int8, M, N, K, &rows, tile_cols, k_parts);
+}
+// (round 6) the tile's rows as well: the weight-streaming kernel's slab height is part of the plan since 64-row slabs serve M > 64
+extern "C" int ao_gemm8_plan_rows(int int8, int64_t M, int64_t N, int64_t K, int* tile_rows) {
+  AO_REQUIRE_PTR(tile_rows);
+  int cols = 0, parts = 0;
+  return gemm8_plan3(int8, M, N, K, tile_rows, &cols, &parts);
 }
 
 extern "C" int ao_int8_int_mm(const int8_t* a, const int8_t* b_t, int32_t* c, int64_t M, int64_t N, int64_t K,

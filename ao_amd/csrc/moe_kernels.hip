@@ -186,3 +186,112 @@ extern "C" int ao_moe_unpad_token_groups(const void* padded, const int32_t* offs
   AO_LAUNCH_CHECK("moe_unpad_rows_kernel launch");
   return AO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// E8M0 block scales -> the "128 x 4 blocked" layout, per token group (round 6; SURVEY.md 8 f4 "scale re-layout").
+//
+// Replaces torchao::mx_block_rearrange_2d_M_groups (schema torchao/prototype/moe_training/kernels/mxfp8/quant.py:969-973, host wrapper
+// csrc/cuda/mx_kernels/mxfp8_extension.cpp:178-300, kernels mx_block_rearrange_2d_M_groups.cu:165-470) with the semantics of the
+// reference's own torch restatement torch_to_blocked_2d_M_groups (quant.py:136-196) over to_blocked (prototype/mx_formats/utils.py:31-72):
+//   in   [rows][cols] bytes, row groups ending at offs[g];
+//   out  [rows + 128 G][pcols], pcols = 4 ceil(cols / 4), zero wherever nothing below lands;
+//   group g starts at out row start_g = sum over h < g of 128 ceil(size_h / 128) and is written as 512-byte tiles: tile (rb, cb) -- rows
+//   128 rb .. + 127 of the group, columns 4 cb .. + 3 -- at byte offset start_g pcols + (rb ncb + cb) 512, element (r, c) of the tile at
+//   (r % 32) 16 + (r / 32) 4 + c; rows past the group and columns past `cols` read as zero.
+// The MI355X GEMMs of this library take row-major scales (the scaled MFMA reads them from VGPRs); this op exists for callers that hold
+// the reference's blocked layout as a data format (checkpoints, an exchange with an NVIDIA peer).  HBM-bound byte shuffle, 2 B moved per
+// scale byte: a workgroup owns one 128-row block x 64 columns, reads it as row-contiguous dwords into LDS and writes its 16 tiles as
+// 16-byte pieces (thread (tile, q): rows q, q + 32, q + 64, q + 96 of column block `tile` are one piece).
+namespace {
+
+constexpr int kBlkCols = 64;  // columns per workgroup (16 column blocks)
+
+template <bool DW>
+__global__ __launch_bounds__(256) void mx_blocked_m_groups_kernel(const uint8_t* __restrict__ in, const int32_t* __restrict__ offs,
+                                                                  uint8_t* __restrict__ out, int rows, int cols, int G, long long out_bytes,
+                                                                  int pcols) {
+  __shared__ uint32_t tile[128][17];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, cb0 = blockIdx.x * (kBlkCols / 4), ncb = pcols >> 2;
+  // the group of padded row block b (uniform: scalar loads; offs == nullptr: one group of all rows)
+  int begin = 0, end = 0, rb = 0;
+  {
+    int prev = 0, blocks = 0;
+    bool found = false;
+    for (int g = 0; g < G && !found; ++g) {
+      const int e = offs != nullptr ? min(max(offs[g], prev), rows) : rows;
+      const int nb = (e - prev + 127) >> 7;
+      if (b < blocks + nb) { found = true; begin = prev; end = e; rb = b - blocks; }
+      blocks += nb;
+      prev = e;
+    }
+  }
+  const int row0 = begin + rb * 128;  // (no group: begin = end = 0 -> every row reads as zero)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = i * 256 + tid, r = idx >> 4, c = idx & 15;
+    const int src = row0 + r, col = (cb0 + c) * 4;
+    uint32_t v = 0u;
+    if (src < end && col < cols) {
+      const uint8_t* p = in + (size_t)src * cols + col;
+      if (DW) {
+        v = *reinterpret_cast<const uint32_t*>(p);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col + j < cols) v |= (uint32_t)p[j] << (8 * j);
+      }
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  const long long base = (long long)b * 128 * pcols;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = i * 256 + tid, t = idx >> 5, q = idx & 31;
+    const long long off = base + (long long)(cb0 + t) * 512 + q * 16;
+    if (cb0 + t < ncb && off + 16 <= out_bytes) {
+      const u32x4 v = {tile[q][t], tile[q + 32][t], tile[q + 64][t], tile[q + 96][t]};
+      *reinterpret_cast<u32x4*>(out + off) = v;
+    }
+  }
+}
+
+int mx_blocked_launch(const char* fn, const uint8_t* scales, const int32_t* offsets, uint8_t* out, int64_t rows, int64_t cols, int64_t G,
+                      int64_t out_rows, hipStream_t st) {
+  AO_REQUIRE(rows >= 0 && cols > 0 && rows < (1ll << 31) - 128 * (G + 1) && cols < (1ll << 24), "%s: rows=%lld cols=%lld out of range", fn,
+             (long long)rows, (long long)cols);
+  const int64_t pcols = (cols + 3) / 4 * 4;
+  if (out_rows == 0) return AO_OK;
+  AO_REQUIRE_PTR(out);
+  AO_REQUIRE(rows == 0 || scales != nullptr, "%s: null scales", fn);
+  AO_REQUIRE((uintptr_t)out % 16 == 0, "%s: the output must be 16-byte aligned", fn);
+  const int64_t blocks = (out_rows + 127) / 128;
+  AO_REQUIRE(blocks <= 65535, "%s: %lld row blocks exceed one launch", fn, (long long)blocks);
+  const dim3 grid((unsigned)((pcols + kBlkCols - 1) / kBlkCols), (unsigned)blocks), block(256);
+  const bool dw = cols % 4 == 0 && (uintptr_t)scales % 4 == 0;
+  if (dw)
+    ao::launch(mx_blocked_m_groups_kernel<true>, grid, block, 0, st, scales, offsets, out, (int)rows, (int)cols, (int)G,
+               (long long)(out_rows * pcols), (int)pcols);
+  else
+    ao::launch(mx_blocked_m_groups_kernel<false>, grid, block, 0, st, scales, offsets, out, (int)rows, (int)cols, (int)G,
+               (long long)(out_rows * pcols), (int)pcols);
+  AO_LAUNCH_CHECK("mx_blocked_m_groups_kernel launch");
+  return AO_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t ao_mx_blocked_rows(int64_t rows, int64_t num_groups) { return rows + 128 * num_groups; }
+
+extern "C" int ao_mx_block_rearrange_2d_m_groups(const uint8_t* scales, const int32_t* offsets, uint8_t* out, int64_t rows, int64_t cols,
+                                                 int64_t num_groups, void* stream) {
+  AO_REQUIRE_PTR(offsets);
+  AO_REQUIRE(num_groups > 0 && num_groups < (1 << 16), "%s: number of groups %lld out of range", __func__, (long long)num_groups);
+  return mx_blocked_launch(__func__, scales, offsets, out, rows, cols, num_groups, ao_mx_blocked_rows(rows, num_groups),
+                           static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ao_mx_to_blocked(const uint8_t* scales, uint8_t* out, int64_t rows, int64_t cols, void* stream) {
+  return mx_blocked_launch(__func__, scales, nullptr, out, rows, cols, 1, (rows + 127) / 128 * 128, static_cast<hipStream_t>(stream));
+}

@@ -64,7 +64,7 @@ struct Rb8Args {
   float* ws;
   unsigned* tickets;
   unsigned long long* trace;  // profiling build only
-  int ablate;  // profiling build (TRACE) only: 1 no MFMAs, 2 no fragment reads, 4 no weight DMAs, 8 no activation DMAs -- wrong results, timing probes
+  int ablate;  // profiling build (TRACE) only: 1 no MFMAs, 2 no fragment reads, 4 no weight DMAs, 8 no activation DMAs, 16 DMA wait + barrier on even steps only -- wrong results, timing probes
 };
 
 // TRACE (profiling build): s_memtime stamps of wave 0, 16 u64 per workgroup: entry, ring primed, barrier of steps 0..7 passed,
@@ -298,11 +298,13 @@ __global__ __launch_bounds__(64 * WAVES) void rb8_kernel(Rb8Args p) {
       // w(k + 1) .. w(k + kWStages - 2), four DMAs a stage) and everyone has finished READING step ksync - 1 (lgkmcnt(0) before the
       // barrier): its slots are refilled, then this step's fragments are requested
       static_assert(AD * (KA - 2) <= 63 && 4 * (kWStages - 2) <= 63, "rb8_kernel: vmcnt is a 6-bit counter");
-      if (is_a) wait_vmcnt<AD * (KA - 2)>(); else wait_vmcnt<4 * (kWStages - 2)>();
+      // (timing probe 16 of the traced build: the DMA wait and the barrier on even steps only -- what a 256-byte K step would save at best)
+      const bool skip_sync = TRACE && (p.ablate & 16) && (ksync & 1);
+      if (!skip_sync) { if (is_a) wait_vmcnt<AD * (KA - 2)>(); else wait_vmcnt<4 * (kWStages - 2)>(); }
       // (the LDS wait as a BUILTIN, not inside the asm: the compiler's wait-count pass has to see it, or it takes the fragments read
       // a step ago for still in flight behind the new reads and waits for those in front of every MFMA -- lgkmcnt(13) .. (0))
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt, expcnt untouched
-      asm volatile("s_barrier" ::: "memory");
+      if (!skip_sync) asm volatile("s_barrier" ::: "memory");
       if (TRACE && ksync < 8) ts[2 + ksync] = __builtin_amdgcn_s_memtime();
       if (is_a) issue_a((stage == 0) ? KA - 1 : stage - 1, ksync + KA - 1);
       else issue_w2((wstage == 0) ? kWStages - 1 : wstage - 1, ksync + kWStages - 1);
@@ -1132,6 +1134,7 @@ __global__ __launch_bounds__(64 * WAVES) void mx_stream_kernel(Rb8Args p) {
 thread_local unsigned long long* g_fp8_rb_trace = nullptr;  // profiling only (ao_int4_set_trace shares the pointer)
 // A/B knobs of the rowwise weight-streaming kernel (ao_gemm8_set_tuning; 0 = product rule): column-tile width, K parts, same-XCD meeting
 thread_local int g_rb8_bn = 0, g_rb8_split = 0, g_rb8_ablate = 0;
+thread_local int g_rb8_bm = 0;  // A/B (ao_gemm8_set_tuning key 3): 64 / 128 = that slab height at any M (0: the cost model's pick)
 thread_local bool g_rb8_sm = true;  // rb8_kernel's 2 x 4 wave arrangement where it is built (ao_gemm8_set_variant 103: off)
 
 template <int WAVES, int KIND, int MT = 8, bool SLIM = false, int QS = 1>
@@ -1203,6 +1206,7 @@ thread_local int g_fp8_rb_force = 0;  // profiling only: 0 product heuristic, 1 
 void fp8_rowwise_rb_set_mode(int mode) { g_fp8_rb_force = mode; }
 void rb8_set_wave_grid(bool two_by_four) { g_rb8_sm = two_by_four; }
 void rb8_set_tuning(int bn, int split, int ablate) { g_rb8_bn = bn; g_rb8_split = split; g_rb8_ablate = ablate; }
+void rb8_set_slab_rows(int rows) { g_rb8_bm = rows; }
 void mx_stream_set_tuning(int proto) { g_mx_proto = proto; }
 void mx_rb_set_stream(int mode, bool quad) { g_mx_stream = mode; g_mx_quad = quad; }
 void fp8_rowwise_rb_set_trace(unsigned long long* p) { g_fp8_rb_trace = p; }
@@ -1226,35 +1230,54 @@ bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
 
 namespace {
 
-// The tile width and K split of a rowwise launch (round 5).  Rounds 1-4 took 128-column tiles where they gave ~half a chip of workgroups
-// and 64-column ones otherwise, with K cut until the grid approached 256 workgroups (up to 16 parts).  The round-5 sweep over
-// (width, parts) next to hipBLASLt (profiles/midm_sweep_r05.jsonl: 8 shapes x M = 128 .. 1024, cold) says the choice is a trade between
-// three costs, which this model prices in microseconds and minimises:
-//   * the k loop: steps per workgroup x ~0.33 us (32 columns) / 0.35 (64) / 0.52 (128) -- one wave's barrier + issue + fragment-read +
-//     MFMA chain per step -- but never less than the weight bytes at ~5.8 TB/s;
-//   * the meeting of the K parts: ~3.2 us for 2 - 4 parts (one level), ~4.5 us from 5 on (two levels), + 0.4 us per extra part of a
-//     128-column tile (the last arriver's gather);
-//   (constants fitted to the sweep: the model's pick is within 0.2 % of the best measured form on average over the 32 cells)
-//   * a fixed ~5.5 us per round of the chip (launch, priming, first data, epilogue), and rounds = ceil(workgroups / 256).
+// The slab height, tile width and K split of a rowwise launch.  Rounds 1-4 took 128-column tiles where they gave ~half a chip of workgroups
+// and 64-column ones otherwise, with K cut until the grid approached 256 workgroups (up to 16 parts).  Round 5 swept (width, parts) next
+// to hipBLASLt and priced the choice as a trade between three costs, in microseconds:
+//   * the k loop: steps per workgroup x a per-step cost by tile width -- one wave's barrier + issue + fragment-read + MFMA chain per
+//     step -- but never less than the weight bytes at the rate the stream reaches;
+//   * the meeting of the K parts: one level for 2 - 4 parts, two levels from 5 on, + the last arriver's gather per extra part;
+//   * a fixed cost per round of the chip (launch, priming, first data, epilogue), and rounds = ceil(workgroups / 256).
 // Narrow tiles re-stage the activation tile once per tile (more steps in total); wide tiles need more K parts to fill the chip.
-struct Rb8Plan { int bn, split; };
-inline Rb8Plan rb8_plan(int64_t M, int64_t N, int64_t K, int bm) {
-  const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
-  const double hbm_us = (double)N * (double)K / 5.85e6;  // weight bytes at 5.85 TB/s
-  Rb8Plan best{128, 1};
+// Round 6 (verdict item 5): 64-ROW slabs above 64 rows as well -- M is cut instead of K: two slabs re-read a weight tile through L2, the
+// parked tiles halve, half as many K parts fill the chip (often none: no meeting at all), a step stages and multiplies half the rows.
+// Measured on the (slab, width, parts) grid of profiles/rb8_grid_r06_{fp8,int8}.jsonl (8 shapes x M = 80 .. 512, cold weights, 36 forms
+// per cell): 64-row slabs win 59 of 84 cells, by 5 - 25 % on the TP = 8 shards at M = 128 (qkv 14.6 -> 12.3 us, o 9.0 -> 7.1, down
+// 17.0 -> 15.0; gate_up keeps 128 rows).  The constants below are a least-squares fit of this model to those 958 measurements, refined
+// within +- 30 % for the least regret of the pick: 0.6 % over the per-cell best form on average (the 128-row-only plan of round 5: 9.4 %).
+struct Rb8Plan { int bm, bn, split; };
+struct Rb8Cost { double fixed, step[3], meet1, meet2, gather; };  // step: 32 / 64 / 128 columns
+constexpr Rb8Cost kRb8Cost128{4.335, {0.407, 0.465, 0.589}, 4.118, 7.041, 0.701};
+constexpr Rb8Cost kRb8Cost64{2.348, {0.319, 0.330, 0.388}, 3.606, 5.628, 1.362};
+constexpr double kRb8StreamBytesPerUs = 4.603e6;  // weight bytes per microsecond the loop sustains (4.6 TB/s)
+// M <= 64 (one 64-row slab): the round-5 constants.  On the grid of profiles/rb8_grid_r06_small.jsonl (M = 40 / 48 / 64, 48 cells) their pick
+// is within 1 % of the per-cell best; the set above, fitted to two and more slabs, is 7 % off there (it prices a meeting too high for a
+// single slab's parts, which arrive together)
+constexpr Rb8Cost kRb8Cost64One{5.5, {0.333, 0.35, 0.52}, 3.17, 4.53, 0.4};
+constexpr double kRb8StreamBytesPerUsOne = 5.85e6;
+inline Rb8Plan rb8_plan(int64_t M, int64_t N, int64_t K, int bm_forced = 0) {
+  const int64_t ksteps = K >> 7;
+  const bool one = M <= 64;
+  const double hbm_us = (double)N * (double)K / (one ? kRb8StreamBytesPerUsOne : kRb8StreamBytesPerUs);
+  Rb8Plan best{M <= 64 ? 64 : 128, 128, 1};
   double best_t = 1e30;
-  for (int bn : {128, 64, 32}) {
-    const int64_t tiles = ((N + bn - 1) / bn) * slabs;
-    const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (tiles * bn * bm) * 4 / 5;  // (x 4 / 5: the two-level meeting parks S + S / 4 tiles)
-    const double c = (bn == 32 ? 0.333 : bn == 64 ? 0.35 : 0.52);
-    for (int S : {1, 2, 3, 4, 6, 8}) {
-      if (S > 1 && (S > fit || S > std::max<int64_t>(1, ksteps / 4))) continue;
-      const int64_t wgs = tiles * S, rounds = (wgs + 255) / 256, steps = (ksteps + S - 1) / S;
-      if (S > 1 && wgs > 256) continue;  // K is never cut into a second round of the chip (1280 x 8192 at M = 2048: 3 parts 52 us, one 45)
-      const double loop = std::max((double)steps * c * (double)rounds, hbm_us);
-      const double meet = S == 1 ? 0.0 : (S <= 4 ? 3.17 : 4.53) + 0.4 * (S - 1) * bn / 128.0 * (bm / 128.0);
-      const double t = 5.5 * (double)rounds + loop + meet;
-      if (t < best_t) { best_t = t; best = Rb8Plan{bn, S}; }
+  for (int bm : {128, 64}) {
+    // (product: 64 rows up to 64, either from 65 to 512 -- the grid's range -- and 128 beyond)
+    if (bm_forced ? bm != bm_forced : ((bm == 128 && M <= 64) || (bm == 64 && M > 512))) continue;
+    const Rb8Cost& c = (bm == 64) ? (one ? kRb8Cost64One : kRb8Cost64) : kRb8Cost128;
+    const int64_t slabs = (M + bm - 1) / bm;
+    for (int bn : {128, 64, 32}) {
+      const int64_t tiles = ((N + bn - 1) / bn) * slabs;
+      const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (tiles * bn * bm) * 4 / 5;  // (x 4 / 5: the two-level meeting parks S + S / 4 tiles)
+      const double step = c.step[bn == 32 ? 0 : bn == 64 ? 1 : 2];
+      for (int S : {1, 2, 3, 4, 6, 8}) {
+        if (S > 1 && (S > fit || S > std::max<int64_t>(1, ksteps / 4))) continue;
+        const int64_t wgs = tiles * S, rounds = (wgs + 255) / 256, steps = (ksteps + S - 1) / S;
+        if (S > 1 && wgs > 256) continue;  // K is never cut into a second round of the chip (1280 x 8192 at M = 2048: 3 parts 52 us, one 45)
+        const double loop = std::max((double)steps * step * (double)rounds, hbm_us);
+        const double meet = S == 1 ? 0.0 : (S <= 4 ? c.meet1 : c.meet2) + c.gather * (S - 1) * bn / 128.0 * (bm / 128.0);
+        const double t = c.fixed * (double)rounds + loop + meet;
+        if (t < best_t) { best_t = t; best = Rb8Plan{bm, bn, S}; }
+      }
     }
   }
   return best;
@@ -1262,11 +1285,11 @@ inline Rb8Plan rb8_plan(int64_t M, int64_t N, int64_t K, int bm) {
 
 }  // namespace
 // what rb8_run picks without tuning overrides (host logic only: ao_gemm8_plan, tests/test_host_dispatch.py)
-void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bn, int* split) {
-  const int bm = (M <= 64) ? 64 : 128;
-  const Rb8Plan plan = rb8_plan(M, N, K, bm);
-  const int64_t base = ((N + plan.bn - 1) / plan.bn) * ((M + bm - 1) / bm);
-  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * plan.bn * bm) * 4 / 5;
+void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bm, int* bn, int* split) {
+  const Rb8Plan plan = rb8_plan(M, N, K);
+  const int64_t base = ((N + plan.bn - 1) / plan.bn) * ((M + plan.bm - 1) / plan.bm);
+  const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * plan.bn * plan.bm) * 4 / 5;
+  *bm = plan.bm;
   *bn = plan.bn;
   *split = (int)std::max<int64_t>(1, std::min<int64_t>(plan.split, fit));
 }
@@ -1278,9 +1301,10 @@ int rb8_run(const uint8_t* a, const uint8_t* b, const float* scale_a, const floa
   Rb8Args p{};
   p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.bias = bias; p.y = y;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  const int bm = (M <= 64) ? 64 : 128;  // slabs of 64 rows for M <= 64, else 128
+  // slab height, tile width, K parts: the cost model's pick (64-row slabs for M <= 64 always; tuning key 3 forces a height)
+  Rb8Plan plan = rb8_plan(M, N, K, (g_rb8_bm == 64 || g_rb8_bm == 128) ? g_rb8_bm : 0);
+  const int bm = plan.bm;
   const int64_t slabs = (M + bm - 1) / bm, ksteps = K >> 7;
-  Rb8Plan plan = rb8_plan(M, N, K, bm);
   if (g_fp8_rb_force == 3) plan.bn = 64;
   int bn = (g_rb8_bn == 32 || g_rb8_bn == 64 || g_rb8_bn == 128) ? g_rb8_bn : plan.bn;
   const int64_t base = ((N + bn - 1) / bn) * slabs;

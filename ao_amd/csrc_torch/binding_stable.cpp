@@ -11,8 +11,9 @@
 // Schemas live in Python (torchao's own, or ao_amd/torch_ops.py when torchao is not imported); dispatch key CUDA (= HIP on ROCm).
 // Host-only C++ over the C ABI of include/ao_mi355.h.  Ownership / errors as in the reference: inputs borrowed, outputs
 // allocated with torch::stable::new_empty and returned, the current stream from the AOTI shim, a device guard per call, failures through
-// STD_TORCH_CHECK (a C++ exception -> Python RuntimeError), never exit().  torchao::mx_block_rearrange_2d_M_groups (the cuBLAS 128 x 4
-// blocked swizzle of the scales) is not registered: CDNA4's scaled MFMA takes plain row-major E8M0 scales.
+// STD_TORCH_CHECK (a C++ exception -> Python RuntimeError), never exit().
+//   torchao::mx_block_rearrange_2d_M_groups(Tensor scales_tensor, Tensor input_offsets, int chunks_per_tb) -> Tensor                :178-300
+//     (round 6: the cuBLAS 128 x 4 blocked swizzle of the scales as a data-format op; the GEMMs here take row-major E8M0 scales)
 // The aten:: overrides (opt-in) and the ao_mi355_c:: test namespace stay in binding.cpp: they take ATen-only argument kinds
 // (ScalarType?, Tensor? with defaults) for schemas PyTorch core owns.
 #include <torch/csrc/inductor/aoti_torch/c/shim.h>
@@ -151,9 +152,36 @@ Tensor fused_unpad_token_groups(const Tensor& padded, const Tensor& offsets, con
   return out;
 }
 
+// mxfp8_extension.cpp:178-300: same checks, same output shape (rows + 128 groups, 4 ceil(cols / 4)); the reference's limit of 32 groups
+// (a shared-memory table of its kernel) does not apply; chunks_per_tb is validated and otherwise its launch-shape knob
+Tensor mx_block_rearrange_2d_M_groups(const Tensor& scales, const Tensor& offsets, int64_t chunks_per_tb) {
+  const char* op = "mx_block_rearrange_2d_M_groups";
+  check_gpu(scales, op, "scales_tensor");
+  check_gpu(offsets, op, "input_group_end_offsets");
+  STD_TORCH_CHECK(scales.dim() == 2, "scales_tensor must be 2D");
+  STD_TORCH_CHECK(scales.is_contiguous(), "scales_tensor must be contiguous (row-major)");
+  // (the dtype as the shim's integer: torch 2.10's stable scalar_type() cannot name float8_e8m0fnu yet, see empty_strided_like)
+  int32_t dt = 0;
+  TORCH_ERROR_CODE_CHECK(aoti_torch_get_dtype(scales.get(), &dt));
+  STD_TORCH_CHECK(dt == static_cast<int32_t>(ScalarType::Byte) || dt == static_cast<int32_t>(ScalarType::Float8_e8m0fnu), "scales_tensor must be uint8 or e8m0");
+  STD_TORCH_CHECK(offsets.scalar_type() == ScalarType::Int, "input_group_end_offsets must be int32");
+  STD_TORCH_CHECK(offsets.dim() == 1 && offsets.is_contiguous(), "input_group_end_offsets must be 1D");
+  STD_TORCH_CHECK(chunks_per_tb == 1 || chunks_per_tb == 4 || chunks_per_tb == 8 || chunks_per_tb == 16, "chunks_per_tb must be 1, 4, 8, or 16, got: ",
+                  chunks_per_tb);
+  const int64_t rows = scales.size(0), cols = scales.size(1), G = offsets.size(0);
+  STD_TORCH_CHECK(G > 0, op, ": input_group_end_offsets must not be empty");
+  tsa::DeviceGuard guard(scales.get_device_index());
+  const int64_t out_rows = ao_mx_blocked_rows(rows, G), pcols = (cols + 3) / 4 * 4;
+  Tensor out = empty_strided_like(scales, {out_rows, pcols}, {pcols, 1}, static_cast<ScalarType>(dt));  // (every byte is written by the kernel)
+  AO_RC(ao_mx_block_rearrange_2d_m_groups(reinterpret_cast<const uint8_t*>(scales.data_ptr()), reinterpret_cast<const int32_t*>(offsets.data_ptr()),
+                                          reinterpret_cast<uint8_t*>(out.data_ptr()), rows, cols, G, current_stream(scales)), op);
+  return out;
+}
+
 }  // namespace
 
 STABLE_TORCH_LIBRARY_IMPL(torchao, CUDA, m) {
+  m.impl("mx_block_rearrange_2d_M_groups", TORCH_BOX(&mx_block_rearrange_2d_M_groups));
   m.impl("mxfp8_quantize", TORCH_BOX(&mxfp8_quantize));
   m.impl("fused_pad_token_groups", TORCH_BOX(&fused_pad_token_groups));
   m.impl("fused_unpad_token_groups", TORCH_BOX(&fused_unpad_token_groups));

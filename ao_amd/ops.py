@@ -32,6 +32,8 @@ __all__ = [
     "fp8_dynamic_linear",
     "fused_pad_token_groups",
     "fused_unpad_token_groups",
+    "mx_block_rearrange_2d_M_groups",
+    "mx_to_blocked",
     "int8_linear",
     "fp8_linear",
     "mxfp8_quantize_colwise",
@@ -878,6 +880,48 @@ def fused_pad_token_groups(inputs, offsets, alignment_size=32):
             )
         )
     return padded, starts, ends
+
+
+def _scale_bytes(name, scales):
+    if scales.dim() != 2:
+        raise AssertionError("scales_tensor must be 2D")
+    if scales.dtype not in (torch.uint8, torch.float8_e8m0fnu):
+        raise AssertionError("scales_tensor must be uint8 or float8_e8m0fnu")
+    return scales.contiguous()
+
+
+def mx_block_rearrange_2d_M_groups(scales_tensor, input_offsets, chunks_per_tb=4):
+    """torchao::mx_block_rearrange_2d_M_groups (kernels/mxfp8/quant.py:969-973, 1183-1225; semantics torch_to_blocked_2d_M_groups,
+    quant.py:136-196): E8M0 scales [rows, cols] of token groups ending at `input_offsets` -> the reference's 128 x 4 blocked layout, every
+    group padded to 128-row blocks, in a [rows + 128 groups, 4 ceil(cols / 4)] tensor (zero elsewhere).  `chunks_per_tb` is the
+    reference's launch-shape knob: validated, no meaning here."""
+    dev = _require_gpu("mx_block_rearrange_2d_M_groups", scales_tensor, input_offsets)
+    s = _scale_bytes("mx_block_rearrange_2d_M_groups", scales_tensor)
+    if input_offsets.dtype != torch.int32:
+        raise AssertionError("input_offsets must be int32")
+    if input_offsets.dim() != 1 or input_offsets.numel() == 0:
+        raise RuntimeError("mx_block_rearrange_2d_M_groups: input_offsets must be a non-empty 1-d tensor of group end offsets")
+    if chunks_per_tb not in (1, 4, 8, 16):
+        raise AssertionError("chunks_per_tb must be 1, 4, 8, or 16")
+    rows, cols = s.shape
+    groups = input_offsets.numel()
+    out = torch.empty((_lib.lib().ao_mx_blocked_rows(rows, groups), (cols + 3) // 4 * 4), dtype=s.dtype, device=dev)  # every byte is written
+    with _on(dev):
+        _lib.check(_lib.lib().ao_mx_block_rearrange_2d_m_groups(_ptr(s), _ptr(input_offsets.contiguous()), _ptr(out), rows, cols, groups, _stream()))
+    return out
+
+
+def mx_to_blocked(scales_tensor):
+    """to_blocked (prototype/mx_formats/utils.py:31-72): E8M0 scales [H, W] -> flat 32 ceil(H / 128) x 16 ceil(W / 4) bytes in the 128 x 4
+    blocked layout."""
+    dev = _require_gpu("mx_to_blocked", scales_tensor)
+    s = _scale_bytes("mx_to_blocked", scales_tensor)
+    rows, cols = s.shape
+    out = torch.empty(((rows + 127) // 128 * 128) * ((cols + 3) // 4 * 4), dtype=s.dtype, device=dev)
+    if out.numel():
+        with _on(dev):
+            _lib.check(_lib.lib().ao_mx_to_blocked(_ptr(s), _ptr(out), rows, cols, _stream()))
+    return out
 
 
 def fp8_int4_linear(xq, x_scale, qdata, scale_and_zero, group_size, bias=None):

@@ -224,7 +224,7 @@ for _name in ("weight_int4pack_mm", "convert_weight_to_int4pack", "int8_scaled_m
 
 
 # ---- the C++ registrations (ao_amd/csrc_torch/binding.cpp -> _C_mi355_ops.so) ------------------------------------------
-# torchao::mxfp8_quantize / fused_pad_token_groups / fused_unpad_token_groups are IMPLEMENTED in the .so under the
+# torchao::mxfp8_quantize / fused_pad_token_groups / fused_unpad_token_groups / mx_block_rearrange_2d_M_groups are IMPLEMENTED in the .so under the
 # reference's names (TORCH_LIBRARY_IMPL(torchao, CUDA)); their schemas are defined by torchao's Python when it is imported
 # (prototype/mx_formats/kernels.py:1022-1026, moe_training/kernels/mxfp8/quant.py:1244-1246, 1319-1321) and by this module
 # otherwise.  Dropped into a torchao checkout as torchao/_C_mi355_ops.so the library is found by torchao's own loader
@@ -235,6 +235,8 @@ _TORCHAO_SCHEMAS = {
     "fused_pad_token_groups": "fused_pad_token_groups(Tensor inputs, Tensor group_offsets, int alignment_size) -> (Tensor, Tensor, Tensor)",
     "fused_unpad_token_groups": "fused_unpad_token_groups(Tensor inputs, Tensor group_offsets, Tensor padded_group_start_offsets, "
                                 "int num_tokens, int alignment_size) -> Tensor",
+    # (kernels/mxfp8/quant.py:969-973)
+    "mx_block_rearrange_2d_M_groups": "mx_block_rearrange_2d_M_groups(Tensor scales_tensor, Tensor input_offsets, int chunks_per_tb) -> Tensor",
 }
 _ops_lib_loaded = False
 _torchao_def = None
@@ -291,6 +293,11 @@ def _register_torchao_fakes():
     def unpad_fake(inputs, group_offsets, padded_group_start_offsets, num_tokens, alignment_size):
         return inputs.new_empty((num_tokens, inputs.shape[1]))
 
+    def rearrange_fake(scales_tensor, input_offsets, chunks_per_tb):  # (kernels/mxfp8/quant.py:1228-1247)
+        rows, cols = scales_tensor.shape
+        return scales_tensor.new_empty((rows + input_offsets.shape[0] * 128, (cols + 3) // 4 * 4))
+
+    _try("mx_block_rearrange_2d_M_groups", rearrange_fake)
     _try("mxfp8_quantize", mx_fake)
     _try("fused_pad_token_groups", pad_fake)
     _try("fused_unpad_token_groups", unpad_fake)

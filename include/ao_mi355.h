@@ -133,11 +133,11 @@ int ao_gemm8_set_variant(int variant);
 /* Profiling only, key / value (every setting computes the SAME result as the product; 0 = product rule; thread-local):
  *   key 1  column-tile width of the rowwise weight-streaming kernel (rb8_kernel): 32, 64 or 128
  *   key 2  its K parts (1 .. 16)
- *   key 3  (unused since round 6: the same-XCD split-K meeting was removed)
+ *   key 3  slab rows of rb8_kernel: 64 or 128 at any M (product: the cost model's pick above 64 rows, 64 up to 64)
  *   key 4  tile rows an XCD's workgroups of gemm8_p8_kernel walk together (product: 4)
  *   key 5  timing probes of the TRACED build of rb8_kernel only (ao_int4_set_trace set; results are wrong): bit 0 no MFMAs, 1 no fragment
- *          reads, 2 no weight DMAs, 3 no activation DMAs -- the product build ignores it
- *   key 6  (unused since round 6: the 256-row slabs of rb8_kernel were removed)
+ *          reads, 2 no weight DMAs, 3 no activation DMAs, 4 DMA wait + barrier on even steps only -- the product build ignores it
+ *   key 6  the persistent form of the 256 x 256 GEMM (gemm8_p8p_kernel): 1 never, 2 wherever the shape allows
  *   key 7  K parts of gemm8_p8h_kernel (1 .. 16, clamped to what fits one round of the chip and the split-K workspace)
  *   key 8  loop form of gemm8_p8h_kernel, laboratory build only (the product build ignores it)
  *   key 9  the MXFP8 stream-K kernel's meeting, A/B: bit 0 the head piece's ticket after the loop, bit 1 no early read of the tail ticket
@@ -154,6 +154,10 @@ const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int64_t K);
 /* The launch shape behind that name: column-tile width and K parts of the product dispatch for the shape (rb8_kernel: the cost model's
  * pick; gemm8_p8h_kernel: 128 columns and 1 .. 4 parts; others: their tile width, one part).  Host logic only.  DESIGN.md 4.5h. */
 int ao_gemm8_plan(int int8, int64_t M, int64_t N, int64_t K, int* tile_cols, int* k_parts);
+/* The rows of that launch's tile: rb8_kernel's slab height (64 up to 64 rows; 64 or 128 beyond, by the cost model -- round 6: 64-row slabs
+ * cut M instead of K where the fixed costs of a launch outweigh its loop), 256 for the 256 x 128 / 256 x 256 GEMMs, 128 / 16 otherwise.
+ * Host logic only.  DESIGN.md 4.5. */
+int ao_gemm8_plan_rows(int int8, int64_t M, int64_t N, int64_t K, int* tile_rows);
 /* Which form of fp8_int4_mm_kernel ao_fp8_int4_linear launches for a shape: "<m-tiles x n-tiles>" of 16 x 16 per workgroup -- "<1x1>" up to
  * 16 rows, "<2x1>" / "<2x2>" beyond (round 5: the weights stream once per 32 rows, the staged activations serve 32 columns), or "invalid".
  * Host logic only.  DESIGN.md 4.9. */
@@ -351,6 +355,21 @@ int ao_moe_pad_token_groups(const void* inputs, const int32_t* offsets, void* pa
 int ao_moe_unpad_token_groups(const void* padded, const int32_t* offsets,
                               const int32_t* padded_starts, void* out, int64_t num_tokens,
                               int64_t dim, int elem_bytes, int64_t num_groups, void* stream);
+
+/* Replaces torchao::mx_block_rearrange_2d_M_groups (schema torchao/prototype/moe_training/kernels/mxfp8/quant.py:969-973; host wrapper
+ * csrc/cuda/mx_kernels/mxfp8_extension.cpp:178-300; semantics torch_to_blocked_2d_M_groups, quant.py:136-196, over to_blocked,
+ * prototype/mx_formats/utils.py:31-72): E8M0 scales [rows][cols] whose rows are grouped by `offsets` (int32 [num_groups] cumulative
+ * ends) -> the reference's "128 x 4 blocked" layout, every group padded to 128-row blocks:
+ *   out [ao_mx_blocked_rows(rows, num_groups)][4 ceil(cols / 4)] bytes, every byte written (zero where no scale lands), 16-byte aligned;
+ *   group g starts at out row sum_{h<g} 128 ceil(size_h / 128); tile (rb, cb) of a group at + (rb ncb + cb) 512 bytes, element (r, c)
+ *   of a tile at (r % 32) 16 + (r / 32) 4 + c.
+ * The GEMMs of this library take row-major scales; this is a data-format op for callers that hold the blocked layout.
+ * ao_mx_blocked_rows = rows + 128 num_groups, the reference's no-host-sync upper bound (mxfp8_extension.cpp:221). */
+int64_t ao_mx_blocked_rows(int64_t rows, int64_t num_groups);
+int ao_mx_block_rearrange_2d_m_groups(const uint8_t* scales, const int32_t* offsets, uint8_t* out, int64_t rows, int64_t cols,
+                                      int64_t num_groups, void* stream);
+/* to_blocked of one matrix (prototype/mx_formats/utils.py:31-72): out [128 ceil(rows / 128)][4 ceil(cols / 4)] bytes, the same tiles. */
+int ao_mx_to_blocked(const uint8_t* scales, uint8_t* out, int64_t rows, int64_t cols, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * One-shot all-reduce over peer-mapped buffers (TP row-parallel linears at decode sizes)

@@ -87,3 +87,41 @@ def grouped_mm(a, a_scale, b, b_scale, offs, return_abs=False):
     if return_abs:
         return bf16.bf16_round(out), mag
     return bf16.bf16_round(out)
+
+
+# ---- the "128 x 4 blocked" layout of the scales (a data format of the reference; the MI355X GEMMs take row-major scales) ----------------
+def to_blocked(scales):
+    """prototype/mx_formats/utils.py:31-72 (to_blocked, the torch path): [H, W] bytes -> flat 32 ceil(H/128) x 16 ceil(W/4) bytes.
+    Pad to 128-row x 4-column blocks with zeros (:51-63), then per block [128, 4] -> [4, 32, 4] -> transpose(0, 1) -> [32, 16] (:66-68).
+    Pinned by tests/golden/mx_blocked.npz (make_golden.py:make_mx_blocked)."""
+    s = np.ascontiguousarray(scales)
+    h, w = s.shape
+    nrb, ncb = -(-h // 128), -(-w // 4)
+    p = np.zeros((nrb * 128, ncb * 4), dtype=s.dtype)
+    p[:h, :w] = s
+    blocks = p.reshape(nrb, 128, ncb, 4).transpose(0, 2, 1, 3)              # :66
+    return blocks.reshape(-1, 4, 32, 4).transpose(0, 2, 1, 3).reshape(-1)    # :67-68
+
+
+def to_blocked_2d_M_groups(scales, group_offs):
+    """moe_training/kernels/mxfp8/quant.py:136-196 (torch_to_blocked_2d_M_groups, the checker of torchao::mx_block_rearrange_2d_M_groups;
+    output allocation of the CUDA op, csrc/cuda/mx_kernels/mxfp8_extension.cpp:221-228): every non-empty row group is blocked on its own
+    and written at the row where the previous groups' 128-row-padded blocks end, inside a zero [rows + 128 G, 4 ceil(cols / 4)] buffer.
+    Returns (blocked, start_row_after_padding int64 [G + 1])."""
+    s = np.ascontiguousarray(scales)
+    rows, cols = s.shape
+    offs = [int(v) for v in np.asarray(group_offs).reshape(-1)]
+    pcols = -(-cols // 4) * 4
+    out = np.zeros((rows + 128 * len(offs), pcols), dtype=s.dtype)           # :159-160
+    starts, begin = [0], 0
+    for end in offs:                                                         # :163-190
+        size = end - begin
+        if size == 0:                                                        # :166-168
+            starts.append(starts[-1])
+            continue
+        blocked = to_blocked(s[begin:end])                                   # :172
+        padded = -(-size // 128) * 128
+        out[starts[-1] : starts[-1] + padded] = blocked.reshape(-1, pcols)   # :181-186
+        starts.append(starts[-1] + padded)
+        begin = end
+    return out, np.asarray(starts, dtype=np.int64)

@@ -173,6 +173,35 @@ def make_moe():
     print("moe_pad.npz", sum(v.nbytes for v in out.values()), "bytes raw")
 
 
+def make_mx_blocked():
+    """Outputs of the reference's to_blocked (prototype/mx_formats/utils.py:31-72) and torch_to_blocked_2d_M_groups
+    (moe_training/kernels/mxfp8/quant.py:136-196: the checker of its CUDA op torchao::mx_block_rearrange_2d_M_groups)."""
+    from torchao.prototype.moe_training.kernels.mxfp8.quant import torch_to_blocked_2d_M_groups
+    from torchao.prototype.mx_formats.utils import from_blocked, to_blocked
+
+    out = {}
+    gen = torch.Generator().manual_seed(23)
+    for name, (h, w) in {"one_block": (128, 4), "ragged": (200, 10), "wide": (130, 68), "tiny": (1, 1), "k4096": (256, 128)}.items():
+        s = torch.randint(0, 256, (h, w), generator=gen, dtype=torch.uint8)
+        b = to_blocked(s)
+        assert torch.equal(from_blocked(b, h, w), s)
+        out.update({f"tb_{name}_in": s.numpy(), f"tb_{name}_out": b.numpy()})
+    cases = {
+        "groups": ([5, 5, 133, 256, 256, 300], 16),     # empty groups, a group that is exactly one block, one of 44 rows
+        "single": ([70], 8),
+        "aligned": ([128, 384], 128),
+        "k224": ([3, 40, 41], 7 * 4),
+    }
+    for name, (ends, cols) in cases.items():
+        s = torch.randint(0, 256, (ends[-1], cols), generator=gen, dtype=torch.uint8)
+        offs = torch.tensor(ends, dtype=torch.int32)
+        blocked, starts = torch_to_blocked_2d_M_groups(s, offs)
+        out.update({f"mg_{name}_in": s.numpy(), f"mg_{name}_offs": offs.numpy(), f"mg_{name}_out": blocked.numpy(),
+                    f"mg_{name}_starts": starts.numpy().astype(np.int64)})
+    np.savez_compressed(os.path.join(HERE, "mx_blocked.npz"), **out)
+    print("mx_blocked.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
 def make_int4_plain():
     """Int4Tensor (PLAIN) weight preparation: mslk is absent, so the fixtures come from the reference's OWN restatements of its
     numerics -- Int4WeightFakeQuantizer (qat/fake_quantizer.py:148-190) and the GPTQ helpers (prototype/gptq/api.py:167-221)."""
@@ -393,6 +422,7 @@ def make_rest():
     make_int8_fp8_variants()
     make_mx()
     make_moe()
+    make_mx_blocked()
     make_moe_permute()
     make_int4_plain()
     make_hqq()

@@ -103,31 +103,33 @@ def test_fp8_int4_tile_forms():
 
 
 def test_8bit_launch_plans_on_the_sweep_shapes():
-    """ao_gemm8_plan: tile width / K parts of the product dispatch on the shapes of profiles/midm_final_r05.jsonl (fp8 = int8).  The
-    weight-streaming kernel's pick comes from a cost model fitted to the round-5 sweep (rb8_plan): this table is the fit's output at the
-    time of the committed measurements -- a change of its constants has to show up here."""
+    """ao_gemm8_plan / ao_gemm8_plan_rows: tile rows / width / K parts of the product dispatch on the shapes of profiles/midm_final_r06.jsonl
+    (fp8 = int8).  The weight-streaming kernel's pick comes from a cost model fitted to the round-6 grid (rb8_plan;
+    profiles/rb8_grid_r06_*.jsonl: 64-row slabs serve 65 .. 512 rows where they win): this table is the fit's output at the time of the
+    committed measurements -- a change of its constants has to show up here."""
     import ctypes
 
     lib = _lib.lib()
     shapes = {"qkv70b": (1280, 8192), "o70b": (8192, 1024), "gate70b": (7168, 8192), "down70b": (8192, 3584),
               "qkv8b": (6144, 4096), "o8b": (4096, 4096), "gate_up8b": (28672, 4096), "down8b": (4096, 14336)}
-    want = {  # M: (kernel, tile columns, K parts)
-        "qkv70b": {128: ("rb8", 32, 6), 256: ("rb8", 64, 4), 512: ("rb8", 64, 3), 768: ("rb8", 128, 4), 1024: ("p8h", 128, 4), 2048: ("p8h", 128, 3)},
-        "o70b": {128: ("rb8", 32, 1), 256: ("rb8", 64, 1), 512: ("rb8", 128, 1), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
-        "gate70b": {128: ("rb8", 128, 4), 256: ("rb8", 128, 2), 512: ("p8h", 128, 2), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
-        "down70b": {128: ("rb8", 64, 2), 256: ("rb8", 64, 1), 512: ("rb8", 128, 1), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
-        "qkv8b": {128: ("rb8", 128, 4), 256: ("rb8", 64, 1), 512: ("rb8", 128, 1), 768: ("p8h", 128, 1), 1024: ("p8h", 128, 1), 2048: ("p8", 256, 1)},
-        "o8b": {128: ("rb8", 64, 4), 256: ("rb8", 128, 4), 512: ("rb8", 64, 1), 768: ("rb8", 128, 1), 1024: ("rb8", 128, 1), 2048: ("p8h", 128, 1)},
-        "gate_up8b": {128: ("rb8", 128, 1), 256: ("p8h", 128, 1), 512: ("p8", 256, 1), 1024: ("p8", 256, 1), 2048: ("p8", 256, 1)},
-        "down8b": {128: ("rb8", 64, 4), 256: ("rb8", 128, 4), 512: ("p8h", 128, 4), 768: ("p8h", 128, 2), 1024: ("p8h", 128, 2), 2048: ("p8h", 128, 1)},
+    want = {  # M: (kernel, tile rows, tile columns, K parts)
+        "qkv70b": {96: ("rb8", 64, 64, 4), 128: ("rb8", 64, 64, 4), 256: ("rb8", 64, 64, 3), 512: ("rb8", 64, 128, 3), 768: ("rb8", 128, 128, 4), 1024: ("p8h", 256, 128, 4), 2048: ("p8h", 256, 128, 3)},
+        "o70b": {96: ("rb8", 64, 64, 1), 128: ("rb8", 64, 64, 1), 256: ("rb8", 64, 128, 1), 512: ("rb8", 128, 128, 1), 768: ("p8h", 256, 128, 1), 1024: ("p8h", 256, 128, 1), 2048: ("p8", 256, 256, 1)},
+        "gate70b": {96: ("rb8", 64, 128, 2), 128: ("rb8", 64, 128, 2), 256: ("rb8", 64, 128, 1), 512: ("p8h", 256, 128, 2), 768: ("p8h", 256, 128, 1), 1024: ("p8h", 256, 128, 1), 2048: ("p8", 256, 256, 1)},
+        "down70b": {96: ("rb8", 64, 64, 1), 128: ("rb8", 64, 64, 1), 256: ("rb8", 64, 128, 1), 512: ("rb8", 128, 128, 1), 768: ("p8h", 256, 128, 1), 1024: ("p8h", 256, 128, 1), 2048: ("p8", 256, 256, 1)},
+        "qkv8b": {96: ("rb8", 64, 128, 2), 128: ("rb8", 64, 128, 2), 256: ("rb8", 64, 128, 1), 512: ("rb8", 128, 128, 1), 768: ("p8h", 256, 128, 1), 1024: ("p8h", 256, 128, 1), 2048: ("p8", 256, 256, 1)},
+        "o8b": {96: ("rb8", 64, 64, 2), 128: ("rb8", 64, 64, 2), 256: ("rb8", 64, 128, 2), 512: ("rb8", 64, 128, 1), 768: ("rb8", 128, 128, 1), 1024: ("rb8", 128, 128, 1), 2048: ("p8h", 256, 128, 1)},
+        "gate_up8b": {96: ("rb8", 128, 128, 1), 128: ("rb8", 128, 128, 1), 256: ("p8h", 256, 128, 1), 512: ("p8", 256, 256, 1), 1024: ("p8", 256, 256, 1), 2048: ("p8", 256, 256, 1)},
+        "down8b": {96: ("rb8", 64, 128, 4), 128: ("rb8", 64, 128, 4), 256: ("rb8", 128, 128, 4), 512: ("p8h", 256, 128, 4), 768: ("p8h", 256, 128, 2), 1024: ("p8h", 256, 128, 2), 2048: ("p8h", 256, 128, 1)},
     }
     short = {"rb8_kernel": "rb8", "gemm8_p8h_kernel": "p8h", "gemm8_p8_kernel": "p8", "gemm8_p8p_kernel": "p8"}
     for name, (n, k) in shapes.items():
         for m, expect in want[name].items():
             for int8 in (0, 1):
-                cols, parts = ctypes.c_int(), ctypes.c_int()
+                rows, cols, parts = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
                 _lib.check(lib.ao_gemm8_plan(int8, m, n, k, ctypes.byref(cols), ctypes.byref(parts)))
-                got = (short[lib.ao_gemm8_kernel_name(int8, m, n, k).decode()], cols.value, parts.value)
+                _lib.check(lib.ao_gemm8_plan_rows(int8, m, n, k, ctypes.byref(rows)))
+                got = (short[lib.ao_gemm8_kernel_name(int8, m, n, k).decode()], rows.value, cols.value, parts.value)
                 assert got == expect, (name, m, int8, got, expect)
     # the per-tile streaming kernels report their 16-wide n-tiles; a shape no kernel takes is an error
     cols, parts = ctypes.c_int(), ctypes.c_int()

@@ -191,3 +191,94 @@ def test_permute_kernels_match_oracle_and_fixtures():
         assert np.array_equal(got, M.gather_rows(x_np, want_idx))
         back = ops.scatter_rows(ops.gather_rows(xt, idx), idx, T).cpu().numpy().view(dt)
         assert np.array_equal(back, x_np)
+
+
+# ---- the 128 x 4 blocked layout of the E8M0 scales (torchao::mx_block_rearrange_2d_M_groups / to_blocked) --------------------------------
+TB_CASES = ["one_block", "ragged", "wide", "tiny", "k4096"]
+MG_CASES = ["groups", "single", "aligned", "k224"]
+
+
+@pytest.fixture(scope="module")
+def golden_blocked():
+    return np.load(os.path.join(GOLDEN, "mx_blocked.npz"))
+
+
+@pytest.mark.parametrize("case", TB_CASES)
+def test_oracle_to_blocked_matches_reference(golden_blocked, case):
+    from oracle import mx_ref
+
+    d = golden_blocked
+    assert np.array_equal(mx_ref.to_blocked(d[f"tb_{case}_in"]), d[f"tb_{case}_out"])
+
+
+@pytest.mark.parametrize("case", MG_CASES)
+def test_oracle_blocked_m_groups_matches_reference(golden_blocked, case):
+    from oracle import mx_ref
+
+    d = golden_blocked
+    out, starts = mx_ref.to_blocked_2d_M_groups(d[f"mg_{case}_in"], d[f"mg_{case}_offs"])
+    assert np.array_equal(out, d[f"mg_{case}_out"]) and np.array_equal(starts, d[f"mg_{case}_starts"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", TB_CASES)
+def test_to_blocked_kernel_matches_reference(golden_blocked, case):
+    from ao_amd import ops
+
+    d = golden_blocked
+    got = ops.mx_to_blocked(torch.from_numpy(d[f"tb_{case}_in"].copy()).cuda())
+    assert np.array_equal(got.cpu().numpy(), d[f"tb_{case}_out"])
+    e8 = ops.mx_to_blocked(torch.from_numpy(d[f"tb_{case}_in"].copy()).cuda().view(torch.float8_e8m0fnu))
+    assert e8.dtype == torch.float8_e8m0fnu and torch.equal(e8.view(torch.uint8), got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", MG_CASES)
+def test_blocked_m_groups_kernel_matches_reference(golden_blocked, case):
+    from ao_amd import ops
+
+    d = golden_blocked
+    s, offs = torch.from_numpy(d[f"mg_{case}_in"].copy()).cuda(), torch.from_numpy(d[f"mg_{case}_offs"].copy()).cuda()
+    torch.full((d[f"mg_{case}_out"].size + 4096,), 0xAB, dtype=torch.uint8, device="cuda")  # dirty the allocator's block
+    got = ops.mx_block_rearrange_2d_M_groups(s, offs)
+    assert got.shape == d[f"mg_{case}_out"].shape and np.array_equal(got.cpu().numpy(), d[f"mg_{case}_out"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,cols,top", [(8, 128, 300), (64, 224, 70), (3, 5, 200), (200, 16, 40), (1, 448, 1000)])
+def test_blocked_m_groups_kernel_vs_oracle_random(groups, cols, top):
+    """Mixtral / DeepSeek-sized scale rows (K / 32 = 128, 224, 448), more groups than the reference's 32, empty groups, a column count
+    that is not a multiple of 4 (byte path); the tail of the upper-bound buffer must be zero although it starts uninitialised."""
+    from ao_amd import ops
+    from oracle import mx_ref
+
+    rng = np.random.default_rng(groups * 100 + cols)
+    sizes = rng.integers(0, top, size=groups)
+    if groups > 1:
+        sizes[rng.integers(0, groups)] = 0
+    ends = np.cumsum(sizes).astype(np.int32)
+    s = rng.integers(0, 256, size=(int(ends[-1]), cols), dtype=np.uint8)
+    want, _ = mx_ref.to_blocked_2d_M_groups(s, ends)
+    torch.full((want.size + 4096,), 0xCD, dtype=torch.uint8, device="cuda")
+    got = ops.mx_block_rearrange_2d_M_groups(torch.from_numpy(s).cuda(), torch.from_numpy(ends).cuda(), chunks_per_tb=8)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_blocked_m_groups_refusals_and_edges():
+    from ao_amd import ops
+
+    s = torch.zeros((4, 8), dtype=torch.uint8, device="cuda")
+    offs = torch.tensor([4], dtype=torch.int32, device="cuda")
+    with pytest.raises(AssertionError, match="chunks_per_tb"):
+        ops.mx_block_rearrange_2d_M_groups(s, offs, 3)
+    with pytest.raises(AssertionError, match="int32"):
+        ops.mx_block_rearrange_2d_M_groups(s, offs.long())
+    with pytest.raises(AssertionError, match="uint8"):
+        ops.mx_block_rearrange_2d_M_groups(s.float(), offs)
+    # no rows at all: the buffer of the upper bound, all zero
+    z = ops.mx_block_rearrange_2d_M_groups(torch.zeros((0, 8), dtype=torch.uint8, device="cuda"), torch.tensor([0, 0], dtype=torch.int32, device="cuda"))
+    assert z.shape == (256, 8) and not z.any()
+    # malformed offsets (decreasing, past the rows) do not fault
+    ops.mx_block_rearrange_2d_M_groups(s, torch.tensor([3, 1, 900], dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()

@@ -4,7 +4,7 @@ a replay reads another copy of the weight (> 256 MiB of copies per shape: nothin
 core's kernel (hipBLASLt: what torchao-on-ROCm runs today), this library's dispatch, and the tuning forms of ao_gemm8_set_tuning /
 ao_gemm8_set_variant named on the command line.  One JSON line per measurement; output goes to profiles/.
 
-    python tools/midm_sweep.py [--ms 128,256,512,1024] [--kinds fp8] [--families 70b,8b] [--forms default,nolocal,bn32,...]
+    python tools/midm_sweep.py [--ms 128,256,512,1024] [--kinds fp8] [--families 70b,8b] [--forms default,bm64,bn32+s2,...]
 
 A form is a comma list of key=value tunings joined by '+', or a name from FORMS below.
 """
@@ -25,8 +25,7 @@ SHAPES = {
 # name -> (variant, {tuning key: value})
 FORMS = {
     "default": (0, {}),
-    "local": (0, {3: 2}),       # the same-XCD meeting (opt-in)
-    "nolocal": (0, {3: 1}),
+    "bm64": (0, {3: 64}),       # 64-row slabs at any M (M is cut instead of K)
     "bn32": (0, {1: 32}),
     "bn64": (0, {1: 64}),
     "bn128": (0, {1: 128}),
@@ -45,8 +44,8 @@ def parse_form(name):
             v, t = FORMS[part]
             variant = v or variant
             tun.update(t)
-        elif part.startswith("bm"):  # slab height
-            tun[6] = int(part[2:])
+        elif part.startswith("bm"):  # slab height (64: two slabs share a weight tile through L2 at M = 128)
+            tun[3] = int(part[2:])
         elif part.startswith("v"):
             variant = int(part[1:])
         elif part.startswith("s"):  # K parts
@@ -86,7 +85,7 @@ def main():
     ap.add_argument("--ms", default="128,256,512,1024")
     ap.add_argument("--kinds", default="fp8")
     ap.add_argument("--families", default="70b,8b")
-    ap.add_argument("--forms", default="default,nolocal")
+    ap.add_argument("--forms", default="default,bm64")
     ap.add_argument("--no-core", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare every form's output with the default dispatch's (max abs diff)")
     args = ap.parse_args()
