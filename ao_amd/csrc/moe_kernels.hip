@@ -250,9 +250,13 @@ __global__ __launch_bounds__(256) void mx_blocked_m_groups_kernel(const uint8_t*
   for (int i = 0; i < 2; ++i) {
     const int idx = i * 256 + tid, t = idx >> 5, q = idx & 31;
     const long long off = base + (long long)(cb0 + t) * 512 + q * 16;
-    if (cb0 + t < ncb && off + 16 <= out_bytes) {
+    if (cb0 + t < ncb && off < out_bytes) {
       const u32x4 v = {tile[q][t], tile[q + 32][t], tile[q + 64][t], tile[q + 96][t]};
-      *reinterpret_cast<u32x4*>(out + off) = v;
+      if (off + 16 <= out_bytes) {
+        *reinterpret_cast<u32x4*>(out + off) = v;
+      } else {  // the upper-bound buffer ends inside this piece (its row count is not a multiple of 128): the bytes it still has
+        for (int j = 0; off + j < out_bytes; ++j) out[off + j] = (uint8_t)(v[j >> 2] >> (8 * (j & 3)));
+      }
     }
   }
 }

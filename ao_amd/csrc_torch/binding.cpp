@@ -129,7 +129,7 @@ Tensor scaled_mm(const Tensor& self, const Tensor& mat2, const Tensor& scale_a, 
 // aten::_scaled_grouped_mm(self, mat2, scale_a, scale_b, offs?, bias?, scale_result?, out_dtype?, use_fast_accum)
 // MXFP8 2d-3d form (mxfp8_grouped_mm.py:541): self e4m3 [M, K]; mat2 e4m3 [E, K, N] whose experts are K-major (the
 // transpose of [E, N, K]); scale_a e8m0 [M, K/32]; scale_b e8m0 [E, N, K/32] -- plain row-major scales: CDNA4's scaled
-// MFMA takes them from VGPRs, the cuBLAS 128x4 blocked swizzle (mx_block_rearrange_2d_M_groups) has no role here.
+// MFMA takes them from VGPRs, the cuBLAS 128x4 blocked swizzle (mx_block_rearrange_2d_M_groups, binding_stable.cpp) has no role on this path.
 Tensor scaled_grouped_mm(const Tensor& self, const Tensor& mat2, const Tensor& scale_a, const Tensor& scale_b,
                          const std::optional<Tensor>& offs, const std::optional<Tensor>& bias, const std::optional<Tensor>& scale_result,
                          std::optional<c10::ScalarType> out_dtype, bool use_fast_accum) {
@@ -164,7 +164,7 @@ bool override_aten() {
 
 }  // namespace
 
-// (torchao::mxfp8_quantize / fused_pad_token_groups / fused_unpad_token_groups: binding_stable.cpp, through the stable ABI like the reference)
+// (torchao::mxfp8_quantize / fused_pad_token_groups / fused_unpad_token_groups / mx_block_rearrange_2d_M_groups: binding_stable.cpp, through the stable ABI like the reference)
 
 // Own namespace: always there, same functions (tests / opcheck / explicit use without touching aten).
 TORCH_LIBRARY(ao_mi355_c, m) {

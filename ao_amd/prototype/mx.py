@@ -7,7 +7,8 @@ Host-side mirror of
     emulated path (:959-1023): both operands dequantised per 32-block, fp32 accumulate, bf16 out.
 CDNA4's scaled MFMA takes the E8M0 bytes as register operands, so scales stay in plain [rows, K/32]
 layout: no 128x4 "blocked" swizzle and no per-group row padding are needed on this path
-(torchao::mx_block_rearrange_2d_M_groups / fused_pad_token_groups have no work to do here).
+(torchao::mx_block_rearrange_2d_M_groups / fused_pad_token_groups have no work to do on this path; both exist as ops for callers that hold
+the reference's padded / blocked formats: ops.mx_block_rearrange_2d_M_groups, ops.fused_pad_token_groups).
 """
 from enum import Enum
 from typing import Optional

@@ -292,7 +292,7 @@ int ao_mxfp8_quantize_colwise_3d(const uint16_t* x, uint8_t* q_t, uint8_t* scale
  *   b e4m3 [E][N][K] (each expert row-major [N][K]); b_scale e8m0 [E][N][K/32];
  *   offs int32 [E] cumulative group ends; out bf16 [M_total][N].
  * Scale layout is plain row-major (CDNA4 scaled-MFMA takes scales in VGPRs; the
- * cuBLAS 128x4 "blocked" swizzle of mx_block_rearrange_2d_M_groups is not used). */
+ * cuBLAS 128x4 "blocked" swizzle is not read by any GEMM here; ao_mx_block_rearrange_2d_m_groups writes it as a data format). */
 int ao_mxfp8_grouped_mm(const uint8_t* a, const uint8_t* a_scale,
                         const uint8_t* b, const uint8_t* b_scale,
                         const int32_t* offs, uint16_t* out, int64_t M_total,

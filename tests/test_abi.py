@@ -61,10 +61,12 @@ def test_ops_library_loads_and_registers_without_a_gpu():
     from ao_amd import torch_ops
 
     assert torch_ops.load_ops_library(), "build it with python -m ao_amd.build"
-    for name in ("mxfp8_quantize", "fused_pad_token_groups", "fused_unpad_token_groups"):
+    for name in ("mxfp8_quantize", "fused_pad_token_groups", "fused_unpad_token_groups", "mx_block_rearrange_2d_M_groups"):
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f"torchao::{name}", "CUDA")
     s = str(torch.ops.torchao.mxfp8_quantize.default._schema)
     assert "bool rowwise, bool colwise, int scale_dim_x, int scale_dim_y, str fp8_format, str scaling_mode" in s
+    s = str(torch.ops.torchao.mx_block_rearrange_2d_M_groups.default._schema)  # (reference: kernels/mxfp8/quant.py:969-973)
+    assert "(Tensor scales_tensor, Tensor input_offsets, int chunks_per_tb) -> Tensor" in s
     for name in ("_weight_int4pack_mm", "_convert_weight_to_int4pack", "_int_mm", "_scaled_mm", "_scaled_grouped_mm"):
         ours = str(getattr(torch.ops.ao_mi355_c, name).default._schema).split("::", 1)[1]
         theirs = str(getattr(torch.ops.aten, name).default._schema).split("::", 1)[1]

@@ -87,6 +87,23 @@ def test_torchao_pad_unpad_ops_match_python_wrappers():
     assert torch.equal(back, x)
 
 
+def test_torchao_block_rearrange_op_matches_python_wrapper():
+    """torchao::mx_block_rearrange_2d_M_groups through the dispatcher (uint8 and float8_e8m0fnu scales) = the C-ABI wrapper; the reference's
+    own argument checks (mxfp8_extension.cpp:183-197) raise RuntimeError."""
+    s = torch.randint(0, 256, (300, 128), dtype=torch.uint8, generator=torch.Generator().manual_seed(4)).to(DEV)
+    offs = torch.tensor([10, 10, 170, 300], dtype=torch.int32, device=DEV)
+    a = torch.ops.torchao.mx_block_rearrange_2d_M_groups(s, offs, 4)
+    assert tuple(a.shape) == (300 + 4 * 128, 128) and torch.equal(a, ops.mx_block_rearrange_2d_M_groups(s, offs))
+    e = torch.ops.torchao.mx_block_rearrange_2d_M_groups(s.view(torch.float8_e8m0fnu), offs, 16)
+    assert e.dtype == torch.float8_e8m0fnu and torch.equal(e.view(torch.uint8), a)
+    with pytest.raises(RuntimeError, match="chunks_per_tb"):
+        torch.ops.torchao.mx_block_rearrange_2d_M_groups(s, offs, 3)
+    with pytest.raises(RuntimeError, match="int32"):
+        torch.ops.torchao.mx_block_rearrange_2d_M_groups(s, offs.long(), 4)
+    with pytest.raises(RuntimeError, match="uint8 or e8m0"):
+        torch.ops.torchao.mx_block_rearrange_2d_M_groups(s.to(torch.int8), offs, 4)
+
+
 def test_cxx_aten_signature_ops_match_the_c_abi_wrappers():
     """ao_mi355_c::* carry the ATen schemas (what the opt-in override installs under aten::) and run the same kernels."""
     n, k, g = 256, 1024, 128
@@ -142,6 +159,8 @@ def test_opcheck_custom_ops():
     opcheck(torch.ops.torchao.mxfp8_quantize.default, (x32, True, True, 32, 32, "e4m3", "rceil"), test_utils=fake)
     offs = torch.tensor([10, 64], dtype=torch.int32, device=DEV)
     opcheck(torch.ops.torchao.fused_pad_token_groups.default, (x32, offs, 32), test_utils=utils)
+    sc = torch.randint(0, 256, (64, 8), dtype=torch.uint8, device=DEV)
+    opcheck(torch.ops.torchao.mx_block_rearrange_2d_M_groups.default, (sc, offs, 4), test_utils=utils)
 
 
 @pytest.mark.parametrize("kind", ["int4", "int4_plain", "int8", "fp8", "int8_asym", "int8_pt", "fp8_pt", "int8_static", "fp8_clamped"])
