@@ -25,10 +25,15 @@ for M, N, K in itertools.product([0, 1, 3, 16, 17, 64, 65, 128, 129, 256, 1000, 
         names.add(lib.ao_gemm8_kernel_name(i8, I(M), I(N), I(K)))
         bn, sp = ctypes.c_int(), ctypes.c_int()
         lib.ao_gemm8_plan(i8, I(M), I(N), I(K), ctypes.byref(bn), ctypes.byref(sp))
+        lib.ao_gemm8_plan_rows(i8, I(M), I(N), I(K), ctypes.byref(bn))
     for g in (32, 128):
         names.add(lib.ao_int4_mm_kernel_name(I(M), I(N), I(K), g))
     for E in (1, 8, 64, 65):
         lib.ao_mxfp8_grouped_mm_dyn_fits(I(M), I(N), I(K), I(E))
         lib.ao_mxfp8_grouped_mm_pair_fits(I(M), I(N), I(K), I(E))
+for rows, groups in itertools.product([0, 1, 127, 128, (1 << 31) - 1], [0, 1, 32, 1 << 20]):
+    lib.ao_mx_blocked_rows(I(rows), I(groups))
+    lib.ao_mx_block_rearrange_2d_m_groups(None, None, None, I(rows), I(16), I(groups), None)  # null pointers: refused before any launch
+    lib.ao_mx_to_blocked(None, None, I(rows), I(0), None)
 print("dispatch queries under ASan / UBSan:", len(names), "kernel names, no report")
 PY

@@ -789,13 +789,13 @@ def test_gemm8_persistent_form_equals_one_workgroup_per_tile(m, n, k, bias):
     assert lib.ao_gemm8_set_variant(0) == 0
 
 
-# ---- round 5: the same-XCD split-K meeting, the LDS-transposed epilogue, the 32-column tiles ------------------------------------------------
+# ---- round 5: the LDS-transposed epilogue, the 32-column tiles; round 6: 64-row slabs above 64 rows ------------------------------------------------
 @pytest.mark.parametrize("kind", ["int8", "fp8"])
 @pytest.mark.parametrize("m,n,k,bias", [(128, 1280, 8192, False), (200, 1296, 2048, True), (33, 8192, 1024, False), (128, 4096, 4096, True),
                                         (512, 1280, 8192, False), (97, 48, 3584, True)])
 def test_rb8_every_tile_width_and_part_count(kind, m, n, k, bias):
-    """The weight-streaming kernel over tile widths 32 / 64 / 128 and 1 .. 16 K parts (one- and two-level write-through meetings) against the
-    oracle: the same parts are added in the same order, so every run of a form gives the same bits (int8: every form the oracle's)."""
+    """The weight-streaming kernel over slab rows 64 / 128, tile widths 32 / 64 / 128 and 1 .. 16 K parts (one- and two-level write-through
+    meetings) against the oracle: the same parts are added in the same order, so every run of a form gives the same bits (int8: every form the oracle's)."""
     from ao_amd import _lib
 
     lib = _lib.lib()
@@ -816,15 +816,17 @@ def test_rb8_every_tile_width_and_part_count(kind, m, n, k, bias):
     outs = {}
     try:
         lib.ao_gemm8_set_variant(101)  # always the weight-streaming kernel
-        for bn in (32, 64, 128):
-            for split in (1, 2, 5, 16):
-                lib.ao_gemm8_set_tuning(1, bn)
-                lib.ao_gemm8_set_tuning(2, split)
-                outs[(bn, split)] = run().clone()
-                assert torch.equal(run(), outs[(bn, split)])
+        for bm in ((64, 128) if m > 64 else (64,)):  # (round 6) slab rows: 64-row slabs serve M > 64 too; 128-row slabs never run M <= 64
+            for bn in (32, 64, 128):
+                for split in (1, 2, 5, 16):
+                    lib.ao_gemm8_set_tuning(3, bm)
+                    lib.ao_gemm8_set_tuning(1, bn)
+                    lib.ao_gemm8_set_tuning(2, split)
+                    outs[(bm, bn, split)] = run().clone()
+                    assert torch.equal(run(), outs[(bm, bn, split)])
     finally:
         lib.ao_gemm8_set_variant(0)
-        for key in (1, 2):
+        for key in (1, 2, 3):
             lib.ao_gemm8_set_tuning(key, 0)
     torch.cuda.synchronize()
     yn = np_from_torch_bf16(next(iter(outs.values())))

@@ -7,6 +7,15 @@ Least squares on log(model / measured) over every single-round form of every cel
 +- 30 % of that fit for the least mean regret of the model's pick (measured time of the pick / the cell's best form).  Prints the constants
 (per slab height: fixed, step by 32 / 64 / 128 columns, meeting <= 4 parts, meeting > 4 parts, gather; then the stream rate in TB/s) and the
 cells where the pick is furthest from the best form.  Host-only: reads the committed measurements.
+
+The grid itself (on the box; 36 forms = slab rows {128, 64} x tile columns {32, 64, 128} x K parts {1, 2, 3, 4, 6, 8}, plus the default):
+
+    FORMS=default; for bm in 128 64; do for bn in 32 64 128; do for s in 1 2 3 4 6 8; do FORMS=$FORMS,bm$bm+bn$bn+s$s; done; done; done
+    python tools/midm_sweep.py --ms 80,96,128,160,192,256,320,384,512 --kinds fp8 --no-core --forms $FORMS > profiles/rb8_grid_r06_fp8.jsonl
+    python tools/midm_sweep.py --ms 128,256,512 --kinds int8 --no-core --forms $FORMS > profiles/rb8_grid_r06_int8.jsonl
+    (one 64-row slab, M = 40 / 48 / 64, the bm64 forms only: profiles/rb8_grid_r06_small.jsonl)
+and the check of the refitted plan next to 128-row slabs forced, 64-row slabs forced and hipBLASLt (profiles/midm_rb8_plan_r06.jsonl):
+    python tools/midm_sweep.py --ms 80,96,128,160,192,256,384,512,768,1024 --kinds fp8,int8 --check --forms default,bm128,bm64
 """
 import json,collections,math,re,sys
 import numpy as np
