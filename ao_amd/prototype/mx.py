@@ -17,7 +17,8 @@ import torch
 
 from .. import ops
 
-__all__ = ["ScaleCalculationMode", "to_mx", "mx_dequantize", "_to_mxfp8_then_scaled_grouped_mm", "pad_token_groups", "unpad_token_groups"]
+__all__ = ["ScaleCalculationMode", "to_mx", "mx_dequantize", "_to_mxfp8_then_scaled_grouped_mm", "pad_token_groups", "unpad_token_groups",
+           "to_blocked", "mx_block_rearrange_2d_M_groups_cuda", "compute_blocked_scale_offsets_for_M_groups"]
 
 BLOCK = 32
 
@@ -192,3 +193,24 @@ def unpad_token_groups(padded_output: torch.Tensor, original_group_end_offsets: 
                        padded_group_start_offsets: torch.Tensor, num_tokens: int, alignment_size: int = 32) -> torch.Tensor:
     """Mirror of torchao.prototype.moe_training.utils.unpad_token_groups (utils.py:448-490)."""
     return ops.fused_unpad_token_groups(padded_output, original_group_end_offsets, padded_group_start_offsets, num_tokens, alignment_size)
+
+
+def to_blocked(input_matrix: torch.Tensor, use_triton_kernel: bool = False) -> torch.Tensor:
+    """Mirror of torchao.prototype.mx_formats.utils.to_blocked (utils.py:31-72): E8M0 scales [H, W] -> the flat 128 x 4 blocked layout,
+    32 ceil(H / 128) x 16 ceil(W / 4) bytes.  `use_triton_kernel` picks between two implementations of the same bytes upstream; one kernel here."""
+    return ops.mx_to_blocked(input_matrix)
+
+
+def mx_block_rearrange_2d_M_groups_cuda(scales_tensor: torch.Tensor, input_offsets: torch.Tensor, chunks_per_tb: int = 4) -> torch.Tensor:
+    """Mirror of torchao.prototype.moe_training.kernels.mxfp8.quant.mx_block_rearrange_2d_M_groups_cuda (quant.py:1183-1225): per token group,
+    the blocked layout of its scales at the row where the previous groups' 128-row-padded blocks end."""
+    return ops.mx_block_rearrange_2d_M_groups(scales_tensor, input_offsets, chunks_per_tb)
+
+
+def compute_blocked_scale_offsets_for_M_groups(offsets: torch.Tensor):
+    """Mirror of quant.py:309-335: (group sizes, starting row of every group's scales after padding each group to 128 rows, leading 0) --
+    where mx_block_rearrange_2d_M_groups_cuda put each group.  Index arithmetic on [num_groups] integers (device-side torch ops, no sync)."""
+    zero = torch.zeros(1, dtype=offsets.dtype, device=offsets.device)
+    group_sizes = torch.diff(offsets, prepend=zero)
+    starts = torch.cumsum((group_sizes + 127) // 128 * 128, dim=0)
+    return group_sizes, torch.cat([zero, starts.to(offsets.dtype)])

@@ -242,6 +242,13 @@ def test_blocked_m_groups_kernel_matches_reference(golden_blocked, case):
     torch.full((d[f"mg_{case}_out"].size + 4096,), 0xAB, dtype=torch.uint8, device="cuda")  # dirty the allocator's block
     got = ops.mx_block_rearrange_2d_M_groups(s, offs)
     assert got.shape == d[f"mg_{case}_out"].shape and np.array_equal(got.cpu().numpy(), d[f"mg_{case}_out"])
+    # the mirror of the reference's Python entry points: same bytes, and the start rows the reference's torch restatement returns
+    from ao_amd.prototype import mx
+
+    assert torch.equal(mx.mx_block_rearrange_2d_M_groups_cuda(s, offs), got)
+    sizes, starts = mx.compute_blocked_scale_offsets_for_M_groups(offs)
+    assert np.array_equal(starts.cpu().numpy().astype(np.int64), d[f"mg_{case}_starts"])
+    assert np.array_equal(sizes.cpu().numpy(), np.diff(d[f"mg_{case}_offs"], prepend=0))
 
 
 @pytest.mark.gpu
