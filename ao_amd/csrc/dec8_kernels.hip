@@ -360,7 +360,7 @@ int launch_dec8(const Dec8Args& p, const Dec8Shape& s, hipStream_t stream) {
   return AO_ERR_INVALID_ARGUMENT;
 }
 
-// Whether the straight-line decode kernel takes this problem: M <= 16, the codes of the activation within 64 KiB of LDS,
+// Whether the straight-line decode kernel takes this problem: M <= 16, the codes of the activation + the slabs within the CU's LDS,
 // K = 128 x depth x waves.  A function of the shape only, so that the fused (cast inside) and the two-launch forms of one linear pick
 // the same wave split and give the same bits.
 bool dec8_takes_shape(int64_t M, int64_t N, int64_t K, Dec8Shape* shape) {
@@ -369,8 +369,15 @@ bool dec8_takes_shape(int64_t M, int64_t N, int64_t K, Dec8Shape* shape) {
   Dec8Shape s;
   const int forced = (g_dec8_mode > 200 && g_dec8_mode <= 208) ? g_dec8_mode - 200 : 0;
   if (!dec8_shape(K, forced, &s)) return false;
-  if (dec8_lds(M, K, s.waves) > 64 * 1024 + 24 * 1024) return false;  // x codes <= 64 KiB (the old fused kernel's bound) + slabs
-  if (M * (K + 16) > 64 * 1024) return false;
+  // Round 6: the activation codes may fill the CU's 160 KiB of LDS (one workgroup per CU from ~80 KiB on).  Rounds 4 - 5 stopped at 64 KiB of
+  // codes (the fused-cast kernel's bound; variant 293 keeps it for A/B), which sent M = 8 .. 16 on K = 8192 to the per-tile streaming kernel:
+  // qkv shard 1280 x 8192 9.1 - 10.6 us -> 5.6 - 6.4, gate_up shard 19 - 21 -> 15.6 - 17.5, qkv 6144 x 4096 at M = 16 11.8 -> 8.9,
+  // down 4096 x 14336 at M = 4 .. 8 16.3 - 17.3 -> 12.8 - 15.7, no cell slower (profiles/dec8_lds_cap_ab_r06.jsonl, cold weights, same bits)
+  if (g_dec8_mode == 293) {
+    if (dec8_lds(M, K, s.waves) > 64 * 1024 + 24 * 1024 || M * (K + 16) > 64 * 1024) return false;
+  } else if (dec8_lds(M, K, s.waves) > 160 * 1024) {
+    return false;
+  }
   if (shape != nullptr) *shape = s;
   return true;
 }

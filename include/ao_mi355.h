@@ -128,7 +128,9 @@ int ao_int4_set_tuning(int waves_per_block, int mode);
  * 32 = the phase-interleaved 256x256 kernel, 33 = its 256x128 form (gemm8_p8h_kernel); 100 / 101 / 102 = the fp8 weight-streaming kernel never / always / always with 64-column tiles; 103 = its round-3 wave arrangement (1 x 8);
  * MXFP8 grouped mm: 110 always the LDS-staged kernels, 111 never (A-stationary / per-tile kernels); decode-size groups: 113 one workgroup
  * per tile instead of the stream-K kernel, 129 the stream-K kernel's per-step-scales form (what K % 512 != 0 takes) on every K
- * (ao_amd/csrc/rb8_kernels.hip).  Thread-local, like ao_int4_set_tuning. */
+ * (ao_amd/csrc/rb8_kernels.hip); the decode kernel (dec8_kernel): 201 .. 208 its ring depth, 290 half-line loads, 291 / 292 never /
+ * always 8-row tiles, 293 the round-4 bound of 64 KiB of activation codes (product since round 6: the CU's whole LDS), 299 never;
+ * 300 / 301 / 31S the register-ring mid-M kernel never / wherever the shape allows / with S K parts.  Thread-local, like ao_int4_set_tuning. */
 int ao_gemm8_set_variant(int variant);
 /* Profiling only, key / value (every setting computes the SAME result as the product; 0 = product rule; thread-local):
  *   key 1  column-tile width of the rowwise weight-streaming kernel (rb8_kernel): 32, 64 or 128

@@ -8,11 +8,15 @@ import pytest
 from ao_amd import _lib
 
 TABLE = [
-    # decode: the straight-line register-ring kernel while the activation slab fits (M (K + 16) <= 64 KiB), else the round-3 per-tile kernel
+    # decode: the straight-line register-ring kernel while the activation codes + slabs fit the CU's 160 KiB of LDS (round 6; rounds 4 - 5:
+    # 64 KiB of codes), else the round-3 per-tile kernel
     ((1, 7168, 8192), "dec8_kernel"),
     ((4, 8192, 1024), "dec8_kernel"),
     ((16, 8192, 1024), "dec8_kernel"),
-    ((16, 7168, 8192), "stream8_kernel"),
+    ((16, 7168, 8192), "dec8_kernel"),     # 128.25 KiB of codes + 8 slabs: 154.8 KiB
+    ((8, 4096, 14336), "dec8_kernel"),     # 16 waves: 112 KiB + 16 slabs + partials
+    ((9, 4096, 14336), "stream8_kernel"),
+    ((16, 4096, 14336), "stream8_kernel"),
     # 17 .. 32 rows on long K: the register-ring mid-M kernel; short K stays with the per-tile kernel
     ((17, 1280, 8192), "mid8_kernel"),
     ((32, 1280, 8192), "mid8_kernel"),
