@@ -952,16 +952,20 @@ def fp8_int4_dynamic_fits(m: int, n: int, k: int) -> bool:
     return bool(_lib.lib().ao_fp8_int4_dynamic_fits(m, n, k))
 
 
-def fp8_int4_act_linear(x, qdata, scale_and_zero, group_size, bias=None):
+def fp8_int4_act_linear(x, qdata, scale_and_zero, group_size, bias=None, fused=None):
     """Float8DynamicActivationInt4WeightConfig's F.linear on a 2-D bf16 activation (int4_tensor.py:205-235): per-row e4m3 cast of x, then
-    mslk.f8i4bf16_rowwise's contract.  Decode sizes run cast + matmul in ONE launch (round 4: the stand-alone cast cost this path 28 %);
+    mslk.f8i4bf16_rowwise's contract.  One row runs cast + matmul in ONE launch (round 4: the stand-alone cast cost this path 28 %);
     everything else ao_fp8_quantize_rowwise + ao_fp8_int4_linear.  Same bits either way."""
     dev = _require_gpu("fp8_int4_act_linear", x, qdata, scale_and_zero)
     if x.dim() != 2 or x.dtype != torch.bfloat16:
         raise RuntimeError(f"fp8_int4_act_linear: x must be a 2-D bfloat16 tensor, got {tuple(x.shape)} {x.dtype}")
     m, k = x.shape
     n = qdata.shape[0] * 8
-    if not fp8_int4_dynamic_fits(m, n, k):
+    # (round 6, tools/bench_fp8_int4.py --batch 1 .. 16, the 160 linears of a Llama-3-8B token, profiles/f3_fused_vs_cast_r06.jsonl: the
+    # fused launch is 1.23 x ahead of cast + matmul at one row, level at two, and 1.17 / 1.32 / 1.72 x BEHIND at 3 / 4 / 8 rows -- every
+    # workgroup casts all rows itself -- so it serves one row only)
+    # `fused`: None = that rule; True = the one-launch form wherever the kernel takes the shape (tests, A/B)
+    if not fp8_int4_dynamic_fits(m, n, k) or not (fused if fused is not None else m == 1):
         xq, xs = fp8_quantize_rowwise(x.contiguous())
         return fp8_int4_linear(xq, xs, qdata, scale_and_zero, group_size, bias)
     if qdata.dim() != 4 or qdata.dtype != torch.int32 or scale_and_zero.dtype != torch.bfloat16 or qdata.shape[1] * 128 != k \
@@ -1057,14 +1061,15 @@ def dynamic_linear_fits(m: int, n: int, k: int) -> bool:
 
 
 def dynamic_linear_preferred(m: int, n: int, k: int) -> bool:
-    """Whether the fused kernel beats cast + matmul: every workgroup (one per 16 output columns) casts the whole activation
-    itself, so the redundant work must stay small.  Measured on Llama-3-8B int8 (us, cast + matmul vs fused): M = 1 qkv 10.3 vs
-    8.2, o 8.9 vs 6.9, down 21.5 vs 17.4, gate_up 26.5 vs 26.5; M = 2 qkv 10.6 vs 8.9 but gate_up 27.0 vs 28.5; M = 4 gate_up
-    28.5 vs 35.1.  16 < M <= 256 (round 4, mid8_kernels.hip: the rows of the cast are shared out among the workgroups of the
-    launch through a ticket counter) is reachable but NOT preferred: three dependent memory round trips (ticket, the row, written
-    through and counted) sit in front of every workgroup's k loop -- measured + 15 .. 20 us per linear against + 4 .. 5 for the
-    stand-alone cast (profiles/mid8_sweep_r04.txt)."""
-    return m <= 16 and dynamic_linear_fits(m, n, k) and m * (n // 16) <= 1024
+    """Whether the fused kernel beats cast + matmul: every workgroup (one per 16 output columns) casts the whole activation itself, so
+    the redundant work grows with M while the stand-alone cast stays one ~3 us launch.  Round 6 re-measured both forms of the whole linear
+    on a bf16 activation (tools/bench_dec8.py --linear --all-shapes, 8 shapes x int8 / fp8 x M = 1 .. 16, cold weights,
+    profiles/dyn_vs_two_r06.jsonl): fused wins at M = 1 on every shape (qkv shard 5.0 vs 7.5 us, o 3.7 vs 6.2, gate_up 13.7 vs 15.7, down
+    4096 x 14336 15.8 vs 16.9), M = 2 is level (+- 5 %), and from 3 rows on cast + matmul is 1.2 - 1.6 x ahead wherever the rule of
+    rounds 2 - 5 (M x N / 16 <= 1024) still took the fused kernel (qkv shard at M = 6: 14.4 vs 9.1 us) -- the decode matmul got faster
+    since (full-line ring, 8-row tiles, the LDS bound), the in-kernel cast did not.  16 < M <= 256 (mid8_kernels.hip) is reachable but was
+    never preferred (profiles/mid8_sweep_r04.txt)."""
+    return m == 1 and dynamic_linear_fits(m, n, k)
 
 
 def int8_linear(x2: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, bias=None) -> torch.Tensor:

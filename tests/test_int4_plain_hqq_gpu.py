@@ -145,8 +145,10 @@ def test_fp8_int4_kernel_matches_oracle(m, g):
         # round 4: the one-op form on the bf16 activation (cast fused into the launch at M <= 16: the wave-private form at M = 1, the
         # workgroup-wide cast up to 16 rows; two launches beyond) gives the bits of cast + ao_fp8_int4_linear
         x_t = torch_bf16_from_f32(x).to(DEV)
-        one = ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g, torch_bf16_from_f32(bias).to(DEV))
+        one = ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g, torch_bf16_from_f32(bias).to(DEV), fused=True)
         assert ops.fp8_int4_dynamic_fits(m, n, k) == (m <= 16)
+        # (the product rule since round 6: fused at one row, two launches beyond -- the same bits)
+        assert np.array_equal(np_from_torch_bf16(ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g, torch_bf16_from_f32(bias).to(DEV))), y)
         assert np.array_equal(np_from_torch_bf16(one), y), (symmetric, m, g, "fused cast != cast + matmul")
 
 
@@ -164,8 +166,8 @@ def test_fp8_int4_fused_cast_at_llama_sizes(m, n, k):
     xq_t, xs_t = ops.fp8_quantize_rowwise(x_t)
     two = ops.fp8_int4_linear(xq_t, xs_t, qdata_tp, sz, g)
     assert ops.fp8_int4_dynamic_fits(m, n, k)
-    one = ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g)
-    assert torch.equal(one, two)
+    one = ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g, fused=True)
+    assert torch.equal(one, two) and torch.equal(ops.fp8_int4_act_linear(x_t, qdata_tp, sz, g), two)
     xq, xs = F8.quantize_rowwise(x)
     want = P.fp8_int4_linear(F8.e4m3_to_f32(xq), xs, wt.qdata.cpu().numpy(), np_from_torch_bf16(wt.scale), np_from_torch_bf16(wt.zero_point), g)
     assert _rel(np_from_torch_bf16(one), want) <= 1e-3

@@ -45,18 +45,30 @@ def graph_time(calls, reps=5):
     return best
 
 
+def _cast(quant, x, wt, wsct):
+    xq, xs = quant(x)
+    return xq, wt, xs, wsct
+
+
+def _int8_cast_mm(x, wq, wsc):
+    xq, xs = ops.int8_quantize_rowwise(x)
+    return ops.int8_scaled_mm(xq, xs, wq, wsc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ms", default="1,4,16")
     ap.add_argument("--variants", default="0,299,290,201,202,204,207,208")
     ap.add_argument("--kinds", default="fp8,int8")
+    ap.add_argument("--linear", action="store_true", help="also time the whole linear on a bf16 activation: cast + matmul (two launches) next to the fused kernel")
+    ap.add_argument("--all-shapes", action="store_true", help="both shape families for both kinds")
     args = ap.parse_args()
     lib = _lib.lib()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     for kind in args.kinds.split(","):
         quant = ops.fp8_quantize_rowwise if kind == "fp8" else ops.int8_quantize_rowwise
-        for name, n, k in SHAPES[kind]:
+        for name, n, k in (SHAPES["fp8"] + SHAPES["int8"] if args.all_shapes else SHAPES[kind]):
             copies = max(2, -(-(300 << 20) // (n * k)))
             ws = []
             for _ in range(copies):
@@ -95,6 +107,13 @@ def main():
                         t = graph_time(two)
                         rec["mm_us"] = round(t * 1e6, 2)
                         rec["mm_TBps"] = round(n * k / t / 1e12, 3)
+                        if args.linear:
+                            if kind == "fp8":
+                                lin = [lambda wq=wq, wsc=wsc: ops.fp8_scaled_mm(*_cast(ops.fp8_quantize_rowwise, x, wq.t(), wsc.t())) for wq, wsc in ws]
+                            else:
+                                lin = [lambda wq=wq, wsc=wsc: _int8_cast_mm(x, wq, wsc) for wq, wsc in ws]
+                            rec["cast_mm_us"] = round(graph_time(lin) * 1e6, 2)
+                            rec["preferred"] = bool(ops.dynamic_linear_preferred(m, n, k))
                         if ops.dynamic_linear_fits(m, n, k):
                             t = graph_time(one)
                             rec["fused_us"] = round(t * 1e6, 2)

@@ -168,8 +168,8 @@ def main():
                 qdata_tp, sz = wt.tile_packed()
                 xq, xs = ops.fp8_quantize_rowwise(x)
                 two = ops.fp8_int4_linear(xq, xs, qdata_tp, sz, g)
-                one = ops.fp8_int4_act_linear(x, qdata_tp, sz, g)
-                ok = torch.equal(one, two) and torch.equal(ops.fp8_int4_linear(xq, xs, qdata_tp, sz, g), two) and torch.equal(ops.fp8_int4_act_linear(x, qdata_tp, sz, g), one)
+                one = ops.fp8_int4_act_linear(x, qdata_tp, sz, g, fused=True)  # (the one-launch form wherever the kernel takes the shape)
+                ok = torch.equal(one, two) and torch.equal(ops.fp8_int4_linear(xq, xs, qdata_tp, sz, g), two) and torch.equal(ops.fp8_int4_act_linear(x, qdata_tp, sz, g, fused=True), one)
                 info = {"g": g, "fused_equal": bool(torch.equal(one, two))}
             elif kind == "mxdyn":
                 e = int(rng.choice([1, 2, 8]))
