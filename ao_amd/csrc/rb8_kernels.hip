@@ -1341,7 +1341,7 @@ int mxfp8_grouped_rb(const uint8_t* a, const uint8_t* a_scale, const uint8_t* b,
   // Slab capacity from the average group size (the sizes themselves live on the device): 64 rows for decode-size groups (two
   // workgroups per CU; a group's real m-tile count is found on the device), else 128.
   const int64_t groups = (offs != nullptr ? E : 1);
-  const int bm = (M_total <= 48 * groups) ? 64 : 128;
+  const int bm = (g_rb8_bm == 64 || g_rb8_bm == 128) ? g_rb8_bm : (M_total <= 48 * groups) ? 64 : 128;  // (tuning key 3 forces a height: A/B)
   p.slabs = (int)std::max<int64_t>(1, (std::min(rows_hint, M_total) + bm - 1) / bm);
   // 64-column tiles when 128-column ones would not give every CU a workgroup even if every group had tokens
   // (cutting K into 2 - 4 parts that meet through the split-K workspace -- finer work items for the last round when few experts
@@ -1402,7 +1402,7 @@ int fp8_rowwise_grouped_rb(const uint8_t* a, const uint8_t* b, const float* scal
   Rb8Args p{};
   p.a = a; p.b = b; p.scale_a = scale_a; p.scale_b = scale_b; p.y = out; p.offs = offs;
   p.M = (int)M_total; p.N = (int)N; p.K = (int)K; p.E = (int)E;
-  const int bm = (M_total <= 48 * E) ? 64 : 128;
+  const int bm = (g_rb8_bm == 64 || g_rb8_bm == 128) ? g_rb8_bm : (M_total <= 48 * E) ? 64 : 128;
   p.slabs = (int)std::max<int64_t>(1, (M_total + bm - 1) / bm);
   if (bm == 64) return launch_rb8<4, RB8_FP8_GROUPED, 4>(p, 1, stream);
   return (((N + 127) / 128) * E * p.slabs < 400) ? launch_rb8<4, RB8_FP8_GROUPED, 8>(p, 1, stream) : launch_rb8<8, RB8_FP8_GROUPED, 8>(p, 1, stream);
