@@ -854,9 +854,13 @@ __global__ __launch_bounds__(512) void gemm8_p8h_kernel(P8Args p) {
 //   qkv shard 1280 x 8192: M = 1024 29.5 -> 27.2 (27.8), M = 2048 45.2 -> 33.1 (42.3); down_proj 4096 x 14336: M = 512 48.0 -> 42.0 (49.4),
 //   768 71.6 -> 58.1 (76.3), 1024 72.2 -> 62.5 (76.7); gate_up shard 7168 x 8192 at M = 512: 44.6 -> 42.6 (48.0).
 // At K <= 4096 the parts lose in every cell (a part's loop is then shorter than its meeting), as do grids below 128 workgroups.
+// Round 6, off the power-of-two grid (profiles/midm_offgrid_r06.jsonl, M = 192 .. 1536 x 9 forms x fp8 / int8): the row bound was 512 because the
+// grid's next point down was 256 -- with two tile rows (257 .. 511 rows) the parts win as well: down_proj 4096 x 14336 at M = 320 / 384 / 448
+// 44.1 / 45.9 / 46.6 (weight-streaming kernel) -> 39.2 / 39.1 / 40.4 with 4 parts, gate_up shard 42.1 / 42.8 / 43.0 -> 38.8 / 39.7 / 39.5 with 2
+// (int8 the same); with ONE tile row (M = 192) 5 % ahead on the gate_up shard and 17 % behind on down_proj -> not taken.
 int p8h_split_rule(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128);
-  if (K < 8192 || M < 512 || tiles > 128) return 1;
+  if (K < 8192 || M <= 256 || tiles > 128) return 1;
   const int64_t S = std::min<int64_t>(4, 256 / tiles);
   return (S >= 2 && tiles * S >= 128) ? (int)S : 1;
 }
@@ -956,9 +960,15 @@ bool gemm8_p8_fits(int64_t M, int64_t N, int64_t K) { return K % 128 == 0 && N %
 // above 128 rows.  profiles/p8h_sweep_r05.jsonl (fp8, cold weights, 8 shapes x M = 256 .. 2048): inside the band it is ahead of every other
 // kernel of the library in all 14 cells (1.1 - 1.5 x) and of hipBLASLt in 13 (o 8192 x 1024 at M = 1024: 0.98); at exactly 128 tiles it loses
 // to the weight-streaming kernel in all 4 cells measured, below that by more.
+// Round 6 (profiles/midm_offgrid_r06.jsonl): on that grid M was a multiple of 256, so the weight-streaming kernel's 128-row slabs always needed a
+// second round of the chip inside the band.  With an odd count of 128-row slabs they may not (qkv 6144 x 4096 at M = 576 / 640: 3 x 48 = 144 tiles
+// here, 5 x 48 = 240 slabs there): 29.5 / 29.3 us here against 24.7 / 24.5 streaming (hipBLASLt 26.2; int8 30.9 / 31.3 against 24.9 / 25.3) -- such
+// shapes stay with the weight-streaming kernel (measured at K = 4096; shorter K not measured and left as it was).
 bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K) {
-  const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128);
-  return M > 128 && gemm8_p8_fits(M, N, K) && ((tiles > 128 && tiles <= 256) || p8h_split_rule(M, N, K) > 1);  // (the rule: with K parts, below)
+  const int64_t tiles = ((M + 255) / 256) * ((N + 127) / 128), slabs = ((M + 127) / 128) * ((N + 127) / 128);
+  if (M <= 128 || !gemm8_p8_fits(M, N, K)) return false;
+  if (p8h_split_rule(M, N, K) > 1) return true;  // (the rule: with K parts, above)
+  return tiles > 128 && tiles <= 256 && !(slabs <= 256 && K >= 4096);
 }
 int gemm8_p8h_parts(int64_t M, int64_t N, int64_t K) { return p8h_split_rule(M, N, K); }  // (product rule; host logic only)
 void gemm8_p8_set_group_rows(int v) { g_p8_group_rows = v; }

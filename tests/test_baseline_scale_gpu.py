@@ -19,7 +19,7 @@ from oracle import bf16, c_ref, fp8_ref as F, int4_ref as R, int8_ref as I, mx_r
 
 pytestmark = pytest.mark.gpu
 
-from ao_amd import ops  # noqa: E402
+from ao_amd import _lib, ops  # noqa: E402
 
 DEV = "cuda"
 
@@ -188,6 +188,38 @@ def test_fp8_rowwise_linear_m2048_vs_oracle(n, k):
     got = np_from_torch_bf16(y[ri][:, ci])
     assert _rel(got, y_ref) <= 1e-3
     assert np.all(np.abs(got - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -14)
+
+
+# Row counts off the power-of-two grid, where round 6 moved dispatch seams (profiles/midm_offgrid_r06.jsonl): two tile rows with K parts on the
+# 256 x 128 kernel (ragged last tile row), an odd count of 128-row slabs on the weight-streaming kernel, the quantisation hole at 1152 rows.
+OFF_GRID = [(320, 4096, 14336, "gemm8_p8h_kernel"), (384, 7168, 8192, "gemm8_p8h_kernel"), (449, 7168, 8192, "gemm8_p8h_kernel"),
+            (576, 6144, 4096, "rb8_kernel"), (640, 6144, 4096, "rb8_kernel"), (1152, 7168, 8192, "gemm8_dma_kernel<128x128>")]
+
+
+@pytest.mark.parametrize("int8", [0, 1])
+@pytest.mark.parametrize("m,n,k,kernel", OFF_GRID)
+def test_8bit_linear_off_grid_rows_vs_oracle(m, n, k, kernel, int8):
+    """float8_tensor.py:410-458 / int8_tensor.py:305-359 through the default dispatch at row counts between the tuned grid points; the kernel each
+    takes is asserted (a moved rule has to show up here); int8 bit for bit, fp8 within 1e-3."""
+    assert _lib.lib().ao_gemm8_kernel_name(int8, m, n, k).decode() == kernel
+    x = _randn_bf16((m, k), n + m, 1.0, DEV)
+    w = _randn_bf16((n, k), k + m, 0.02, DEV)
+    rows, cols = _sample(n, m, n + k + m)
+    ri, ci = torch.from_numpy(rows).to(DEV), torch.from_numpy(cols).to(DEV)
+    if int8:
+        wq, ws = ops.int8_quantize_rowwise(w)
+        xq, xs = ops.int8_quantize_rowwise(x)
+        y = ops.int8_scaled_mm(xq, xs, wq, ws)
+        y_ref = c_ref.int8_dynamic_linear(_bits(x[ri]), wq[ci].cpu().numpy(), ws.flatten()[ci].cpu().numpy())
+        assert np.array_equal(_bits(y[ri][:, ci]), y_ref)
+    else:
+        wq, ws = ops.fp8_quantize_rowwise(w)
+        xq, xs = ops.fp8_quantize_rowwise(x)
+        y = ops.fp8_scaled_mm(xq, wq.t(), xs, ws.t())
+        y_ref = bf16.from_bits(c_ref.fp8_rowwise_linear(_bits(x[ri]), wq.view(torch.uint8)[ci].cpu().numpy(), ws.flatten()[ci].cpu().numpy()))
+        got = np_from_torch_bf16(y[ri][:, ci])
+        assert _rel(got, y_ref) <= 1e-3
+        assert np.all(np.abs(got - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -14)
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 1024, 8192), (1, 8192, 3584), (4, 4096, 4096), (2, 256, 1024)])

@@ -45,8 +45,17 @@ TABLE = [
     ((1024, 1280, 8192), "gemm8_p8h_kernel"),
     ((2048, 1280, 8192), "gemm8_p8h_kernel"),
     ((768, 4096, 14336), "gemm8_p8h_kernel"),
-    ((256, 7168, 8192), "rb8_kernel"),
+    ((256, 7168, 8192), "rb8_kernel"),           # one tile row: never with parts
     ((128, 28672, 4096), "rb8_kernel"),          # 128 rows: never
+    # round 6 (profiles/midm_offgrid_r06.jsonl): two tile rows take the parts as well (was: from 512 rows) ...
+    ((320, 4096, 14336), "gemm8_p8h_kernel"),
+    ((384, 7168, 8192), "gemm8_p8h_kernel"),
+    ((320, 1280, 8192), "rb8_kernel"),           # 20 tiles x 4 parts: below 128 workgroups
+    ((448, 8192, 3584), "rb8_kernel"),           # K < 8192
+    # ... and an odd count of 128-row slabs that fits one round of the chip stays with the weight-streaming kernel at K >= 4096
+    ((576, 6144, 4096), "rb8_kernel"),           # 3 x 48 = 144 tiles of 256 x 128, but 5 x 48 = 240 slabs
+    ((640, 6144, 4096), "rb8_kernel"),
+    ((768, 6144, 4096), "gemm8_p8h_kernel"),     # 6 x 48 slabs: a second round
     # two rounds of 128 x 128 tiles and more: the tiled GEMMs -- 256 x 256 phase-interleaved from 160 such tiles on (from 128 at short K / > 512 small tiles)
     ((1024, 28672, 4096), "gemm8_p8p_kernel"),  # 448 full tiles: the persistent form (round 6)
     ((2048, 8192, 4096), "gemm8_p8_kernel"),   # 256 tiles of 256 x 256
