@@ -369,6 +369,48 @@ bool dec8_takes_shape(int64_t M, int64_t N, int64_t K, Dec8Shape* shape) {
   Dec8Shape s;
   const int forced = (g_dec8_mode > 200 && g_dec8_mode <= 208) ? g_dec8_mode - 200 : 0;
   if (!dec8_shape(K, forced, &s)) return false;
+  // Round 6: 9 .. 16 rows pick the ring by occupancy.  The deepest ring (round 4's rule, measured at M = 1) means the fewest waves per workgroup;
+  // with many rows the activation codes cap the workgroups per CU, and on narrow weights there are few workgroups to begin with -- o shard
+  // 8192 x 1024 ran ONE wave x 2 workgroups per CU.  Resident waves per CU = waves x min(workgroups LDS admits, workgroups the grid offers);
+  // among the rings that do not add a round of the chip: the deepest with >= 8 resident waves (two per SIMD; asking for 12 cost 3 - 7 % on
+  // the qkv shard 1280 x 8192 and on 8192 x 3584), else the one with the most.  Measured
+  // (profiles/dec8_depth_tuned_r06.jsonl, other_shapes_dec8_r06.jsonl, cold weights, M = 9 / 12 / 16): o shard 8192 x 1024 5.1 / 5.3 / 6.1 ->
+  // 4.2 us, o 4096^2 6.3 / 6.6 / 7.2 -> 6.0 / 6.0 / 6.4, 8192 x 2048 6.7 - 7.8 -> 5.5 - 5.8, 3584^2 5.5 - 6.2 -> 5.0 - 5.3, K = 5120 at
+  // 14 - 16 rows (5 waves alone on a CU) 24.7 - 25.9 -> 21.9 - 22.3.
+  if (forced == 0 && !s.loop && M >= 9 && g_dec8_mode != 293) {
+    const int ksteps = (int)(K / 128);
+    const int64_t wgs = N / 16, offered = std::max<int64_t>(1, wgs / 256);
+    static const int depths[] = {8, 7, 4, 2, 1};
+    int best_d = 0, best_res = -1;
+    int64_t best_rounds = 0;
+    bool settled = false;
+    for (int pass = 0; pass < 2 && !settled; ++pass) {  // pass 0: the fewest rounds any ring reaches; pass 1: pick among those
+      for (int d : depths) {
+        if (ksteps % d != 0) continue;
+        const int w = ksteps / d;
+        if (w < 1 || w > 16) continue;
+        const size_t lds = dec8_lds(M, K, w);
+        if (lds > 160 * 1024) continue;
+        const int64_t cap = (int64_t)((160 * 1024) / lds), rounds = (wgs + 256 * cap - 1) / (256 * cap);
+        const int res = (int)(w * std::min<int64_t>(cap, offered));
+        if (pass == 0) {
+          if (best_rounds == 0 || rounds < best_rounds) best_rounds = rounds;
+          continue;
+        }
+        if (rounds != best_rounds) continue;
+        if (res >= 8) {  // depths run deepest first
+          best_d = d;
+          settled = true;
+          break;
+        }
+        if (res > best_res) {
+          best_res = res;
+          best_d = d;
+        }
+      }
+    }
+    if (best_d != 0) s = Dec8Shape{ksteps / best_d, best_d, false};
+  }
   // Round 6: the activation codes may fill the CU's 160 KiB of LDS (one workgroup per CU from ~80 KiB on).  Rounds 4 - 5 stopped at 64 KiB of
   // codes (the fused-cast kernel's bound; variant 293 keeps it for A/B), which sent M = 8 .. 16 on K = 8192 to the per-tile streaming kernel:
   // qkv shard 1280 x 8192 9.1 - 10.6 us -> 5.6 - 6.4, gate_up shard 19 - 21 -> 15.6 - 17.5, qkv 6144 x 4096 at M = 16 11.8 -> 8.9,

@@ -32,6 +32,7 @@ bool gemm8_p8h_band(int64_t M, int64_t N, int64_t K);
 int gemm8_p8h_parts(int64_t M, int64_t N, int64_t K);
 void rb8_plan_query(int64_t M, int64_t N, int64_t K, int* bm, int* bn, int* split);
 bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K);
+bool rb8_small_m_preferred(int64_t M, int64_t N, int64_t K);  // rb8_kernels.hip: 8 .. 64 rows on weights the decode kernels leave
 void rb8_set_wave_grid(bool two_by_four);  // rb8_kernels.hip
 void rb8_set_tuning(int bn, int split, int ablate);
 void rb8_set_slab_rows(int rows);
@@ -509,9 +510,10 @@ extern "C" int ao_int8_scaled_mm(const int8_t* xq, const float* x_scale, const i
     return dec8_scaled(true, xq, x_scale, wq, w_scale, bias, y, M, N, K, (hipStream_t)stream);  // round 4: full-line register ring
   if (M > 16 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only && g_gemm8_tm == 0 && !g_gemm8_force_regstage && mid8_takes(M, N, K))
     return mid8_scaled(true, xq, x_scale, wq, w_scale, bias, y, M, N, K, (hipStream_t)stream);  // round 4: 16 < M <= 256, few output tiles
-  if (N % 16 == 0 && K % 128 == 0 && M <= 32 && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only)
+  const bool rb_small = !g_gemm8_tiled_only && g_gemm8_tm == 0 && !g_gemm8_force_regstage && rb8_small_m_preferred(M, N, K);  // round 6
+  if (N % 16 == 0 && K % 128 == 0 && M <= 32 && !rb_small && !fp8_rowwise_rb_forced() && !g_gemm8_tiled_only)
     return int8_scaled_stream(xq, wq, x_scale, w_scale, bias, y, M, N, K, (hipStream_t)stream);
-  if (N % 16 == 0 && fp8_rowwise_rb_preferred(M, N, K)) return int8_scaled_rb(xq, wq, x_scale, w_scale, bias, y, M, N, K, (hipStream_t)stream);
+  if (N % 16 == 0 && (rb_small || fp8_rowwise_rb_preferred(M, N, K))) return int8_scaled_rb(xq, wq, x_scale, w_scale, bias, y, M, N, K, (hipStream_t)stream);
   Gemm8Args p{reinterpret_cast<const uint8_t*>(xq), reinterpret_cast<const uint8_t*>(wq), x_scale, w_scale, bias, y,
               (int)M, (int)N, (int)K};
   return launch_gemm8<EPI_INT8_SCALED>(p, (hipStream_t)stream);
@@ -523,14 +525,15 @@ extern "C" const char* ao_gemm8_kernel_name(int int8, int64_t M, int64_t N, int6
   if (M <= 0 || N <= 0 || K <= 0 || K % 16 != 0) return "invalid";
   if (M <= 16 && dec8_takes(M, N, K)) return "dec8_kernel";
   if (M > 16 && mid8_takes(M, N, K)) return "mid8_kernel";
-  const bool rb_shape = N % 16 == 0 && fp8_rowwise_rb_preferred(M, N, K);
+  const bool rb_small = rb8_small_m_preferred(M, N, K);
+  const bool rb_shape = N % 16 == 0 && (rb_small || fp8_rowwise_rb_preferred(M, N, K));
   if (int8) {
-    if (N % 16 == 0 && K % 128 == 0 && M <= 32) return "stream8_kernel";
+    if (N % 16 == 0 && K % 128 == 0 && M <= 32 && !rb_small) return "stream8_kernel";
     if (rb_shape) return "rb8_kernel";
   } else {
     if (N % 16 != 0) return "invalid";
-    const bool rb = rb_shape && M > 32;
-    if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb))) return "stream8_kernel";
+    const bool rb = rb_shape && (M > 32 || rb_small);
+    if (K % 128 == 0 && ((M <= 32 && !rb_small) || (M <= 64 && !rb))) return "stream8_kernel";
     if (rb) return "rb8_kernel";
   }
   if (K % BK != 0) return "gemm8_kernel";  // register-staged tiles (K % 128 != 0)
@@ -616,8 +619,9 @@ extern "C" int ao_fp8_scaled_mm(const uint8_t* a, const uint8_t* b, const float*
   // (round 4, cold weights -- every call of the replay reads another copy: the LDS-staged kernel wins from 33 rows on at every K of the
   // 70B / TP8 shards, down 8192 x 3584 at M = 64: 14.0 us against 20.9 through the per-tile kernel, o 8192 x 1024: 8.5 against 9.2; the
   // round-1 rule -- "only from K >= 4096 at 32 < M <= 64" -- had been measured on ONE re-used weight, i.e. out of the Infinity Cache)
-  const bool rb = fp8_rowwise_rb_preferred(M, N, K) && (M > 32 || fp8_rowwise_rb_forced());
-  if (K % 128 == 0 && (M <= 32 || (M <= 64 && !rb)) && !(fp8_rowwise_rb_forced() && rb) && !g_gemm8_tiled_only)
+  const bool rb_small = !g_gemm8_tiled_only && g_gemm8_tm == 0 && !g_gemm8_force_regstage && rb8_small_m_preferred(M, N, K);  // round 6
+  const bool rb = rb_small || (fp8_rowwise_rb_preferred(M, N, K) && (M > 32 || fp8_rowwise_rb_forced()));
+  if (K % 128 == 0 && ((M <= 32 && !rb_small) || (M <= 64 && !rb)) && !(fp8_rowwise_rb_forced() && rb) && !g_gemm8_tiled_only)
     return fp8_rowwise_stream(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
   if (rb) return fp8_rowwise_rb(a, b, scale_a, scale_b, bias, y, M, N, K, (hipStream_t)stream);
   Gemm8Args p{a, b, scale_a, scale_b, bias, y, (int)M, (int)N, (int)K};

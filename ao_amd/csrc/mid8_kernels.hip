@@ -223,6 +223,10 @@ bool mid8_plan(int64_t M, int64_t N, int64_t K, Mid8Plan* out) {
   for (int64_t s = 1; s <= std::min<int64_t>(groups, 16); ++s)
     if (groups % s == 0 && s <= want) split = (int)s;
   // the meeting's workspace: (S + ceil(S / 4)) parked tiles per output tile
+  // Round 6 (profiles/other_shapes_forms_r06.jsonl): a K whose 512-byte groups do not factor (K = 18944: 37 groups, prime -- one part where 9
+  // were wanted) leaves a few dozen workgroups on the chip: down 3584 x 18944 at M = 24 / 32 took 68 us here against 23 through rb8_kernel.
+  // Refused when the divisors of the group count give less than half the parts the shape would otherwise get.
+  if (!forced && 2 * split < std::min<int64_t>({want, groups, 16})) return false;
   if (split > 1 && base * (split + (split + 3) / 4) * 128 * 16 * mt > (int64_t)kSplitMaxTiles * 128 * 128) return false;
   if (split > 1 && base * (1 + (split + 3) / 4) > kSplitMaxTickets - 8) return false;
   *out = Mid8Plan{mt, split};

@@ -1228,6 +1228,18 @@ bool fp8_rowwise_rb_preferred(int64_t M, int64_t N, int64_t K) {
   return ((N + 127) / 128) * ((M + 127) / 128) <= 256 && !gemm8_p8h_band(M, N, K);
 }
 
+// Round 6, shapes no rule had been fitted on (Llama-2-13B, Qwen2-7B, Llama-3-70B / TP4; profiles/other_shapes_forms_r06.jsonl, cold weights, fp8):
+// what the decode kernels (dec8 / mid8) do not take at 8 .. 64 rows used to fall to the per-tile streaming kernel (up to 32 rows, and up to 64
+// when the weight has more than 256 column tiles).  On weights of 16 MB and more this kernel is ahead there -- gate_up 37888 x 3584 at
+// M = 24 / 32 / 48 / 64: 52 / 58 / 74 / 90 us -> 37 / 38 / 38 / 40; down 5120 x 13824 at M = 8 .. 16: 31 - 34 -> 22 - 23; down 3584 x 18944 at
+// M = 24 / 32 (once mid8 refuses a K it cannot split): 34 -> 23; qkv 4608 x 3584 at 24 / 32: 12.7 / 13.8 -> 10.3; the 70B / TP8 down shard
+// 8192 x 3584 at 24 / 32: 13.7 / 14.2 -> 13.0 / 12.6 -- and level or behind on smaller ones (o 3584 x 3584: 8.8 against 9.6), which stay.
+bool rb8_small_m_preferred(int64_t M, int64_t N, int64_t K) {
+  if (g_fp8_rb_force == 1) return false;
+  if (K % 128 != 0 || N % 16 != 0 || M * K >= (1ll << 32) || N * K >= (1ll << 32)) return false;
+  return M >= 8 && M <= 64 && N * K >= 16000000;
+}
+
 namespace {
 
 // The slab height, tile width and K split of a rowwise launch.  Rounds 1-4 took 128-column tiles where they gave ~half a chip of workgroups

@@ -193,7 +193,11 @@ def test_fp8_rowwise_linear_m2048_vs_oracle(n, k):
 # Row counts off the power-of-two grid, where round 6 moved dispatch seams (profiles/midm_offgrid_r06.jsonl): two tile rows with K parts on the
 # 256 x 128 kernel (ragged last tile row), an odd count of 128-row slabs on the weight-streaming kernel, the quantisation hole at 1152 rows.
 OFF_GRID = [(320, 4096, 14336, "gemm8_p8h_kernel"), (384, 7168, 8192, "gemm8_p8h_kernel"), (449, 7168, 8192, "gemm8_p8h_kernel"),
-            (576, 6144, 4096, "rb8_kernel"), (640, 6144, 4096, "rb8_kernel"), (1152, 7168, 8192, "gemm8_dma_kernel<128x128>")]
+            (576, 6144, 4096, "rb8_kernel"), (640, 6144, 4096, "rb8_kernel"), (1152, 7168, 8192, "gemm8_dma_kernel<128x128>"),
+            # shapes of other models (Qwen2-7B, Llama-2-13B) at decode / small-batch rows, where round 6 moved what the decode kernels leave to
+            # the weight-streaming kernel, and 9 .. 16 rows where the decode kernel now picks its ring by occupancy
+            (24, 37888, 3584, "rb8_kernel"), (64, 37888, 3584, "rb8_kernel"), (8, 5120, 13824, "rb8_kernel"), (24, 3584, 18944, "rb8_kernel"),
+            (16, 8192, 1024, "dec8_kernel"), (12, 4096, 4096, "dec8_kernel"), (16, 15360, 5120, "dec8_kernel"), (9, 3584, 3584, "dec8_kernel")]
 
 
 @pytest.mark.parametrize("int8", [0, 1])

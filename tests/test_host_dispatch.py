@@ -15,8 +15,17 @@ TABLE = [
     ((16, 8192, 1024), "dec8_kernel"),
     ((16, 7168, 8192), "dec8_kernel"),     # 128.25 KiB of codes + 8 slabs: 154.8 KiB
     ((8, 4096, 14336), "dec8_kernel"),     # 16 waves: 112 KiB + 16 slabs + partials
-    ((9, 4096, 14336), "stream8_kernel"),
-    ((16, 4096, 14336), "stream8_kernel"),
+    ((9, 4096, 14336), "rb8_kernel"),      # round 6: what the decode kernels leave at 8 .. 64 rows on weights of >= 16 MB (was stream8_kernel; level
+    ((16, 4096, 14336), "rb8_kernel"),     # here, 1.3 - 2.3 x ahead on the shapes of profiles/other_shapes_forms_r06.jsonl)
+    ((7, 5120, 13824), "dec8_kernel"),     # (7 rows of K = 13824 still fit the decode kernel's LDS; 8 do not)
+    ((8, 5120, 13824), "rb8_kernel"),
+    ((24, 37888, 3584), "rb8_kernel"),     # K < 4096: not mid8; 296 column tiles
+    ((64, 37888, 3584), "rb8_kernel"),
+    ((96, 37888, 3584), "gemm8_p8_kernel"),
+    ((24, 3584, 18944), "rb8_kernel"),     # mid8 refuses a K it cannot split (37 groups of 512)
+    ((24, 5120, 13824), "mid8_kernel"),
+    ((24, 3584, 3584), "stream8_kernel"),  # 12.8 MB
+    ((24, 8192, 3584), "rb8_kernel"),      # the 70B / TP8 down shard
     # 17 .. 32 rows on long K: the register-ring mid-M kernel; short K stays with the per-tile kernel
     ((17, 1280, 8192), "mid8_kernel"),
     ((32, 1280, 8192), "mid8_kernel"),

@@ -21,6 +21,10 @@ from ao_amd import _lib, ops  # noqa: E402
 SHAPES = {
     "70b": [("qkv70b/8", 1280, 8192), ("o70b/8", 8192, 1024), ("gate_up70b/8", 7168, 8192), ("down70b/8", 8192, 3584)],
     "8b": [("qkv8b", 6144, 4096), ("o8b", 4096, 4096), ("gate_up8b", 28672, 4096), ("down8b", 4096, 14336)],
+    # shapes no rule was fitted on (round 6, generalisation check): Llama-2-13B, Qwen2-7B, Llama-3-70B TP = 4 shards
+    "13b": [("qkv13b", 15360, 5120), ("o13b", 5120, 5120), ("gate_up13b", 27648, 5120), ("down13b", 5120, 13824)],
+    "qwen7b": [("qkvq7b", 4608, 3584), ("oq7b", 3584, 3584), ("gate_upq7b", 37888, 3584), ("downq7b", 3584, 18944)],
+    "70b4": [("qkv70b/4", 2560, 8192), ("o70b/4", 8192, 2048), ("gate_up70b/4", 14336, 8192), ("down70b/4", 8192, 7168)],
 }
 # name -> (variant, {tuning key: value})
 FORMS = {

@@ -18,15 +18,20 @@ from ao_amd import ops  # noqa: E402
 from tools.bench_dec8 import graph_time  # noqa: E402
 
 SHAPES = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate", 14336, 4096), ("down", 4096, 14336)]
+# shapes no rule was fitted on (--other): Llama-2-13B, Qwen2-7B, Llama-3-70B
+OTHER = [("qkv13b", 15360, 5120), ("o13b", 5120, 5120), ("gate13b", 13824, 5120), ("down13b", 5120, 13824),
+         ("qkvq7b", 4608, 3584), ("oq7b", 3584, 3584), ("gateq7b", 18944, 3584), ("downq7b", 3584, 18944),
+         ("qkv70b", 10240, 8192), ("o70b", 8192, 8192), ("gate70b", 28672, 8192), ("down70b", 8192, 28672)]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ms", default="1,2,4,8,16,32,64,128,256,512,2048")
+    ap.add_argument("--other", action="store_true", help="the shapes of OTHER instead of the Llama-3-8B linears")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    for name, n, k in SHAPES:
+    for name, n, k in (OTHER if args.other else SHAPES):
         copies = max(2, -(-(300 << 20) // (n * k // 2)))
         ws = []
         for _ in range(copies):
