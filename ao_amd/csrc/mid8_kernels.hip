@@ -227,6 +227,9 @@ bool mid8_plan(int64_t M, int64_t N, int64_t K, Mid8Plan* out) {
   // were wanted) leaves a few dozen workgroups on the chip: down 3584 x 18944 at M = 24 / 32 took 68 us here against 23 through rb8_kernel.
   // Refused when the divisors of the group count give less than half the parts the shape would otherwise get.
   if (!forced && 2 * split < std::min<int64_t>({want, groups, 16})) return false;
+  // ... and where they leave about half of the chip without a workgroup (8192 x 7168: 64 tiles x 2 parts, 5120 x 13824: 40 x 3) rb8_kernel is
+  // 7 - 8 % ahead (20.4 -> 19.0 us, 24.4 -> 22.4); every shape of round 4's fit makes 160 .. 256 workgroups (a single column tile is a test shape)
+  if (!forced && base >= 16 && base * split < 144) return false;
   if (split > 1 && base * (split + (split + 3) / 4) * 128 * 16 * mt > (int64_t)kSplitMaxTiles * 128 * 128) return false;
   if (split > 1 && base * (1 + (split + 3) / 4) > kSplitMaxTickets - 8) return false;
   *out = Mid8Plan{mt, split};

@@ -23,7 +23,9 @@ TABLE = [
     ((64, 37888, 3584), "rb8_kernel"),
     ((96, 37888, 3584), "gemm8_p8_kernel"),
     ((24, 3584, 18944), "rb8_kernel"),     # mid8 refuses a K it cannot split (37 groups of 512)
-    ((24, 5120, 13824), "mid8_kernel"),
+    ((24, 5120, 13824), "rb8_kernel"),     # 40 column tiles x 3 parts: half the chip idle in mid8
+    ((24, 8192, 7168), "rb8_kernel"),      # 64 x 2
+    ((24, 15360, 5120), "mid8_kernel"),
     ((24, 3584, 3584), "stream8_kernel"),  # 12.8 MB
     ((24, 8192, 3584), "rb8_kernel"),      # the 70B / TP8 down shard
     # 17 .. 32 rows on long K: the register-ring mid-M kernel; short K stays with the per-tile kernel
