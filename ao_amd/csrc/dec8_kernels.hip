@@ -377,6 +377,21 @@ bool dec8_takes_shape(int64_t M, int64_t N, int64_t K, Dec8Shape* shape) {
   // (profiles/dec8_depth_tuned_r06.jsonl, other_shapes_dec8_r06.jsonl, cold weights, M = 9 / 12 / 16): o shard 8192 x 1024 5.1 / 5.3 / 6.1 ->
   // 4.2 us, o 4096^2 6.3 / 6.6 / 7.2 -> 6.0 / 6.0 / 6.4, 8192 x 2048 6.7 - 7.8 -> 5.5 - 5.8, 3584^2 5.5 - 6.2 -> 5.0 - 5.3, K = 5120 at
   // 14 - 16 rows (5 waves alone on a CU) 24.7 - 25.9 -> 21.9 - 22.3.
+  // 5 .. 8 rows: the deepest ring whose activation slice a wave can still hold in registers (XFAST: M x depth <= 32 -- depth 4), where K has one.
+  // profiles/dec8_small_m_forms_r06.jsonl (fp8, cold, 20 shapes, M = 6 / 8): o shard 8192 x 1024 4.5 / 4.7 -> 3.9 us, 8192 x 2048 6.1 / 6.3 ->
+  // 5.2 / 5.3, qkv shard 1280 x 8192 5.3 / 5.4 -> 4.9 / 5.1, gate_up shard at 8 rows 15.4 -> 14.2 (at 6: 13.4 -> 14.0, the one cell behind),
+  // 37888 x 3584 at 8 rows 28.6 -> 25.6; level elsewhere.  Up to 4 rows the deepest ring is ahead on every shape (round 4's rule holds).
+  if (forced == 0 && !s.loop && M >= 5 && M <= 8 && M * s.depth > 32 && g_dec8_mode != 293) {
+    const int ksteps = (int)(K / 128);
+    static const int depths[] = {8, 7, 4, 2, 1};
+    for (int d : depths) {
+      if (M * d > 32 || ksteps % d != 0) continue;
+      const int w = ksteps / d;
+      if (w < 1 || w > 16) break;  // shallower rings only add waves
+      if (dec8_lds(M, K, w) <= 160 * 1024) s = Dec8Shape{w, d, false};
+      break;
+    }
+  }
   if (forced == 0 && !s.loop && M >= 9 && g_dec8_mode != 293) {
     const int ksteps = (int)(K / 128);
     const int64_t wgs = N / 16, offered = std::max<int64_t>(1, wgs / 256);
