@@ -1202,7 +1202,13 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   const bool wide = (N >> 4) >= 1024 && g_tune_mode != 94;
   if (M == 1 && g_tune_mode == 98) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);
   if (g_tune_mode == 99) return launch_mm<G, 16>(x, qdata, sz, y, M, N, K, stream);
-  if (M <= 16 && g_tune_mode < 600 && !(wide && (M > 4 || g_tune_mode == 93))) {
+  // Round 6 (profiles/int4_forms_r06.jsonl, int4_forms_parts_r06.jsonl: 16 shapes of four models x M = 5 .. 16 x 9 forms, cold): the 16-row per-tile
+  // build (9 .. 16 rows) is 1.3 - 1.6 x the 8-row build's time, and from 288 n-tiles on the batched kernel's 16-row slabs with K parts pass it --
+  // gate 14336 x 4096 at M = 12 / 16 19.0 / 19.4 -> 14.1 us, 15360 x 5120 25.1 / 26.5 -> 16.6 / 16.8, 5120 x 13824 25.7 -> 17.4, 10240 x 8192
+  // 24.0 / 25.3 -> 17.5 / 17.9, qkv 6144 x 4096 10.0 / 10.2 -> 9.5; at 224 - 256 n-tiles (o 4096^2: 6.2 against 8.5) and up to 8 rows the per-tile
+  // kernel stays ahead.
+  const bool tall = M > 8 && (N >> 4) >= 288 && g_tune_mode != 94;
+  if (M <= 16 && g_tune_mode < 600 && !tall && !(wide && (M > 4 || g_tune_mode == 93))) {
     if (M == 1 && g_tune_mode != 97) {
       // round 3: when the weight's K divides into (waves <= 16) x (2 | 4 | 7 | 14 blocks), every block of the tile is requested in the
       // prologue and the kernel is straight-line code (58 - 64 VGPRs: four 8-wave workgroups per CU, so gate / up's 896 tiles are
@@ -1334,7 +1340,11 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   int split = 1;
   if (forced_split > 0) split = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)forced_split, kblocks, fit}));
   // (16-row slabs are light -- 27 KiB of LDS, 4 waves -- so several workgroups share a CU: aim for ~1000 of them)
-  else if (waves == 4) split = (int)std::max<int64_t>(1, std::min<int64_t>({(mt == 1 ? 1024 : 256) / base, fit, 8, kblocks / 8}));
+  // (round 6, the same files: with 16-row slabs at least 4 parts up to 512 column tiles -- 18944 x 3584: 3 -> 4 parts 15.9 -> 15.0 us, 28672 x 8192:
+  // 2 -> 4 41.4 -> 36.9 -- and parts down to 4 k-blocks: 5120 x 5120 5 -> 8 parts 10.7 -> 9.6)
+  else if (waves == 4 && mt == 1)
+    split = (int)std::max<int64_t>(1, std::min<int64_t>({std::max<int64_t>(base <= 512 ? 4 : 1, 1024 / base), fit, 8, kblocks / 4}));
+  else if (waves == 4) split = (int)std::max<int64_t>(1, std::min<int64_t>({256 / base, fit, 8, kblocks / 8}));
   if (waves == 8) {
     if (mt == 8) return launch_mm_rb<G, 8, 1, 8>(x, qdata, sz, y, M, N, K, split, stream);
     if (mt == 4) return launch_mm_rb<G, 8, 1, 4>(x, qdata, sz, y, M, N, K, split, stream);
@@ -1374,7 +1384,7 @@ extern "C" const char* ao_int4_mm_kernel_name(int64_t M, int64_t N, int64_t K, i
   (void)K;
   if (M > 64 && (M > 128 || (N + 127) / 128 >= 64))  // round 5: 128 x 128 tiles, 32 x 32 x 16 MFMAs; round 6: 128 x 256 where they fill whole rounds
     return (group_size >= 128 && int4_mm_w32_tiles64(M, N)) ? "int4_mm_w32_kernel<128x256>" : "int4_mm_w32_kernel";
-  if (M > 16 || (M > 4 && (N >> 4) >= 1024)) return "int4_mm_rb_kernel";
+  if (M > 16 || (M > 4 && (N >> 4) >= 1024) || (M > 8 && (N >> 4) >= 288)) return "int4_mm_rb_kernel";  // (round 6: 9 .. 16 rows from 288 n-tiles)
   return "int4_mm_kernel";
 }
 

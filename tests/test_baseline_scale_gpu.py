@@ -88,6 +88,30 @@ def test_int4_mm_bs128_baseline_shapes_default_dispatch(n, k, g, kernel):
     assert np.mean(ys == y_ref) > 0.9
 
 
+# ---- int4 at 9 .. 16 rows: round 6 moved weights of >= 288 n-tiles from the 16-row per-tile build to the batched kernel's 16-row slabs with K parts ----
+@pytest.mark.parametrize("m,n,k,g,kernel", [(12, 14336, 4096, 128, "int4_mm_rb_kernel"), (16, 14336, 4096, 128, "int4_mm_rb_kernel"), (9, 6144, 4096, 128, "int4_mm_rb_kernel"),
+                                            (16, 4608, 3584, 32, "int4_mm_rb_kernel"), (16, 5120, 13824, 64, "int4_mm_rb_kernel"), (16, 4096, 4096, 128, "int4_mm_kernel"),
+                                            (8, 14336, 4096, 128, "int4_mm_kernel"), (6, 28672, 4096, 128, "int4_mm_rb_kernel")])
+def test_int4_mm_small_batch_default_dispatch(m, n, k, g, kernel):
+    """int4_tile_packed_to_4d_tensor.py:243-299 at 5 .. 16 rows through the default dispatch (profiles/int4_forms_r06.jsonl: which kernel serves
+    which weight width); output against the C port of the reference's dequant -> bf16 matmul path on a sample of columns, every row."""
+    assert _lib.lib().ao_int4_mm_kernel_name(m, n, k, g).decode() == kernel
+    w = _randn_bf16((n, k), n + k + g + m, 0.02, DEV)
+    x = _randn_bf16((m, k), n + k + g + m + 1, 1.0, DEV)
+    qdata, sz = ops.int4_quantize_tinygemm(w, g)
+    y = np_from_torch_bf16(ops.weight_int4pack_mm(x, qdata, g, sz))
+    assert np.array_equal(np_from_torch_bf16(ops.weight_int4pack_mm(x, qdata, g, sz)), y)  # K parts meet in part order: reproducible
+    tiles = np.unique(np.concatenate([np.arange(0, n // 16, 7), [n // 16 - 1]]))
+    blocks = (tiles[:, None] * 2 + np.arange(2)[None, :]).reshape(-1)
+    cols = (tiles[:, None] * 16 + np.arange(16)[None, :]).reshape(-1)
+    bi, ci = torch.from_numpy(blocks).to(DEV), torch.from_numpy(cols).to(DEV)
+    y_ref = bf16.from_bits(c_ref.int4_linear(_bits(x), qdata[bi].cpu().numpy(), _bits(sz[:, ci].contiguous()), len(cols), k, g))
+    ys = y[:, cols]
+    assert _rel(ys, y_ref) <= 1e-3
+    assert np.all(np.abs(ys - y_ref) <= np.abs(y_ref) * 2.0 ** -7 + np.abs(y_ref).max() * 2.0 ** -12)
+    assert np.mean(ys == y_ref) > 0.9
+
+
 # ---- MXFP8 grouped GEMM: Mixtral-8x7B expert shapes ------------------------------------------------------------------
 def _mixtral_offs(kind, rows=128, experts=8, seed=0):
     if kind == "uniform16":

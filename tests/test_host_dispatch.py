@@ -100,7 +100,10 @@ def test_int4_dispatch_bands():
     lib = _lib.lib()
     name = lambda m, n, k, g=128: lib.ao_int4_mm_kernel_name(m, n, k, g).decode()  # noqa: E731
     # per-tile kernel (1-, 4-, 8- and 16-row builds) up to 16 rows; wide weights (>= 1024 n-tiles) switch to the batched kernel from 5 rows
-    assert [name(m, 14336, 4096) for m in (1, 4, 5, 8, 16)] == ["int4_mm_kernel"] * 5
+    assert [name(m, 14336, 4096) for m in (1, 4, 5, 8)] == ["int4_mm_kernel"] * 4
+    # round 6: 9 .. 16 rows take the batched kernel's 16-row slabs from 288 n-tiles (profiles/int4_forms_r06.jsonl); narrower weights stay
+    assert [name(m, 14336, 4096) for m in (9, 16)] == ["int4_mm_rb_kernel"] * 2 and [name(m, 4608, 3584) for m in (8, 9)] == ["int4_mm_kernel", "int4_mm_rb_kernel"]
+    assert [name(m, 4096, 4096) for m in (9, 16)] == ["int4_mm_kernel"] * 2 and name(16, 4096, 14336) == "int4_mm_kernel"
     assert [name(m, 28672, 4096) for m in (1, 4)] == ["int4_mm_kernel"] * 2
     assert [name(m, 28672, 4096) for m in (5, 16)] == ["int4_mm_rb_kernel"] * 2
     assert name(17, 4096, 4096) == "int4_mm_rb_kernel" and name(128, 6144, 4096) == "int4_mm_rb_kernel"
