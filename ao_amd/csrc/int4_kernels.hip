@@ -1333,7 +1333,8 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
     return launch_mm_w32<G, true>(x, qdata, sz, y, M, N, K, sp, stream);
   }
   const int64_t slabs = (M + 16 * mt - 1) / (16 * mt);
-  if (waves == 0) waves = (mt >= 2 && ((N + 127) / 128) * slabs >= 190) ? 8 : 4;
+  // (32-row slabs: 4 waves x K parts beat the 8-wave tile that cuts nothing -- 28672 x 8192 at M = 24 / 32: 53 -> 43.5 us)
+  if (waves == 0) waves = (mt >= 4 && ((N + 127) / 128) * slabs >= 190) ? 8 : 4;
   const int bn = waves * 16;
   const int64_t base = ((N + bn - 1) / bn) * slabs;
   const int64_t fit = (int64_t)kSplitMaxTiles * 128 * 128 / (base * bn * 16 * mt);
@@ -1342,8 +1343,12 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
   // (16-row slabs are light -- 27 KiB of LDS, 4 waves -- so several workgroups share a CU: aim for ~1000 of them)
   // (round 6, the same files: with 16-row slabs at least 4 parts up to 512 column tiles -- 18944 x 3584: 3 -> 4 parts 15.9 -> 15.0 us, 28672 x 8192:
   // 2 -> 4 41.4 -> 36.9 -- and parts down to 4 k-blocks: 5120 x 5120 5 -> 8 parts 10.7 -> 9.6)
-  else if (waves == 4 && mt == 1)
+  // 32-row slabs the same; 64-row slabs aim for ~512 workgroups (was 256) -- profiles/int4_forms_mt2_r06.jsonl, int4_forms_mt4_r06.jsonl, M = 24 / 32 and
+  // 48 / 64, us before -> with this rule's count: qkv 6144 x 4096 13.1 -> 10.5 and 15.4 -> 13.5, gate 14336 x 4096 20.4 -> 16.2, down 4096 x 14336
+  // 20.0 -> 16.5 and 23.8 -> 20.3, 10240 x 8192 35.3 -> 20.2 and 39.6 -> ~31, 8192 x 28672 65.1 -> 43.4 and 77.5 -> 59.1; o 4096^2 level.
+  else if (waves == 4 && mt <= 2)
     split = (int)std::max<int64_t>(1, std::min<int64_t>({std::max<int64_t>(base <= 512 ? 4 : 1, 1024 / base), fit, 8, kblocks / 4}));
+  else if (waves == 4 && mt == 4) split = (int)std::max<int64_t>(1, std::min<int64_t>({512 / base, fit, 8, kblocks / 8}));
   else if (waves == 4) split = (int)std::max<int64_t>(1, std::min<int64_t>({256 / base, fit, 8, kblocks / 8}));
   if (waves == 8) {
     if (mt == 8) return launch_mm_rb<G, 8, 1, 8>(x, qdata, sz, y, M, N, K, split, stream);
