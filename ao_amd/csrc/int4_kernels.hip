@@ -1174,7 +1174,7 @@ int launch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uint1
                (int)M, (int)N, (int)K, (float*)nullptr, (unsigned*)nullptr);
     return (int)AO_OK;
   };
-  if constexpr (MAXM == 1 && DEPTH != 4 && (DEPTH == 7 || DEPTH == 14 || DEPTH == 2)) {
+  if constexpr (MAXM == 1 && DEPTH != 4 && (DEPTH == 7 || DEPTH == 14 || DEPTH == 2 || DEPTH == 8 || DEPTH == 9)) {
     AO_REQUIRE(straight && kblocks == wpb * DEPTH && wpb <= 16, "int4_mm: the %d-deep form is straight-line only", DEPTH);
     if (int rc = go(int4_mm_kernel<G, MAXM, DEPTH, true>)) return rc;
   } else if constexpr (MAXM == 1 && DEPTH == 4) {
@@ -1219,6 +1219,14 @@ int dispatch_mm(const uint16_t* x, const int32_t* qdata, const uint16_t* sz, uin
       if (kbl % 7 == 0 && kbl / 7 >= 4 && kbl / 7 <= 16) return launch_mm<G, 1, 7>(x, qdata, sz, y, M, N, K, stream, true);
       if (kbl % 14 == 0 && kbl / 14 >= 4 && kbl / 14 <= 16) return launch_mm<G, 1, 14>(x, qdata, sz, y, M, N, K, stream, true);
       if (kbl % 2 == 0 && kbl / 2 >= 4 && kbl / 2 <= 16) return launch_mm<G, 1, 2>(x, qdata, sz, y, M, N, K, stream, true);
+      // round 6: K of other models that none of the four factors -- 8 blocks (K = 10240 / 12288 / 16384: 10 / 12 / 16 waves) and 9 (K = 13824,
+      // Llama-2-13B's down_proj: 12 waves) -- had fallen to the ring kernel (mode 97 = that, for A/B: profiles/int4_depth_other_r06.jsonl)
+      // Ahead on weights of up to 768 n-tiles (4096 x 12288 10.3 -> 9.1 us, 5120 x 13824 17.1 -> 16.0, 12288^2 22.8 -> 21.8, 6144 x 16384 19.5 -> 19.0),
+      // behind on wider ones (13824 x 10240 23.7 -> 27.2, 14336 x 16384 35.2 -> 37.7: 10 - 16 waves per workgroup x 864+ workgroups), which keep the ring.
+      if ((N >> 4) <= 768) {
+        if (kbl % 8 == 0 && kbl / 8 >= 4 && kbl / 8 <= 16) return launch_mm<G, 1, 8>(x, qdata, sz, y, M, N, K, stream, true);
+        if (kbl % 9 == 0 && kbl / 9 >= 4 && kbl / 9 <= 16) return launch_mm<G, 1, 9>(x, qdata, sz, y, M, N, K, stream, true);
+      }
     }
     if (M == 1) return launch_mm<G, 1>(x, qdata, sz, y, M, N, K, stream);
     if (M <= 4) return launch_mm<G, 4>(x, qdata, sz, y, M, N, K, stream);

@@ -40,7 +40,8 @@ def _bits(t):
 
 
 # ---- int4: the merged gate_up_proj launch of the headline ---------------------------------------------------------
-@pytest.mark.parametrize("n,k,m", [(28672, 4096, 1), (14336, 4096, 1), (4096, 14336, 1), (28672, 4096, 3)])
+@pytest.mark.parametrize("n,k,m", [(28672, 4096, 1), (14336, 4096, 1), (4096, 14336, 1), (28672, 4096, 3),
+                                   (4096, 12288, 1), (5120, 13824, 1)])  # round 6: the 8- and 9-block straight-line forms (K of other models)
 def test_int4_mm_baseline_shapes_vs_oracle(n, k, m):
     g = 128
     w = _randn_bf16((n, k), n + k, 0.02, DEV)

@@ -26,12 +26,15 @@ def main():
     ap.add_argument("--forms", default="0:0,4:701,4:702,4:704")
     ap.add_argument("--other", action="store_true")
     ap.add_argument("--both", action="store_true")
+    ap.add_argument("--shapes", default="", help="name:N:K,... instead of the built-in lists")
     args = ap.parse_args()
     lib = _lib.lib()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     forms = [tuple(int(v) for v in f.split(":")) for f in args.forms.split(",")]
     shapes = (SHAPES + OTHER) if args.both else (OTHER if args.other else SHAPES)
+    if args.shapes:
+        shapes = [(a, int(b), int(c)) for a, b, c in (t.split(":") for t in args.shapes.split(","))]
     for name, n, k in shapes:
         copies = max(2, -(-(300 << 20) // (n * k // 2)))
         ws = []
