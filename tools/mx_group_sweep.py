@@ -25,12 +25,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", default="1,2,4,8,16,32,48,49,64,96,128,256")
     ap.add_argument("--slab-rows", default="0", help="comma list of forced slab heights (ao_gemm8_set_tuning key 3: 0 product rule, 64, 128)")
+    ap.add_argument("--shapes", default="", help="name:N:K,... instead of the Mixtral-8x7B pair (round 6: other MoE models)")
+    ap.add_argument("--experts", type=int, default=8)
+    ap.add_argument("--variants", default="0", help="comma list of ao_gemm8_set_variant values (0 product, 113 one workgroup per tile, 129 per-step scales)")
     args = ap.parse_args()
     from ao_amd import _lib
     lib = _lib.lib()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    for name, n, k in SHAPES:
+    global E
+    E = args.experts
+    shapes = SHAPES if not args.shapes else [(a, int(b), int(c)) for a, b, c in (t.split(":") for t in args.shapes.split(","))]
+    for name, n, k in shapes:
         mx, f8 = [], []
         for _ in range(2):
             w = torch.randn(E, n, k, device=dev, dtype=torch.bfloat16) * 0.05
@@ -51,9 +57,10 @@ def main():
             }
             if ops.mxfp8_grouped_mm_dyn_fits(m, n, k, E):
                 forms["mxfp8_grouped_mm_dyn"] = [lambda w=w: ops.mxfp8_grouped_mm_dyn(a, w[0], w[1], offs, "rceil") for w in mx]
-            for op, calls, bm in ((o, c, b) for b in [int(v) for v in args.slab_rows.split(",")] for o, c in forms.items()):
-                rec = {"op": op, "shape": name, "N": n, "K": k, "tokens_per_expert": t, "M": m, "slab_rows": bm}
+            for op, calls, bm, var in ((o, c, b, v) for v in [int(v) for v in args.variants.split(",")] for b in [int(v) for v in args.slab_rows.split(",")] for o, c in forms.items()):
+                rec = {"op": op, "shape": name, "N": n, "K": k, "E": E, "tokens_per_expert": t, "M": m, "slab_rows": bm, "variant": var}
                 try:
+                    lib.ao_gemm8_set_variant(var)
                     lib.ao_gemm8_set_tuning(3, bm)
                     sec = graph_time(calls)
                     rec["us"] = round(sec * 1e6, 2)
@@ -62,6 +69,7 @@ def main():
                     rec["error"] = repr(e)[:200]
                 finally:
                     lib.ao_gemm8_set_tuning(3, 0)
+                    lib.ao_gemm8_set_variant(0)
                 print(json.dumps(rec), flush=True)
         del mx, f8
 
