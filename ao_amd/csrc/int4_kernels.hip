@@ -662,10 +662,14 @@ __global__ __launch_bounds__(64 * WAVES * (PROD ? 2 : 1), (WAVES == 4 && !PROD) 
 
 thread_local unsigned long long* g_mm_trace = nullptr;  // profiling only (ao_int4_set_trace)
 thread_local int g_tune_wpb = 0;
-// 128 x 256 tiles (64-column wave tiles) of the batched kernel: M >= 512 and tiles that fill >= 7/8 of every round of the 256 CUs
+// 128 x 256 tiles (64-column wave tiles) of the batched kernel.  Round 6, first fit (Llama-3-8B shapes): M >= 512 and tiles that fill >= 7/8 of every
+// round of the 256 CUs.  Re-fitted on 16 shapes of four models x M = 256 / 512 / 1024 x 7 forms (profiles/int4_forms_big_r06.jsonl): within ONE round
+// they are ahead from 144 tiles on (qkv 6144 x 4096 at M = 1024, 192 tiles: 70.3 -> 61.3 us; 5120^2, 160: 84.9 -> 71.6; 4608 x 3584, 144: 60.7 -> 52.9;
+// 18944 x 3584 at M = 256, 148: 64.0 -> 57.5; 10240 x 8192 at 512, 160: 131 -> 121) and behind up to 128 (8192^2 at 512: 75.7 -> 88.4); over several
+// rounds from 0.8 of full (13824 x 5120 at 1024, 432 tiles: 193 -> 174; at 0.58 - 0.63: 10 - 13 % behind).
 inline bool int4_mm_w32_tiles64(int64_t M, int64_t N) {
   const int64_t tiles = ((N + 255) / 256) * ((M + 127) / 128), rounds = (tiles + 255) / 256;
-  return M >= 512 && tiles >= 200 && tiles * 8 >= rounds * 256 * 7;
+  return M >= 256 && ((rounds == 1 && tiles >= 144) || (tiles >= 200 && tiles * 10 >= rounds * 256 * 8));
 }
 
 // ---------------------------------------------------------------------------

@@ -113,6 +113,9 @@ def test_int4_dispatch_bands():
     big = "int4_mm_w32_kernel<128x256>"
     assert name(2048, 4096, 14336) == big and name(2048, 4096, 4096) == big and name(512, 14336, 4096) == big and name(2048, 14336, 4096) == big
     assert name(512, 4096, 14336) == "int4_mm_w32_kernel" and name(256, 14336, 4096) == "int4_mm_w32_kernel"  # 64 / 112 such tiles: K parts would be needed
+    # last pass of round 6 (profiles/int4_forms_big_r06.jsonl): within one round of the chip from 144 such tiles, from 256 rows; over several rounds from 0.8 of full
+    assert name(1024, 6144, 4096) == big and name(1024, 5120, 5120) == big and name(256, 18944, 3584) == big and name(1024, 13824, 5120) == big
+    assert name(512, 18944, 3584) == "int4_mm_w32_kernel" and name(512, 8192, 8192) == "int4_mm_w32_kernel" and name(2048, 6144, 4096) == "int4_mm_w32_kernel"
     assert name(2048, 4096, 4096, 32) == "int4_mm_w32_kernel" and name(2048, 4096, 4096, 256) == big  # the weight rings of groups of 32 / 64 do not fit
     assert name(64, 14336, 4096) == "int4_mm_rb_kernel"
 
